@@ -1,0 +1,149 @@
+"""ctypes bindings of oracle/puffer_oracle.c (CPU ORACLE — test infrastructure only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_build', 'libpuffer_oracle.so')
+        if not os.path.exists(path):
+            path = _build.build_oracle()
+        L = C.CDLL(path)
+        L.po_squared_create.restype = C.c_void_p
+        L.po_squared_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.po_squared_free.argtypes = [C.c_void_p]
+        L.po_squared_async_reset.argtypes = [C.c_void_p, C.c_int64]
+        L.po_squared_send.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_squared_obs_size.argtypes = [C.c_void_p]
+        for name, rt in [('observations', C.c_float), ('rewards', C.c_float), ('terminals', C.c_uint8),
+                         ('truncations', C.c_uint8), ('masks', C.c_uint8), ('info_env', C.c_int32),
+                         ('info_return', C.c_double), ('info_length', C.c_int32), ('info_score', C.c_double)]:
+            f = getattr(L, 'po_squared_' + name)
+            f.restype = C.POINTER(rt)
+            f.argtypes = [C.c_void_p]
+        L.po_squared_num_infos.argtypes = [C.c_void_p]
+        L.po_squared_targets.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.po_squared_stream_pos.restype = C.c_uint64
+        L.po_squared_stream_pos.argtypes = [C.c_void_p]
+        L.po_compute_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.po_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.po_mt_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.po_mt_u32.restype = C.c_uint32
+        L.po_mt_u32.argtypes = [C.c_void_p]
+        L.po_mt_randbelow.restype = C.c_uint32
+        L.po_mt_randbelow.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_mt_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class MT(C.Structure):
+    """CPython ``random.Random`` restated (seed/getrandbits/_randbelow/sample)."""
+    _fields_ = [('mt', C.c_uint32 * 624), ('idx', C.c_int32), ('count', C.c_uint64)]
+
+    def seed(self, s):
+        lib().po_mt_seed(C.byref(self), abs(int(s)))
+        return self
+
+    def u32(self):
+        return int(lib().po_mt_u32(C.byref(self)))
+
+    def randbelow(self, n):
+        return int(lib().po_mt_randbelow(C.byref(self), n))
+
+    def sample(self, n, k):
+        out = (C.c_int * max(k, 1))()
+        lib().po_mt_sample(C.byref(self), n, k, out)
+        return list(out[:k])
+
+    def state_words(self):
+        return np.ctypeslib.as_array(self.mt).copy(), int(self.idx)
+
+
+class SquaredSerial:
+    """``pufferlib.vector.Serial`` over ``make_squared`` envs, restated in C.
+
+    Same call protocol as the reference backend (vector.py:112-162): async_reset / recv / send.
+    ``recv`` returns live views of the C buffers, like Serial returns its numpy buffers.
+    """
+
+    def __init__(self, num_envs, distance_to_target=3, num_targets=1):
+        self.L = lib()
+        self.num_envs = num_envs
+        self.d = distance_to_target
+        self.nt = 4 * distance_to_target if num_targets == -1 else num_targets
+        self.g = 2 * distance_to_target + 1
+        self.h = self.L.po_squared_create(num_envs, distance_to_target, num_targets)
+        n, s = num_envs, self.L.po_squared_obs_size(self.h)
+        as_arr = np.ctypeslib.as_array
+        self.observations = as_arr(self.L.po_squared_observations(self.h), (n, s)).reshape(n, self.g, self.g)
+        self.rewards = as_arr(self.L.po_squared_rewards(self.h), (n,))
+        self.terminals = as_arr(self.L.po_squared_terminals(self.h), (n,)).view(bool)
+        self.truncations = as_arr(self.L.po_squared_truncations(self.h), (n,)).view(bool)
+        self.masks = as_arr(self.L.po_squared_masks(self.h), (n,)).view(bool)
+        self.agent_ids = np.arange(n)
+
+    def __del__(self):
+        try:
+            self.L.po_squared_free(self.h)
+        except Exception:
+            pass
+
+    def _infos(self):
+        k = self.L.po_squared_num_infos(self.h)
+        if k == 0:
+            return []
+        env = np.ctypeslib.as_array(self.L.po_squared_info_env(self.h), (k,))
+        ret = np.ctypeslib.as_array(self.L.po_squared_info_return(self.h), (k,))
+        ln = np.ctypeslib.as_array(self.L.po_squared_info_length(self.h), (k,))
+        sc = np.ctypeslib.as_array(self.L.po_squared_info_score(self.h), (k,))
+        return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i]), _env=int(env[i]))
+                for i in range(k)]
+
+    def async_reset(self, seed=42):
+        self.L.po_squared_async_reset(self.h, int(seed))
+        self.infos = self._infos()
+
+    def send(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions), dtype=np.int64)
+        assert a.shape == (self.num_envs,)
+        self.L.po_squared_send(self.h, a.ctypes.data)
+        self.infos = self._infos()
+
+    def recv(self):
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos,
+                self.agent_ids, self.masks)
+
+    def targets(self, env):
+        out = (C.c_int * max(self.nt, 1))()
+        self.L.po_squared_targets(self.h, env, out)
+        return [(c // self.g, c % self.g) for c in out[:self.nt] if c >= 0]
+
+    def stream_pos(self):
+        return int(self.L.po_squared_stream_pos(self.h))
+
+
+def compute_gae(dones, values, rewards, gamma, gae_lambda):
+    """c_gae.compute_gae restated (c_gae.pyx:11-32)."""
+    dones = np.ascontiguousarray(dones, dtype=np.float32)
+    values = np.ascontiguousarray(values, dtype=np.float32)
+    rewards = np.ascontiguousarray(rewards, dtype=np.float32)
+    adv = np.empty(len(rewards), dtype=np.float32)
+    lib().po_compute_gae(dones.ctypes.data, values.ctypes.data, rewards.ctypes.data, adv.ctypes.data,
+                         len(rewards), gamma, gae_lambda)
+    return adv
+
+
+def philox4x32_10(ctr, key):
+    c = np.ascontiguousarray(ctr, dtype=np.uint32)
+    k = np.ascontiguousarray(key, dtype=np.uint32)
+    out = np.empty(4, dtype=np.uint32)
+    lib().po_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
+    return out

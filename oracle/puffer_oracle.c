@@ -1,0 +1,341 @@
+/* puffer_oracle.c — CPU ORACLE (test infrastructure, NOT product code).  See puffer_oracle.h.
+ *
+ * Build: gcc -O2 -fPIC -shared -ffp-contract=off oracle/puffer_oracle.c -o oracle/_build/libpuffer_oracle.so
+ * (-ffp-contract=off: the reference's Cython GAE is compiled without FMA contraction on x86-64.)
+ */
+#include "puffer_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ======================================================================================== */
+/* MT19937 + CPython `random`                                                                */
+/* ======================================================================================== */
+#define MT_N 624
+#define MT_M 397
+
+static void mt_init_genrand(po_mt_t *g, uint32_t s) {
+    g->mt[0] = s;
+    for (int i = 1; i < MT_N; i++)
+        g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = MT_N;
+    g->count = 0;
+}
+
+static void mt_init_by_array(po_mt_t *g, const uint32_t *key, int key_len) {
+    mt_init_genrand(g, 19650218u);
+    uint32_t *mt = g->mt;
+    int i = 1, j = 0;
+    int k = MT_N > key_len ? MT_N : key_len;
+    for (; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++;
+        j++;
+        if (i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+        if (j >= key_len) j = 0;
+    }
+    for (k = MT_N - 1; k; k--) {
+        mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= MT_N) { mt[0] = mt[MT_N - 1]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+    g->idx = MT_N;
+}
+
+/* random.seed(a) for int a: key = 32-bit little-endian digits of abs(a) (at least one word).
+ * Follows CPython Modules/_randommodule.c random_seed(); called from ocean.py:449-450. */
+void po_mt_seed(po_mt_t *g, uint64_t seed_abs) {
+    uint32_t key[2] = {(uint32_t)(seed_abs & 0xffffffffu), (uint32_t)(seed_abs >> 32)};
+    mt_init_by_array(g, key, key[1] ? 2 : 1);
+}
+
+static void mt_regenerate(po_mt_t *g) {
+    uint32_t *mt = g->mt;
+    for (int kk = 0; kk < MT_N; kk++) {
+        uint32_t y = (mt[kk] & 0x80000000u) | (mt[(kk + 1) % MT_N] & 0x7fffffffu);
+        mt[kk] = mt[(kk + MT_M) % MT_N] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->idx = 0;
+}
+
+uint32_t po_mt_u32(po_mt_t *g) {
+    if (g->idx >= MT_N) mt_regenerate(g);
+    uint32_t y = g->mt[g->idx++];
+    g->count++;
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+/* Random.getrandbits(k), k <= 32: top k bits of one output word. */
+uint32_t po_mt_getrandbits(po_mt_t *g, int k) { return po_mt_u32(g) >> (32 - k); }
+
+static int bit_length(uint32_t n) {
+    int k = 0;
+    while (n) { k++; n >>= 1; }
+    return k;
+}
+
+/* Lib/random.py Random._randbelow_with_getrandbits */
+uint32_t po_mt_randbelow(po_mt_t *g, uint32_t n) {
+    if (!n) return 0;
+    int k = bit_length(n);
+    uint32_t r = po_mt_getrandbits(g, k);
+    while (r >= n) r = po_mt_getrandbits(g, k);
+    return r;
+}
+
+/* Lib/random.py Random.sample(population, k) restricted to index output:
+ * returns the k chosen positions of a length-n population. */
+void po_mt_sample(po_mt_t *g, int n, int k, int *out) {
+    int setsize = 21;
+    if (k > 5) { /* 4 ** ceil(log(3k, 4)) */
+        int p = 1;
+        while (p < 3 * k) p *= 4;
+        setsize += p;
+    }
+    if (n <= setsize) {
+        int *pool = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+        for (int i = 0; i < n; i++) pool[i] = i;
+        for (int i = 0; i < k; i++) {
+            int j = (int)po_mt_randbelow(g, (uint32_t)(n - i));
+            out[i] = pool[j];
+            pool[j] = pool[n - i - 1];
+        }
+        free(pool);
+    } else {
+        for (int i = 0; i < k; i++) {
+            int j;
+            for (;;) {
+                j = (int)po_mt_randbelow(g, (uint32_t)n);
+                int dup = 0;
+                for (int q = 0; q < i; q++) dup |= (out[q] == j);
+                if (!dup) break;
+            }
+            out[i] = j;
+        }
+    }
+}
+
+/* ======================================================================================== */
+/* Serial vecenv of ocean Squared                                                            */
+/* ======================================================================================== */
+static const int MOVES[8][2] = {/* ocean.py:424 */
+                                {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {1, -1}, {-1, -1}, {1, 1}, {-1, 1}};
+
+typedef struct {
+    int x, y, tick;
+    int n_remaining;
+    int *targets; /* remaining target cells (x*g+y), insertion order (list.remove semantics) */
+    int done;     /* GymnasiumPufferEnv.done, emulation.py:130,226 */
+    /* EpisodeStats (postprocess.py:18-31) */
+    double ret_sum;
+    int ep_len;
+} sq_env;
+
+struct po_squared_vec {
+    int n, d, nt, g, obs_size, n_perim;
+    int *perim; /* possible_targets, row-major over perimeter cells (ocean.py:444-446) */
+    sq_env *envs;
+    int *target_store;
+    float *obs;
+    float *rewards;
+    uint8_t *terminals, *truncations, *masks;
+    po_mt_t rng; /* the process-global `random` generator */
+    int n_infos;
+    int32_t *info_env, *info_len;
+    double *info_ret, *info_score;
+    int *scratch;
+};
+
+static int iabs(int a) { return a < 0 ? -a : a; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+po_squared_vec *po_squared_create(int num_envs, int d, int nt) {
+    po_squared_vec *v = (po_squared_vec *)calloc(1, sizeof(*v));
+    v->n = num_envs;
+    v->d = d;
+    v->g = 2 * d + 1;
+    if (nt == -1) nt = 4 * d; /* ocean.py:432-433 */
+    v->nt = nt;
+    v->obs_size = v->g * v->g;
+    v->perim = (int *)malloc(sizeof(int) * (size_t)(8 * d + 1));
+    v->n_perim = 0;
+    for (int x = 0; x < v->g; x++)
+        for (int y = 0; y < v->g; y++)
+            if (x == 0 || y == 0 || x == v->g - 1 || y == v->g - 1) v->perim[v->n_perim++] = x * v->g + y;
+    v->envs = (sq_env *)calloc((size_t)num_envs, sizeof(sq_env));
+    v->target_store = (int *)calloc((size_t)num_envs * (size_t)(nt > 0 ? nt : 1), sizeof(int));
+    for (int i = 0; i < num_envs; i++) {
+        v->envs[i].targets = v->target_store + (size_t)i * (size_t)nt;
+        v->envs[i].done = 1;
+    }
+    v->obs = (float *)calloc((size_t)num_envs * (size_t)v->obs_size, sizeof(float));
+    v->rewards = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->terminals = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->truncations = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->masks = (uint8_t *)malloc((size_t)num_envs);
+    memset(v->masks, 1, (size_t)num_envs); /* vector.py:124 */
+    v->info_env = (int32_t *)calloc((size_t)num_envs, sizeof(int32_t));
+    v->info_len = (int32_t *)calloc((size_t)num_envs, sizeof(int32_t));
+    v->info_ret = (double *)calloc((size_t)num_envs, sizeof(double));
+    v->info_score = (double *)calloc((size_t)num_envs, sizeof(double));
+    v->scratch = (int *)calloc((size_t)(nt > 0 ? nt : 1), sizeof(int));
+    po_mt_seed(&v->rng, 0);
+    return v;
+}
+
+void po_squared_free(po_squared_vec *v) {
+    if (!v) return;
+    free(v->perim); free(v->envs); free(v->target_store); free(v->obs); free(v->rewards);
+    free(v->terminals); free(v->truncations); free(v->masks); free(v->info_env); free(v->info_len);
+    free(v->info_ret); free(v->info_score); free(v->scratch); free(v);
+}
+
+/* ocean.py:448-463 Squared.reset + emulation.py:169-192 GymnasiumPufferEnv.reset +
+ * postprocess.py:18-20 EpisodeStats.reset. */
+static void env_reset(po_squared_vec *v, int i, int has_seed, int64_t seed) {
+    sq_env *e = &v->envs[i];
+    if (has_seed) {
+        po_mt_seed(&v->rng, (uint64_t)(seed < 0 ? -seed : seed));
+    }
+    float *grid = v->obs + (size_t)i * (size_t)v->obs_size;
+    memset(grid, 0, sizeof(float) * (size_t)v->obs_size);
+    grid[v->d * v->g + v->d] = -1.0f;
+    e->x = v->d;
+    e->y = v->d;
+    e->tick = 0;
+    po_mt_sample(&v->rng, v->n_perim, v->nt, v->scratch); /* random.sample(possible_targets, nt) */
+    e->n_remaining = v->nt;
+    for (int t = 0; t < v->nt; t++) {
+        int cell = v->perim[v->scratch[t]];
+        e->targets[t] = cell;
+        grid[cell] = 1.0f;
+    }
+    e->done = 0;
+    e->ret_sum = 0.0;
+    e->ep_len = 0;
+    v->rewards[i] = 0.0f;
+    v->terminals[i] = 0;
+    v->truncations[i] = 0;
+    v->masks[i] = 1;
+}
+
+/* ocean.py:465-513 Squared.step + postprocess.py:22-54 EpisodeStats.step +
+ * emulation.py:194-228 GymnasiumPufferEnv.step. */
+static void env_step(po_squared_vec *v, int i, int64_t action) {
+    sq_env *e = &v->envs[i];
+    const int g = v->g, d = v->d;
+    float *grid = v->obs + (size_t)i * (size_t)v->obs_size;
+    int x = e->x, y = e->y;
+    grid[x * g + y] = 0.0f;
+    x += MOVES[action][0];
+    y += MOVES[action][1];
+    int min_dist = 1 << 30;
+    for (int t = 0; t < e->n_remaining; t++) {
+        int tx = e->targets[t] / g, ty = e->targets[t] % g;
+        int dist = imax(iabs(x - tx), iabs(y - ty));
+        if (dist < min_dist) min_dist = dist;
+    }
+    double reward = 1.0 - (double)min_dist / (double)d; /* python float arithmetic */
+    for (int t = 0; t < e->n_remaining; t++) {
+        if (e->targets[t] == x * g + y) { /* list.remove: first match, keep order */
+            for (int u = t; u + 1 < e->n_remaining; u++) e->targets[u] = e->targets[u + 1];
+            e->n_remaining--;
+            break;
+        }
+    }
+    int dist_from_origin = imax(iabs(x - d), iabs(y - d));
+    if (dist_from_origin >= d) { x = d; y = d; }
+    e->x = x;
+    e->y = y;
+    grid[x * g + y] = -1.0f;
+    e->tick += 1;
+    int done = e->tick >= v->nt * d; /* max_ticks, ocean.py:438 */
+
+    e->ret_sum += reward; /* sum(list of python floats), left to right from 0 */
+    e->ep_len += 1;
+    if (done) {
+        int k = v->n_infos++;
+        v->info_env[k] = i;
+        v->info_ret[k] = e->ret_sum;
+        v->info_len[k] = e->ep_len;
+        v->info_score[k] = (double)(v->nt - e->n_remaining) / (double)v->nt;
+    }
+    v->rewards[i] = (float)reward; /* emulation.py:221, double -> float32 */
+    v->terminals[i] = (uint8_t)done;
+    v->truncations[i] = 0;
+    v->masks[i] = 1;
+    e->done = done;
+}
+
+void po_squared_async_reset(po_squared_vec *v, int64_t seed) {
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) env_reset(v, i, 1, seed + i); /* vector.py:114,129-130,639-641 */
+}
+
+void po_squared_send(po_squared_vec *v, const int64_t *actions) {
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) {
+        if (v->envs[i].done)
+            env_reset(v, i, 0, 0); /* vector.py:147-149: action ignored, unseeded reset */
+        else
+            env_step(v, i, actions[i]);
+    }
+}
+
+int po_squared_obs_size(const po_squared_vec *v) { return v->obs_size; }
+const float *po_squared_observations(const po_squared_vec *v) { return v->obs; }
+const float *po_squared_rewards(const po_squared_vec *v) { return v->rewards; }
+const uint8_t *po_squared_terminals(const po_squared_vec *v) { return v->terminals; }
+const uint8_t *po_squared_truncations(const po_squared_vec *v) { return v->truncations; }
+const uint8_t *po_squared_masks(const po_squared_vec *v) { return v->masks; }
+int po_squared_num_infos(const po_squared_vec *v) { return v->n_infos; }
+const int32_t *po_squared_info_env(const po_squared_vec *v) { return v->info_env; }
+const double *po_squared_info_return(const po_squared_vec *v) { return v->info_ret; }
+const int32_t *po_squared_info_length(const po_squared_vec *v) { return v->info_len; }
+const double *po_squared_info_score(const po_squared_vec *v) { return v->info_score; }
+void po_squared_targets(const po_squared_vec *v, int env, int *out_cells) {
+    for (int t = 0; t < v->nt; t++) out_cells[t] = t < v->envs[env].n_remaining ? v->envs[env].targets[t] : -1;
+}
+uint64_t po_squared_stream_pos(const po_squared_vec *v) { return v->rng.count; }
+
+/* ======================================================================================== */
+/* GAE — c_gae.pyx:11-32                                                                      */
+/* ======================================================================================== */
+void po_compute_gae(const float *dones, const float *values, const float *rewards,
+                    float *advantages, int num_steps, float gamma, float gae_lambda) {
+    for (int i = 0; i < num_steps; i++) advantages[i] = 0.0f; /* np.zeros, :15 */
+    float lastgaelam = 0.0f;
+    for (int t = 0; t < num_steps - 1; t++) {
+        int t_cur = num_steps - 2 - t;
+        int t_next = num_steps - 1 - t;
+        float nextnonterminal = 1.0f - dones[t_next];
+        float delta = rewards[t_next] + gamma * values[t_next] * nextnonterminal - values[t_cur];
+        lastgaelam = delta + gamma * gae_lambda * nextnonterminal * lastgaelam;
+        advantages[t_cur] = lastgaelam;
+    }
+}
+
+/* ======================================================================================== */
+/* Philox4x32-10 (Salmon et al., SC'11) — our own noise definition, restated for checking     */
+/* ======================================================================================== */
+void po_philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+    uint32_t k0 = key_in[0], k1 = key_in[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}

@@ -1,0 +1,81 @@
+/* puffer_oracle.h — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the integer / sequential part of the PufferLib 1.0.1 PPO hot path
+ * (SURVEY.md §8a rows a2–a8, a16).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may link or call this; the product path (pufferlib_amd/) never does.
+ *
+ * Each function cites the reference file:line it follows (paths relative to /root/reference).
+ * Parity status: PINNED — tests/test_oracle_golden.py checks every function here against
+ * fixtures in tests/golden/ that were produced by running the unmodified reference in the
+ * build container (tests/golden/make_golden.py), plus the known answers in SURVEY.md App. B.
+ *
+ * Third-party arithmetic restated here (absent from /root/reference):
+ *   CPython 3.10.12 stdlib `random` (Lib/random.py: seed, getrandbits, _randbelow_with_getrandbits,
+ *   sample; Modules/_randommodule.c: init_by_array seeding) on top of MT19937
+ *   (Matsumoto & Nishimura 1998/2002, mt19937ar).  Anchored on the reference's call sites
+ *   pufferlib/environments/ocean/ocean.py:449-459 and checked against `random` itself.
+ */
+#ifndef PUFFER_ORACLE_H
+#define PUFFER_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- CPython `random` on MT19937 ------------------------------------------------------ */
+typedef struct {
+    uint32_t mt[624];
+    int32_t idx;    /* next word to hand out, 624 = regenerate first */
+    uint64_t count; /* words handed out since the last seeding */
+} po_mt_t;
+
+void po_mt_seed(po_mt_t *g, uint64_t seed_abs);          /* random.seed(int) */
+uint32_t po_mt_u32(po_mt_t *g);                          /* genrand_uint32 */
+uint32_t po_mt_getrandbits(po_mt_t *g, int k);           /* k in 1..32 */
+uint32_t po_mt_randbelow(po_mt_t *g, uint32_t n);        /* _randbelow_with_getrandbits */
+void po_mt_sample(po_mt_t *g, int n, int k, int *out);   /* random.sample(range(n), k) */
+
+/* ---- Serial vecenv of ocean Squared ---------------------------------------------------- */
+typedef struct po_squared_vec po_squared_vec;
+
+/* vector.py:78-95 Serial.__init__ over make_squared (ocean/environment.py:28-31). */
+po_squared_vec *po_squared_create(int num_envs, int distance_to_target, int num_targets);
+void po_squared_free(po_squared_vec *v);
+/* vector.py:112-135 Serial.async_reset: env i is reset with seed+i. */
+void po_squared_async_reset(po_squared_vec *v, int64_t seed);
+/* vector.py:137-156 Serial.send: done envs reset (unseeded), others step. */
+void po_squared_send(po_squared_vec *v, const int64_t *actions);
+
+int po_squared_obs_size(const po_squared_vec *v);         /* (2d+1)^2 */
+const float *po_squared_observations(const po_squared_vec *v);  /* [N][obs_size] */
+const float *po_squared_rewards(const po_squared_vec *v);       /* [N] */
+const uint8_t *po_squared_terminals(const po_squared_vec *v);   /* [N] */
+const uint8_t *po_squared_truncations(const po_squared_vec *v); /* [N] */
+const uint8_t *po_squared_masks(const po_squared_vec *v);       /* [N] */
+/* infos emitted by the last async_reset/send (postprocess.py:18-54): one per finished episode. */
+int po_squared_num_infos(const po_squared_vec *v);
+const int32_t *po_squared_info_env(const po_squared_vec *v);
+const double *po_squared_info_return(const po_squared_vec *v);
+const int32_t *po_squared_info_length(const po_squared_vec *v);
+const double *po_squared_info_score(const po_squared_vec *v);
+/* introspection for tests: target cells (x*g+y) currently remaining / drawn at last reset */
+void po_squared_targets(const po_squared_vec *v, int env, int *out_cells /* [num_targets] */);
+/* word position of the shared stream (number of 32-bit outputs consumed since the last seeding) */
+uint64_t po_squared_stream_pos(const po_squared_vec *v);
+
+/* ---- GAE ---------------------------------------------------------------------------------- */
+/* c_gae.pyx:11-32 */
+void po_compute_gae(const float *dones, const float *values, const float *rewards,
+                    float *advantages, int num_steps, float gamma, float gae_lambda);
+
+/* ---- counter-based action noise (our own definition, restated for checking) --------------- */
+/* Philox4x32-10 keyed by (seed_lo, seed_hi); counter = (row_lo, row_hi, step, 0); the four output
+ * words give exponential(1) variates q = -log(u), u = (w >> 8 + 0.5) * 2^-24, for action columns
+ * 4*j .. 4*j+3 with counter word 3 = j.  See pufferlib_amd/csrc/philox.hpp. */
+void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

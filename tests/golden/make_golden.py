@@ -1,0 +1,211 @@
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE UNMODIFIED REFERENCE.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference is imported read-only from /root/reference with the tests-only shims in
+tests/shims/ standing in for gymnasium / gym / pettingzoo (not installed, no network).  Nothing
+from the reference is copied: this script calls its public functions and records inputs/outputs.
+
+Fixtures written (all small, committed):
+  gae.npz            c_gae.compute_gae (c_gae.pyx:11-32) on KAT / random / boundary inputs
+  squared_<tag>.npz  pufferlib.vector.Serial over ocean make_squared (vector.py:70-166,
+                     ocean.py:406-513, emulation.py:124-234, postprocess.py:8-54): lock-step trajectories
+  ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
+  ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path[:0] = [os.path.join(REPO, 'tests', 'shims'), '/root/reference']
+
+import warnings  # noqa: E402
+warnings.filterwarnings('ignore')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def gen_gae(compute_gae):
+    out = {}
+    rng = np.random.RandomState(0)
+    cases = {
+        'kat8': (np.zeros(8, np.float32), np.arange(8, dtype=np.float32), np.ones(8, np.float32), .99, .95),
+        'len1': (np.zeros(1, np.float32), np.ones(1, np.float32), np.ones(1, np.float32), .99, .95),
+        'len2': (np.array([0, 1], np.float32), np.array([.5, -1], np.float32), np.array([1, 2], np.float32), .99, .95),
+        'alldone': (np.ones(257, np.float32), rng.randn(257).astype(np.float32), rng.randn(257).astype(np.float32), .99, .95),
+        'nodone': (np.zeros(1000, np.float32), rng.randn(1000).astype(np.float32), rng.randn(1000).astype(np.float32), .99, .95),
+        'p01': ((rng.rand(4097) < .01).astype(np.float32), rng.randn(4097).astype(np.float32), rng.randn(4097).astype(np.float32), .99, .95),
+        'p25': ((rng.rand(65537) < .25).astype(np.float32), rng.randn(65537).astype(np.float32), rng.randn(65537).astype(np.float32), .9, .8),
+        'gamma1': (np.zeros(300, np.float32), rng.randn(300).astype(np.float32), rng.randn(300).astype(np.float32), 1.0, 1.0),
+    }
+    for k, (d, v, r, g, l) in cases.items():
+        adv = compute_gae(d, v, r, g, l)
+        out[k + '_dones'], out[k + '_values'], out[k + '_rewards'] = d, v, r
+        out[k + '_gl'] = np.array([g, l], np.float64)
+        out[k + '_adv'] = np.asarray(adv)
+    np.savez_compressed(os.path.join(HERE, 'gae.npz'), **out)
+    print('gae.npz', len(cases), 'cases')
+
+
+def gen_squared(tag, num_envs, d, nt, seed, steps):
+    import pufferlib.vector
+    import pufferlib.environments.ocean as ocean
+    vec = pufferlib.vector.make(ocean.env_creator('squared'), env_kwargs=dict(distance_to_target=d, num_targets=nt),
+                                num_envs=num_envs, backend=pufferlib.vector.Serial)
+    rng = np.random.RandomState(1000 + seed)
+    vec.async_reset(seed)
+    obs, rew, term, trunc, acts = [], [], [], [], []
+    info_rows = []  # (recv index, ordinal in list, episode_return, episode_length, score)
+    targets = []    # remaining target cells per env after every recv, -1 padded
+    g = 2 * d + 1
+    nt_eff = 4 * d if nt == -1 else nt
+
+    def snap(k):
+        o, r, te, tr, infos, ids, masks = vec.recv()
+        assert masks.all() and (ids == np.arange(num_envs)).all()
+        obs.append(o.copy()); rew.append(r.copy()); term.append(te.copy()); trunc.append(tr.copy())
+        for j, i in enumerate(infos):
+            info_rows.append((k, j, i['episode_return'], i['episode_length'], i['score']))
+        tg = -np.ones((num_envs, nt_eff), np.int16)
+        for e, env in enumerate(vec.envs):
+            for j, (x, y) in enumerate(env.env.env.targets):
+                tg[e, j] = x * g + y
+        targets.append(tg)
+
+    snap(0)
+    for k in range(1, steps + 1):
+        a = rng.randint(0, 8, size=num_envs)
+        acts.append(a)
+        vec.send(a)
+        snap(k)
+    obs = np.stack(obs)
+    assert set(np.unique(obs)) <= {-1.0, 0.0, 1.0}
+    np.savez_compressed(
+        os.path.join(HERE, f'squared_{tag}.npz'),
+        config=np.array([num_envs, d, nt, seed, steps], np.int64),
+        obs=obs.astype(np.int8), rewards=np.stack(rew), terminals=np.stack(term), truncations=np.stack(trunc),
+        actions=np.stack(acts).astype(np.int8), infos=np.array(info_rows, np.float64).reshape(-1, 5),
+        targets=np.stack(targets))
+    print(f'squared_{tag}.npz', obs.shape, 'infos', len(info_rows))
+
+
+def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
+    import pufferlib
+    import pufferlib.vector
+    import pufferlib.models
+    import pufferlib.frameworks.cleanrl
+    import pufferlib.environments.ocean as ocean
+    import clean_pufferl
+
+    class _NoUtil:
+        def __init__(self, *a, **k):
+            self.cpu_util = self.cpu_mem = self.gpu_util = self.gpu_mem = [0]
+
+        def stop(self):
+            pass
+
+    clean_pufferl.Utilization = _NoUtil
+    clean_pufferl.print_dashboard = lambda *a, **k: None
+    clean_pufferl.save_checkpoint = lambda data: None
+
+    batch = num_envs * horizon
+    config = pufferlib.namespace(
+        env='squared', seed=1, torch_deterministic=True, cpu_offload=False, device='cpu',
+        total_timesteps=batch * 8, learning_rate=2.5e-4, anneal_lr=True, gamma=0.99, gae_lambda=0.95,
+        update_epochs=2, norm_adv=True, clip_coef=0.1, clip_vloss=True, vf_coef=0.5, vf_clip_coef=0.1,
+        max_grad_norm=0.5, ent_coef=0.01, target_kl=None, batch_size=batch, minibatch_size=batch // 4,
+        bptt_horizon=8, compile=False, compile_mode='reduce-overhead', checkpoint_interval=10 ** 9,
+        data_dir='/tmp/golden_experiments', exp_id='golden')
+    vec = pufferlib.vector.make(ocean.env_creator('squared'), num_envs=num_envs, backend=pufferlib.vector.Serial)
+
+    torch.manual_seed(1)
+    policy = pufferlib.models.Default(vec.driver_env, hidden_size=128)
+    if use_rnn:
+        policy = pufferlib.models.LSTMWrapper(vec.driver_env, policy, input_size=128, hidden_size=128)
+        policy = pufferlib.frameworks.cleanrl.RecurrentPolicy(policy)
+    else:
+        policy = pufferlib.frameworks.cleanrl.Policy(policy)
+
+    out = {}
+    for k, v in policy.state_dict().items():
+        out['w0.' + k] = v.detach().numpy().copy()
+
+    # record the exponential noise behind every torch.multinomial call (rollout sampling)
+    noise = []
+    orig_multinomial = torch.multinomial
+
+    def recording_multinomial(p, n, *a, **kw):
+        st = torch.get_rng_state()
+        res = orig_multinomial(p, n, *a, **kw)
+        st2 = torch.get_rng_state()
+        torch.set_rng_state(st)
+        q = torch.empty_like(p).exponential_(1)
+        assert torch.equal((p / q).argmax(-1, keepdim=True), res), 'multinomial != argmax(p/q)'
+        torch.set_rng_state(st2)
+        noise.append(q.numpy().copy())
+        return res
+
+    torch.multinomial = recording_multinomial
+    try:
+        data = clean_pufferl.create(config, vec, policy)
+        exp = data.experience
+        for it in range(iters):
+            noise.clear()
+            clean_pufferl.evaluate(data)
+            out[f'it{it}.noise'] = np.stack(noise)                       # (T, N, A)
+            out[f'it{it}.obs'] = exp.obs.numpy().reshape(batch, -1).astype(np.int8)  # storage (step-major) order
+            out[f'it{it}.actions'] = exp.actions_np.copy().astype(np.int8)
+            out[f'it{it}.logprobs'] = exp.logprobs_np.copy()
+            out[f'it{it}.rewards'] = exp.rewards_np.copy()
+            out[f'it{it}.dones'] = exp.dones_np.copy()
+            out[f'it{it}.values'] = exp.values_np.copy()
+            out[f'it{it}.global_step'] = np.array(data.global_step, np.int64)
+            out[f'it{it}.stats'] = np.array([data.stats.get('episode_return', np.nan),
+                                             data.stats.get('episode_length', np.nan),
+                                             data.stats.get('score', np.nan)], np.float64)
+            if use_rnn:
+                out[f'it{it}.lstm_h'] = exp.lstm_h.numpy().copy()
+                out[f'it{it}.lstm_c'] = exp.lstm_c.numpy().copy()
+            lr_used = data.optimizer.param_groups[0]['lr']
+            clean_pufferl.train(data)
+            out[f'it{it}.lr_used'] = np.array(lr_used, np.float64)
+            out[f'it{it}.lr_next'] = np.array(data.optimizer.param_groups[0]['lr'], np.float64)
+            out[f'it{it}.advantages'] = exp.b_advantages.numpy().copy()   # (nmb, minibatch)
+            out[f'it{it}.returns'] = exp.b_returns.numpy().copy()
+            out[f'it{it}.b_idxs'] = exp.b_idxs.numpy().copy()
+            L = data.losses
+            out[f'it{it}.losses'] = np.array([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl,
+                                              L.approx_kl, L.clipfrac, L.explained_variance], np.float64)
+            for k, v in policy.state_dict().items():
+                out[f'it{it}.w.' + k] = v.detach().numpy().copy()
+            st = data.optimizer.state_dict()['state']
+            names = [k for k, _ in policy.named_parameters()]
+            for i, nme in enumerate(names):
+                out[f'it{it}.m.' + nme] = st[i]['exp_avg'].numpy().copy()
+                out[f'it{it}.v.' + nme] = st[i]['exp_avg_sq'].numpy().copy()
+    finally:
+        torch.multinomial = orig_multinomial
+    out['config'] = np.array([num_envs, horizon, config.minibatch_size, config.bptt_horizon,
+                              config.update_epochs, config.total_timesteps, iters], np.int64)
+    out['hparams'] = np.array([config.learning_rate, config.gamma, config.gae_lambda, config.clip_coef,
+                               config.vf_coef, config.vf_clip_coef, config.max_grad_norm, config.ent_coef],
+                              np.float64)
+    np.savez_compressed(os.path.join(HERE, f'ppo_{tag}.npz'), **out)
+    print(f'ppo_{tag}.npz', len(out), 'arrays; losses it0', out['it0.losses'])
+
+
+if __name__ == '__main__':
+    import clean_pufferl  # builds c_gae through pyximport exactly as the reference does (clean_pufferl.py:24-27)
+    gen_gae(clean_pufferl.compute_gae)
+    gen_squared('d3t1', 64, 3, 1, 1, 60)
+    gen_squared('d1t4', 8, 1, -1, 42, 40)      # n=8 <= 21: pool-swap sampling, variable bit widths
+    gen_squared('d2t2', 16, 2, 2, 7, 40)       # n=16: pool path with 2 draws
+    gen_squared('d4t3', 16, 4, 3, 3, 60)       # n=32 > 21: set-rejection sampling
+    gen_squared('d3t1_big', 700, 3, 1, 4090, 12)  # crosses several MT19937 regenerations per reset round
+    gen_ppo('mlp', use_rnn=False)
+    gen_ppo('lstm', use_rnn=True)

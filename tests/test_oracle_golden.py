@@ -1,0 +1,152 @@
+"""Pin the CPU oracle (oracle/) against outputs of the unmodified reference (tests/golden/*.npz,
+produced by tests/golden/make_golden.py) and the known answers in SURVEY.md Appendix B."""
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle, ppo_torch
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+# ---------------------------------------------------------------- MT19937 / random.sample
+@pytest.mark.parametrize('seed', [0, 1, 42, 4097, 2 ** 32 + 5, 2 ** 45 + 77])
+def test_mt_stream_matches_cpython(seed):
+    random.seed(seed)
+    m = c_oracle.MT().seed(seed)
+    assert [random.getrandbits(32) for _ in range(1500)] == [m.u32() for _ in range(1500)]
+
+
+@pytest.mark.parametrize('n,k', [(24, 1), (8, 4), (16, 2), (32, 3), (21, 5), (22, 5), (85, 6), (86, 6), (1, 1)])
+def test_sample_matches_cpython(n, k):
+    random.seed(11)
+    m = c_oracle.MT().seed(11)
+    for _ in range(300):
+        assert random.sample(range(n), k) == m.sample(n, k)
+
+
+def test_appendix_b_first_targets():
+    # first-episode targets after reset(seed=s), d=3, nt=1
+    want = {1: (0, 4), 2: (0, 1), 3: (1, 0), 4: (1, 0), 42: (6, 3)}
+    for s, t in want.items():
+        v = c_oracle.SquaredSerial(1, 3, 1)
+        v.async_reset(s)
+        assert v.targets(0) == [t]
+
+
+# ---------------------------------------------------------------- Squared Serial vecenv
+@pytest.mark.parametrize('tag', ['d3t1', 'd1t4', 'd2t2', 'd4t3', 'd3t1_big'])
+def test_squared_trajectory_bit_exact(golden_dir, tag):
+    g = _load(golden_dir, f'squared_{tag}.npz')
+    n, d, nt, seed, steps = (int(x) for x in g['config'])
+    v = c_oracle.SquaredSerial(n, d, nt)
+    v.async_reset(seed)
+    infos = []
+    for k in range(steps + 1):
+        o, r, te, tr, info, ids, masks = v.recv()
+        assert np.array_equal(o.astype(np.int8), g['obs'][k]), (tag, k)
+        assert np.array_equal(o, g['obs'][k].astype(np.float32))
+        assert np.array_equal(r.view(np.uint32), g['rewards'][k].view(np.uint32)), (tag, k)
+        assert np.array_equal(te, g['terminals'][k]) and np.array_equal(tr, g['truncations'][k])
+        assert masks.all()
+        for j, i in enumerate(info):
+            infos.append((k, j, i['episode_return'], i['episode_length'], i['score']))
+        tg = g['targets'][k]
+        for e in range(n):
+            want = [(c // v.g, c % v.g) for c in tg[e] if c >= 0]
+            assert v.targets(e) == want, (tag, k, e)
+        if k < steps:
+            v.send(g['actions'][k].astype(np.int64))
+    got = np.array(infos, np.float64).reshape(-1, 5)
+    assert np.array_equal(got, g['infos'])  # python-float sums reproduced exactly
+
+
+# ---------------------------------------------------------------- GAE
+def test_gae_matches_reference(golden_dir):
+    g = _load(golden_dir, 'gae.npz')
+    cases = sorted({k.split('_')[0] for k in g.files})
+    assert len(cases) == 8
+    for c in cases:
+        gamma, lam = g[c + '_gl']
+        adv = c_oracle.compute_gae(g[c + '_dones'], g[c + '_values'], g[c + '_rewards'], gamma, lam)
+        assert np.array_equal(adv.view(np.uint32), g[c + '_adv'].view(np.uint32)), c
+
+
+def test_gae_appendix_b():
+    adv = c_oracle.compute_gae(np.zeros(8), np.arange(8), np.ones(8), .99, .95)
+    want = [11.514251, 10.126795, 8.662194, 7.11557, 5.481733, 3.7551653, 1.9300003, 0.]
+    assert np.allclose(adv, want, rtol=1e-6, atol=0)
+
+
+def test_ref_c_gae_agrees_when_built(golden_dir):
+    """oracle/_ref/c_gae*.so is the reference's own Cython kernel compiled from /root/reference."""
+    import importlib.util
+    import glob
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = glob.glob(os.path.join(here, 'oracle', '_ref', 'c_gae*.so'))
+    if not so:
+        pytest.skip('oracle/_ref not built (no /root/reference here)')
+    spec = importlib.util.spec_from_file_location('c_gae', so[0])
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.RandomState(5)
+    d = (rng.rand(5000) < .05).astype(np.float32)
+    v, r = rng.randn(5000).astype(np.float32), rng.randn(5000).astype(np.float32)
+    a = mod.compute_gae(d, v, r, .99, .95)
+    b = c_oracle.compute_gae(d, v, r, .99, .95)
+    assert np.array_equal(np.asarray(a).view(np.uint32), b.view(np.uint32))
+
+
+# ---------------------------------------------------------------- policy / PPO update
+def _replay(golden_dir, tag):
+    g = _load(golden_dir, f'ppo_{tag}.npz')
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    lr, gamma, lam, clip, vf_coef, vf_clip, mgn, ent = (float(x) for x in g['hparams'])
+    sd = {k[3:]: g[k] for k in g.files if k.startswith('w0.')}
+    pol = ppo_torch.Policy.from_reference_state_dict(sd)
+    vec = c_oracle.SquaredSerial(n, 3, 1)
+    tr = ppo_torch.Trainer(pol, vec, batch_size=n * horizon, minibatch_size=mbs, bptt_horizon=bptt,
+                           update_epochs=epochs, learning_rate=lr, gamma=gamma, gae_lambda=lam, clip_coef=clip,
+                           vf_coef=vf_coef, vf_clip_coef=vf_clip, max_grad_norm=mgn, ent_coef=ent,
+                           total_timesteps=total, seed=1)
+    return g, pol, tr, iters
+
+
+@pytest.mark.parametrize('tag', ['mlp', 'lstm'])
+def test_ppo_replay_matches_reference(golden_dir, tag):
+    torch.set_num_threads(1)
+    g, pol, tr, iters = _replay(golden_dir, tag)
+    recurrent = tag == 'lstm'
+    for it in range(iters):
+        assert abs(tr.opt.param_groups[0]['lr'] - float(g[f'it{it}.lr_used'])) < 1e-15
+        stats = tr.evaluate(g[f'it{it}.noise'])
+        assert np.array_equal(tr.actions, g[f'it{it}.actions'].astype(np.int64)), 'actions differ'
+        assert np.array_equal(tr.obs.numpy().astype(np.int8), g[f'it{it}.obs'])
+        assert np.array_equal(tr.rewards, g[f'it{it}.rewards'])
+        assert np.array_equal(tr.dones, g[f'it{it}.dones'])
+        tol = dict(rtol=1e-5, atol=1e-6) if recurrent else dict(rtol=0, atol=0)
+        np.testing.assert_allclose(tr.logprobs, g[f'it{it}.logprobs'], **tol)
+        np.testing.assert_allclose(tr.values, g[f'it{it}.values'], **tol)
+        assert tr.global_step == int(g[f'it{it}.global_step'])
+        np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']],
+                                   g[f'it{it}.stats'], rtol=1e-12)
+        L = tr.train()
+        np.testing.assert_allclose(tr.b_advantages.numpy(), g[f'it{it}.advantages'], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(tr.b_returns.numpy(), g[f'it{it}.returns'], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(tr.b_idxs.numpy(), g[f'it{it}.b_idxs'])
+        got = [L['policy_loss'], L['value_loss'], L['entropy'], L['old_approx_kl'], L['approx_kl'], L['clipfrac'],
+               L['explained_variance']]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=2e-5, atol=1e-7)
+        prefix = 'policy.policy.' if recurrent else 'policy.'
+        m, v = tr.adam_moments()
+        for name, arr in pol.state_arrays().items():
+            key = ('policy.recurrent.' + name) if name.endswith('_l0') else (prefix + name)
+            np.testing.assert_allclose(arr, g[f'it{it}.w.' + key], rtol=1e-5, atol=1e-6, err_msg=name)
+            np.testing.assert_allclose(m[name], g[f'it{it}.m.' + key], rtol=1e-4, atol=1e-7, err_msg=name)
+            np.testing.assert_allclose(v[name], g[f'it{it}.v.' + key], rtol=1e-4, atol=1e-9, err_msg=name)
+        assert abs(tr.opt.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-15
