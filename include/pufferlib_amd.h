@@ -1,0 +1,178 @@
+/* pufferlib_amd.h — C ABI of the MI355X-native PPO rollout-and-update engine.
+ *
+ * The reference (PufferLib 1.0.1) has exactly one native entry point on this path,
+ * c_gae.compute_gae (c_gae.pyx:11-32); everything else is Python calling stock PyTorch ops.
+ * This header freezes the C ABI a maintainer would bind (ctypes / cffi / Cython) to replace the
+ * body of each reference function named below.  Conventions:
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - nothing here allocates or frees caller memory; sizes come from the *_bytes() helpers;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream); calls only enqueue work;
+ *   - return 0 on success, negative on error (pfa_last_error() gives the message);
+ *   - no torch types; PyTorch is only the allocator / stream owner on the Python side.
+ * gfx950 only.  All arithmetic fp32 unless stated (fp64 for episode-return sums, python-float parity).
+ */
+#ifndef PUFFERLIB_AMD_H
+#define PUFFERLIB_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *pfa_stream_t;
+
+int pfa_version(void);
+const char *pfa_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GAE — replaces c_gae.compute_gae (c_gae.pyx:11-32), called from clean_pufferl.py:168-169.
+ * One reverse affine scan over the whole flat (env-major) batch, crossing env boundaries exactly
+ * like the reference; advantages[n-1] = 0.  `returns` (nullable) = advantages + values
+ * (clean_pufferl.py:482).  workspace >= pfa_gae_workspace_bytes(n).
+ * ------------------------------------------------------------------------------------------ */
+size_t pfa_gae_workspace_bytes(int64_t n);
+int pfa_gae_f32(const float *dones, const float *values, const float *rewards, float *advantages,
+                float *returns, int64_t n, float gamma, float gae_lambda, void *workspace,
+                pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Squared vecenv — replaces pufferlib.vector.Serial (vector.py:70-166) over
+ * ocean.environment.make_squared (ocean/environment.py:28-31), i.e. GymnasiumPufferEnv
+ * (emulation.py:169-228) + EpisodeStats (postprocess.py:18-54) + ocean.Squared (ocean.py:406-513),
+ * including the process-global MT19937 `random.sample` stream shared by all envs in index order.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t num_envs;           /* N */
+    int32_t distance_to_target; /* d; grid is (2d+1)^2 */
+    int32_t num_targets;        /* nt >= 1 (already resolved from -1 -> 4d) */
+    int32_t obs_stride;         /* floats per observation row in every obs buffer (>= (2d+1)^2) */
+    int32_t tape_rounds;        /* capacity of the reset-target tape, in reset rounds */
+} pfa_squared_config;
+
+size_t pfa_squared_state_bytes(const pfa_squared_config *cfg);
+/* Serial.async_reset(seed) (vector.py:112-135): env i reseeds the shared generator with seed+i and
+ * resets.  Writes the live buffers recv() returns: obs [N][obs_stride] f32, rewards [N] f32,
+ * terminals/truncations/masks [N] u8. */
+int pfa_squared_async_reset(void *state, const pfa_squared_config *cfg, int64_t seed, float *obs,
+                            float *rewards, uint8_t *terminals, uint8_t *truncations, uint8_t *masks,
+                            pfa_stream_t stream);
+/* Pre-draw the targets of the next `rounds` reset rounds (N random.sample calls each, in env order)
+ * from the shared stream into the tape.  The stream does not depend on actions, so this can run
+ * ahead of the steps that consume it.  rounds <= tape_rounds - (rounds filled but not yet consumed). */
+int pfa_squared_fill_tape(void *state, const pfa_squared_config *cfg, int32_t rounds, pfa_stream_t stream);
+/* Serial.send(actions) (vector.py:137-156): done envs reset (action ignored), others step.
+ * actions: int64 [N] on device. */
+int pfa_squared_send(void *state, const pfa_squared_config *cfg, const int64_t *actions, float *obs,
+                     float *rewards, uint8_t *terminals, uint8_t *truncations, uint8_t *masks,
+                     pfa_stream_t stream);
+/* Episode statistics of episodes finished since the last call with reset != 0
+ * (what clean_pufferl.evaluate averages from infos, clean_pufferl.py:119-121,144-152):
+ * out[0]=count, out[1]=sum episode_return, out[2]=sum episode_length, out[3]=sum score (f64, device). */
+int pfa_squared_episode_stats(void *state, const pfa_squared_config *cfg, double *out4, int32_t reset,
+                              pfa_stream_t stream);
+/* Per-env view for infos of the LAST send: finished[N] u8, episode_return[N] f64, episode_length[N] i32,
+ * score[N] f64 (valid where finished). */
+int pfa_squared_last_infos(void *state, const pfa_squared_config *cfg, uint8_t *finished,
+                           double *episode_return, int32_t *episode_length, double *score,
+                           pfa_stream_t stream);
+/* Introspection for tests: remaining target cells [N][nt] int32 (-1 = hit), stream word position. */
+int pfa_squared_debug_targets(void *state, const pfa_squared_config *cfg, int32_t *cells, pfa_stream_t stream);
+int pfa_squared_debug_stream_pos(void *state, const pfa_squared_config *cfg, uint64_t *pos_device, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * MLP policy — pufferlib.models.Default (models.py:24-62) wrapped by frameworks.cleanrl.Policy
+ * (cleanrl.py:50-66) with sample_logits (cleanrl.py:25-47), one Discrete head.
+ * Flat fp32 parameter vector, in this order (obs_stride columns per encoder row, pad columns 0):
+ *   encoder.weight [H][obs_stride], encoder.bias [H], decoder.weight [A][H], decoder.bias [A],
+ *   value_head.weight [1][H], value_head.bias [1].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t obs_dim;     /* true feature count (informational) */
+    int32_t obs_stride;  /* floats per obs row, multiple of 16, <= 128 */
+    int32_t hidden;      /* 128 */
+    int32_t num_actions; /* A <= 15 */
+} pfa_mlp_dims;
+
+int64_t pfa_mlp_param_count(const pfa_mlp_dims *dims);
+
+/* Philox4x32-10 action-noise stream: key=(seed lo, seed hi), counter=(row, column/4, step lo, step hi),
+ * row = global env index (env_offset + local env), so the stream is invariant to how envs are sharded. */
+typedef struct {
+    uint64_t seed;
+    uint64_t step; /* rollout step counter (monotonic across rollouts) */
+} pfa_noise_key;
+
+/* policy(obs) in rollout mode: actions int64 [rows], logprob/entropy/value f32 [rows].
+ * `noise` (nullable) is an explicit Exp(1) tensor [rows][A] (parity with torch.multinomial:
+ * action = argmax(softmax(logits)/noise)); when null the Philox stream above is used with
+ * row index = row_offset + r. */
+int pfa_mlp_forward_sample(const float *obs, int64_t rows, const float *params, const pfa_mlp_dims *dims,
+                           const float *noise, const pfa_noise_key *key, int64_t row_offset,
+                           int64_t *actions, float *logprob, float *entropy, float *value,
+                           pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Experience — clean_pufferl.Experience (clean_pufferl.py:380-482) kept ENV-MAJOR on device:
+ * row (env e, step t) lives at flat index e*T + t, which is the order sort_training_data (:452-464)
+ * produces for a Serial backend; no sort, no gather.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float *obs;        /* [N*T][obs_stride] */
+    int32_t *actions;  /* [N*T] */
+    float *logprobs;   /* [N*T] */
+    float *values;     /* [N*T] */
+    float *rewards;    /* [N*T] */
+    float *dones;      /* [N*T] (terminals as 0/1 floats, clean_pufferl.py:447) */
+    float *advantages; /* [N*T] written by pfa_gae_f32 */
+    float *returns;    /* [N*T] */
+    int32_t horizon_T; /* steps per env per rollout */
+} pfa_experience;
+
+/* Fused rollout — clean_pufferl.evaluate (clean_pufferl.py:76-154) for a Squared vecenv and an MLP
+ * policy: T x { recv, policy forward + sample, Experience.store, send }, all on device, envs resident
+ * in LDS/registers for the whole rollout.  The tape must hold the reset rounds these T steps consume.
+ * `noise` nullable [T][N][A]; env_offset = global index of local env 0 (rank * N).  On return the live
+ * buffers hold what recv() would return next. */
+int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cfg, const float *params,
+                            const pfa_mlp_dims *dims, const pfa_experience *exp, const float *noise,
+                            const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards,
+                            uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PPO update — the minibatch loop of clean_pufferl.train (clean_pufferl.py:175-258).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float clip_coef, vf_clip_coef, vf_coef, ent_coef;
+    int32_t norm_adv, clip_vloss;
+    int32_t num_minibatches; /* nmb */
+    int32_t bptt_horizon;    /* segment length; minibatch m = segments {m + k*nmb} (:455-457) */
+} pfa_ppo_hparams;
+
+size_t pfa_ppo_workspace_bytes(const pfa_mlp_dims *dims, int64_t batch_rows, const pfa_ppo_hparams *hp);
+/* Per-minibatch advantage statistics (sum, sum of squares in f64; count) for norm_adv (:211-213).
+ * stats: f64 [nmb][2] on device.  Call once per update after GAE; with several ranks, all-reduce(sum)
+ * `stats` and pass the global row count per minibatch to the update. */
+int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_ppo_hparams *hp,
+                      double *stats, void *workspace, pfa_stream_t stream);
+/* Forward + loss + backward for minibatch `mb`: writes the flat gradient (same layout as params, already
+ * divided by `global_mb_rows`, so an all-reduce SUM over ranks yields the global-minibatch mean gradient)
+ * followed by 8 floats of loss sums over this rank's rows:
+ *   grads[P+0..5] = sum pg_loss, sum v_loss, sum entropy, sum -logratio, sum (ratio-1-logratio), sum clipped. */
+int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
+                     const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
+                     int64_t global_mb_rows, float *grads, void *workspace, pfa_stream_t stream);
+/* clip_grad_norm_(max_grad_norm) + Adam(eps) step (:240-244; torch.optim.Adam single-tensor semantics, bias
+ * correction with `step` = 1-based optimizer step count).  grad_scale multiplies grads first.
+ * If loss_sums/losses are given: losses[i] += loss_sums[i] * loss_scale for i < 6, i.e. the running
+ * {policy_loss, value_loss, entropy, old_approx_kl, approx_kl, clipfrac} of clean_pufferl.py:249-254 with
+ * loss_scale = 1 / (global_mb_rows * num_minibatches). */
+int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t count,
+                       float lr, float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
+                       float grad_scale, const float *loss_sums, float *losses, float loss_scale,
+                       pfa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

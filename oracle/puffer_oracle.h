@@ -70,9 +70,9 @@ void po_compute_gae(const float *dones, const float *values, const float *reward
                     float *advantages, int num_steps, float gamma, float gae_lambda);
 
 /* ---- counter-based action noise (our own definition, restated for checking) --------------- */
-/* Philox4x32-10 keyed by (seed_lo, seed_hi); counter = (row_lo, row_hi, step, 0); the four output
- * words give exponential(1) variates q = -log(u), u = (w >> 8 + 0.5) * 2^-24, for action columns
- * 4*j .. 4*j+3 with counter word 3 = j.  See pufferlib_amd/csrc/philox.hpp. */
+/* Philox4x32-10 keyed by (seed_lo, seed_hi); counter = (row, j, step_lo, step_hi); the four output
+ * words give exponential(1) variates q = -log(u), u = ((w >> 8) + 0.5) * 2^-24, for action columns
+ * 4*j .. 4*j+3.  See pufferlib_amd/csrc/philox.hpp. */
 void po_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 #ifdef __cplusplus

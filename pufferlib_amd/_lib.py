@@ -1,0 +1,160 @@
+"""ctypes binding of libpufferlib_amd.so (the C ABI in include/pufferlib_amd.h) + the hipcc build recipe.
+
+The library is built IN-TREE (pufferlib_amd/_lib/libpufferlib_amd.so) so that it travels with the source
+snapshot.  ``lib()`` raises ExtensionError when it is missing — there is deliberately no CPU fallback.
+``import torch`` must happen before the library is loaded so that the HIP runtime already mapped by PyTorch
+(same SONAME libamdhip64.so.7) is the one our kernels launch on; stream handles are then interchangeable.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from .exceptions import ExtensionError
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, 'csrc')
+LIB_DIR = os.path.join(HERE, '_lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
+SOURCES = ['common.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip']
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp',
+           os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950: cross-compiles without a GPU.  One object per source, then link."""
+    if not force and not _stale():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + '.o')
+        objs.append(obj)
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c',
+               os.path.join(CSRC, src), '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise ExtensionError(f'hipcc failed on {src}:\n{out.decode()}')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise ExtensionError(f'link failed:\n{r.stdout.decode()}')
+    return LIB_PATH
+
+
+class SquaredConfig(C.Structure):
+    _fields_ = [('num_envs', C.c_int32), ('distance_to_target', C.c_int32), ('num_targets', C.c_int32),
+                ('obs_stride', C.c_int32), ('tape_rounds', C.c_int32)]
+
+
+class MlpDims(C.Structure):
+    _fields_ = [('obs_dim', C.c_int32), ('obs_stride', C.c_int32), ('hidden', C.c_int32), ('num_actions', C.c_int32)]
+
+
+class NoiseKey(C.Structure):
+    _fields_ = [('seed', C.c_uint64), ('step', C.c_uint64)]
+
+
+class Experience(C.Structure):
+    _fields_ = [('obs', C.c_void_p), ('actions', C.c_void_p), ('logprobs', C.c_void_p), ('values', C.c_void_p),
+                ('rewards', C.c_void_p), ('dones', C.c_void_p), ('advantages', C.c_void_p), ('returns', C.c_void_p),
+                ('horizon_T', C.c_int32)]
+
+
+class PpoHparams(C.Structure):
+    _fields_ = [('clip_coef', C.c_float), ('vf_clip_coef', C.c_float), ('vf_coef', C.c_float), ('ent_coef', C.c_float),
+                ('norm_adv', C.c_int32), ('clip_vloss', C.c_int32), ('num_minibatches', C.c_int32),
+                ('bptt_horizon', C.c_int32)]
+
+
+P = C.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes) — must list every symbol include/pufferlib_amd.h declares
+    'pfa_version': (C.c_int, []),
+    'pfa_last_error': (C.c_char_p, []),
+    'pfa_gae_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'pfa_gae_f32': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_float, C.c_float, P, P]),
+    'pfa_squared_state_bytes': (C.c_size_t, [C.POINTER(SquaredConfig)]),
+    'pfa_squared_async_reset': (C.c_int, [P, C.POINTER(SquaredConfig), C.c_int64, P, P, P, P, P, P]),
+    'pfa_squared_fill_tape': (C.c_int, [P, C.POINTER(SquaredConfig), C.c_int32, P]),
+    'pfa_squared_send': (C.c_int, [P, C.POINTER(SquaredConfig), P, P, P, P, P, P, P]),
+    'pfa_squared_episode_stats': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.c_int32, P]),
+    'pfa_squared_last_infos': (C.c_int, [P, C.POINTER(SquaredConfig), P, P, P, P, P]),
+    'pfa_squared_debug_targets': (C.c_int, [P, C.POINTER(SquaredConfig), P, P]),
+    'pfa_squared_debug_stream_pos': (C.c_int, [P, C.POINTER(SquaredConfig), P, P]),
+    'pfa_mlp_param_count': (C.c_int64, [C.POINTER(MlpDims)]),
+    'pfa_mlp_forward_sample': (C.c_int, [P, C.c_int64, P, C.POINTER(MlpDims), P, C.POINTER(NoiseKey), C.c_int64,
+                                         P, P, P, P, P]),
+    'pfa_rollout_mlp_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), C.POINTER(Experience),
+                                          P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
+    'pfa_ppo_workspace_bytes': (C.c_size_t, [C.POINTER(MlpDims), C.c_int64, C.POINTER(PpoHparams)]),
+    'pfa_ppo_adv_stats': (C.c_int, [C.POINTER(Experience), C.c_int64, C.POINTER(PpoHparams), P, P, P]),
+    'pfa_ppo_mlp_grad': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),
+                                   C.POINTER(PpoHparams), P, C.c_int64, P, P, P]),
+    'pfa_adam_clip_step': (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
+                                     C.c_float, C.c_float, P, P, C.c_float, P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (after torch, see module docstring) and bind every symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ExtensionError(
+            f'{LIB_PATH} is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950).  pufferlib_amd has no CPU fallback.')
+    import torch  # noqa: F401  (maps libamdhip64.so.7 first)
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise ExtensionError(f'cannot load {LIB_PATH}: {e}') from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            f = getattr(L, name)
+        except AttributeError as e:
+            raise ExtensionError(f'{LIB_PATH} does not export {name}') from e
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().pfa_last_error().decode(errors='replace')
+        raise ExtensionError(f'{what} failed ({rc}): {msg}')
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_handle():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise ExtensionError('pufferlib_amd needs a ROCm GPU (torch.cuda.is_available() is False); '
+                             'there is no CPU fallback')

@@ -1,0 +1,40 @@
+// common.hpp — error plumbing and small device helpers shared by every kernel file (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/pufferlib_amd.h"
+
+namespace pfa {
+
+void set_error(const char *fmt, ...);
+
+#define PFA_CHECK_HIP(expr)                                                                   \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::pfa::set_error("%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            return -1;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+#define PFA_REQUIRE(cond, ...)              \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::pfa::set_error(__VA_ARGS__);  \
+            return -2;                      \
+        }                                   \
+    } while (0)
+
+#define PFA_LAUNCH_CHECK() PFA_CHECK_HIP(hipGetLastError())
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace pfa

@@ -1,0 +1,172 @@
+// gae.hip — Generalized Advantage Estimation as a reverse affine scan (replaces c_gae.compute_gae,
+// /root/reference c_gae.pyx:11-32, called at clean_pufferl.py:168-169).
+//
+//   adv[t] = delta_t + coef_t * adv[t+1],   adv[n-1] = 0
+//   delta_t = r[t+1] + gamma*v[t+1]*(1-d[t+1]) - v[t],   coef_t = gamma*lambda*(1-d[t+1])
+//
+// over the whole flat env-major batch (the recurrence deliberately runs across env boundaries, like the
+// reference — SURVEY.md App. A.4).  Each element is the affine map f_t(x) = coef_t*x + delta_t; maps
+// compose associatively, so:
+//   pass 1  per 2048-element block: compose the block's maps (thread-serial over 8 items, wavefront
+//           shuffle scan over 64 lanes, LDS over 4 waves) -> one (C, D) pair per block, in fp64;
+//   pass 2  each block composes the aggregates of all LATER blocks (<= a few hundred pairs) to get its
+//           carry-in, rebuilds per-thread carry-ins with the same wavefront scan, then every thread runs the
+//           reference's exact fp32 recurrence over its own 8 items.  Only the carry-in (which decays by
+//           gamma*lambda per step) is re-associated, so most outputs are bit-identical to the sequential code.
+// Roofline: HBM.  Algorithmic bytes: read r,v,d (12 B) + write adv, returns (8 B) = 20 B per element.
+#include "common.hpp"
+
+namespace pfa {
+
+constexpr int kGaeThreads = 256;
+constexpr int kGaeItems = 8;
+constexpr int kGaeBlock = kGaeThreads * kGaeItems;
+
+struct Affine {
+    double c, d;  // x -> c*x + d
+};
+
+// apply `inner` first, then `outer`
+__device__ __forceinline__ Affine compose(const Affine &outer, const Affine &inner) {
+    return {outer.c * inner.c, outer.d + outer.c * inner.d};
+}
+
+__device__ __forceinline__ Affine shfl_down_affine(const Affine &a, int off) {
+    return {__shfl_down(a.c, off, 64), __shfl_down(a.d, off, 64)};
+}
+
+// Loads the 9 values a thread needs (its 8 items + the successor) and returns the thread's composite map.
+struct GaeItems {
+    float v[kGaeItems + 1], r[kGaeItems + 1], d[kGaeItems + 1];
+};
+
+__device__ __forceinline__ void gae_load(const float *dones, const float *values, const float *rewards, long long s,
+                                         long long n, GaeItems &it) {
+#pragma unroll
+    for (int i = 0; i <= kGaeItems; ++i) {
+        const long long t = s + i;
+        const bool ok = t < n;
+        it.v[i] = ok ? values[t] : 0.0f;
+        it.r[i] = ok ? rewards[t] : 0.0f;
+        it.d[i] = ok ? dones[t] : 0.0f;
+    }
+}
+
+__device__ __forceinline__ Affine gae_thread_map(const GaeItems &it, long long s, long long n, float gamma, float lam) {
+    Affine f = {1.0, 0.0};
+#pragma unroll
+    for (int i = kGaeItems - 1; i >= 0; --i) {
+        const long long t = s + i;
+        if (t >= n) continue;  // identity
+        if (t == n - 1) {      // adv[n-1] = 0 whatever follows
+            f = {0.0, 0.0};
+            continue;
+        }
+        const float nnt = 1.0f - it.d[i + 1];
+        const float delta = it.r[i + 1] + gamma * it.v[i + 1] * nnt - it.v[i];
+        const float coef = gamma * lam * nnt;
+        f = compose({(double)coef, (double)delta}, f);
+    }
+    return f;
+}
+
+// Inclusive suffix scan over the 256 threads of the block: on return `mine` = F_tid o F_tid+1 o ... o F_255,
+// and `after` = F_tid+1 o ... o F_255 (identity for the last thread).  sh must hold 2*4 Affines.
+__device__ __forceinline__ void block_suffix_scan(Affine &mine, Affine &after, Affine *sh) {
+    const int lane = lane_id(), wv = wave_id();
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Affine o = shfl_down_affine(mine, off);
+        if (lane + off < 64) mine = compose(mine, o);
+    }
+    if (lane == 0) sh[wv] = mine;
+    __syncthreads();
+    Affine tail = {1.0, 0.0};  // composition of all later waves
+    for (int q = kGaeThreads / 64 - 1; q > wv; --q) tail = compose(sh[q], tail);
+    mine = compose(mine, tail);
+    after = shfl_down_affine(mine, 1);
+    if (lane == 63) after = tail;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kGaeThreads) gae_aggregate_kernel(const float *dones, const float *values,
+                                                                   const float *rewards, long long n, float gamma,
+                                                                   float lam, Affine *agg) {
+    __shared__ Affine sh[kGaeThreads / 64];
+    const long long s = (long long)blockIdx.x * kGaeBlock + (long long)threadIdx.x * kGaeItems;
+    GaeItems it;
+    gae_load(dones, values, rewards, s, n, it);
+    Affine mine = gae_thread_map(it, s, n, gamma, lam), after;
+    block_suffix_scan(mine, after, sh);
+    if (threadIdx.x == 0) agg[blockIdx.x] = mine;
+}
+
+__global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *dones, const float *values,
+                                                               const float *rewards, float *adv, float *ret, long long n,
+                                                               float gamma, float lam, const Affine *agg, int nblocks) {
+    __shared__ Affine sh[kGaeThreads / 64];
+    __shared__ double s_carry;
+    // carry-in of this block = (agg[b+1] o agg[b+2] o ... o agg[nblocks-1])(0), composed in order by wave 0
+    if (wave_id() == 0) {
+        const int first = blockIdx.x + 1, cnt = nblocks - first;
+        const int per = (cnt + 63) / 64;
+        const int lane = lane_id();
+        Affine f = {1.0, 0.0};
+        for (int i = per - 1; i >= 0; --i) {
+            const int b = first + lane * per + i;
+            if (b < nblocks) f = compose(agg[b], f);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const Affine o = shfl_down_affine(f, off);
+            if (lane + off < 64) f = compose(f, o);
+        }
+        if (lane == 0) s_carry = f.d;  // applied to x = 0
+    }
+    const long long s = (long long)blockIdx.x * kGaeBlock + (long long)threadIdx.x * kGaeItems;
+    GaeItems it;
+    gae_load(dones, values, rewards, s, n, it);
+    Affine mine = gae_thread_map(it, s, n, gamma, lam), after;
+    block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
+    float last = (float)(after.c * s_carry + after.d);  // adv at the first element after this thread's items
+#pragma unroll
+    for (int i = kGaeItems - 1; i >= 0; --i) {
+        const long long t = s + i;
+        if (t >= n) continue;
+        if (t == n - 1) {
+            last = 0.0f;
+        } else {  // the reference's statement order and rounding (c_gae.pyx:27-30)
+            const float nnt = 1.0f - it.d[i + 1];
+            const float delta = it.r[i + 1] + gamma * it.v[i + 1] * nnt - it.v[i];
+            last = delta + gamma * lam * nnt * last;
+        }
+        adv[t] = last;
+        if (ret) ret[t] = last + it.v[i];
+    }
+}
+
+}  // namespace pfa
+
+using namespace pfa;
+
+extern "C" size_t pfa_gae_workspace_bytes(int64_t n) {
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    return (size_t)(nb > 0 ? nb : 1) * sizeof(Affine);
+}
+
+extern "C" int pfa_gae_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
+                           int64_t n, float gamma, float gae_lambda, void *workspace, pfa_stream_t stream) {
+    PFA_REQUIRE(n >= 0, "gae: negative length");
+    if (n == 0) return 0;
+    PFA_REQUIRE(dones && values && rewards && advantages && workspace, "gae: null buffer");
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
+    Affine *agg = (Affine *)workspace;
+    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
+                       rewards, (long long)n, gamma, gae_lambda, agg);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gae_apply_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,443 @@
+// squared.hip — vecenv kernels for ocean Squared behind the pufferlib.vector backend protocol
+// (async_reset / send; pufferlib/vector.py:112-156) and the reset-target tape that reproduces the
+// process-global `random.sample` stream (ocean.py:449-459) bit-exactly.
+//
+// Roofline: integer state machines, one thread per env, ~300 B touched per env per step -> HBM/latency
+// bound; nothing here is GEMM-shaped.
+#include "common.hpp"
+#include "mt19937.hpp"
+#include "squared_env.hpp"
+
+namespace pfa {
+
+// ---------------------------------------------------------------------------------------------
+// random.sample(range(n), k) as a word-at-a-time state machine (Lib/random.py Random.sample +
+// _randbelow_with_getrandbits).  feed() consumes ONE tempered 32-bit output and returns true when the
+// sample is complete.  The pool-swap branch (n <= setsize) is kept as an override list
+// (position -> value) instead of an n-entry pool.
+// ---------------------------------------------------------------------------------------------
+struct Sampler {
+    int n, k, i;
+    bool pool_path;
+    uint8_t picks[kMaxTargets];   // chosen population indices
+    uint8_t ov_pos[kMaxTargets];  // pool overrides
+    uint8_t ov_val[kMaxTargets];
+
+    __device__ void begin(int n_, int k_) {
+        n = n_;
+        k = k_;
+        i = 0;
+        int setsize = 21;
+        if (k > 5) {
+            int p = 1;
+            while (p < 3 * k) p *= 4;
+            setsize += p;
+        }
+        pool_path = n <= setsize;
+    }
+    __device__ int lookup(int pos, int upto) const {
+        for (int q = upto - 1; q >= 0; --q)
+            if (ov_pos[q] == pos) return ov_val[q];
+        return pos;
+    }
+    __device__ bool feed(uint32_t word) {
+        const int m = pool_path ? n - i : n;
+        const int bits = 32 - __clz(m);  // m.bit_length(), m >= 1
+        const int r = (int)(word >> (32 - bits));
+        if (r >= m) return false;
+        if (pool_path) {
+            picks[i] = (uint8_t)lookup(r, i);
+            ov_val[i] = (uint8_t)lookup(m - 1, i);
+            ov_pos[i] = (uint8_t)r;
+        } else {
+            for (int q = 0; q < i; ++q)
+                if (picks[q] == r) return false;
+            picks[i] = (uint8_t)r;
+        }
+        ++i;
+        return i == k;
+    }
+};
+
+// population index -> cell (x*g+y) of possible_targets (ocean.py:444-446): row-major perimeter.
+__device__ __forceinline__ int perimeter_cell(int idx, int g) {
+    if (idx < g) return idx;                       // x = 0, y = idx
+    const int last_row_start = g + 2 * (g - 2);    // entries before x = g-1
+    if (idx >= last_row_start) return (g - 1) * g + (idx - last_row_start);
+    const int q = idx - g;                         // rows 1..g-2 contribute (x,0),(x,g-1)
+    const int x = 1 + (q >> 1);
+    return x * g + ((q & 1) ? g - 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// async_reset: env i runs random.seed(seed+i); reset()  (vector.py:129-130, ocean.py:448-463)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) squared_seed_kernel(SquaredView v, long long seed, float *obs, float *rewards,
+                                                          uint8_t *terminals, uint8_t *truncations, uint8_t *masks) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= v.n) return;
+    uint32_t *mt = v.seed_mt + e;
+    const size_t stride = (size_t)v.n;
+    long long s = seed + e;
+    mt_seed_strided(mt, stride, (uint64_t)(s < 0 ? -s : s));
+    int idx = kMtN;
+    unsigned long long words = 0;
+    Sampler sm;
+    sm.begin(8 * v.d, v.nt);
+    for (;;) {
+        if (idx >= kMtN) {
+            mt_regenerate_strided(mt, stride);
+            idx = 0;
+        }
+        const uint32_t w = mt_temper(mt[(size_t)idx * stride]);
+        ++idx;
+        ++words;
+        if (sm.feed(w)) break;
+    }
+    float *grid = obs + (size_t)e * v.stride;
+    for (int i = 0; i < v.stride; ++i) grid[i] = 0.0f;
+    grid[v.d * v.g + v.d] = -1.0f;
+    for (int t = 0; t < v.nt; ++t) {
+        const int c = perimeter_cell(sm.picks[t], v.g);
+        v.tgt[(size_t)t * v.n + e] = (uint16_t)c;
+        grid[c] = 1.0f;
+    }
+    v.ax[e] = (int8_t)v.d;
+    v.ay[e] = (int8_t)v.d;
+    v.tick[e] = 0;
+    v.done[e] = 0;
+    v.rem[e] = v.nt >= 32 ? 0xffffffffu : ((1u << v.nt) - 1u);
+    v.rounds[e] = 0;
+    v.ep_ret[e] = 0.0;
+    v.ep_len[e] = 0;
+    v.fin[e] = 0;
+    v.acc_cnt[e] = 0;
+    v.acc_ret[e] = 0.0;
+    v.acc_len[e] = 0;
+    v.acc_score[e] = 0.0;
+    rewards[e] = 0.0f;
+    terminals[e] = 0;
+    truncations[e] = 0;
+    masks[e] = 1;
+    if (e == v.n - 1) {  // the generator every later unseeded reset() draws from (SURVEY.md hard part 1)
+        for (int i = 0; i < kMtN; ++i) v.hdr->mt[i] = mt[(size_t)i * stride];
+        v.hdr->mt_idx = idx;
+        v.hdr->underrun = 0;
+        v.hdr->words = words;
+        v.hdr->rounds_filled = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tape fill: draw `rounds` x N samples from the shared stream, in env order.
+// One workgroup; the 624-word MT block is regenerated cooperatively in LDS (3 dependent phases),
+// tempered, then either (nt == 1) all words are tested in parallel and accepted draws compacted with a
+// ballot prefix scan, or (general) lane 0 walks the block feeding the Sampler state machine.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTapeThreads = 256;
+
+__device__ void mt_regenerate_lds(uint32_t *mt) {  // all kTapeThreads threads
+    const int t = threadIdx.x;
+    // phase 1: kk in [0,227) reads only old words
+    uint32_t v0 = 0, v1 = 0, v2 = 0;
+    if (t < 227) v0 = mt_twist(mt[t], mt[t + 1], mt[t + kMtM]);
+    __syncthreads();
+    if (t < 227) mt[t] = v0;
+    __syncthreads();
+    // phase 2: kk in [227,454) reads new [0,227)
+    if (t < 227) v1 = mt_twist(mt[t + 227], mt[t + 228], mt[t]);
+    __syncthreads();
+    if (t < 227) mt[t + 227] = v1;
+    __syncthreads();
+    // phase 3: kk in [454,624) reads new [227,397); kk = 623 wraps to new mt[0]
+    if (t < 170) v2 = mt_twist(mt[t + 454], t + 455 < kMtN ? mt[t + 455] : mt[0], mt[t + 227]);
+    __syncthreads();
+    if (t < 170) mt[t + 454] = v2;
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView v, int rounds) {
+    __shared__ uint32_t mt[kMtN];
+    __shared__ uint32_t out[kMtN];
+    __shared__ int wave_cnt[kTapeThreads / 64];
+    __shared__ int s_idx_end;
+    __shared__ Sampler s_sm;
+    __shared__ long long s_produced;
+    __shared__ int s_idx;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kMtN; i += kTapeThreads) mt[i] = v.hdr->mt[i];
+    int idx = v.hdr->mt_idx;
+    const long long first_round = v.hdr->rounds_filled;
+    const long long need = (long long)rounds * v.n;  // samples to draw
+    long long produced = 0;
+    unsigned long long words = 0;
+    const int n_pop = 8 * v.d;
+    const int bits = 32 - __clz(n_pop);
+    __syncthreads();
+    bool fresh = false;  // `out` holds tempered words of the current block
+    if (tid == 0) {
+        s_sm.begin(n_pop, v.nt);
+    }
+    __syncthreads();
+    while (produced < need) {
+        if (idx >= kMtN) {
+            mt_regenerate_lds(mt);
+            idx = 0;
+            fresh = false;
+        }
+        if (!fresh) {
+            for (int i = tid; i < kMtN; i += kTapeThreads) out[i] = mt_temper(mt[i]);
+            fresh = true;
+            __syncthreads();
+        }
+        if (v.nt == 1) {
+            // parallel: word w accepted iff (out[w] >> (32-bits)) < n_pop; sample index = running count
+            if (tid == 0) s_idx_end = kMtN;
+            __syncthreads();
+            long long base = produced;
+            for (int w0 = idx; w0 < kMtN; w0 += kTapeThreads) {
+                const int w = w0 + tid;
+                int r = -1;
+                if (w < kMtN) {
+                    const int c = (int)(out[w] >> (32 - bits));
+                    if (c < n_pop) r = c;
+                }
+                const unsigned long long bal = __ballot(r >= 0);
+                const int lane = tid & 63, wv = tid >> 6;
+                if (lane == 0) wave_cnt[wv] = __popcll(bal);
+                __syncthreads();
+                int before = 0, total = 0;
+                for (int q = 0; q < kTapeThreads / 64; ++q) {
+                    if (q < wv) before += wave_cnt[q];
+                    total += wave_cnt[q];
+                }
+                const long long pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+                if (r >= 0 && pos < need) {
+                    const long long round = first_round + pos / v.n;
+                    const int env = (int)(pos % v.n);
+                    v.tape[((size_t)(round % v.tape_rounds) * v.nt) * v.n + env] = (uint16_t)perimeter_cell(r, v.g);
+                    if (pos == need - 1) s_idx_end = w + 1;
+                }
+                base += total;
+                __syncthreads();
+            }
+            const int idx_end = s_idx_end;
+            words += (unsigned long long)(idx_end - idx);
+            idx = idx_end;
+            produced = base < need ? base : need;
+            __syncthreads();
+        } else {
+            // general: lane 0 feeds words to the resumable sampler until the block or the job ends
+            if (tid == 0) {
+                long long p = produced;
+                int i = idx;
+                while (i < kMtN && p < need) {
+                    if (s_sm.feed(out[i++])) {
+                        const long long round = first_round + p / v.n;
+                        const int env = (int)(p % v.n);
+                        for (int t = 0; t < v.nt; ++t)
+                            v.tape[((size_t)(round % v.tape_rounds) * v.nt + t) * v.n + env] =
+                                (uint16_t)perimeter_cell(s_sm.picks[t], v.g);
+                        ++p;
+                        s_sm.begin(n_pop, v.nt);
+                    }
+                }
+                s_produced = p;
+                s_idx = i;
+            }
+            __syncthreads();
+            words += (unsigned long long)(s_idx - idx);
+            produced = s_produced;
+            idx = s_idx;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kMtN; i += kTapeThreads) v.hdr->mt[i] = mt[i];
+    if (tid == 0) {
+        v.hdr->mt_idx = idx;
+        v.hdr->words += words;
+        v.hdr->rounds_filled = first_round + rounds;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// send: Serial.send (vector.py:137-156), one thread per env
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) squared_send_kernel(SquaredView v, const long long *actions, float *obs,
+                                                          float *rewards, uint8_t *terminals, uint8_t *truncations,
+                                                          uint8_t *masks) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= v.n) return;
+    SquaredEnv s;
+    squared_load(v, e, s);
+    float *grid = obs + (size_t)e * v.stride;
+    uint16_t tc[kMaxTargets];
+    float reward;
+    bool terminal, finished = false;
+    double fr = 0.0, fs = 0.0;
+    int fl = 0;
+    if (s.done) {
+        if ((long long)s.rounds >= v.hdr->rounds_filled) v.hdr->underrun = 1;
+        const uint16_t *tr = v.tape + (size_t)(s.rounds % (uint32_t)v.tape_rounds) * v.nt * v.n;
+        squared_reset(v, e, s, grid, tr, tc, reward, terminal);
+        for (int t = 0; t < v.nt; ++t) v.tgt[(size_t)t * v.n + e] = tc[t];
+        s.rounds += 1;
+    } else {
+        for (int t = 0; t < v.nt; ++t) tc[t] = v.tgt[(size_t)t * v.n + e];
+        squared_step(v, s, grid, tc, (int)actions[e], reward, terminal, finished, fr, fl, fs);
+    }
+    squared_store(v, e, s);
+    v.fin[e] = finished ? 1 : 0;
+    if (finished) {
+        v.fin_ret[e] = fr;
+        v.fin_len[e] = fl;
+        v.fin_score[e] = fs;
+    }
+    rewards[e] = reward;
+    terminals[e] = terminal ? 1 : 0;
+    truncations[e] = 0;
+    masks[e] = 1;
+}
+
+// deterministic fixed-order reduction of the per-env episode accumulators
+__global__ void __launch_bounds__(256) squared_stats_kernel(SquaredView v, double *out4, int reset) {
+    __shared__ double sh[4][256];
+    double a[4] = {0, 0, 0, 0};
+    for (int e = threadIdx.x; e < v.n; e += 256) {
+        a[0] += (double)v.acc_cnt[e];
+        a[1] += v.acc_ret[e];
+        a[2] += (double)v.acc_len[e];
+        a[3] += v.acc_score[e];
+        if (reset) {
+            v.acc_cnt[e] = 0;
+            v.acc_ret[e] = 0.0;
+            v.acc_len[e] = 0;
+            v.acc_score[e] = 0.0;
+        }
+    }
+    for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] = a[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) out4[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+__global__ void squared_infos_kernel(SquaredView v, uint8_t *fin, double *ret, int32_t *len, double *score) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= v.n) return;
+    fin[e] = v.fin[e];
+    ret[e] = v.fin_ret[e];
+    len[e] = v.fin_len[e];
+    score[e] = v.fin_score[e];
+}
+
+__global__ void squared_debug_targets_kernel(SquaredView v, int32_t *cells) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= v.n) return;
+    const uint32_t rem = v.rem[e];
+    for (int t = 0; t < v.nt; ++t) cells[(size_t)e * v.nt + t] = ((rem >> t) & 1u) ? (int)v.tgt[(size_t)t * v.n + e] : -1;
+}
+
+__global__ void squared_debug_pos_kernel(SquaredView v, unsigned long long *pos) { *pos = v.hdr->words; }
+
+static int check_cfg(const pfa_squared_config *c) {
+    PFA_REQUIRE(c != nullptr, "squared: null config");
+    PFA_REQUIRE(c->num_envs >= 1, "squared: num_envs must be at least 1");
+    PFA_REQUIRE(c->distance_to_target >= 1 && c->distance_to_target <= 15, "squared: distance_to_target must be in 1..15");
+    PFA_REQUIRE(c->num_targets >= 1 && c->num_targets <= kMaxTargets && c->num_targets <= 8 * c->distance_to_target,
+                "squared: num_targets must be in 1..min(32, 8*distance_to_target)");
+    const int g = 2 * c->distance_to_target + 1;
+    PFA_REQUIRE(c->obs_stride >= g * g, "squared: obs_stride %d < grid cells %d", c->obs_stride, g * g);
+    PFA_REQUIRE(c->tape_rounds >= 1, "squared: tape_rounds must be >= 1");
+    return 0;
+}
+
+}  // namespace pfa
+
+using namespace pfa;
+
+extern "C" size_t pfa_squared_state_bytes(const pfa_squared_config *cfg) {
+    if (check_cfg(cfg)) return 0;
+    size_t total = 0;
+    squared_view(nullptr, *cfg, &total);
+    return total;
+}
+
+extern "C" int pfa_squared_async_reset(void *state, const pfa_squared_config *cfg, int64_t seed, float *obs, float *rewards,
+                                       uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    PFA_REQUIRE(state && obs && rewards && terminals && truncations && masks, "squared.async_reset: null buffer");
+    SquaredView v = squared_view(state, *cfg);
+    const int blocks = (cfg->num_envs + 255) / 256;
+    hipLaunchKernelGGL(squared_seed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, (long long)seed, obs, rewards,
+                       terminals, truncations, masks);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_squared_fill_tape(void *state, const pfa_squared_config *cfg, int32_t rounds, pfa_stream_t stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    PFA_REQUIRE(state, "squared.fill_tape: null state");
+    PFA_REQUIRE(rounds >= 0 && rounds <= cfg->tape_rounds, "squared.fill_tape: rounds %d exceeds tape capacity %d", rounds,
+                cfg->tape_rounds);
+    if (rounds == 0) return 0;
+    SquaredView v = squared_view(state, *cfg);
+    hipLaunchKernelGGL(squared_tape_kernel, dim3(1), dim3(kTapeThreads), 0, (hipStream_t)stream, v, (int)rounds);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_squared_send(void *state, const pfa_squared_config *cfg, const int64_t *actions, float *obs, float *rewards,
+                                uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    PFA_REQUIRE(state && actions && obs && rewards && terminals && truncations && masks, "squared.send: null buffer");
+    SquaredView v = squared_view(state, *cfg);
+    const int blocks = (cfg->num_envs + 255) / 256;
+    hipLaunchKernelGGL(squared_send_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, (const long long *)actions, obs,
+                       rewards, terminals, truncations, masks);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_squared_episode_stats(void *state, const pfa_squared_config *cfg, double *out4, int32_t reset,
+                                         pfa_stream_t stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    PFA_REQUIRE(state && out4, "squared.episode_stats: null buffer");
+    SquaredView v = squared_view(state, *cfg);
+    hipLaunchKernelGGL(squared_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, v, out4, (int)reset);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_squared_last_infos(void *state, const pfa_squared_config *cfg, uint8_t *finished, double *episode_return,
+                                      int32_t *episode_length, double *score, pfa_stream_t stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    PFA_REQUIRE(state && finished && episode_return && episode_length && score, "squared.last_infos: null buffer");
+    SquaredView v = squared_view(state, *cfg);
+    const int blocks = (cfg->num_envs + 255) / 256;
+    hipLaunchKernelGGL(squared_infos_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, finished, episode_return,
+                       episode_length, score);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_squared_debug_targets(void *state, const pfa_squared_config *cfg, int32_t *cells, pfa_stream_t stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    SquaredView v = squared_view(state, *cfg);
+    const int blocks = (cfg->num_envs + 255) / 256;
+    hipLaunchKernelGGL(squared_debug_targets_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, v, cells);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_squared_debug_stream_pos(void *state, const pfa_squared_config *cfg, uint64_t *pos_device, pfa_stream_t stream) {
+    if (int rc = check_cfg(cfg)) return rc;
+    SquaredView v = squared_view(state, *cfg);
+    hipLaunchKernelGGL(squared_debug_pos_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, v, (unsigned long long *)pos_device);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}

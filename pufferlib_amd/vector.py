@@ -1,0 +1,358 @@
+"""Vectorised-env boundary: ``make`` and the device-resident Squared backend.
+
+Mirrors pufferlib/vector.py of the reference:
+  make(...)                      vector.py:577-637  (same validation, same APIUsageError messages)
+  reset / step helpers           vector.py:44-53
+  recv_precheck / send_precheck  vector.py:25-42    (RESET -> RECV -> SEND state machine)
+  Squared (backend class)        replaces Serial (vector.py:70-166) for ocean ``make_squared`` envs: the N envs
+                                 live in HBM and are stepped by HIP kernels (csrc/squared.hip); ``recv`` returns
+                                 *device tensors* that alias the backend-owned live buffers, exactly like Serial
+                                 returns aliases of its numpy buffers (vector.py:158-162).
+
+Drop-in use with the reference's factory:  pufferlib.vector.make(make_squared, backend=pufferlib_amd.vector.Squared,
+num_envs=N, env_kwargs=dict(distance_to_target=3, num_targets=1)).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, spaces
+from .exceptions import APIUsageError
+from .namespace import Namespace, namespace
+
+RESET = 0
+STEP = 1
+SEND = 2
+RECV = 3
+CLOSE = 4
+MAIN = 5
+INFO = 6
+
+
+def recv_precheck(vecenv):
+    if vecenv.flag != RECV:
+        raise APIUsageError('Call reset before stepping')
+    vecenv.flag = SEND
+
+
+def send_precheck(vecenv, actions):
+    if vecenv.flag != SEND:
+        raise APIUsageError('Call (async) reset + recv before sending')
+    vecenv.flag = RECV
+
+
+def reset(vecenv, seed=42):
+    vecenv.async_reset(seed)
+    obs, rewards, terminals, truncations, infos, env_ids, masks = vecenv.recv()
+    return obs, infos
+
+
+def step(vecenv, actions):
+    vecenv.send(actions)
+    obs, rewards, terminals, truncations, infos, env_ids, masks = vecenv.recv()
+    return obs, rewards, terminals, truncations, infos
+
+
+def make_seeds(seed, num_envs):
+    if isinstance(seed, int):
+        return [seed + i for i in range(num_envs)]
+    err = f'seed {seed} must be an integer or a list of integers'
+    if isinstance(seed, (list, tuple)):
+        if len(seed) != num_envs:
+            raise APIUsageError(err)
+        return seed
+    raise APIUsageError(err)
+
+
+def make_squared(distance_to_target=3, num_targets=1, **kwargs):
+    """Env creator token with the signature of ocean.environment.make_squared (ocean/environment.py:28-31).
+    The Squared backend never calls it: it only reads its keyword defaults / env_kwargs."""
+    return SquaredSpec(distance_to_target, num_targets)
+
+
+def env_creator(name='squared'):
+    """pufferlib.environments.ocean.env_creator (ocean/environment.py:6-26), squared only."""
+    if name == 'squared':
+        return make_squared
+    raise ValueError('Invalid environment name')
+
+
+class SquaredSpec:
+    """What ``driver_env`` exposes to policies (models.py:26-37) and to clean_pufferl (:40-43)."""
+
+    def __init__(self, distance_to_target=3, num_targets=1):
+        self.distance_to_target = int(distance_to_target)
+        self.num_targets = 4 * self.distance_to_target if num_targets == -1 else int(num_targets)
+        g = 2 * self.distance_to_target + 1
+        self.grid_size = g
+        self.single_observation_space = spaces.Box(low=-1, high=1, shape=(g, g), dtype=np.float32)
+        self.single_action_space = spaces.Discrete(8)
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+        self.num_agents = 1
+        self.render_mode = 'ansi'
+        self.emulated = namespace(observation_dtype=np.dtype(np.float32),
+                                  emulated_observation_dtype=np.dtype((np.float32, (g, g))))
+        self.done = True
+
+    def render(self):
+        return ''
+
+    def close(self):
+        pass
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _squared_kwargs(creator, args, kwargs):
+    """Resolve (distance_to_target, num_targets) the way make_squared's signature would."""
+    import inspect
+    name = getattr(creator, '__name__', '')
+    if 'squared' not in name.lower():
+        raise APIUsageError(
+            f'pufferlib_amd.vector.Squared only hosts ocean make_squared envs on device (got creator {name!r})')
+    d, nt = 3, 1
+    try:
+        sig = inspect.signature(creator)
+        if 'distance_to_target' in sig.parameters and sig.parameters['distance_to_target'].default is not inspect._empty:
+            d = sig.parameters['distance_to_target'].default
+        if 'num_targets' in sig.parameters and sig.parameters['num_targets'].default is not inspect._empty:
+            nt = sig.parameters['num_targets'].default
+    except (TypeError, ValueError):
+        pass
+    args = list(args)
+    if len(args) > 0:
+        d = args[0]
+    if len(args) > 1:
+        nt = args[1]
+    d = kwargs.get('distance_to_target', d)
+    nt = kwargs.get('num_targets', nt)
+    return int(d), int(nt)
+
+
+class Squared:
+    """Device-resident vecenv of N ocean Squared envs (backend protocol of pufferlib/vector.py).
+
+    State, live buffers and the reset-target tape are torch device tensors (torch is the allocator); every
+    method only enqueues HIP kernels on torch's current stream.  ``infos`` follow ``info_mode``:
+      'sync'  (default) one tiny D2H per send: exact list of per-episode dicts like Serial/EpisodeStats
+      'lazy'  recv() returns [] and episode statistics are read with ``episode_stats()`` (no per-step sync;
+              this is what pufferlib_amd.clean_pufferl.evaluate uses)
+    """
+    reset = reset
+    step = step
+
+    @property
+    def num_envs(self):
+        return self.agents_per_batch
+
+    def __init__(self, env_creators, env_args, env_kwargs, num_envs, obs_stride=None, info_mode='sync',
+                 env_offset=0, device=None, **kwargs):
+        import torch
+        for k in kwargs:
+            if k not in ('num_workers', 'batch_size', 'zero_copy', 'backend'):
+                raise APIUsageError(f'Invalid argument: {k}')
+        if len(env_creators) != num_envs:
+            raise APIUsageError('env_creators must be a list of length num_envs')
+        specs = {_squared_kwargs(c, a, k) for c, a, k in zip(env_creators, env_args, env_kwargs)}
+        if len(specs) != 1:
+            raise APIUsageError(f'obs/atn space mismatch: all envs must share one Squared configuration, got {specs}')
+        d, nt = specs.pop()
+        self.driver_env = SquaredSpec(d, nt)
+        d, nt = self.driver_env.distance_to_target, self.driver_env.num_targets
+        _lib.require_gpu()
+        self.L = _lib.lib()
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.emulated = self.driver_env.emulated
+        self.agents_per_env = [1] * num_envs
+        self.agents_per_batch = num_envs
+        self.num_agents = num_envs
+        self.single_observation_space = self.driver_env.single_observation_space
+        self.single_action_space = self.driver_env.single_action_space
+        self.action_space = spaces.MultiDiscrete([8] * num_envs)
+        g = self.driver_env.grid_size
+        self.observation_space = spaces.Box(low=-1, high=1, shape=(num_envs, g, g), dtype=np.float32)
+        self.agent_ids = np.arange(num_envs)
+        self.initialized = False
+        self.flag = RESET
+        self.info_mode = info_mode
+        self.env_offset = int(env_offset)   # global index of local env 0 (multi-GPU sharding)
+
+        self.obs_dim = g * g
+        self.obs_stride = int(obs_stride) if obs_stride is not None else max(16, _round_up(self.obs_dim, 16))
+        self.episode_len = nt * d + 1        # max_ticks steps + the auto-reset row
+        self.tape_rounds = 64
+        self.cfg = _lib.SquaredConfig(num_envs, d, nt, self.obs_stride, self.tape_rounds)
+        nbytes = self.L.pfa_squared_state_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise APIUsageError(self.L.pfa_last_error().decode())
+        dev = self.device
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.float32, device=dev)
+        self.observations = self.obs_buf[:, :self.obs_dim].unflatten(1, (g, g))   # view, shape (N, g, g)
+        self.rewards = torch.zeros(num_envs, dtype=torch.float32, device=dev)
+        self.terminals_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self.truncations_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self.masks_u8 = torch.ones(num_envs, dtype=torch.uint8, device=dev)
+        self.terminals = self.terminals_u8.view(torch.bool)
+        self.truncations = self.truncations_u8.view(torch.bool)
+        self.masks = self.masks_u8.view(torch.bool)
+        self._actions = torch.zeros(num_envs, dtype=torch.int64, device=dev)
+        self._fin = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self._fin_ret = torch.zeros(num_envs, dtype=torch.float64, device=dev)
+        self._fin_len = torch.zeros(num_envs, dtype=torch.int32, device=dev)
+        self._fin_score = torch.zeros(num_envs, dtype=torch.float64, device=dev)
+        self._stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.infos = []
+        self.sends = 0            # sends since async_reset
+        self.rounds_filled = 0    # reset rounds drawn into the tape (mirrors the device counter)
+
+    # -- tape bookkeeping (host mirror; the stream position itself lives on device) --------------------
+    def _rounds_needed(self, upto_send):
+        """Number of reset rounds consumed by sends 1..upto_send (every env resets on sends k*episode_len)."""
+        return upto_send // self.episode_len
+
+    def ensure_tape(self, extra_sends):
+        need = self._rounds_needed(self.sends + extra_sends)
+        consumed = self._rounds_needed(self.sends)
+        if need - consumed > self.tape_rounds:
+            raise APIUsageError(f'{extra_sends} sends need {need - consumed} reset rounds; tape holds {self.tape_rounds}')
+        if need > self.rounds_filled:
+            _lib.check(self.L.pfa_squared_fill_tape(_lib.ptr(self.state), C.byref(self.cfg), need - self.rounds_filled,
+                                                    _lib.stream_handle()), 'fill_tape')
+            self.rounds_filled = need
+
+    def _live(self):
+        return (_lib.ptr(self.obs_buf), _lib.ptr(self.rewards), _lib.ptr(self.terminals_u8),
+                _lib.ptr(self.truncations_u8), _lib.ptr(self.masks_u8))
+
+    # -- protocol ---------------------------------------------------------------------------------------
+    def async_reset(self, seed=42):
+        self.flag = RECV
+        seeds = make_seeds(seed, self.num_agents)
+        if any(s != seeds[0] + i for i, s in enumerate(seeds)):
+            raise APIUsageError('pufferlib_amd.vector.Squared needs consecutive seeds (seed + env index)')
+        _lib.check(self.L.pfa_squared_async_reset(_lib.ptr(self.state), C.byref(self.cfg), int(seeds[0]), *self._live(),
+                                                  _lib.stream_handle()), 'async_reset')
+        self.sends = 0
+        self.rounds_filled = 0
+        self.infos = []
+
+    def send(self, actions):
+        import torch
+        send_precheck(self, actions)
+        if not torch.is_tensor(actions):
+            a = np.asarray(actions)
+            if not self.initialized and not self.action_space.contains(a):
+                raise APIUsageError('Actions do not match action space')
+            actions = torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64))
+        elif not self.initialized:
+            if actions.shape != (self.num_agents,) or actions.dtype not in (torch.int64, torch.int32):
+                raise APIUsageError('Actions do not match action space')
+        self.initialized = True
+        self._actions.copy_(actions.reshape(-1), non_blocking=True)
+        self.ensure_tape(1)
+        _lib.check(self.L.pfa_squared_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._actions), *self._live(),
+                                           _lib.stream_handle()), 'send')
+        self.sends += 1
+        self.infos = self._collect_infos() if self.info_mode == 'sync' else []
+
+    def recv(self):
+        recv_precheck(self)
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids,
+                self.masks)
+
+    def close(self):
+        self.flag = CLOSE
+
+    # -- infos -------------------------------------------------------------------------------------------
+    def _collect_infos(self):
+        # every env of a Squared vecenv finishes on the same sends: skip the readback on the others
+        if self.sends % self.episode_len != self.episode_len - 1:
+            return []
+        _lib.check(self.L.pfa_squared_last_infos(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._fin),
+                                                 _lib.ptr(self._fin_ret), _lib.ptr(self._fin_len),
+                                                 _lib.ptr(self._fin_score), _lib.stream_handle()), 'last_infos')
+        fin = self._fin.cpu().numpy().astype(bool)
+        if not fin.any():
+            return []
+        ret, ln, sc = self._fin_ret.cpu().numpy(), self._fin_len.cpu().numpy(), self._fin_score.cpu().numpy()
+        return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i]))
+                for i in np.nonzero(fin)[0]]
+
+    def episode_stats(self, reset=True):
+        """(count, mean episode_return, mean episode_length, mean score) over episodes finished since the last
+        reset of the accumulators — what clean_pufferl.evaluate reports (clean_pufferl.py:144-152)."""
+        _lib.check(self.L.pfa_squared_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._stats),
+                                                    1 if reset else 0, _lib.stream_handle()), 'episode_stats')
+        return self._stats
+
+    # -- test introspection -------------------------------------------------------------------------------
+    def debug_targets(self):
+        import torch
+        out = torch.zeros(self.num_agents, self.cfg.num_targets, dtype=torch.int32, device=self.device)
+        _lib.check(self.L.pfa_squared_debug_targets(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(out),
+                                                    _lib.stream_handle()), 'debug_targets')
+        return out.cpu().numpy()
+
+    def debug_stream_pos(self):
+        import torch
+        out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.pfa_squared_debug_stream_pos(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(out),
+                                                       _lib.stream_handle()), 'debug_stream_pos')
+        return int(out.item())
+
+
+def make(env_creator_or_creators, env_args=None, env_kwargs=None, backend=Squared, num_envs=1, **kwargs):
+    """pufferlib.vector.make (vector.py:577-637): same argument validation and error messages."""
+    if num_envs < 1:
+        raise APIUsageError('num_envs must be at least 1')
+    if num_envs != int(num_envs):
+        raise APIUsageError('num_envs must be an integer')
+
+    if 'num_workers' in kwargs:
+        num_workers = kwargs['num_workers']
+        envs_per_worker = num_envs / num_workers
+        if envs_per_worker != int(envs_per_worker):
+            raise APIUsageError('num_envs must be divisible by num_workers')
+        if 'batch_size' in kwargs:
+            batch_size = kwargs['batch_size']
+            if batch_size is None:
+                batch_size = num_envs
+            if batch_size % envs_per_worker != 0:
+                raise APIUsageError('batch_size must be divisible by (num_envs / num_workers)')
+
+    if env_args is None:
+        env_args = []
+    if env_kwargs is None:
+        env_kwargs = {}
+
+    if not isinstance(env_creator_or_creators, (list, tuple)):
+        env_creators = [env_creator_or_creators] * num_envs
+        env_args = [env_args] * num_envs
+        env_kwargs = [env_kwargs] * num_envs
+    else:
+        env_creators = env_creator_or_creators
+
+    if len(env_creators) != num_envs:
+        raise APIUsageError('env_creators must be a list of length num_envs')
+    if len(env_args) != num_envs:
+        raise APIUsageError('env_args must be a list of length num_envs')
+    if len(env_kwargs) != num_envs:
+        raise APIUsageError('env_kwargs must be a list of length num_envs')
+
+    for i in range(num_envs):
+        if not callable(env_creators[i]):
+            raise APIUsageError('env_creators must be a list of callables')
+        if not isinstance(env_args[i], (list, tuple)):
+            raise APIUsageError('env_args must be a list of lists or tuples')
+        if not isinstance(env_kwargs[i], (dict, Namespace)):
+            raise APIUsageError('env_kwargs must be a list of dictionaries')
+
+    for k in kwargs:
+        if k not in ['num_workers', 'batch_size', 'zero_copy', 'backend', 'obs_stride', 'info_mode', 'env_offset', 'device']:
+            raise APIUsageError(f'Invalid argument: {k}')
+
+    return backend(env_creators, env_args, env_kwargs, num_envs, **kwargs)
