@@ -1,0 +1,486 @@
+"""PPO trainer with the surface of the reference's clean_pufferl.py, device-resident end to end.
+
+  create(config, vecenv, policy, optimizer=None, wandb=None)   clean_pufferl.py:30-73
+  evaluate(data)   rollout: T x {recv, policy, store, send}      clean_pufferl.py:76-154
+  train(data)      GAE + the epoch/minibatch PPO loop            clean_pufferl.py:157-292
+  close(data), save_checkpoint, try_load_checkpoint, Experience, Profile, make_losses, seed_everything
+
+``data`` is the same namespace (config, vecenv, policy, uncompiled_policy, optimizer, experience, profile,
+losses, wandb, global_step, epoch, stats, msg, last_log_time, utilization), so the reference's demo.py loop
+``while data.global_step < total: evaluate(data); train(data)`` runs unchanged.
+
+What is different underneath: there is no host round-trip per step.  For a
+pufferlib_amd.vector.Squared vecenv and an MLP policy evaluate() is ONE persistent kernel (csrc/rollout.hip) and
+train() is GAE (2 launches) + per optimizer step 3 launches (fused fwd/loss/bwd, partial reduce, clip+Adam).
+Experience is stored env-major on device, which is the order the reference gets after sort_training_data
+(clean_pufferl.py:452-464), so there is no sort and no gather.
+
+Data parallel (no reference counterpart): one process per GPU; rank r owns envs
+[r*N, (r+1)*N) (seeds seed + global index), parameters are broadcast from rank 0 at create(), and every
+optimizer step all-reduces one flat bucket (gradient + 8 loss sums) over RCCL; the advantage-normalisation sums
+are all-reduced once per update so every rank normalises with the global-minibatch mean/std.
+"""
+import ctypes as C
+import os
+import random
+import time
+from collections import deque
+from threading import Thread
+
+import numpy as np
+import torch
+
+from . import _lib, utils
+from .cleanrl import Policy
+from .models import FlatParams
+from .namespace import namespace
+from .vector import Squared
+
+
+def seed_everything(seed, torch_deterministic=True):
+    """clean_pufferl.py:596-601"""
+    random.seed(seed)
+    np.random.seed(seed)
+    if seed is not None:
+        torch.manual_seed(seed)
+    torch.backends.cudnn.deterministic = torch_deterministic
+
+
+def make_losses():
+    return namespace(policy_loss=0, value_loss=0, entropy=0, old_approx_kl=0, approx_kl=0, clipfrac=0,
+                     explained_variance=0)
+
+
+def _dist():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+class HipAdam:
+    """torch.optim.Adam(lr, eps=1e-5)-shaped handle (clean_pufferl.py:54-55) over the flat device buffers that
+    csrc/ppo_update.hip's adam_clip_kernel updates.  Exposes param_groups[0]['lr'] (written by the lr anneal,
+    clean_pufferl.py:261-264) and a torch-compatible state_dict for checkpoints (clean_pufferl.py:520-527)."""
+
+    def __init__(self, flat_params, lr, betas=(0.9, 0.999), eps=1e-5):
+        self.fp = flat_params
+        self.exp_avg = flat_params.flat_like()
+        self.exp_avg_sq = flat_params.flat_like()
+        self.step_count = 0
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
+                                  params=list(range(6)))]
+
+    def zero_grad(self):
+        pass
+
+    def state_dict(self):
+        m, v = self.fp.split(self.exp_avg), self.fp.split(self.exp_avg_sq)
+        state = {}
+        if self.step_count > 0:
+            for i, k in enumerate(m):
+                state[i] = dict(step=torch.tensor(float(self.step_count)), exp_avg=m[k].clone(), exp_avg_sq=v[k].clone())
+        return dict(state=state, param_groups=[dict(self.param_groups[0])])
+
+    def load_state_dict(self, sd):
+        m, v = self.fp.split(self.exp_avg), self.fp.split(self.exp_avg_sq)
+        for i, k in enumerate(m):
+            if i in sd['state']:
+                m[k].copy_(sd['state'][i]['exp_avg'])
+                v[k].copy_(sd['state'][i]['exp_avg_sq'])
+                self.step_count = int(sd['state'][i]['step'])
+        self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
+
+
+class Experience:
+    """clean_pufferl.Experience (clean_pufferl.py:380-482) as device tensors in env-major order:
+    row (env e, step t) at flat index e*T + t."""
+
+    def __init__(self, batch_size, bptt_horizon, minibatch_size, obs_stride, num_envs, device):
+        if minibatch_size is None:
+            minibatch_size = batch_size
+        num_minibatches = batch_size / minibatch_size
+        self.num_minibatches = int(num_minibatches)
+        if self.num_minibatches != num_minibatches:
+            raise ValueError('batch_size must be divisible by minibatch_size')
+        minibatch_rows = minibatch_size / bptt_horizon
+        self.minibatch_rows = int(minibatch_rows)
+        if self.minibatch_rows != minibatch_rows:
+            raise ValueError('minibatch_size must be divisible by bptt_horizon')
+        if batch_size % num_envs != 0:
+            raise ValueError('batch_size must be divisible by the number of envs (whole rollout steps)')
+        self.horizon = batch_size // num_envs
+        if self.horizon % bptt_horizon != 0:
+            # every env must contribute whole bptt segments
+            raise ValueError('batch_size / num_envs must be divisible by bptt_horizon')
+        B = batch_size
+        self.obs = torch.zeros(B, obs_stride, dtype=torch.float32, device=device)
+        self.actions = torch.zeros(B, dtype=torch.int32, device=device)
+        self.logprobs = torch.zeros(B, dtype=torch.float32, device=device)
+        self.rewards = torch.zeros(B, dtype=torch.float32, device=device)
+        self.dones = torch.zeros(B, dtype=torch.float32, device=device)
+        self.values = torch.zeros(B, dtype=torch.float32, device=device)
+        self.advantages = torch.zeros(B, dtype=torch.float32, device=device)
+        self.returns = torch.zeros(B, dtype=torch.float32, device=device)
+        self.lstm_h = self.lstm_c = None
+        self.batch_size, self.bptt_horizon, self.minibatch_size = B, bptt_horizon, minibatch_size
+        self.num_envs, self.device = num_envs, device
+        self.ptr = 0
+        self.step = 0
+        self.c = _lib.Experience(self.obs.data_ptr(), self.actions.data_ptr(), self.logprobs.data_ptr(),
+                                 self.values.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr(),
+                                 self.advantages.data_ptr(), self.returns.data_ptr(), self.horizon)
+
+    @property
+    def full(self):
+        return self.ptr >= self.batch_size
+
+    def minibatch_rows_index(self, mb):
+        """Flat env-major rows of minibatch `mb`: segments {mb + k*nmb} of bptt_horizon rows (clean_pufferl.py:455-457)."""
+        k = torch.arange(self.minibatch_rows, device=self.device)
+        h = torch.arange(self.bptt_horizon, device=self.device)
+        return ((mb + k[:, None] * self.num_minibatches) * self.bptt_horizon + h[None, :]).reshape(-1)
+
+
+class Profile:
+    """clean_pufferl.Profile (clean_pufferl.py:306-367): same fields; the six section timers bracket kernel
+    *enqueues* (the device runs asynchronously), while SPS / eval_time / train_time come from the
+    evaluate()/train() wall timers, which end in one stream sync each."""
+    SPS = 0
+    uptime = 0
+    remaining = 0
+    eval_time = 0
+    env_time = 0
+    eval_forward_time = 0
+    eval_misc_time = 0
+    train_time = 0
+    train_forward_time = 0
+    learn_time = 0
+    train_misc_time = 0
+
+    def __init__(self):
+        self.start = time.time()
+        self.env = utils.Profiler()
+        self.eval_forward = utils.Profiler()
+        self.eval_misc = utils.Profiler()
+        self.train_forward = utils.Profiler()
+        self.learn = utils.Profiler()
+        self.train_misc = utils.Profiler()
+        self.prev_steps = 0
+
+    def __iter__(self):
+        for k in ('SPS', 'uptime', 'remaining', 'eval_time', 'env_time', 'eval_forward_time', 'eval_misc_time',
+                  'train_time', 'train_forward_time', 'learn_time', 'train_misc_time'):
+            yield k, getattr(self, k)
+
+    @property
+    def epoch_time(self):
+        return self.train_time + self.eval_time
+
+    def update(self, data, interval_s=1):
+        global_step = data.global_step
+        if global_step == 0:
+            return True
+        uptime = time.time() - self.start
+        if uptime - self.uptime < interval_s:
+            return False
+        self.SPS = (global_step - self.prev_steps) / (uptime - self.uptime)
+        self.prev_steps = global_step
+        self.uptime = uptime
+        self.remaining = (data.config.total_timesteps - global_step) / max(self.SPS, 1e-9)
+        self.eval_time = data._timers['evaluate'].elapsed
+        self.eval_forward_time = self.eval_forward.elapsed
+        self.env_time = self.env.elapsed
+        self.eval_misc_time = self.eval_misc.elapsed
+        self.train_time = data._timers['train'].elapsed
+        self.train_forward_time = self.train_forward.elapsed
+        self.learn_time = self.learn.elapsed
+        self.train_misc_time = self.train_misc.elapsed
+        return True
+
+
+class Utilization(Thread):
+    """clean_pufferl.Utilization (clean_pufferl.py:484-507) — sampling thread for the dashboard; optional."""
+
+    def __init__(self, delay=1, maxlen=20):
+        super().__init__(daemon=True)
+        self.cpu_mem, self.cpu_util = deque(maxlen=maxlen), deque(maxlen=maxlen)
+        self.gpu_util, self.gpu_mem = deque(maxlen=maxlen), deque(maxlen=maxlen)
+        self.delay, self.stopped = delay, False
+        self.start()
+
+    def run(self):
+        import psutil
+        while not self.stopped:
+            self.cpu_util.append(psutil.cpu_percent())
+            mem = psutil.virtual_memory()
+            self.cpu_mem.append(mem.active / mem.total)
+            try:
+                free, total = torch.cuda.mem_get_info()
+                self.gpu_mem.append(free / total)
+            except Exception:
+                self.gpu_mem.append(0)
+            self.gpu_util.append(0)
+            time.sleep(self.delay)
+
+    def stop(self):
+        self.stopped = True
+
+
+class _NoUtilization:
+    cpu_mem = cpu_util = gpu_util = gpu_mem = (0,)
+
+    def stop(self):
+        pass
+
+
+def _cfg(config, key, default):
+    try:
+        return config[key]
+    except (KeyError, AttributeError):
+        return getattr(config, key, default)
+
+
+def create(config, vecenv, policy, optimizer=None, wandb=None):
+    seed_everything(config.seed, _cfg(config, 'torch_deterministic', True))
+    profile = Profile()
+    losses = make_losses()
+    utilization = Utilization() if _cfg(config, 'utilization_thread', False) else _NoUtilization()
+    n_params = sum(p.numel() for p in policy.parameters())
+    msg = f'Model Size: {n_params} parameters'
+
+    if not isinstance(vecenv, Squared):
+        raise NotImplementedError('pufferlib_amd.clean_pufferl drives pufferlib_amd.vector.Squared vecenvs '
+                                  '(device-resident envs); CPU backends are a later row of SURVEY.md §8f')
+    if not isinstance(policy, Policy):
+        policy = Policy(policy, seed=config.seed)     # e.g. the reference's cleanrl.Policy(models.Default)
+    dist, rank, world = _dist()
+    device = vecenv.device
+    vecenv.info_mode = 'lazy'
+    vecenv.env_offset = rank * vecenv.num_agents
+    vecenv.async_reset(config.seed + vecenv.env_offset)   # clean_pufferl.py:39; env i of rank r gets seed + r*N + i
+    fp = policy.adopt(vecenv.obs_stride, device)
+    if world > 1:
+        dist.broadcast(fp.flat, src=0)
+    policy.noise_seed = int(config.seed)
+
+    total_agents = vecenv.num_agents
+    experience = Experience(config.batch_size, config.bptt_horizon, _cfg(config, 'minibatch_size', None),
+                            vecenv.obs_stride, total_agents, device)
+    optimizer = HipAdam(fp, lr=config.learning_rate, eps=1e-5)
+
+    L = _lib.lib()
+    hp = _make_hparams(config, experience)
+    ws_bytes = max(L.pfa_ppo_workspace_bytes(C.byref(fp.dims), config.batch_size, C.byref(hp)),
+                   L.pfa_gae_workspace_bytes(config.batch_size))
+    data = namespace(
+        config=config, vecenv=vecenv, policy=policy, uncompiled_policy=policy, optimizer=optimizer,
+        experience=experience, profile=profile, losses=losses, wandb=wandb, global_step=0, epoch=0, stats={},
+        msg=msg, last_log_time=0, utilization=utilization,
+        # engine state
+        flat_params=fp, rank=rank, world_size=world,
+        workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
+        grads=torch.zeros(fp.count + 8, dtype=torch.float32, device=device),
+        adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
+        loss_acc=torch.zeros(8, dtype=torch.float32, device=device),
+        noise=None,            # optional explicit Exp(1) tensor [T][N][A] for the next evaluate() (parity tests)
+    )
+    return data
+
+
+def _make_hparams(config, experience):
+    return _lib.PpoHparams(float(config.clip_coef), float(config.vf_clip_coef), float(config.vf_coef),
+                           float(config.ent_coef), 1 if config.norm_adv else 0, 1 if config.clip_vloss else 0,
+                           experience.num_minibatches, int(config.bptt_horizon))
+
+
+@utils.profile
+def evaluate(data):
+    config, profile, experience, vecenv = data.config, data.profile, data.experience, data.vecenv
+    L = _lib.lib()
+    fp = data.flat_params
+    T, N = experience.horizon, vecenv.num_agents
+    with profile.eval_misc:
+        policy = data.policy
+        if vecenv.flag != 3:  # RECV: evaluate starts with a recv (clean_pufferl.py:86); the state machine must allow it
+            from .exceptions import APIUsageError
+            raise APIUsageError('Call reset before stepping')
+        noise = data.noise
+        if noise is not None:
+            noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
+            assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
+        key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
+    with profile.env:
+        vecenv.ensure_tape(T)
+    with profile.eval_forward:
+        _lib.check(L.pfa_rollout_mlp_squared(
+            _lib.ptr(vecenv.state), C.byref(vecenv.cfg), _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(experience.c),
+            _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
+            _lib.ptr(vecenv.terminals_u8), _lib.ptr(vecenv.truncations_u8), _lib.ptr(vecenv.masks_u8),
+            _lib.stream_handle()), 'rollout')
+    with profile.eval_misc:
+        vecenv.sends += T
+        policy.noise_step += T
+        data.noise = None
+        experience.ptr = experience.batch_size
+        experience.step = T
+        data.global_step += N * T * data.world_size      # sum(mask) per recv (clean_pufferl.py:90), all ranks
+        st = vecenv.episode_stats(reset=True)
+        if data.world_size > 1:
+            dist, _, _ = _dist()
+            dist.all_reduce(st)
+        st = st.cpu().numpy()                            # the one sync of evaluate()
+        data.stats = {}
+        infos = {}
+        if st[0] > 0:
+            data.stats = dict(episode_return=st[1] / st[0], episode_length=st[2] / st[0], score=st[3] / st[0])
+            infos = {k: [v] for k, v in data.stats.items()}
+    return data.stats, infos
+
+
+@utils.profile
+def train(data):
+    config, profile, experience = data.config, data.profile, data.experience
+    data.losses = make_losses()
+    losses = data.losses
+    L = _lib.lib()
+    fp, opt = data.flat_params, data.optimizer
+    stream = _lib.stream_handle()
+    B, nmb = experience.batch_size, experience.num_minibatches
+    hp = _make_hparams(config, experience)
+    dist, rank, world = _dist()
+
+    with profile.train_misc:
+        # compute_gae over the env-major batch (clean_pufferl.py:163-169) + returns (:482)
+        _lib.check(L.pfa_gae_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
+                                 _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
+                                 float(config.gae_lambda), _lib.ptr(data.workspace), stream), 'gae')
+        if config.norm_adv:
+            _lib.check(L.pfa_ppo_adv_stats(C.byref(experience.c), B, C.byref(hp), _lib.ptr(data.adv_stats),
+                                           _lib.ptr(data.workspace), stream), 'adv_stats')
+            if world > 1:
+                dist.all_reduce(data.adv_stats)
+        data.loss_acc.zero_()
+        experience.ptr = 0
+        experience.step = 0
+
+    global_mb_rows = experience.minibatch_size * world
+    loss_scale = 1.0 / (global_mb_rows * nmb)
+    epochs_run = 0
+    for epoch in range(config.update_epochs):
+        for mb in range(nmb):
+            with profile.train_forward:
+                _lib.check(L.pfa_ppo_mlp_grad(C.byref(experience.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims),
+                                              C.byref(hp), _lib.ptr(data.adv_stats), global_mb_rows,
+                                              _lib.ptr(data.grads), _lib.ptr(data.workspace), stream), 'ppo_grad')
+            with profile.learn:
+                if world > 1:
+                    dist.all_reduce(data.grads)      # one flat bucket per optimizer step (RCCL over xGMI)
+                opt.step_count += 1
+                g = opt.param_groups[0]
+                _lib.check(L.pfa_adam_clip_step(
+                    _lib.ptr(fp.flat), _lib.ptr(data.grads), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), fp.count,
+                    float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), opt.step_count,
+                    float(config.max_grad_norm), 1.0, C.c_void_p(data.grads.data_ptr() + 4 * fp.count),
+                    _lib.ptr(data.loss_acc), loss_scale, stream), 'adam')
+        epochs_run += 1
+        if config.target_kl is not None:
+            # approx_kl of the LAST minibatch of this epoch (clean_pufferl.py:256-258) — needs a sync
+            last_kl = float(data.grads[fp.count + 4].item()) / global_mb_rows
+            if last_kl > config.target_kl:
+                break
+
+    with profile.train_misc:
+        if config.anneal_lr:
+            frac = 1.0 - data.global_step / config.total_timesteps
+            opt.param_groups[0]['lr'] = frac * config.learning_rate
+
+        # explained variance exactly as the reference logs it (clean_pufferl.py:266-270, App. A.8):
+        # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred
+        T, N = experience.horizon, experience.num_envs
+        y_pred = experience.values.view(N, T).t().reshape(-1).double()
+        y_true = experience.advantages.double() + y_pred
+        var_y = y_true.var(unbiased=False)
+        ev = torch.where(var_y == 0, torch.full_like(var_y, float('nan')),
+                         1 - (y_true - y_pred).var(unbiased=False) / var_y)
+        acc = torch.cat([data.loss_acc[:6].double(), ev.reshape(1)]).cpu().numpy()   # the one sync of train()
+        (losses.policy_loss, losses.value_loss, losses.entropy, losses.old_approx_kl, losses.approx_kl,
+         losses.clipfrac, losses.explained_variance) = (float(x) for x in acc)
+        data.epoch += 1
+
+        done_training = data.global_step >= config.total_timesteps
+        if profile.update(data) or done_training:
+            if _cfg(config, 'dashboard', False) and rank == 0:
+                print_dashboard(config.env, data.utilization, data.global_step, data.epoch, profile, data.losses,
+                                data.stats, data.msg)
+            if data.wandb is not None and data.global_step > 0 and time.time() - data.last_log_time > 3.0:
+                data.last_log_time = time.time()
+                data.wandb.log({
+                    '0verview/SPS': profile.SPS, '0verview/agent_steps': data.global_step,
+                    '0verview/epoch': data.epoch, '0verview/learning_rate': opt.param_groups[0]['lr'],
+                    **{f'environment/{k}': v for k, v in data.stats.items()},
+                    **{f'losses/{k}': v for k, v in data.losses.items()},
+                    **{f'performance/{k}': v for k, v in data.profile},
+                })
+        interval = _cfg(config, 'checkpoint_interval', 0)
+        if rank == 0 and interval and (data.epoch % interval == 0 or done_training):
+            save_checkpoint(data)
+            data.msg = f'Checkpoint saved at update {data.epoch}'
+
+
+def close(data):
+    data.vecenv.close()
+    data.utilization.stop()
+    config = data.config
+    if data.wandb is not None:
+        artifact = data.wandb.Artifact(f'{config.exp_id}_model', type='model')
+        artifact.add_file(save_checkpoint(data))
+        data.wandb.run.log_artifact(artifact)
+        data.wandb.finish()
+
+
+def save_checkpoint(data):
+    """clean_pufferl.py:509-530: whole-module pickle + trainer_state.pt (tmp-then-rename)."""
+    config = data.config
+    path = os.path.join(config.data_dir, config.exp_id)
+    os.makedirs(path, exist_ok=True)
+    model_name = f'model_{data.epoch:06d}.pt'
+    model_path = os.path.join(path, model_name)
+    if os.path.exists(model_path):
+        return model_path
+    torch.save(data.uncompiled_policy.state_dict(), model_path)
+    state = dict(optimizer_state_dict=data.optimizer.state_dict(), global_step=data.global_step,
+                 agent_step=data.global_step, update=data.epoch, model_name=model_name, exp_id=config.exp_id)
+    state_path = os.path.join(path, 'trainer_state.pt')
+    torch.save(state, state_path + '.tmp')
+    os.rename(state_path + '.tmp', state_path)
+    return model_path
+
+
+def try_load_checkpoint(data):
+    """clean_pufferl.py:532-546"""
+    config = data.config
+    path = os.path.join(config.data_dir, config.exp_id)
+    trainer_path = os.path.join(path, 'trainer_state.pt')
+    if not os.path.exists(trainer_path):
+        print('No checkpoint found. Assuming new experiment')
+        return
+    resume = torch.load(trainer_path, weights_only=False)
+    sd = torch.load(os.path.join(path, resume['model_name']), map_location=data.flat_params.flat.device)
+    with torch.no_grad():
+        for k, v in data.uncompiled_policy.state_dict().items():
+            v.copy_(sd[k])
+    data.optimizer.load_state_dict(resume['optimizer_state_dict'])
+    data.global_step = resume['global_step']
+    data.epoch = resume['update']
+    print(f'Loaded checkpoint {resume["model_name"]}')
+
+
+def print_dashboard(env_name, utilization, global_step, epoch, profile, losses, stats, msg, clear=False):
+    """Plain-text stand-in for the rich dashboard (clean_pufferl.py:644-738): same numbers, one block."""
+    lines = [f'[pufferlib_amd] env={env_name} steps={global_step} epoch={epoch} SPS={profile.SPS:,.0f} '
+             f'uptime={profile.uptime:.1f}s',
+             '  eval {:.3f}s train {:.3f}s'.format(profile.eval_time, profile.train_time),
+             '  losses ' + ' '.join(f'{k}={v:.5f}' for k, v in losses.items()),
+             '  stats ' + ' '.join(f'{k}={v:.4f}' for k, v in stats.items()), f'  {msg}']
+    print('\n'.join(lines), flush=True)

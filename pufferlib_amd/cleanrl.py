@@ -1,0 +1,74 @@
+"""frameworks.cleanrl.Policy (pufferlib/frameworks/cleanrl.py:50-66) over the HIP forward+sample kernel.
+
+``policy(obs)`` (rollout mode, action=None) returns (actions, logprob, entropy, value) like the reference; the
+multinomial draw is argmax(softmax(logits)/q) with q ~ Exp(1) from either an explicit ``noise`` tensor (parity with
+torch.multinomial given its exponential draw) or the Philox stream keyed by ``seed`` (include/pufferlib_amd.h).
+``policy(obs, action=...)`` (training mode) is not offered as a standalone op: the fused update kernel owns that
+path (pufferlib_amd.clean_pufferl.train)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .models import FlatParams
+
+
+class Policy(torch.nn.Module):
+    def __init__(self, policy, seed=0):
+        super().__init__()
+        self.policy = policy
+        self.noise_seed = int(seed)
+        self.noise_step = 0
+        self._flat = None
+
+    def adopt(self, obs_stride, device):
+        """Move the parameters into one flat device buffer (idempotent for the same stride/device)."""
+        if (self._flat is None or self._flat.obs_stride != obs_stride
+                or self._flat.flat.device != torch.device(device)):
+            self._flat = FlatParams(self.policy, obs_stride, device)
+        return self._flat
+
+    @property
+    def flat_params(self):
+        return self._flat
+
+    def get_value(self, x, state=None):
+        return self.forward(x)[3]
+
+    def get_action_and_value(self, x, action=None, noise=None):
+        return self.forward(x, action=action, noise=noise)
+
+    def forward(self, x, action=None, noise=None):
+        if action is not None:
+            raise NotImplementedError('training-mode forward lives in the fused PPO update kernel '
+                                      '(pufferlib_amd.clean_pufferl.train)')
+        _lib.require_gpu()
+        L = _lib.lib()
+        if not x.is_cuda:
+            x = x.cuda()
+        rows = x.shape[0]
+        x2 = x.reshape(rows, -1)
+        D = x2.shape[1]
+        stride = max(16, (D + 15) // 16 * 16)
+        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) % 16 == 0 and x2.stride(0) <= 128 \
+                and x2.data_ptr() % 16 == 0:
+            stride = x2.stride(0)            # e.g. the vecenv's live buffer, already padded
+            src = x2
+        else:
+            src = torch.zeros(rows, stride, dtype=torch.float32, device=x.device)
+            src[:, :D] = x2.float()
+        fp = self.adopt(stride, x.device)
+        actions = torch.empty(rows, dtype=torch.int64, device=x.device)
+        logprob = torch.empty(rows, dtype=torch.float32, device=x.device)
+        entropy = torch.empty(rows, dtype=torch.float32, device=x.device)
+        value = torch.empty(rows, dtype=torch.float32, device=x.device)
+        key = _lib.NoiseKey(self.noise_seed, self.noise_step)
+        if noise is not None:
+            noise = noise.to(device=x.device, dtype=torch.float32).contiguous()
+            assert noise.shape == (rows, fp.num_actions)
+        else:
+            self.noise_step += 1
+        _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(src), rows, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(noise),
+                                            C.byref(key), 0, _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(entropy),
+                                            _lib.ptr(value), _lib.stream_handle()), 'mlp_forward_sample')
+        return actions, logprob, entropy, value.unsqueeze(1)

@@ -47,8 +47,8 @@ def test_vs_oracle_full_size(n, p_done):
     want = c_oracle.compute_gae(d, v, r, 0.99, 0.95)
     got = hip_gae(d, v, r, 0.99, 0.95)
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
-    # most elements are bit-identical: only the re-associated carry-in differs, and it decays
-    assert (got.view(np.uint32) == want.view(np.uint32)).mean() > 0.5
+    # tighter than the contract: a few ulps of the largest advantage
+    assert np.abs(got - want).max() <= 8 * np.finfo(np.float32).eps * max(1.0, np.abs(want).max())
 
 
 def test_linearity_property():

@@ -1,0 +1,224 @@
+"""HIP policy forward / fused rollout / PPO update vs the golden outputs of the unmodified reference
+(tests/golden/ppo_mlp.npz) and vs the torch-fp32 oracle at larger sizes.  Tolerance: north_star's 1e-5 fp32,
+stated as allclose(rtol=1e-5, atol=1e-5); actions (integers) bit-exact given the same multinomial noise."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _config(n, horizon, mbs, bptt, epochs, total, hp, **over):
+    from pufferlib_amd import namespace
+    lr, gamma, lam, clip, vf_coef, vf_clip, mgn, ent = hp
+    cfg = dict(env='squared', seed=1, torch_deterministic=True, cpu_offload=False, device='cuda', total_timesteps=total,
+               learning_rate=lr, anneal_lr=True, gamma=gamma, gae_lambda=lam, update_epochs=epochs, norm_adv=True,
+               clip_coef=clip, clip_vloss=True, vf_coef=vf_coef, vf_clip_coef=vf_clip, max_grad_norm=mgn, ent_coef=ent,
+               target_kl=None, batch_size=n * horizon, minibatch_size=mbs, bptt_horizon=bptt, compile=False,
+               checkpoint_interval=0, data_dir='/tmp/pfa_experiments', exp_id='test')
+    cfg.update(over)
+    return namespace(**cfg)
+
+
+def _make(n, d=3, nt=1):
+    from pufferlib_amd import vector, models, cleanrl
+    vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=d, num_targets=nt), num_envs=n,
+                      backend=vector.Squared)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    return vec, pol
+
+
+def _load_weights(pol, g, prefix):
+    sd = {k[len(prefix):]: torch.as_tensor(g[k]) for k in g.files if k.startswith(prefix)}
+    pol.load_state_dict(sd)
+
+
+def _step_major(x, n, t):
+    """env-major device tensor -> the reference's storage (step-major) order as numpy."""
+    return x.view(n, t, *x.shape[1:]).transpose(0, 1).reshape(n * t, *x.shape[1:]).cpu().numpy()
+
+
+def test_forward_sample_matches_reference_rollout(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'ppo_mlp.npz'))
+    n, horizon = int(g['config'][0]), int(g['config'][1])
+    vec, pol = _make(n)
+    _load_weights(pol, g, 'w0.')
+    obs = torch.as_tensor(g['it0.obs'].astype(np.float32)).cuda()
+    for t in (0, 1, 5, horizon - 1):
+        rows = slice(t * n, (t + 1) * n)
+        a, lp, ent, val = pol(obs[rows].view(n, 7, 7), noise=torch.as_tensor(g['it0.noise'][t]))
+        assert np.array_equal(a.cpu().numpy(), g['it0.actions'][rows].astype(np.int64)), t
+        np.testing.assert_allclose(lp.cpu().numpy(), g['it0.logprobs'][rows], **TOL)
+        np.testing.assert_allclose(val.flatten().cpu().numpy(), g['it0.values'][rows], **TOL)
+        np.testing.assert_allclose(ent.cpu().numpy(), np.full(n, np.log(8)), rtol=1e-3)
+
+
+def test_create_evaluate_train_replays_golden(golden_dir):
+    from pufferlib_amd import clean_pufferl
+    g = np.load(os.path.join(golden_dir, 'ppo_mlp.npz'))
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    vec, pol = _make(n)
+    _load_weights(pol, g, 'w0.')
+    data = clean_pufferl.create(_config(n, horizon, mbs, bptt, epochs, total, [float(x) for x in g['hparams']]), vec, pol)
+    exp = data.experience
+    for it in range(iters):
+        assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_used'])) < 1e-12
+        data.noise = torch.as_tensor(g[f'it{it}.noise'])
+        stats, _ = clean_pufferl.evaluate(data)
+        assert np.array_equal(_step_major(exp.actions, n, horizon), g[f'it{it}.actions'].astype(np.int32))
+        assert np.array_equal(_step_major(exp.obs, n, horizon)[:, :49], g[f'it{it}.obs'].astype(np.float32))
+        assert np.array_equal(_step_major(exp.rewards, n, horizon), g[f'it{it}.rewards'])
+        assert np.array_equal(_step_major(exp.dones, n, horizon), g[f'it{it}.dones'])
+        np.testing.assert_allclose(_step_major(exp.logprobs, n, horizon), g[f'it{it}.logprobs'], **TOL)
+        np.testing.assert_allclose(_step_major(exp.values, n, horizon), g[f'it{it}.values'], **TOL)
+        assert data.global_step == int(g[f'it{it}.global_step'])
+        np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']],
+                                   g[f'it{it}.stats'], rtol=1e-9)
+        clean_pufferl.train(data)
+        # golden b_advantages[m, q] is minibatch m's q-th row; same partition on our env-major buffer
+        for m in range(exp.num_minibatches):
+            idx = exp.minibatch_rows_index(m)
+            np.testing.assert_allclose(exp.advantages[idx].cpu().numpy(), g[f'it{it}.advantages'][m], **TOL)
+            np.testing.assert_allclose(exp.returns[idx].cpu().numpy(), g[f'it{it}.returns'][m], **TOL)
+        L = data.losses
+        got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=1e-4, atol=1e-5)
+        sd = pol.state_dict()
+        m_, v_ = data.flat_params.split(data.optimizer.exp_avg), data.flat_params.split(data.optimizer.exp_avg_sq)
+        for k in sd:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'it{it}.w.{k}'], err_msg=k, **TOL)
+            short = k[len('policy.'):]
+            np.testing.assert_allclose(m_[short].cpu().numpy(), g[f'it{it}.m.{k}'], rtol=1e-4, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(v_[short].cpu().numpy(), g[f'it{it}.v.{k}'], rtol=1e-4, atol=1e-8, err_msg=k)
+        assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-12
+    # pad columns of the encoder never move
+    H, DP = 128, vec.obs_stride
+    assert float(data.flat_params.flat[:H * DP].view(H, DP)[:, 49:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize('n,horizon,nmb,bptt', [(256, 64, 4, 16), (64, 32, 2, 4), (1024, 128, 4, 16)])
+def test_update_vs_torch_oracle(n, horizon, nmb, bptt):
+    """Same experience into the HIP update and the torch-fp32 restatement of clean_pufferl.train."""
+    from pufferlib_amd import clean_pufferl
+    from oracle import c_oracle, ppo_torch
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    B = n * horizon
+    vec, pol = _make(n)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.05 * torch.randn_like(p))     # move off the near-uniform init so ratios/clipping engage
+    cfg = _config(n, horizon, B // nmb, bptt, 2, B * 10, hp)
+    data = clean_pufferl.create(cfg, vec, pol)
+    w0 = {k[len('policy.'):]: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    clean_pufferl.evaluate(data)          # Philox noise; fills the experience on device
+    exp = data.experience
+
+    ovec = c_oracle.SquaredSerial(n, 3, 1)
+    opol = ppo_torch.Policy(w0)
+    tr = ppo_torch.Trainer(opol, ovec, batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt, update_epochs=2,
+                           learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3], vf_coef=hp[4],
+                           vf_clip_coef=hp[5], max_grad_norm=hp[6], ent_coef=hp[7], total_timesteps=B * 10, seed=1)
+    # hand the oracle the device rollout's experience in its storage (step-major) order
+    tr.obs = torch.as_tensor(_step_major(exp.obs, n, horizon)[:, :49].copy())
+    tr.actions = _step_major(exp.actions, n, horizon).astype(np.int64)
+    tr.logprobs = _step_major(exp.logprobs, n, horizon).copy()
+    tr.rewards = _step_major(exp.rewards, n, horizon).copy()
+    tr.dones = _step_major(exp.dones, n, horizon).copy()
+    tr.values = _step_major(exp.values, n, horizon).copy()
+    tr.global_step = data.global_step
+    torch.set_num_threads(8)
+    Lo = tr.train()
+    clean_pufferl.train(data)
+    L = data.losses
+    np.testing.assert_allclose(
+        [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
+        [Lo['policy_loss'], Lo['value_loss'], Lo['entropy'], Lo['old_approx_kl'], Lo['approx_kl'], Lo['clipfrac']],
+        rtol=1e-4, atol=1e-5)
+    sd = pol.state_dict()
+    for k, arr in opol.state_arrays().items():
+        np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=k, **TOL)
+
+
+def test_fused_rollout_equals_stepwise_protocol():
+    """evaluate()'s persistent kernel == T x {recv, policy(obs), store, send} through the public protocol,
+    bit for bit (same Philox stream)."""
+    from pufferlib_amd import clean_pufferl
+    n, horizon = 48, 20          # not a multiple of 16 envs: exercises the masked tail tile
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    vec, pol = _make(n)
+    cfg = _config(n, horizon, n * horizon // 2, 4, 1, n * horizon * 4, hp, seed=5)
+    data = clean_pufferl.create(cfg, vec, pol)
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+
+    vec2, pol2 = _make(n)
+    pol2.load_state_dict(pol.state_dict())
+    pol2.noise_seed = 5
+    vec2.async_reset(5)
+    obs_l, act_l, lp_l, val_l, rew_l, done_l = [], [], [], [], [], []
+    for t in range(horizon):
+        o, r, d, tr_, info, ids, mask = vec2.recv()
+        a, lp, ent, val = pol2(o)
+        obs_l.append(o.reshape(n, -1).clone()); rew_l.append(r.clone()); done_l.append(d.clone().float())
+        act_l.append(a.clone()); lp_l.append(lp.clone()); val_l.append(val.flatten().clone())
+        vec2.send(a)
+    assert torch.equal(_t(exp.obs, n, horizon)[:, :49], torch.cat(obs_l))
+    assert torch.equal(_t(exp.actions, n, horizon).long(), torch.cat(act_l))
+    assert torch.equal(_t(exp.logprobs, n, horizon), torch.cat(lp_l))
+    assert torch.equal(_t(exp.values, n, horizon), torch.cat(val_l))
+    assert torch.equal(_t(exp.rewards, n, horizon), torch.cat(rew_l))
+    assert torch.equal(_t(exp.dones, n, horizon), torch.cat(done_l))
+    # and the live buffers continue identically
+    assert torch.equal(vec.observations, vec2.observations)
+    assert torch.equal(vec.rewards, vec2.rewards) and torch.equal(vec.terminals, vec2.terminals)
+
+
+def _t(x, n, t):
+    return x.view(n, t, *x.shape[1:]).transpose(0, 1).reshape(n * t, *x.shape[1:])
+
+
+def test_philox_actions_match_oracle_at_full_size():
+    """4096 envs x 128 steps with the in-kernel Philox noise: replay the same stream on the CPU oracle
+    (C env + torch MLP + C Philox) and require identical integer trajectories, modulo near-ties."""
+    from pufferlib_amd import clean_pufferl
+    from oracle import c_oracle, ppo_torch
+    n, horizon = 4096, 128
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    vec, pol = _make(n)
+    cfg = _config(n, horizon, n * horizon // 4, 16, 1, n * horizon * 4, hp, seed=1)
+    data = clean_pufferl.create(cfg, vec, pol)
+    w0 = {k[len('policy.'):]: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    # CPU side: Philox -> Exp(1) noise for the first 8 steps (the oracle is slow; 8 x 4096 rows suffices)
+    steps = 8
+    rows = np.arange(n)
+    noise = np.empty((steps, n, 8), np.float32)
+    for t in range(steps):
+        for e in rows:
+            for j in range(2):
+                w = c_oracle.philox4x32_10([e, j, t, 0], [1, 0])
+                u = ((w >> 8).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+                noise[t, e, 4 * j:4 * j + 4] = -np.log(u)
+    ovec = c_oracle.SquaredSerial(n, 3, 1)
+    opol = ppo_torch.Policy(w0)
+    ovec.async_reset(1)
+    acts = _step_major(exp.actions, n, horizon)
+    obs = _step_major(exp.obs, n, horizon)[:, :49]
+    mism = 0
+    for t in range(steps):
+        o = ovec.recv()[0]
+        assert np.array_equal(o.reshape(n, -1), obs[t * n:(t + 1) * n]), t     # envs in lock-step so far
+        with torch.no_grad():
+            logits, value, _ = opol.forward(torch.as_tensor(o.reshape(n, -1).copy()))
+            a, lp, _ = ppo_torch.sample_logits(logits, noise=torch.as_tensor(noise[t]))
+        dev = acts[t * n:(t + 1) * n]
+        bad = np.nonzero(a.numpy() != dev)[0]
+        mism += len(bad)
+        ovec.send(dev.astype(np.int64))       # follow the device's actions so later steps stay comparable
+    assert mism <= 2, f'{mism} action mismatches in {steps * n} samples (only near-ties in p/q may differ)'
