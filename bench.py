@@ -1,0 +1,190 @@
+"""bench.py — end-to-end PPO throughput of the device-resident engine on BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is ONE pass of the hot path over one batch: clean_pufferl.evaluate() (128-step rollout of 4096 Squared
+envs per GPU: env step + MLP forward + sample + store) followed by clean_pufferl.train() (GAE + 4 epochs x 4
+minibatches of fused fwd/loss/bwd + clip + Adam) = 524 288 env steps per GPU.  Workload = BASELINE.json
+configs[1] ("squared env, 4096 envs, 64-dim flat obs, MLP policy, 1xMI355X"); with N > 1 every rank runs that
+workload on its own env shard (weak scaling, configs[4] at N = 8) and all-reduces one flat gradient bucket per
+optimizer step over RCCL.  Inputs are synthetic by construction (the env IS the generator) and resident in HBM.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     dominant kernel ppo_mlp_grad (fp32 MFMA bound): algorithmic FLOPs per launch / average launch
+               duration measured with HIP events on the launch stream over the timed region
+  cpu_baseline the CPU oracle port (C env + torch-fp32 policy/update, oracle/) timed on a bounded sample of
+               the same workload on this box's host cores (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+NUM_ENVS = 4096          # per GPU
+HORIZON = 128
+NMB = 4
+EPOCHS = 4
+BPTT = 16
+D, NT = 3, 1             # obs 7x7 = 49 floats, padded to a 64-float row (256 B)
+# SURVEY.md §8d algorithmic figures (MLP, obs row 64 f32, 8 actions, hidden 128)
+FLOP_PER_ROW_UPDATE = 39680          # fwd 18 688 + bwd 20 992 per row per epoch
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def make_config(total_timesteps):
+    from pufferlib_amd import namespace
+    B = NUM_ENVS * HORIZON
+    return namespace(env='squared', seed=1, torch_deterministic=True, device='cuda', total_timesteps=total_timesteps,
+                     learning_rate=2.5e-4, anneal_lr=True, gamma=0.99, gae_lambda=0.95, update_epochs=EPOCHS,
+                     norm_adv=True, clip_coef=0.1, clip_vloss=True, vf_coef=0.5, vf_clip_coef=0.1, max_grad_norm=0.5,
+                     ent_coef=0.01, target_kl=None, batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT,
+                     checkpoint_interval=0, data_dir='/tmp/pfa_bench', exp_id='bench')
+
+
+def cpu_baseline(budget_s=20.0):
+    """The oracle port timed on a bounded sample: same per-env workload (squared d=3, T=128, 4 minibatches,
+    4 epochs, MLP 128) at 256 envs; >= 1 timed evaluate+train iteration after a warm-up one."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle, ppo_torch
+    n = 256
+    B = n * HORIZON
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    vec = c_oracle.SquaredSerial(n, D, NT)
+    torch.manual_seed(1)
+    w = {'encoder.weight': torch.randn(128, 49) * 0.1, 'encoder.bias': torch.zeros(128),
+         'decoder.weight': torch.randn(8, 128) * 0.01, 'decoder.bias': torch.zeros(8),
+         'value_head.weight': torch.randn(1, 128) * 0.1, 'value_head.bias': torch.zeros(1)}
+    pol = ppo_torch.Policy({k: v.numpy() for k, v in w.items()})
+    tr = ppo_torch.Trainer(pol, vec, batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT, update_epochs=EPOCHS,
+                           learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, vf_coef=0.5,
+                           vf_clip_coef=0.1, max_grad_norm=0.5, ent_coef=0.01, total_timesteps=B * 1000, seed=1)
+    rng = np.random.default_rng(0)
+
+    def one():
+        tr.evaluate(rng.exponential(size=(HORIZON, n, 8)).astype(np.float32))
+        tr.train()
+
+    one()  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        one()
+        iters += 1
+        if time.perf_counter() - t0 > budget_s / 2 or iters >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=iters * B / dt, unit='env_steps/s', cores=cores, kind='port',
+                sample=f'{iters} evaluate+train iterations of {n} envs x {HORIZON} steps (same env, policy, '
+                       f'{NMB} minibatches x {EPOCHS} epochs) after 1 warm-up; C env on 1 core, torch-fp32 on {cores} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local_rank}'))
+    else:
+        torch.cuda.set_device(0)
+
+    from pufferlib_amd import _lib, clean_pufferl, cleanrl, models, vector
+    L = _lib.lib()
+    K, W = args.steps, args.warmup
+    per_gpu = NUM_ENVS * HORIZON
+    vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=D, num_targets=NT), num_envs=NUM_ENVS,
+                      backend=vector.Squared, obs_stride=64)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    data = clean_pufferl.create(make_config(per_gpu * world * (K + W) * 4), vec, pol)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(W):
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+    L.pfa_timing_reset()
+    L.pfa_timing_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+    barrier()
+    dt = time.perf_counter() - t0
+    L.pfa_timing_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    def kernel_ms(name):
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        _lib.check(L.pfa_timing_read(name.encode(), C.byref(n), C.byref(ms)), 'timing_read')
+        return n.value, ms.value
+
+    if rank == 0:
+        value = world * per_gpu * K / dt
+        launches, total_ms = kernel_ms('ppo_mlp_grad')
+        avg_ms = total_ms / max(launches, 1)
+        rows_per_launch = per_gpu // NMB
+        achieved = FLOP_PER_ROW_UPDATE * rows_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(REPO, 'profiles', 'pmc_summary.json')
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get('ppo_mlp_grad', {}).get('hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        breakdown = {}
+        for name in ('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip'):
+            n, ms = kernel_ms(name)
+            breakdown[name] = dict(launches=n, ms_per_step=round(ms / K, 4))
+        out = {
+            'metric': 'env steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs',
+            'value': value, 'unit': 'env_steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'squared d={D} nt={NT}, {NUM_ENVS} envs/GPU x {HORIZON} steps, obs 49->64 f32 rows, '
+                                   f'MLP 128, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[1]'
+                                   + (', sharded as configs[4]' if world > 1 else '') + ')',
+                       'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
+            'roofline': {'bound': 'mfma', 'kernel': 'ppo_mlp_grad', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                         'avg_launch_ms': avg_ms, 'launches': launches,
+                         'flop_per_launch': FLOP_PER_ROW_UPDATE * rows_per_launch},
+            'kernel_ms_per_step': breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -25,6 +25,14 @@ typedef void *pfa_stream_t;
 int pfa_version(void);
 const char *pfa_last_error(void);
 
+/* Optional measurement hook (bench.py roofline leg): when enabled, the launches of the named kernels
+ * ("rollout_mlp_squared", "gae", "ppo_mlp_grad", "ppo_reduce", "adam_clip", "squared_tape") are bracketed by
+ * hipEvents recorded on the launch stream.  pfa_timing_read synchronises on the recorded events and returns
+ * the launch count and the summed device time in ms (HOST pointers). */
+int pfa_timing_enable(int on);
+int pfa_timing_reset(void);
+int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms_host);
+
 /* ------------------------------------------------------------------------------------------
  * GAE — replaces c_gae.compute_gae (c_gae.pyx:11-32), called from clean_pufferl.py:168-169.
  * One reverse affine scan over the whole flat (env-major) batch, crossing env boundaries exactly

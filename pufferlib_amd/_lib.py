@@ -86,6 +86,9 @@ _SIGNATURES = {
     # name: (restype, argtypes) — must list every symbol include/pufferlib_amd.h declares
     'pfa_version': (C.c_int, []),
     'pfa_last_error': (C.c_char_p, []),
+    'pfa_timing_enable': (C.c_int, [C.c_int]),
+    'pfa_timing_reset': (C.c_int, []),
+    'pfa_timing_read': (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'pfa_gae_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'pfa_gae_f32': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_float, C.c_float, P, P]),
     'pfa_squared_state_bytes': (C.c_size_t, [C.POINTER(SquaredConfig)]),

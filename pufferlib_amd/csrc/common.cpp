@@ -1,6 +1,13 @@
-// common.cpp — pfa_last_error / pfa_version.
+// common.cpp — pfa_last_error / pfa_version and the optional per-kernel HIP-event timing registry
+// (bench.py's roofline leg: events are recorded on the SAME stream the kernel is launched on).
+#include <hip/hip_runtime.h>
+
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
 
 #include "../../include/pufferlib_amd.h"
 
@@ -12,7 +19,60 @@ void set_error(const char *fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+struct TimedKernel {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+    size_t used = 0;
+};
+static bool g_timing = false;
+static std::map<std::string, TimedKernel> g_timed;
+
+bool timing_enabled() { return g_timing; }
+
+// Returns the stop event (to be recorded after the launch) or nullptr when timing is off.
+void *timing_begin(const char *name, hipStream_t stream) {
+    if (!g_timing) return nullptr;
+    TimedKernel &k = g_timed[name];
+    if (k.used == k.pairs.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return nullptr;
+        k.pairs.emplace_back(a, b);
+    }
+    auto &p = k.pairs[k.used++];
+    (void)hipEventRecord(p.first, stream);
+    return (void *)p.second;
+}
+void timing_end(void *stop, hipStream_t stream) {
+    if (stop) (void)hipEventRecord((hipEvent_t)stop, stream);
+}
 }  // namespace pfa
 
 extern "C" int pfa_version(void) { return 1; }
 extern "C" const char *pfa_last_error(void) { return pfa::g_err; }
+
+extern "C" int pfa_timing_enable(int on) {
+    pfa::g_timing = on != 0;
+    return 0;
+}
+extern "C" int pfa_timing_reset(void) {
+    for (auto &kv : pfa::g_timed) kv.second.used = 0;
+    return 0;
+}
+extern "C" int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms_host) {
+    if (!kernel || !launches_host || !total_ms_host) return -2;
+    *launches_host = 0;
+    *total_ms_host = 0.0;
+    auto it = pfa::g_timed.find(kernel);
+    if (it == pfa::g_timed.end()) return 0;
+    double total = 0.0;
+    for (size_t i = 0; i < it->second.used; ++i) {
+        auto &p = it->second.pairs[i];
+        if (hipEventSynchronize(p.second) != hipSuccess) return -1;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.first, p.second) != hipSuccess) return -1;
+        total += ms;
+    }
+    *launches_host = (int64_t)it->second.used;
+    *total_ms_host = total;
+    return 0;
+}

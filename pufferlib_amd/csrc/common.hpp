@@ -10,6 +10,16 @@
 namespace pfa {
 
 void set_error(const char *fmt, ...);
+bool timing_enabled();
+void *timing_begin(const char *name, hipStream_t stream);  // records the start event when timing is on
+void timing_end(void *stop, hipStream_t stream);
+
+struct ScopedKernelTimer {  // brackets ONE kernel launch with HIP events on its own stream (bench.py roofline)
+    void *stop;
+    hipStream_t stream;
+    ScopedKernelTimer(const char *name, hipStream_t s) : stop(timing_begin(name, s)), stream(s) {}
+    ~ScopedKernelTimer() { timing_end(stop, stream); }
+};
 
 #define PFA_CHECK_HIP(expr)                                                                   \
     do {                                                                                      \

@@ -164,6 +164,7 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
     const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
     PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
     Affine *agg = (Affine *)workspace;
+    ScopedKernelTimer timer("gae", (hipStream_t)stream);  // both passes
     hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
                        rewards, (long long)n, gamma, gae_lambda, agg);
     PFA_LAUNCH_CHECK();

@@ -549,13 +549,17 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
         hipLaunchKernelGGL(ppo_mlp_grad_kernel<DPV>, dim3(grid), dim3(kGradThreads), lds_bytes, (hipStream_t)stream, *exp,  \
                            map, (long long)mbs, params, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, partials); \
     }
-    switch (dims->obs_stride) {
-        case 16: PFA_LAUNCH_GRAD(16) break;
-        case 32: PFA_LAUNCH_GRAD(32) break;
-        default: PFA_LAUNCH_GRAD(64) break;
+    {
+        ScopedKernelTimer timer("ppo_mlp_grad", (hipStream_t)stream);
+        switch (dims->obs_stride) {
+            case 16: PFA_LAUNCH_GRAD(16) break;
+            case 32: PFA_LAUNCH_GRAD(32) break;
+            default: PFA_LAUNCH_GRAD(64) break;
+        }
     }
 #undef PFA_LAUNCH_GRAD
     PFA_LAUNCH_CHECK();
+    ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
     hipLaunchKernelGGL(ppo_reduce_kernel, dim3((pp + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, grid, pp, grads);
     PFA_LAUNCH_CHECK();
     return 0;
@@ -566,6 +570,7 @@ extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_
                                   const float *loss_sums, float *losses, float loss_scale, pfa_stream_t stream) {
     PFA_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam: null buffer");
     PFA_REQUIRE(count >= 1 && step >= 1, "adam: count and step must be >= 1");
+    ScopedKernelTimer timer("adam_clip", (hipStream_t)stream);
     hipLaunchKernelGGL(adam_clip_kernel, dim3(1), dim3(kAdamThreads), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                        (long long)count, lr, beta1, beta2, eps, (long long)step, max_grad_norm, grad_scale, loss_sums, losses,
                        loss_scale);

@@ -268,6 +268,7 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     SquaredView v = squared_view(state, *cfg);
     const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
     const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
+    ScopedKernelTimer timer("rollout_mlp_squared", (hipStream_t)stream);
     PFA_DISPATCH_DP(dims->obs_stride,
                     hipLaunchKernelGGL(rollout_mlp_squared_kernel<DP>, dim3(grid), dim3(64), 0, (hipStream_t)stream, v, params,
                                        dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,

@@ -386,6 +386,7 @@ extern "C" int pfa_squared_fill_tape(void *state, const pfa_squared_config *cfg,
                 cfg->tape_rounds);
     if (rounds == 0) return 0;
     SquaredView v = squared_view(state, *cfg);
+    ScopedKernelTimer timer("squared_tape", (hipStream_t)stream);
     hipLaunchKernelGGL(squared_tape_kernel, dim3(1), dim3(kTapeThreads), 0, (hipStream_t)stream, v, (int)rounds);
     PFA_LAUNCH_CHECK();
     return 0;
