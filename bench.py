@@ -55,7 +55,9 @@ def cpu_baseline(budget_s=20.0):
     from oracle import c_oracle, ppo_torch
     n = 256
     B = n * HORIZON
-    cores = os.cpu_count() or 1
+    # threads actually used: the reference's torch CPU path scales poorly past a socket's worth of cores on
+    # these tiny GEMMs (256 threads measured 800x slower than 16 on the GPU box), so cap and report the cap
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     vec = c_oracle.SquaredSerial(n, D, NT)
     torch.manual_seed(1)
