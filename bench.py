@@ -94,6 +94,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-breakdown', action='store_true', help='skip the extra (untimed) per-kernel breakdown pass')
     args = ap.parse_args()
 
     import torch
@@ -129,7 +130,7 @@ def main():
         clean_pufferl.evaluate(data)
         clean_pufferl.train(data)
     L.pfa_timing_reset()
-    L.pfa_timing_enable(1)
+    L.pfa_timing_enable(1)   # dominant kernel only
     barrier()
     t0 = time.perf_counter()
     for _ in range(K):
@@ -148,9 +149,28 @@ def main():
         _lib.check(L.pfa_timing_read(name.encode(), C.byref(n), C.byref(ms)), 'timing_read')
         return n.value, ms.value
 
+    grad_launches, grad_total_ms = kernel_ms('ppo_mlp_grad')   # HIP events over the timed region, launch stream
+    breakdown = {}
+    if rank == 0 and not args.no_breakdown:
+        # separate, untimed pass with every instrumented kernel bracketed by events (the extra event packets cost
+        # a few us per launch, so they stay out of the timed region)
+        KB = min(K, 5)
+        L.pfa_timing_reset()
+        L.pfa_timing_enable(2)
+    if not args.no_breakdown:
+        for _ in range(min(K, 5)):
+            clean_pufferl.evaluate(data)
+            clean_pufferl.train(data)
+        barrier()
+    if rank == 0 and not args.no_breakdown:
+        L.pfa_timing_enable(0)
+        for name in ('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip'):
+            n, ms = kernel_ms(name)
+            breakdown[name] = dict(launches_per_step=n // KB, ms_per_step=round(ms / KB, 4))
+
     if rank == 0:
         value = world * per_gpu * K / dt
-        launches, total_ms = kernel_ms('ppo_mlp_grad')
+        launches, total_ms = grad_launches, grad_total_ms
         avg_ms = total_ms / max(launches, 1)
         rows_per_launch = per_gpu // NMB
         achieved = FLOP_PER_ROW_UPDATE * rows_per_launch / (avg_ms * 1e-3) / 1e12
@@ -161,10 +181,6 @@ def main():
                 traffic = json.load(open(pmc)).get('ppo_mlp_grad', {}).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
-        breakdown = {}
-        for name in ('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip'):
-            n, ms = kernel_ms(name)
-            breakdown[name] = dict(launches=n, ms_per_step=round(ms / K, 4))
         out = {
             'metric': 'env steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs',
             'value': value, 'unit': 'env_steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,

@@ -25,11 +25,12 @@ typedef void *pfa_stream_t;
 int pfa_version(void);
 const char *pfa_last_error(void);
 
-/* Optional measurement hook (bench.py roofline leg): when enabled, the launches of the named kernels
+/* Optional measurement hook (bench.py roofline leg).  mode 0 = off, 1 = only the dominant kernel
+ * ("ppo_mlp_grad"), 2 = every instrumented kernel.  When enabled, the launches of the named kernels
  * ("rollout_mlp_squared", "gae", "ppo_mlp_grad", "ppo_reduce", "adam_clip", "squared_tape") are bracketed by
  * hipEvents recorded on the launch stream.  pfa_timing_read synchronises on the recorded events and returns
  * the launch count and the summed device time in ms (HOST pointers). */
-int pfa_timing_enable(int on);
+int pfa_timing_enable(int mode);
 int pfa_timing_reset(void);
 int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms_host);
 
@@ -174,11 +175,22 @@ int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, 
  * correction with `step` = 1-based optimizer step count).  grad_scale multiplies grads first.
  * If loss_sums/losses are given: losses[i] += loss_sums[i] * loss_scale for i < 6, i.e. the running
  * {policy_loss, value_loss, entropy, old_approx_kl, approx_kl, clipfrac} of clean_pufferl.py:249-254 with
- * loss_scale = 1 / (global_mb_rows * num_minibatches). */
+ * loss_scale = 1 / (global_mb_rows * num_minibatches).  norm_partials (nullable): n f64 pieces of sum(g^2) left in
+ * the workspace by pfa_ppo_mlp_grad (valid only when grads were not modified since, i.e. single rank); when
+ * null the norm is recomputed from `grads` (after an all-reduce). */
 int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t count,
                        float lr, float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
                        float grad_scale, const float *loss_sums, float *losses, float loss_scale,
-                       pfa_stream_t stream);
+                       const double *norm_partials, int32_t n_norm_partials, pfa_stream_t stream);
+
+/* The whole minibatch loop of one clean_pufferl.train call on ONE rank (clean_pufferl.py:175-258 without the
+ * target_kl early exit): update_epochs x num_minibatches x { pfa_ppo_mlp_grad, pfa_adam_clip_step } enqueued from
+ * native code (no per-step host work).  opt_step = optimizer steps taken before this call; losses as above. */
+int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
+                      const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
+                      float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
+                      float max_grad_norm, int32_t update_epochs, float *losses, void *workspace,
+                      pfa_stream_t stream);
 
 #ifdef __cplusplus
 }

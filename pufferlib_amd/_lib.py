@@ -108,8 +108,10 @@ _SIGNATURES = {
     'pfa_ppo_adv_stats': (C.c_int, [C.POINTER(Experience), C.c_int64, C.POINTER(PpoHparams), P, P, P]),
     'pfa_ppo_mlp_grad': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),
                                    C.POINTER(PpoHparams), P, C.c_int64, P, P, P]),
+    'pfa_ppo_mlp_train': (C.c_int, [C.POINTER(Experience), C.c_int64, P, C.POINTER(MlpDims), C.POINTER(PpoHparams), P, P, P, P,
+                                    C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P, P]),
     'pfa_adam_clip_step': (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
-                                     C.c_float, C.c_float, P, P, C.c_float, P]),
+                                     C.c_float, C.c_float, P, P, C.c_float, P, C.c_int32, P]),
 }
 
 _lib = None

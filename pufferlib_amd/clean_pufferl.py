@@ -284,6 +284,8 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
         loss_acc=torch.zeros(8, dtype=torch.float32, device=device),
         noise=None,            # optional explicit Exp(1) tensor [T][N][A] for the next evaluate() (parity tests)
+        tape_stream=torch.cuda.Stream(device=device),   # reset-target tape is drawn one rollout ahead, off the critical path
+        tape_event=None,
     )
     return data
 
@@ -311,15 +313,30 @@ def evaluate(data):
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
     with profile.env:
-        vecenv.ensure_tape(T)
+        main = torch.cuda.current_stream()
+        if data.tape_event is not None:
+            main.wait_event(data.tape_event)     # rounds for this rollout were drawn under the previous rollout
+        vecenv.ensure_tape(T)                    # no-op when the prefetch covered it
+        start_point = torch.cuda.Event()
+        start_point.record(main)                 # everything before this rollout (incl. the rollout before it) is done
     with profile.eval_forward:
         _lib.check(L.pfa_rollout_mlp_squared(
             _lib.ptr(vecenv.state), C.byref(vecenv.cfg), _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(experience.c),
             _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
             _lib.ptr(vecenv.terminals_u8), _lib.ptr(vecenv.truncations_u8), _lib.ptr(vecenv.masks_u8),
             _lib.stream_handle()), 'rollout')
-    with profile.eval_misc:
+    with profile.env:
         vecenv.sends += T
+        # The tape does not depend on actions: draw the NEXT rollout's reset rounds on the side stream while THIS
+        # rollout runs (its small workgroup co-resides with the rollout's).  The ring slots it writes belong to the
+        # rollout before this one, which `start_point` guarantees has finished.
+        if 3 * (vecenv._rounds_needed(T) + 1) <= vecenv.tape_rounds:
+            with torch.cuda.stream(data.tape_stream):
+                data.tape_stream.wait_event(start_point)
+                vecenv.ensure_tape(T)
+                data.tape_event = torch.cuda.Event()
+                data.tape_event.record(data.tape_stream)
+    with profile.eval_misc:
         policy.noise_step += T
         data.noise = None
         experience.ptr = experience.batch_size
@@ -367,7 +384,18 @@ def train(data):
     global_mb_rows = experience.minibatch_size * world
     loss_scale = 1.0 / (global_mb_rows * nmb)
     epochs_run = 0
-    for epoch in range(config.update_epochs):
+    native_loop = world == 1 and config.target_kl is None
+    if native_loop:
+        # single rank, no early exit: the whole epoch x minibatch loop is enqueued by one native call
+        with profile.learn:
+            g = opt.param_groups[0]
+            _lib.check(L.pfa_ppo_mlp_train(
+                C.byref(experience.c), B, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hp), _lib.ptr(data.adv_stats),
+                _lib.ptr(data.grads), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), opt.step_count, float(g['lr']),
+                float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(config.max_grad_norm),
+                int(config.update_epochs), _lib.ptr(data.loss_acc), _lib.ptr(data.workspace), stream), 'ppo_train')
+            opt.step_count += config.update_epochs * nmb
+    for epoch in range(0 if native_loop else config.update_epochs):
         for mb in range(nmb):
             with profile.train_forward:
                 _lib.check(L.pfa_ppo_mlp_grad(C.byref(experience.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims),
@@ -382,7 +410,7 @@ def train(data):
                     _lib.ptr(fp.flat), _lib.ptr(data.grads), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), fp.count,
                     float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), opt.step_count,
                     float(config.max_grad_norm), 1.0, C.c_void_p(data.grads.data_ptr() + 4 * fp.count),
-                    _lib.ptr(data.loss_acc), loss_scale, stream), 'adam')
+                    _lib.ptr(data.loss_acc), loss_scale, None, 0, stream), 'adam')
         epochs_run += 1
         if config.target_kl is not None:
             # approx_kl of the LAST minibatch of this epoch (clean_pufferl.py:256-258) — needs a sync

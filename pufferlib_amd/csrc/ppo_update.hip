@@ -17,6 +17,8 @@
 //                              which is what the two weight-gradient contractions over batch rows need as B operand
 //   dW1^T[k][u] += X[row][k]^T . dh[row][u]      A from the LDS X tile
 //   dW2v^T[u][o] += hidden[row][u]^T . dout[row][o]   A from the LDS hidden tile, B from the LDS dout tile
+#include <cmath>
+
 #include "common.hpp"
 #include "mlp_tile.hpp"
 
@@ -24,16 +26,39 @@ namespace pfa {
 
 constexpr int kGradThreads = 256;
 constexpr int kGradWaves = kGradThreads / 64;
+constexpr int kTPI = 2;       // 16-row tiles processed together by one wavefront (independent MFMA chains)
 constexpr int kNumStats = 8;  // 6 used: pg, v, entropy, old_kl, kl, clipfrac
 
+// LDS map of kernel A (floats).  Per wave and per in-flight tile: X tile, hidden tile, dout tile.  Shared by the
+// waves: lane-major MFMA fragment tables so every fragment read is one conflict-free ds_read_b128:
+//   w1t[m][lane][KS(+4)] A frags of the forward GEMM: W1[16m + c][4kk + g]
+//   b1t[m][lane][4] accumulator init   w2t[m][lane][4] A frags of the heads   w2bt[m][lane][4] B frags of dh = dout.W2v
 template <int DP>
 struct GradLds {
     static constexpr int XS = XTile<DP>::XS;
-    static constexpr int HS = kHidden + 4;  // hidden tile row stride (16B aligned rows, conflict-free reads)
-    static constexpr int DS = 20;           // dout tile row stride
-    static constexpr int kWaveFloats = 16 * XS + 16 * HS + 16 * DS;
-    static constexpr int kTableFloats = 3 * kMT * 4 * 64;  // b1, w2 (A frags), w2b (B frags), lane-major
-    static constexpr int kFloats = kGradWaves * kWaveFloats + kTableFloats;
+    static constexpr int KS = DP / 4;
+    static constexpr int W1S = KS + 4;        // lane stride of w1t (16 B aligned, spreads 16 lanes over all banks)
+    static constexpr int HH = kHidden / 2;    // hidden columns per half
+    static constexpr int HS = HH + 4;         // row stride of the half hidden tile (16 B aligned, conflict-free reads)
+    static constexpr int DS = 20;             // dout tile row stride
+    static constexpr int kTileFloats = 16 * XS + 16 * HS + 16 * DS;
+    static constexpr int kWaveFloats = kTPI * kTileFloats;
+    static constexpr int kW1Floats = kMT * 64 * W1S;
+    static constexpr int kTabFloats = kMT * 64 * 4;
+    static constexpr int kFloats = kGradWaves * kWaveFloats + kW1Floats + 3 * kTabFloats;
+};
+
+// "Native" layout of one workgroup partial: gradients in MFMA C-fragment order (conflict-free LDS reduction and
+// coalesced global traffic); ppo_reduce_kernel undoes the permutation once.
+template <int DP>
+struct NativeLayout {
+    static constexpr int KT = DP / 16;
+    static constexpr int kDw1 = 0;                          // ((kt*8+m)*4+r)*64 + lane -> W1[16m+c][16kt+4g+r]
+    static constexpr int kDw2 = kDw1 + KT * kMT * 4 * 64;   // ((m*4+r)*64 + lane)      -> W2v[o=c][16m+4g+r]
+    static constexpr int kDb1 = kDw2 + kMT * 4 * 64;        // u
+    static constexpr int kDb2 = kDb1 + kHidden;             // o (16)
+    static constexpr int kStats = kDb2 + kOut;              // 8
+    static constexpr int kCount = kStats + kNumStats;
 };
 
 struct RowMap {  // minibatch row q -> flat env-major experience row (clean_pufferl.py:455-457)
@@ -44,34 +69,140 @@ struct RowMap {  // minibatch row q -> flat env-major experience row (clean_puff
     }
 };
 
+__device__ __forceinline__ void wave_lds_fence() {
+    // LDS is in-order per wave; this only stops the compiler from moving LDS accesses across the hand-off
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct RowScalars {
+    int action;
+    float old_logprob, old_value, adv, ret, weight;  // weight 0 for rows of a padding tile
+};
+
+struct LossOut {
+    f32x4 dout;
+    float pg, v_loss, ent, neg_logratio, kl, clipped;
+};
+
+// PPO loss for the rows of one tile (clean_pufferl.py:202-238) and d(loss)/d(out^T fragment).
+__device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScalars &rs, int a, int g, const pfa_ppo_hparams &hp,
+                                                 float adv_mean, float adv_den, float inv_rows) {
+    // log-softmax over the A logits of row c, spread over lane groups: reduce with xor 16 / 32
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * g + r < a) lmax = fmaxf(lmax, out[r]);
+    lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
+    lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
+    float se = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (4 * g + r < a) se += expf(out[r] - lmax);
+    se += __shfl_xor(se, 16, 64);
+    se += __shfl_xor(se, 32, 64);
+    const float lse = lmax + logf(se);
+    float nl[4], p[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * g + r;
+        nl[r] = out[r] - lse;
+        p[r] = o < a ? expf(nl[r]) : 0.0f;
+        if (o < a) ent -= nl[r] * p[r];
+        if (o == rs.action) new_logprob = nl[r];
+        if (o == a) new_value = out[r];
+    }
+    ent += __shfl_xor(ent, 16, 64);
+    ent += __shfl_xor(ent, 32, 64);
+    new_logprob += __shfl_xor(new_logprob, 16, 64);
+    new_logprob += __shfl_xor(new_logprob, 32, 64);
+    new_value += __shfl_xor(new_value, 16, 64);
+    new_value += __shfl_xor(new_value, 32, 64);
+
+    const float logratio = new_logprob - rs.old_logprob;
+    const float ratio = expf(logratio);
+    const float adv = hp.norm_adv ? (rs.adv - adv_mean) / adv_den : rs.adv;
+    const float lo = 1.0f - hp.clip_coef, hi = 1.0f + hp.clip_coef;
+    const float pg1 = -adv * ratio;
+    const float pg2 = -adv * fminf(fmaxf(ratio, lo), hi);
+    const bool inside = ratio >= lo && ratio <= hi;
+    // d pg / d ratio under torch.max's tie rule (grad/2 to each side) and clamp's pass-through inside [lo, hi]
+    float dpg_dratio;
+    if (pg1 > pg2) dpg_dratio = -adv;
+    else if (pg1 < pg2) dpg_dratio = inside ? -adv : 0.0f;
+    else dpg_dratio = inside ? -adv : -0.5f * adv;
+    const float scale = inv_rows * rs.weight;
+    const float g_lp = dpg_dratio * ratio * scale;  // d loss / d new_logprob
+
+    float v_loss, dv;
+    if (hp.clip_vloss) {
+        const float du = new_value - rs.ret;
+        const float vl_u = du * du;
+        const float delta = new_value - rs.old_value;
+        const float v_clipped = rs.old_value + fminf(fmaxf(delta, -hp.vf_clip_coef), hp.vf_clip_coef);
+        const float dc = v_clipped - rs.ret;
+        const float vl_c = dc * dc;
+        const bool vin = delta >= -hp.vf_clip_coef && delta <= hp.vf_clip_coef;
+        v_loss = 0.5f * fmaxf(vl_u, vl_c);
+        const float gu = 2.0f * du, gc = vin ? 2.0f * dc : 0.0f;
+        const float sel = vl_u > vl_c ? gu : (vl_u < vl_c ? gc : 0.5f * (gu + gc));
+        dv = 0.5f * sel;
+    } else {
+        const float du = new_value - rs.ret;
+        v_loss = 0.5f * du * du;
+        dv = du;
+    }
+    dv *= hp.vf_coef * scale;
+
+    LossOut lo_;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = 4 * g + r;
+        float d = 0.0f;
+        if (o < a) {
+            // d new_logprob/d logit_o = [o==action] - p_o ; d entropy/d logit_o = -p_o (nl_o + H)
+            d = g_lp * ((o == rs.action ? 1.0f : 0.0f) - p[r]) + hp.ent_coef * scale * p[r] * (nl[r] + ent);
+        } else if (o == a) {
+            d = dv;
+        }
+        lo_.dout[r] = d;
+    }
+    lo_.pg = fmaxf(pg1, pg2) * rs.weight;
+    lo_.v_loss = v_loss * rs.weight;
+    lo_.ent = ent * rs.weight;
+    lo_.neg_logratio = -logratio * rs.weight;
+    lo_.kl = ((ratio - 1.0f) - logratio) * rs.weight;
+    lo_.clipped = (fabsf(ratio - 1.0f) > hp.clip_coef ? 1.0f : 0.0f) * rs.weight;
+    return lo_;
+}
+
 template <int DP>
 __global__ void __launch_bounds__(kGradThreads, 1)
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, pfa_ppo_hparams hp,
                         const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
     using L = GradLds<DP>;
-    constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KT = DP / 16;
+    using NL = NativeLayout<DP>;
+    constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KT = DP / 16, KS = DP / 4, V = DP / 4, W1S = L::W1S;
+    constexpr int NLD = (16 * V + 63) / 64;  // float4 loads per lane per tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
-    float *xs = lds + wv * L::kWaveFloats;
-    float *hs = xs + 16 * XS;
-    float *ds = hs + 16 * HS;
-    float *tab_b1 = lds + kGradWaves * L::kWaveFloats;
-    float *tab_w2 = tab_b1 + kMT * 4 * 64;
-    float *tab_w2b = tab_w2 + kMT * 4 * 64;
+    float *wave_lds = lds + wv * L::kWaveFloats;
+    float *w1t = lds + kGradWaves * L::kWaveFloats;
+    float *b1t = w1t + L::kW1Floats;
+    float *w2t = b1t + L::kTabFloats;
+    float *w2bt = w2t + L::kTabFloats;
     const MlpOffsets off = mlp_offsets(DP, a);
 
-    // fragment tables shared by the 4 waves (lane-major so every read is lds[idx*64 + lane])
-    for (int i = threadIdx.x; i < kMT * 4 * 64; i += kGradThreads) {
-        const int ln = i & 63, idx = i >> 6, m = idx >> 2, r = idx & 3, cc = ln & 15, gg = ln >> 4;
-        tab_b1[i] = params[off.b1 + 16 * m + 4 * gg + r];
-        tab_w2[i] = w2v_at(params, off, a, cc, 16 * m + 4 * gg + r);   // A[i=o=cc][k-slot gg] for u = 16m+4gg+r
-        tab_w2b[i] = w2v_at(params, off, a, 4 * gg + r, 16 * m + cc);   // B[k-slot gg][j=u=16m+cc] for o = 4gg+r
+    for (int i = threadIdx.x; i < kMT * 64 * KS; i += kGradThreads) {
+        const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64), cc = ln & 15, gg = ln >> 4;
+        w1t[(m * 64 + ln) * W1S + kk] = params[off.w1 + (16 * m + cc) * DP + 4 * kk + gg];
     }
-    float w1f[kMT][DP / 4];
-#pragma unroll
-    for (int m = 0; m < kMT; ++m)
-#pragma unroll
-        for (int kk = 0; kk < DP / 4; ++kk) w1f[m][kk] = params[off.w1 + (16 * m + c) * DP + 4 * kk + g];
+    for (int i = threadIdx.x; i < kMT * 64 * 4; i += kGradThreads) {
+        const int r = i & 3, ln = (i >> 2) & 63, m = i >> 8, cc = ln & 15, gg = ln >> 4;
+        b1t[i] = params[off.b1 + 16 * m + 4 * gg + r];
+        w2t[i] = w2v_at(params, off, a, cc, 16 * m + 4 * gg + r);    // A[i=o=cc][k-slot gg] for u = 16m+4gg+r
+        w2bt[i] = w2v_at(params, off, a, 4 * gg + r, 16 * m + cc);   // B[k-slot gg][j=u=16m+cc] for o = 4gg+r
+    }
     float bo[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) bo[r] = b2v_at(params, off, a, 4 * g + r);
@@ -104,201 +235,193 @@ __global__ void __launch_bounds__(kGradThreads, 1)
     for (int r = 0; r < 4; ++r) db2[r] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 6; ++i) stats[i] = 0.0f;
-    __syncthreads();
 
     const long long tiles = mb_rows / 16;
     const long long wave_global = (long long)blockIdx.x * kGradWaves + wv;
     const long long wave_count = (long long)gridDim.x * kGradWaves;
-    for (long long tile = wave_global; tile < tiles; tile += wave_count) {
-        // ---- stage X tile (16 rows of DP floats) ------------------------------------------------
-        {
-            constexpr int V = DP / 4;
+
+    // register prefetch of the next iteration's tiles (HBM latency hides under the current tiles' MFMAs)
+    float4 xpre[kTPI][NLD];
+    auto prefetch = [&](long long first_tile) {
 #pragma unroll
-            for (int j = 0; j < (16 * V + 63) / 64; ++j) {
+        for (int t = 0; t < kTPI; ++t) {
+            const long long tile = first_tile + t;
+            const bool ok = tile < tiles;
+#pragma unroll
+            for (int j = 0; j < NLD; ++j) {
                 const int idx = lane + 64 * j;
-                if (idx < 16 * V) {
+                xpre[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && idx < 16 * V) {
                     const int r = idx / V, c4 = idx - r * V;
-                    const long long fr = map.flat(tile * 16 + r);
-                    const float4 v = *reinterpret_cast<const float4 *>(ex.obs + fr * DP + 4 * c4);
-                    float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
-                    d[0] = make_float2(v.x, v.y);
-                    d[1] = make_float2(v.z, v.w);
+                    xpre[t][j] = *reinterpret_cast<const float4 *>(ex.obs + map.flat(tile * 16 + r) * DP + 4 * c4);
                 }
             }
         }
-        // per-row scalars (lane c <-> row c of the tile, replicated over the 4 lane groups)
-        const long long frow = map.flat(tile * 16 + c);
-        const int action = ex.actions[frow];
-        const float old_logprob = ex.logprobs[frow];
-        const float old_value = ex.values[frow];
-        const float adv_raw = ex.advantages[frow];
-        const float ret = ex.returns[frow];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+    };
+    prefetch(wave_global * kTPI);
+    __syncthreads();  // fragment tables ready
 
-        // ---- forward: hidden^T then out^T ----------------------------------------------------------
-        f32x4 h[kMT];
+    for (long long base = wave_global * kTPI; base < tiles; base += wave_count * kTPI) {
+        RowScalars rs[kTPI];
 #pragma unroll
-        for (int m = 0; m < kMT; ++m)
-            h[m] = f32x4{tab_b1[(4 * m + 0) * 64 + lane], tab_b1[(4 * m + 1) * 64 + lane], tab_b1[(4 * m + 2) * 64 + lane],
-                         tab_b1[(4 * m + 3) * 64 + lane]};
+        for (int t = 0; t < kTPI; ++t) {
+            float *xs = wave_lds + t * L::kTileFloats;
 #pragma unroll
-        for (int kk = 0; kk < DP / 4; ++kk) {
-            const float b = xs[c * XS + 4 * kk + g];
-#pragma unroll
-            for (int m = 0; m < kMT; ++m) h[m] = mfma16(w1f[m][kk], b, h[m]);
-        }
-        f32x4 o0 = f32x4{bo[0], bo[1], bo[2], bo[3]}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.0f);
-            // hidden tile, row-major [row][u], for the relu mask and the dW2v contraction
-            *reinterpret_cast<f32x4 *>(hs + c * HS + 16 * m + 4 * g) = h[m];
-        }
-#pragma unroll
-        for (int m = 0; m < kMT; m += 2) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                o0 = mfma16(tab_w2[(4 * m + r) * 64 + lane], h[m][r], o0);
-                o1 = mfma16(tab_w2[(4 * (m + 1) + r) * 64 + lane], h[m + 1][r], o1);
+            for (int j = 0; j < NLD; ++j) {
+                const int idx = lane + 64 * j;
+                if (idx < 16 * V) {
+                    const int r = idx / V, c4 = idx - r * V;
+                    float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
+                    d[0] = make_float2(xpre[t][j].x, xpre[t][j].y);
+                    d[1] = make_float2(xpre[t][j].z, xpre[t][j].w);
+                }
+            }
+            // per-row scalars (lane c <-> row c, replicated over the 4 lane groups); consumed after the forward pass
+            rs[t] = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (base + t < tiles) {
+                const long long fr = map.flat((base + t) * 16 + c);
+                rs[t] = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
             }
         }
-        const f32x4 out = o0 + o1;  // out^T[o = 4g + r][row = c]
+        prefetch(base + wave_count * kTPI);
+        wave_lds_fence();
+
+        // ---- forward: hidden^T (kTPI x 8 independent accumulator chains) then out^T ---------------------------
+        f32x4 h[kTPI][kMT];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(b1t + (m * 64 + lane) * 4);
+#pragma unroll
+            for (int t = 0; t < kTPI; ++t) h[t][m] = b;
+        }
+#pragma unroll
+        for (int k4 = 0; k4 < KS / 4; ++k4) {
+            float xb[kTPI][4];
+#pragma unroll
+            for (int t = 0; t < kTPI; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xb[t][j] = wave_lds[t * L::kTileFloats + c * XS + 4 * (4 * k4 + j) + g];
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) {
+                const f32x4 wq = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + 4 * k4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < kTPI; ++t) h[t][m] = mfma16(wq[j], xb[t][j], h[t][m]);
+            }
+        }
+        f32x4 out[kTPI];
+        {
+            f32x4 o0[kTPI], o1[kTPI];
+#pragma unroll
+            for (int t = 0; t < kTPI; ++t) {
+                o0[t] = f32x4{bo[0], bo[1], bo[2], bo[3]};
+                o1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int t = 0; t < kTPI; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[t][m][r] = fmaxf(h[t][m][r], 0.0f);
+                }
+#pragma unroll
+            for (int m = 0; m < kMT; m += 2) {
+                const f32x4 wa = *reinterpret_cast<const f32x4 *>(w2t + (m * 64 + lane) * 4);
+                const f32x4 wb = *reinterpret_cast<const f32x4 *>(w2t + ((m + 1) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < kTPI; ++t) {
+                        o0[t] = mfma16(wa[r], h[t][m][r], o0[t]);
+                        o1[t] = mfma16(wb[r], h[t][m + 1][r], o1[t]);
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < kTPI; ++t) out[t] = o0[t] + o1[t];  // out^T[o = 4g + r][row = c]
+        }
 
         // ---- loss and d(loss)/d(out) -----------------------------------------------------------------
-        // log-softmax over the A logits of row c, spread over lane groups: reduce with xor 16 / 32.
-        float lmax = -INFINITY;
+        f32x4 dout[kTPI];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * g + r < a) lmax = fmaxf(lmax, out[r]);
-        lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
-        lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
-        float se = 0.0f;
+        for (int t = 0; t < kTPI; ++t) {
+            const LossOut lo = ppo_loss_tile(out[t], rs[t], a, g, hp, adv_mean, adv_den, inv_rows);
+            dout[t] = lo.dout;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (4 * g + r < a) se += expf(out[r] - lmax);
-        se += __shfl_xor(se, 16, 64);
-        se += __shfl_xor(se, 32, 64);
-        const float lse = lmax + logf(se);
-        float nl[4], p[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 4 * g + r;
-            nl[r] = out[r] - lse;
-            p[r] = o < a ? expf(nl[r]) : 0.0f;
-            if (o < a) ent -= nl[r] * p[r];
-            if (o == action) new_logprob = nl[r];
-            if (o == a) new_value = out[r];
-        }
-        ent += __shfl_xor(ent, 16, 64);
-        ent += __shfl_xor(ent, 32, 64);
-        new_logprob += __shfl_xor(new_logprob, 16, 64);
-        new_logprob += __shfl_xor(new_logprob, 32, 64);
-        new_value += __shfl_xor(new_value, 16, 64);
-        new_value += __shfl_xor(new_value, 32, 64);
-
-        const float logratio = new_logprob - old_logprob;
-        const float ratio = expf(logratio);
-        const float adv = hp.norm_adv ? (adv_raw - adv_mean) / adv_den : adv_raw;
-        const float lo = 1.0f - hp.clip_coef, hi = 1.0f + hp.clip_coef;
-        const float pg1 = -adv * ratio;
-        const float pg2 = -adv * fminf(fmaxf(ratio, lo), hi);
-        const float pg = fmaxf(pg1, pg2);
-        const bool inside = ratio >= lo && ratio <= hi;
-        // d pg / d ratio under torch.max tie rule (grad/2 to each side) and clamp's pass-through inside [lo, hi]
-        float dpg_dratio;
-        if (pg1 > pg2) dpg_dratio = -adv;
-        else if (pg1 < pg2) dpg_dratio = inside ? -adv : 0.0f;
-        else dpg_dratio = inside ? -adv : -0.5f * adv;
-        const float g_lp = dpg_dratio * ratio * inv_rows;  // d loss / d new_logprob
-
-        float v_loss, dv;
-        if (hp.clip_vloss) {
-            const float du = new_value - ret;
-            const float vl_u = du * du;
-            const float delta = new_value - old_value;
-            const float v_clipped = old_value + fminf(fmaxf(delta, -hp.vf_clip_coef), hp.vf_clip_coef);
-            const float dc = v_clipped - ret;
-            const float vl_c = dc * dc;
-            const bool vin = delta >= -hp.vf_clip_coef && delta <= hp.vf_clip_coef;
-            v_loss = 0.5f * fmaxf(vl_u, vl_c);
-            const float gu = 2.0f * du, gc = vin ? 2.0f * dc : 0.0f;
-            const float sel = vl_u > vl_c ? gu : (vl_u < vl_c ? gc : 0.5f * (gu + gc));
-            dv = 0.5f * sel;
-        } else {
-            const float du = new_value - ret;
-            v_loss = 0.5f * du * du;
-            dv = du;
-        }
-        dv *= hp.vf_coef * inv_rows;
-
-        f32x4 dout;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int o = 4 * g + r;
-            float d = 0.0f;
-            if (o < a) {
-                // d new_logprob/d logit_o = [o==action] - p_o ; d entropy/d logit_o = -p_o (nl_o + H)
-                d = g_lp * ((o == action ? 1.0f : 0.0f) - p[r]) + hp.ent_coef * inv_rows * p[r] * (nl[r] + ent);
-            } else if (o == a) {
-                d = dv;
+            for (int r = 0; r < 4; ++r) db2[r] += lo.dout[r];
+            if (g == 0) {  // one lane group owns the per-row scalars
+                stats[0] += lo.pg;
+                stats[1] += lo.v_loss;
+                stats[2] += lo.ent;
+                stats[3] += lo.neg_logratio;
+                stats[4] += lo.kl;
+                stats[5] += lo.clipped;
             }
-            dout[r] = d;
-            db2[r] += d;
+            *reinterpret_cast<f32x4 *>(wave_lds + t * L::kTileFloats + 16 * XS + 16 * HS + c * DS + 4 * g) = lo.dout;
         }
-        if (g == 0) {  // one lane group owns the per-row scalars
-            stats[0] += pg;
-            stats[1] += v_loss;
-            stats[2] += ent;
-            stats[3] += -logratio;
-            stats[4] += (ratio - 1.0f) - logratio;
-            stats[5] += fabsf(ratio - 1.0f) > hp.clip_coef ? 1.0f : 0.0f;
-        }
-        *reinterpret_cast<f32x4 *>(ds + c * DS + 4 * g) = dout;  // dout[row=c][o=4g..4g+3]
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_fence();
 
         // ---- backward -----------------------------------------------------------------------------------
-        // B fragments of dout[row][o] (k-slot g <-> row 4g+r, j = o = c) for the dW2v contraction
-        float dfrag[4];
+        float dfrag[kTPI][4];   // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c) for the dW2v contraction
+        float xa[kTPI][KT][4];  // A frags of X^T (i = k = 16kt + c, k-slot g <-> row 4g+r) for the dW1 contraction
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dfrag[r] = ds[(4 * g + r) * DS + c];
-        // A fragments of X^T (i = k = 16kt + c, k-slot g <-> row 4g+r) for the dW1 contraction
-        float xa[KT][4];
+        for (int t = 0; t < kTPI; ++t) {
+            const float *xs = wave_lds + t * L::kTileFloats;
+            const float *ds = xs + 16 * XS + 16 * HS;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
-
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-            // dh[row = 4g+r][u = 16m + c] = sum_o dout[row][o] W2v[o][u]; A = dout^T C-fragment (A = C^T)
-            f32x4 dh = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dh = mfma16(dout[r], tab_w2b[(4 * m + r) * 64 + lane], dh);
-            float hrow[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                hrow[r] = hs[(4 * g + r) * HS + 16 * m + c];  // hidden[row = 4g+r][u = 16m+c]
-                dh[r] = hrow[r] > 0.0f ? dh[r] : 0.0f;       // relu'
-                db1[m] += dh[r];
-            }
+            for (int r = 0; r < 4; ++r) dfrag[t][r] = ds[(4 * g + r) * DS + c];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc_dw1[kt][m] = mfma16(xa[kt][r], dh[r], acc_dw1[kt][m]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc_dw2[m] = mfma16(hrow[r], dfrag[r], acc_dw2[m]);
+                for (int r = 0; r < 4; ++r) xa[t][kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            // half of the hidden tile, row-major [row][u - 64*half], for the relu mask and the dW2v contraction
+#pragma unroll
+            for (int t = 0; t < kTPI; ++t)
+#pragma unroll
+                for (int mm = 0; mm < kMT / 2; ++mm)
+                    *reinterpret_cast<f32x4 *>(wave_lds + t * L::kTileFloats + 16 * XS + c * HS + 16 * mm + 4 * g) =
+                        h[t][half * (kMT / 2) + mm];
+            wave_lds_fence();
+#pragma unroll
+            for (int mm = 0; mm < kMT / 2; ++mm) {
+                const int m = half * (kMT / 2) + mm;
+                // dh[row = 4g+r][u = 16m + c] = sum_o dout[row][o] W2v[o][u]; A = dout^T C-fragment (A = C^T)
+                const f32x4 wb = *reinterpret_cast<const f32x4 *>(w2bt + (m * 64 + lane) * 4);
+                f32x4 dh[kTPI];
+                float hrow[kTPI][4];
+#pragma unroll
+                for (int t = 0; t < kTPI; ++t) dh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < kTPI; ++t) dh[t] = mfma16(dout[t][r], wb[r], dh[t]);
+#pragma unroll
+                for (int t = 0; t < kTPI; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        hrow[t][r] = wave_lds[t * L::kTileFloats + 16 * XS + (4 * g + r) * HS + 16 * mm + c];
+                        dh[t][r] = hrow[t][r] > 0.0f ? dh[t][r] : 0.0f;  // relu'
+                        db1[m] += dh[t][r];
+                    }
+#pragma unroll
+                for (int t = 0; t < kTPI; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt) acc_dw1[kt][m] = mfma16(xa[t][kt][r], dh[t][r], acc_dw1[kt][m]);
+                        acc_dw2[m] = mfma16(hrow[t][r], dfrag[t][r], acc_dw2[m]);
+                    }
+                }
+            }
+            wave_lds_fence();
+        }
     }
 
-    // ---- reduce the 4 waves' accumulators into one workgroup partial, in fixed wave order -------------------
+    // ---- reduce the waves' accumulators into one workgroup partial (native order, conflict-free), fixed order -----
     __syncthreads();
-    float *red = lds;  // reuse the tile regions (tables are no longer needed either)
-    const int PP = off.count + kNumStats;
 #pragma unroll
     for (int m = 0; m < kMT; ++m) {
         db1[m] += __shfl_xor(db1[m], 16, 64);
@@ -313,8 +436,9 @@ __global__ void __launch_bounds__(kGradThreads, 1)
 #pragma unroll
         for (int s = 1; s < 16; s <<= 1) stats[i] += __shfl_xor(stats[i], s, 64);
 
-    for (int turn = 0; turn < kGradWaves; ++turn) {
-        if (wv == turn) {
+    float *red = lds + (wv & 1) * NL::kCount;  // buffer 0: even waves, buffer 1: odd waves
+    for (int turn = 0; turn < kGradWaves / 2; ++turn) {
+        if ((wv >> 1) == turn) {
             const bool first = turn == 0;
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
@@ -322,66 +446,98 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                 for (int m = 0; m < kMT; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int idx = off.w1 + (16 * m + c) * DP + 16 * kt + 4 * g + r;
+                        const int idx = NL::kDw1 + ((kt * kMT + m) * 4 + r) * 64 + lane;
                         red[idx] = (first ? 0.0f : red[idx]) + acc_dw1[kt][m][r];
                     }
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int u = 16 * m + 4 * g + r;
-                    if (c <= a) {
-                        const int idx = c < a ? off.w2 + c * kHidden + u : off.wv + u;
-                        red[idx] = (first ? 0.0f : red[idx]) + acc_dw2[m][r];
-                    }
+                    const int idx = NL::kDw2 + (m * 4 + r) * 64 + lane;
+                    red[idx] = (first ? 0.0f : red[idx]) + acc_dw2[m][r];
                 }
             if (g == 0) {
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) {
-                    const int idx = off.b1 + 16 * m + c;
+                    const int idx = NL::kDb1 + 16 * m + c;
                     red[idx] = (first ? 0.0f : red[idx]) + db1[m];
                 }
             }
             if (c == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int o = 4 * g + r;
-                    if (o <= a) {
-                        const int idx = o < a ? off.b2 + o : off.bv;
-                        red[idx] = (first ? 0.0f : red[idx]) + db2[r];
-                    }
+                    const int idx = NL::kDb2 + 4 * g + r;
+                    red[idx] = (first ? 0.0f : red[idx]) + db2[r];
                 }
             }
             if (lane == 0) {
 #pragma unroll
                 for (int i = 0; i < kNumStats; ++i) {
-                    const int idx = off.count + i;
+                    const int idx = NL::kStats + i;
                     red[idx] = (first ? 0.0f : red[idx]) + (i < 6 ? stats[i] : 0.0f);
                 }
             }
         }
         __syncthreads();
     }
-    float *dst = partials + (size_t)blockIdx.x * PP;
-    for (int i = threadIdx.x; i < PP; i += kGradThreads) dst[i] = red[i];
+    float *dst = partials + (size_t)blockIdx.x * NL::kCount;
+    for (int i = threadIdx.x; i < NL::kCount; i += kGradThreads) dst[i] = lds[i] + lds[NL::kCount + i];
 }
 
-// Sum of workgroup partials in a fixed order.  Block = 32 params x 8 slices.
-__global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, int nparts, int pp, float *grads) {
-    __shared__ float sh[8][33];
-    const int pl = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int p = blockIdx.x * 32 + pl;
+// Fixed-order sum of the workgroup partials (native layout) + scatter into the flat gradient layout, plus one
+// f64 partial of sum(g^2) per block for the gradient-norm clip.  Block = 64 native slots x 4 slices of the
+// partial index; 16 independent loads in flight per thread.
+template <int DP>
+__global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, int nparts, int a, float *grads,
+                                                        double *norm_partials) {
+    using NL = NativeLayout<DP>;
+    __shared__ float sh[4][64];
+    const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + ql;
     float acc = 0.0f;
-    if (p < pp)
-        for (int i = sl; i < nparts; i += 8) acc += partials[(size_t)i * pp + p];
-    sh[sl][pl] = acc;
-    __syncthreads();
-    if (sl == 0 && p < pp) {
-        float s = 0.0f;
+    if (q < NL::kCount) {
+        for (int i0 = sl; i0 < nparts; i0 += 64) {
+            float v[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += sh[i][pl];
-        grads[p] = s;
+            for (int u = 0; u < 16; ++u) {
+                const int i = i0 + 4 * u;
+                v[u] = i < nparts ? partials[(size_t)i * NL::kCount + q] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
     }
+    sh[sl][ql] = acc;
+    __syncthreads();
+    if (sl != 0) return;
+    const MlpOffsets off = mlp_offsets(DP, a);
+    float s = 0.0f;
+    int p = -1;
+    if (q < NL::kCount) {
+        s = (sh[0][ql] + sh[1][ql]) + (sh[2][ql] + sh[3][ql]);
+        if (q < NL::kDw2) {
+            const int ln = q & 63, r = (q >> 6) & 3, m = (q >> 8) & (kMT - 1), kt = q >> 11;
+            p = off.w1 + (16 * m + (ln & 15)) * DP + 16 * kt + 4 * (ln >> 4) + r;
+        } else if (q < NL::kDb1) {
+            const int t = q - NL::kDw2, ln = t & 63, r = (t >> 6) & 3, m = t >> 8;
+            const int o = ln & 15, u = 16 * m + 4 * (ln >> 4) + r;
+            if (o < a) p = off.w2 + o * kHidden + u;
+            else if (o == a) p = off.wv + u;
+        } else if (q < NL::kDb2) {
+            p = off.b1 + (q - NL::kDb1);
+        } else if (q < NL::kStats) {
+            const int o = q - NL::kDb2;
+            if (o < a) p = off.b2 + o;
+            else if (o == a) p = off.bv;
+        } else {
+            p = off.count + (q - NL::kStats);
+        }
+        if (p >= 0) grads[p] = s;
+    }
+    double sq = (p >= 0 && p < off.count) ? (double)s * (double)s : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if (ql == 0) norm_partials[blockIdx.x] = sq;
 }
 
 // Per-minibatch advantage sums (f64).  grid = (chunks, nmb); deterministic two-stage reduction.
@@ -427,36 +583,48 @@ __global__ void adv_stats_final_kernel(const double *partial, int nmb, double *s
 }
 
 // clip_grad_norm_ + torch.optim.Adam (single-tensor path) on the flat parameter vector.
-constexpr int kAdamThreads = 1024;
+// Every workgroup recomputes the global gradient norm from the (L2-resident, ~38 KB) gradient in the same fixed
+// order — deterministic and no grid-wide hand-off — then updates its own 256-element slice.
+constexpr int kAdamThreads = 256;
 __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, const float *grads, float *exp_avg,
-                                                                float *exp_avg_sq, long long count, float lr, float beta1,
-                                                                float beta2, float eps, long long step, float max_grad_norm,
-                                                                float grad_scale, const float *loss_sums, float *losses,
-                                                                float loss_scale) {
-    __shared__ double sh[kAdamThreads];
+                                                                float *exp_avg_sq, long long count, float neg_step_size,
+                                                                float bc2_sqrt, float beta1, float beta2, float eps,
+                                                                float max_grad_norm, float grad_scale, const float *loss_sums,
+                                                                float *losses, float loss_scale, const double *norm_partials,
+                                                                int n_norm_partials) {
+    __shared__ double sh[kAdamThreads / 64];
     double ss = 0.0;
-    for (long long i = threadIdx.x; i < count; i += kAdamThreads) {
-        const float gi = grads[i] * grad_scale;
-        ss += (double)gi * (double)gi;
+    if (norm_partials) {  // sum(g^2) pieces left by ppo_reduce_kernel (single rank: no all-reduce in between)
+        for (int i = threadIdx.x; i < n_norm_partials; i += kAdamThreads) ss += norm_partials[i];
+        ss *= (double)grad_scale * (double)grad_scale;
+    } else {
+        for (long long base = threadIdx.x; base < count; base += kAdamThreads * 8) {
+            float gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long i = base + (long long)u * kAdamThreads;
+                gv[u] = i < count ? grads[i] * grad_scale : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) ss += (double)gv[u] * (double)gv[u];
+        }
     }
-    sh[threadIdx.x] = ss;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if (lane_id() == 0) sh[wave_id()] = ss;
     __syncthreads();
-    for (int s = kAdamThreads / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
-        __syncthreads();
-    }
-    const float total_norm = (float)sqrt(sh[0]);
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kAdamThreads / 64; ++w) tot += sh[w];
+    const float total_norm = (float)sqrt(tot);
     float clip = 1.0f;
     if (max_grad_norm > 0.0f) {
         clip = max_grad_norm / (total_norm + 1e-6f);
         clip = clip > 1.0f ? 1.0f : clip;
     }
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float neg_step_size = (float)(-(double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
-    for (long long i = threadIdx.x; i < count; i += kAdamThreads) {
+    const long long i = (long long)blockIdx.x * kAdamThreads + threadIdx.x;
+    if (i < count) {
         const float gi = grads[i] * grad_scale * clip;
         float m = exp_avg[i], v = exp_avg_sq[i];
         m = m + w1 * (gi - m);               // exp_avg.lerp_(grad, 1 - beta1)
@@ -466,7 +634,7 @@ __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, 
         exp_avg[i] = m;
         exp_avg_sq[i] = v;
     }
-    if (loss_sums && losses && threadIdx.x < 6) losses[threadIdx.x] += loss_sums[threadIdx.x] * loss_scale;
+    if (blockIdx.x == 0 && loss_sums && losses && threadIdx.x < 6) losses[threadIdx.x] += loss_sums[threadIdx.x] * loss_scale;
 }
 
 static int check_update_args(const pfa_experience *ex, int64_t batch_rows, const pfa_mlp_dims *dims,
@@ -480,9 +648,14 @@ static int check_update_args(const pfa_experience *ex, int64_t batch_rows, const
     return 0;
 }
 
+static size_t native_count(int dp) { return (size_t)(dp / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats; }
+static double *norm_partials_of(void *workspace, int dp) {  // after the gradient partials
+    return (double *)((char *)workspace + align_up((size_t)256 * native_count(dp) * sizeof(float), 256));
+}
+
 static int grad_grid(int64_t mb_rows) {
     const int64_t tiles = mb_rows / 16;
-    const int64_t wgs = (tiles + kGradWaves - 1) / kGradWaves;
+    const int64_t wgs = (tiles + kGradWaves * kTPI - 1) / (kGradWaves * kTPI);
     return (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
 }
 
@@ -492,11 +665,12 @@ using namespace pfa;
 
 extern "C" size_t pfa_ppo_workspace_bytes(const pfa_mlp_dims *dims, int64_t batch_rows, const pfa_ppo_hparams *hp) {
     if (!dims || !hp || hp->num_minibatches < 1) return 0;
-    const int pp = mlp_offsets(dims->obs_stride, dims->num_actions).count + kNumStats;
     (void)batch_rows;
-    const size_t partials = align_up((size_t)256 * pp * sizeof(float), 256);
+    const size_t native = (size_t)(dims->obs_stride / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats;
+    const size_t partials = align_up((size_t)256 * native * sizeof(float), 256);
     const size_t advp = align_up((size_t)hp->num_minibatches * kAdvChunks * 2 * sizeof(double), 256);
-    return partials + advp;
+    const size_t normp = align_up(((native + 63) / 64) * sizeof(double), 256);
+    return partials + (advp > normp ? advp : normp);
 }
 
 extern "C" int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_ppo_hparams *hp, double *stats,
@@ -531,15 +705,14 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     const int64_t mbs = batch_rows / hp->num_minibatches;
     PFA_REQUIRE(mbs % 16 == 0, "ppo.grad: minibatch_size must be a multiple of 16 (got %lld)", (long long)mbs);
     PFA_REQUIRE(global_mb_rows >= mbs, "ppo.grad: global_mb_rows < local minibatch rows");
-    const int pp = mlp_offsets(dims->obs_stride, dims->num_actions).count + kNumStats;
     const int grid = grad_grid(mbs);
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
 #define PFA_LAUNCH_GRAD(DPV)                                                                                               \
     {                                                                                                                      \
         constexpr size_t lds_bytes = (size_t)GradLds<DPV>::kFloats * sizeof(float);                                        \
-        static_assert((size_t)(kHidden * DPV + kHidden + 16 * kHidden + 16 + kNumStats) * sizeof(float) <= lds_bytes,       \
-                      "reduction buffer must fit in the tile area");                                                      \
+        static_assert((size_t)2 * NativeLayout<DPV>::kCount * sizeof(float) <= lds_bytes,                                   \
+                      "the two reduction buffers must fit in the tile/table area");                                       \
         static bool attr_set = false;                                                                                      \
         if (!attr_set) {                                                                                                   \
             PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV>,                                      \
@@ -560,20 +733,57 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
 #undef PFA_LAUNCH_GRAD
     PFA_LAUNCH_CHECK();
     ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
-    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((pp + 31) / 32), dim3(256), 0, (hipStream_t)stream, partials, grid, pp, grads);
+    double *normp = norm_partials_of(workspace, dims->obs_stride);
+    switch (dims->obs_stride) {
+        case 16: hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3((NativeLayout<16>::kCount + 63) / 64), dim3(256), 0,
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+        case 32: hipLaunchKernelGGL(ppo_reduce_kernel<32>, dim3((NativeLayout<32>::kCount + 63) / 64), dim3(256), 0,
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+        default: hipLaunchKernelGGL(ppo_reduce_kernel<64>, dim3((NativeLayout<64>::kCount + 63) / 64), dim3(256), 0,
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+    }
     PFA_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, float lr,
                                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, float grad_scale,
-                                  const float *loss_sums, float *losses, float loss_scale, pfa_stream_t stream) {
+                                  const float *loss_sums, float *losses, float loss_scale, const double *norm_partials,
+                                  int32_t n_norm_partials, pfa_stream_t stream) {
     PFA_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam: null buffer");
     PFA_REQUIRE(count >= 1 && step >= 1, "adam: count and step must be >= 1");
+    // torch.optim.Adam (single tensor): bias corrections and step size are python floats (f64)
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    const float neg_step_size = (float)(-(double)lr / bc1);
+    const float bc2_sqrt = (float)std::sqrt(bc2);
     ScopedKernelTimer timer("adam_clip", (hipStream_t)stream);
-    hipLaunchKernelGGL(adam_clip_kernel, dim3(1), dim3(kAdamThreads), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                       (long long)count, lr, beta1, beta2, eps, (long long)step, max_grad_norm, grad_scale, loss_sums, losses,
-                       loss_scale);
+    hipLaunchKernelGGL(adam_clip_kernel, dim3((unsigned)((count + kAdamThreads - 1) / kAdamThreads)), dim3(kAdamThreads), 0,
+                       (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long long)count, neg_step_size, bc2_sqrt, beta1,
+                       beta2, eps, max_grad_norm, grad_scale, loss_sums, losses, loss_scale, norm_partials, (int)n_norm_partials);
     PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
+                                 const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
+                                 float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
+                                 float max_grad_norm, int32_t update_epochs, float *losses, void *workspace,
+                                 pfa_stream_t stream) {
+    if (int rc = check_update_args(exp, batch_rows, dims, hp)) return rc;
+    PFA_REQUIRE(update_epochs >= 0 && opt_step >= 0, "ppo.train: bad epoch / step count");
+    const int64_t mbs = batch_rows / hp->num_minibatches;
+    const int64_t count = mlp_offsets(dims->obs_stride, dims->num_actions).count;
+    const float loss_scale = (float)(1.0 / ((double)mbs * hp->num_minibatches));
+    for (int e = 0; e < update_epochs; ++e)
+        for (int mb = 0; mb < hp->num_minibatches; ++mb) {
+            if (int rc = pfa_ppo_mlp_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, mbs, grads, workspace, stream)) return rc;
+            ++opt_step;
+            if (int rc = pfa_adam_clip_step(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, opt_step,
+                                            max_grad_norm, 1.0f, grads + count, losses, loss_scale,
+                                            norm_partials_of(workspace, dims->obs_stride),
+                                            (int)((native_count(dims->obs_stride) + 63) / 64), stream))
+                return rc;
+        }
     return 0;
 }

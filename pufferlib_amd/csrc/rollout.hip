@@ -14,101 +14,211 @@
 
 namespace pfa {
 
-// Exp(1) noise for (row, step): explicit tensor if given, else the Philox stream (philox.hpp).
-__device__ __forceinline__ void noise_row(const float *noise_row_ptr, uint64_t seed, uint64_t step, uint64_t row, int a,
-                                          float (&q)[15]) {
+// ---------------------------------------------------------------------------------------------
+// Shared by the standalone forward and the fused rollout: a 256-thread workgroup (4 wavefronts) owns one
+// 16-row tile.  Wave w computes hidden tiles m in {2w, 2w+1} and its K-slice of the heads; after a barrier
+// thread (le, lo) = (tid/16, tid%16) owns output `lo` of row `le`.  Both kernels run exactly this code, so
+// policy(obs) through the protocol and the fused rollout give bit-identical numbers.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRollThreads = 256;
+constexpr int kRollWaves = 4;
+constexpr int kMW = kMT / kRollWaves;  // hidden tiles per wave
+
+template <int DP>
+struct SliceFrags {
+    float w1f[kMW][DP / 4], b1f[kMW][4], w2f[kMW][4], bo[4];
+    __device__ __forceinline__ void load(const float *params, int a) {
+        const MlpOffsets off = mlp_offsets(DP, a);
+        const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
 #pragma unroll
-    for (int o = 0; o < 15; ++o) q[o] = 1.0f;
-    if (noise_row_ptr) {
+        for (int i = 0; i < kMW; ++i) {
+            const int m = kMW * wv + i;
 #pragma unroll
-        for (int o = 0; o < 15; ++o)
-            if (o < a) q[o] = noise_row_ptr[o];
-        return;
+            for (int kk = 0; kk < DP / 4; ++kk) w1f[i][kk] = params[off.w1 + (16 * m + c) * DP + 4 * kk + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                b1f[i][r] = params[off.b1 + 16 * m + 4 * g + r];
+                w2f[i][r] = w2v_at(params, off, a, c, 16 * m + 4 * g + r);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bo[r] = wv == 0 ? b2v_at(params, off, a, 4 * g + r) : 0.0f;
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (4 * j < a) {
-            const u32x4 w = philox4x32_10((uint32_t)row, (uint32_t)j, (uint32_t)step,
-                                          (uint32_t)(step >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
-            const uint32_t ws[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (4 * j + i < 15) q[4 * j + i] = -logf(philox_uniform(ws[i]));
+};
+
+// Global rows -> padded LDS tile, all 256 threads.
+template <int DP>
+__device__ __forceinline__ void stage_rows(const float *src, long long first_row, long long rows, float *xs) {
+    constexpr int XS = XTile<DP>::XS, V = DP / 4;
+    for (int idx = threadIdx.x; idx < 16 * V; idx += kRollThreads) {
+        const int r = idx / V, c4 = idx - r * V;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (first_row + r < rows) x = *reinterpret_cast<const float4 *>(src + (first_row + r) * DP + 4 * c4);
+        float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
+        d[0] = make_float2(x.x, x.y);
+        d[1] = make_float2(x.z, x.w);
+    }
+}
+
+// LDS tile -> global rows (dst row r at dst + (first_row + r) * row_stride floats), all 256 threads.
+template <int DP>
+__device__ __forceinline__ void unstage_rows(const float *xs, float *dst, long long first_row, long long rows, size_t row_stride) {
+    constexpr int XS = XTile<DP>::XS, V = DP / 4;
+    for (int idx = threadIdx.x; idx < 16 * V; idx += kRollThreads) {
+        const int r = idx / V, c4 = idx - r * V;
+        if (first_row + r < rows) {
+            const float2 *sp = reinterpret_cast<const float2 *>(xs + r * XS + 4 * c4);
+            const float2 lo2 = sp[0], hi2 = sp[1];
+            *reinterpret_cast<float4 *>(dst + (size_t)(first_row + r) * row_stride + 4 * c4) = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
         }
     }
 }
 
-// Stage 16 rows x DP floats (global, row stride DP) into the padded LDS tile.
+// This wave's slice of models.Default.forward (models.py:41-62) for the 16 rows in xs -> part[wave][o*16 + row].
 template <int DP>
-__device__ __forceinline__ void stage_rows(const float *src, long long first_row, long long rows, float *xs) {
+__device__ __forceinline__ void forward_slice(const SliceFrags<DP> &w, const float *xs, float (*part)[kOut * 16]) {
     constexpr int XS = XTile<DP>::XS;
-    constexpr int V = DP / 4;  // float4 per row
-    const int lane = lane_id();
+    const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
+    f32x4 h[kMW];
 #pragma unroll
-    for (int j = 0; j < (16 * V + 63) / 64; ++j) {
-        const int idx = lane + 64 * j;
-        if (idx < 16 * V) {
-            const int r = idx / V, c4 = idx - r * V;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (first_row + r < rows) v = *reinterpret_cast<const float4 *>(src + (first_row + r) * DP + 4 * c4);
-            float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
-            d[0] = make_float2(v.x, v.y);
-            d[1] = make_float2(v.z, v.w);
+    for (int i = 0; i < kMW; ++i) h[i] = f32x4{w.b1f[i][0], w.b1f[i][1], w.b1f[i][2], w.b1f[i][3]};
+#pragma unroll
+    for (int kk = 0; kk < DP / 4; ++kk) {
+        const float b = xs[c * XS + 4 * kk + g];
+#pragma unroll
+        for (int i = 0; i < kMW; ++i) h[i] = mfma16(w.w1f[i][kk], b, h[i]);
+    }
+    f32x4 o0 = f32x4{w.bo[0], w.bo[1], w.bo[2], w.bo[3]}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o0 = mfma16(w.w2f[0][r], fmaxf(h[0][r], 0.0f), o0);
+        o1 = mfma16(w.w2f[1][r], fmaxf(h[1][r], 0.0f), o1);
+    }
+    const f32x4 po = o0 + o1;  // partial out^T[o = 4g + r][row = c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * 16 + c] = po[r];
+}
+
+// sample_logits for one Discrete head (frameworks/cleanrl.py:25-47), action=None branch, on the 16 lanes of a row:
+//   action = argmax(softmax(logits) / q)  == torch.multinomial(softmax(logits), 1) given its Exp(1) draw q.
+struct LaneSample {
+    int action;
+    float logprob, entropy, value;
+};
+__device__ __forceinline__ LaneSample sample_lanes(const float (*part)[kOut * 16], int le, int lo, int a, float q) {
+    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+    const bool is_logit = lo < a;
+    float mx = is_logit ? mine : -INFINITY;
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft, 64));
+    const float ex_ = is_logit ? expf(mine - mx) : 0.0f;
+    float se = ex_;
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) se += __shfl_xor(se, sft, 64);
+    const float lse = mx + logf(se);
+    // argmax of p/q with torch's first-index tie rule
+    float best = is_logit ? (ex_ / se) / q : -INFINITY;
+    int besti = lo;
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) {
+        const float ob = __shfl_xor(best, sft, 64);
+        const int oi = __shfl_xor(besti, sft, 64);
+        if (ob > best || (ob == best && oi < besti)) {
+            best = ob;
+            besti = oi;
         }
     }
+    LaneSample r;
+    r.action = besti;
+    const float nl = mine - lse;
+    float lp = lo == besti ? nl : 0.0f;
+    float ent = is_logit ? -nl * expf(nl) : 0.0f;
+#pragma unroll
+    for (int sft = 1; sft < 16; sft <<= 1) {
+        lp += __shfl_xor(lp, sft, 64);
+        ent += __shfl_xor(ent, sft, 64);
+    }
+    r.logprob = lp;
+    r.entropy = ent;
+    r.value = __shfl(mine, (lane_id() & 48) | a, 64);  // lane `a` of this row's 16-lane group
+    return r;
+}
+
+// Exp(1) noise of (row, step, column lo): explicit tensor if given, else the Philox stream (philox.hpp).
+__device__ __forceinline__ float noise_lane(const float *noise_row_ptr, uint64_t seed, uint64_t step, uint64_t row, int lo,
+                                            int a) {
+    if (lo >= a) return 1.0f;
+    if (noise_row_ptr) return noise_row_ptr[lo];
+    const u32x4 w = philox4x32_10((uint32_t)row, (uint32_t)(lo >> 2), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+    const uint32_t wsel = (lo & 3) == 0 ? w.x : (lo & 3) == 1 ? w.y : (lo & 3) == 2 ? w.z : w.w;
+    return -logf(philox_uniform(wsel));
 }
 
 // ---------------------------------------------------------------------------------------------
 // standalone forward + sample over `rows` observation rows
 // ---------------------------------------------------------------------------------------------
 template <int DP>
-__global__ void __launch_bounds__(64) mlp_forward_sample_kernel(const float *obs, long long rows, const float *params, int a,
-                                                               const float *noise, uint64_t seed, uint64_t step,
-                                                               long long row_offset, long long *actions, float *logprob,
-                                                               float *entropy, float *value) {
+__global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const float *obs, long long rows, const float *params,
+                                                                         int a, const float *noise, uint64_t seed,
+                                                                         uint64_t step, long long row_offset,
+                                                                         long long *actions, float *logprob, float *entropy,
+                                                                         float *value) {
     __shared__ float xs[XTile<DP>::kFloats];
-    MlpFwdFrags<DP> w;
+    __shared__ float part[kRollWaves][kOut * 16];
+    SliceFrags<DP> w;
     w.load(params, a);
+    const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
     const long long tiles = (rows + 15) / 16;
     for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         __syncthreads();
         stage_rows<DP>(obs, tile * 16, rows, xs);
         __syncthreads();
-        f32x4 h[kMT], out;
-        mlp_forward_tile<DP>(w, xs, h, out);
-        float logits[15], val;
-        gather_row_outputs(out, a, logits, val);
-        const long long row = tile * 16 + lane_id();
-        if (lane_id() < 16 && row < rows) {
-            float q[15];
-            noise_row(noise ? noise + row * a : nullptr, seed, step, (uint64_t)(row_offset + row), a, q);
-            const SampleOut s = sample_logits_row(logits, a, q);
-            actions[row] = s.action;
-            logprob[row] = s.logprob;
-            if (entropy) entropy[row] = s.entropy;
-            value[row] = val;
+        forward_slice<DP>(w, xs, part);
+        __syncthreads();
+        const long long row = tile * 16 + le;
+        const bool ok = row < rows;
+        const float q = ok ? noise_lane(noise ? noise + row * a : nullptr, seed, step, (uint64_t)(row_offset + row), lo, a) : 1.0f;
+        const LaneSample sm = sample_lanes(part, le, lo, a, q);
+        if (ok && lo == 0) {
+            actions[row] = sm.action;
+            logprob[row] = sm.logprob;
+            if (entropy) entropy[row] = sm.entropy;
+            value[row] = sm.value;
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // fused persistent rollout
+//
+// One workgroup of 4 wavefronts owns 16 envs for all T steps (grid = N/16, one workgroup per CU at N = 4096).
+// Per step:
+//   all 256 threads   store the 16 observation rows (LDS -> experience, one float4 each at obs_stride 64)
+//   wave w            forward_slice: 2 x KS MFMAs against W1 fragments held in registers + its 8 head MFMAs
+//   barrier
+//   thread (e, o)     sample_lanes: softmax / Exp(1) noise / argmax(p/q) / logprob over the row's 16 lanes
+//   thread (e, 0)     Experience.store of the scalars, then send(): env step or tape reset, rewriting row e of the
+//                     LDS observation tile
+//   barrier
 // ---------------------------------------------------------------------------------------------
 template <int DP>
-__global__ void __launch_bounds__(64) rollout_mlp_squared_kernel(SquaredView v, const float *params, int a, pfa_experience ex,
-                                                                const float *noise, uint64_t seed, uint64_t step0,
-                                                                long long env_offset, float *live_obs, float *live_rew,
-                                                                uint8_t *live_term, uint8_t *live_trunc,
-                                                                uint8_t *live_mask) {
+__global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(SquaredView v, const float *params, int a,
+                                                                          pfa_experience ex, const float *noise,
+                                                                          uint64_t seed, uint64_t step0, long long env_offset,
+                                                                          float *live_obs, float *live_rew, uint8_t *live_term,
+                                                                          uint8_t *live_trunc, uint8_t *live_mask) {
     constexpr int XS = XTile<DP>::XS;
     __shared__ float xs[XTile<DP>::kFloats];
+    __shared__ float part[kRollWaves][kOut * 16];  // partial out^T[o][row] per wave
     __shared__ uint16_t tg[16 * kMaxTargets];
-    const int lane = lane_id();
-    const int e = blockIdx.x * 16 + lane;  // env owned by lanes 0..15
-    const bool owner = lane < 16 && e < v.n;
+    const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;  // sampling role: local env, output index
+    const int e = blockIdx.x * 16 + le;
+    const bool env_ok = e < v.n;
+    const bool owner = lo == 0 && env_ok;  // the thread that carries env `e`
     const int T = ex.horizon_T;
 
-    MlpFwdFrags<DP> w;
+    SliceFrags<DP> w;
     w.load(params, a);
 
     // recv(): the live buffers are the current observation / reward / terminal of every env
@@ -118,49 +228,31 @@ __global__ void __launch_bounds__(64) rollout_mlp_squared_kernel(SquaredView v, 
     bool terminal = false;
     if (owner) {
         squared_load(v, e, s);
-        for (int t = 0; t < v.nt; ++t) tg[lane * kMaxTargets + t] = v.tgt[(size_t)t * v.n + e];
+        for (int t = 0; t < v.nt; ++t) tg[le * kMaxTargets + t] = v.tgt[(size_t)t * v.n + e];
         reward = live_rew[e];
         terminal = live_term[e] != 0;
     }
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
-        // Experience.store of the observation row (clean_pufferl.py:443), env-major
-        {
-            constexpr int V = DP / 4;
-#pragma unroll
-            for (int j = 0; j < (16 * V + 63) / 64; ++j) {
-                const int idx = lane + 64 * j;
-                if (idx < 16 * V) {
-                    const int r = idx / V, c4 = idx - r * V;
-                    const int er = blockIdx.x * 16 + r;
-                    if (er < v.n) {
-                        const float2 *sp = reinterpret_cast<const float2 *>(xs + r * XS + 4 * c4);
-                        const float2 lo = sp[0], hi = sp[1];
-                        *reinterpret_cast<float4 *>(ex.obs + ((size_t)er * T + t) * DP + 4 * c4) =
-                            make_float4(lo.x, lo.y, hi.x, hi.y);
-                    }
-                }
-            }
-        }
-        f32x4 h[kMT], out;
-        mlp_forward_tile<DP>(w, xs, h, out);
-        float logits[15], val;
-        gather_row_outputs(out, a, logits, val);
-        __syncthreads();  // all lanes are done reading xs before the env step rewrites it
+        // Experience.store of the observation rows (clean_pufferl.py:443), env-major: row (e, t) at e*T + t
+        unstage_rows<DP>(xs, ex.obs + (size_t)t * DP, (long long)blockIdx.x * 16, v.n, (size_t)T * DP);
+        forward_slice<DP>(w, xs, part);
+        __syncthreads();
+        const float q = env_ok ? noise_lane(noise ? noise + ((size_t)t * v.n + e) * a : nullptr, seed, step0 + t,
+                                            (uint64_t)(env_offset + e), lo, a)
+                               : 1.0f;
+        const LaneSample sm = sample_lanes(part, le, lo, a, q);
         if (owner) {
             const size_t row = (size_t)e * T + t;
-            float q[15];
-            noise_row(noise ? noise + ((size_t)t * v.n + e) * a : nullptr, seed, step0 + t, (uint64_t)(env_offset + e), a, q);
-            const SampleOut so = sample_logits_row(logits, a, q);
             ex.rewards[row] = reward;
             ex.dones[row] = terminal ? 1.0f : 0.0f;
-            ex.actions[row] = so.action;
-            ex.logprobs[row] = so.logprob;
-            ex.values[row] = val;
+            ex.actions[row] = sm.action;
+            ex.logprobs[row] = sm.logprob;
+            ex.values[row] = sm.value;
             // send(): vector.py:144-151
-            float *grid = xs + lane * XS;
-            uint16_t *tc = tg + lane * kMaxTargets;
+            float *grid = xs + le * XS;
+            uint16_t *tc = tg + le * kMaxTargets;
             if (s.done) {
                 if ((long long)s.rounds >= v.hdr->rounds_filled) v.hdr->underrun = 1;
                 const uint16_t *tr = v.tape + (size_t)(s.rounds % (uint32_t)v.tape_rounds) * v.nt * v.n;
@@ -170,7 +262,7 @@ __global__ void __launch_bounds__(64) rollout_mlp_squared_kernel(SquaredView v, 
                 bool fin;
                 double fr, fs;
                 int fl;
-                squared_step(v, s, grid, tc, so.action, reward, terminal, fin, fr, fl, fs);
+                squared_step(v, s, grid, tc, sm.action, reward, terminal, fin, fr, fl, fs);
             }
         }
         __syncthreads();
@@ -179,29 +271,14 @@ __global__ void __launch_bounds__(64) rollout_mlp_squared_kernel(SquaredView v, 
     // write back: env state + the live buffers the next recv() returns
     if (owner) {
         squared_store(v, e, s);
-        for (int t = 0; t < v.nt; ++t) v.tgt[(size_t)t * v.n + e] = tg[lane * kMaxTargets + t];
+        for (int t = 0; t < v.nt; ++t) v.tgt[(size_t)t * v.n + e] = tg[le * kMaxTargets + t];
         v.fin[e] = 0;
         live_rew[e] = reward;
         live_term[e] = terminal ? 1 : 0;
         live_trunc[e] = 0;
         live_mask[e] = 1;
     }
-    {
-        constexpr int V = DP / 4;
-#pragma unroll
-        for (int j = 0; j < (16 * V + 63) / 64; ++j) {
-            const int idx = lane + 64 * j;
-            if (idx < 16 * V) {
-                const int r = idx / V, c4 = idx - r * V;
-                const int er = blockIdx.x * 16 + r;
-                if (er < v.n) {
-                    const float2 *sp = reinterpret_cast<const float2 *>(xs + r * XS + 4 * c4);
-                    const float2 lo = sp[0], hi = sp[1];
-                    *reinterpret_cast<float4 *>(live_obs + (size_t)er * DP + 4 * c4) = make_float4(lo.x, lo.y, hi.x, hi.y);
-                }
-            }
-        }
-    }
+    unstage_rows<DP>(xs, live_obs, (long long)blockIdx.x * 16, v.n, (size_t)DP);
 }
 
 static int check_dims(const pfa_mlp_dims *d) {
@@ -245,7 +322,7 @@ extern "C" int pfa_mlp_forward_sample(const float *obs, int64_t rows, const floa
     const int64_t tiles = (rows + 15) / 16;
     const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
     PFA_DISPATCH_DP(dims->obs_stride,
-                    hipLaunchKernelGGL(mlp_forward_sample_kernel<DP>, dim3(grid), dim3(64), 0, (hipStream_t)stream, obs,
+                    hipLaunchKernelGGL(mlp_forward_sample_kernel<DP>, dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, obs,
                                        (long long)rows, params, dims->num_actions, noise, seed, step, (long long)row_offset,
                                        (long long *)actions, logprob, entropy, value));
     PFA_LAUNCH_CHECK();
@@ -270,7 +347,7 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
     ScopedKernelTimer timer("rollout_mlp_squared", (hipStream_t)stream);
     PFA_DISPATCH_DP(dims->obs_stride,
-                    hipLaunchKernelGGL(rollout_mlp_squared_kernel<DP>, dim3(grid), dim3(64), 0, (hipStream_t)stream, v, params,
+                    hipLaunchKernelGGL(rollout_mlp_squared_kernel<DP>, dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, v, params,
                                        dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
                                        terminals, truncations, masks));
     PFA_LAUNCH_CHECK();

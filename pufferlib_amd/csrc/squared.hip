@@ -130,42 +130,53 @@ __global__ void __launch_bounds__(256) squared_seed_kernel(SquaredView v, long l
 
 // ---------------------------------------------------------------------------------------------
 // Tape fill: draw `rounds` x N samples from the shared stream, in env order.
-// One workgroup; the 624-word MT block is regenerated cooperatively in LDS (3 dependent phases),
-// tempered, then either (nt == 1) all words are tested in parallel and accepted draws compacted with a
-// ballot prefix scan, or (general) lane 0 walks the block feeding the Sampler state machine.
+// One workgroup of 640 threads (one per word of the padded 624-word MT block).  Per block:
+//   3 dependent phases of the MT recurrence into the OTHER state buffer (double-buffered, so a phase only needs
+//   the barrier that publishes the previous phase) with the tempering fused into the store  -> 3 barriers
+//   nt == 1: every word is tested in parallel; accepted draws are compacted with ballot + per-wave counts -> 2 barriers
+//   general: thread 0 walks the block feeding the resumable Sampler.
+// The stream does not depend on actions, so the trainer runs this on a side stream under the previous rollout.
 // ---------------------------------------------------------------------------------------------
-constexpr int kTapeThreads = 256;
+constexpr int kTapeThreads = 640;
+constexpr int kTapeWaves = kTapeThreads / 64;
 
-__device__ void mt_regenerate_lds(uint32_t *mt) {  // all kTapeThreads threads
+// new_[.] = next MT block computed from old_[.]; out[.] = tempered new_.  All threads; ends with a barrier.
+__device__ __forceinline__ void mt_next_block(const uint32_t *old_, uint32_t *new_, uint32_t *out) {
     const int t = threadIdx.x;
-    // phase 1: kk in [0,227) reads only old words
-    uint32_t v0 = 0, v1 = 0, v2 = 0;
-    if (t < 227) v0 = mt_twist(mt[t], mt[t + 1], mt[t + kMtM]);
+    if (t < 227) {  // kk in [0,227): old words only
+        const uint32_t x = mt_twist(old_[t], old_[t + 1], old_[t + kMtM]);
+        new_[t] = x;
+        out[t] = mt_temper(x);
+    }
     __syncthreads();
-    if (t < 227) mt[t] = v0;
+    if (t >= 227 && t < 454) {  // kk in [227,454): new [0,227)
+        const uint32_t x = mt_twist(old_[t], old_[t + 1], new_[t - 227]);
+        new_[t] = x;
+        out[t] = mt_temper(x);
+    }
     __syncthreads();
-    // phase 2: kk in [227,454) reads new [0,227)
-    if (t < 227) v1 = mt_twist(mt[t + 227], mt[t + 228], mt[t]);
-    __syncthreads();
-    if (t < 227) mt[t + 227] = v1;
-    __syncthreads();
-    // phase 3: kk in [454,624) reads new [227,397); kk = 623 wraps to new mt[0]
-    if (t < 170) v2 = mt_twist(mt[t + 454], t + 455 < kMtN ? mt[t + 455] : mt[0], mt[t + 227]);
-    __syncthreads();
-    if (t < 170) mt[t + 454] = v2;
+    if (t >= 454 && t < kMtN) {  // kk in [454,624): new [227,397); kk = 623 wraps to new[0]
+        const uint32_t x = mt_twist(old_[t], t + 1 < kMtN ? old_[t + 1] : new_[0], new_[t - 227]);
+        new_[t] = x;
+        out[t] = mt_temper(x);
+    }
     __syncthreads();
 }
 
 __global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView v, int rounds) {
-    __shared__ uint32_t mt[kMtN];
+    __shared__ uint32_t mt[2][kMtN];
     __shared__ uint32_t out[kMtN];
-    __shared__ int wave_cnt[kTapeThreads / 64];
+    __shared__ int wave_cnt[kTapeWaves];
     __shared__ int s_idx_end;
     __shared__ Sampler s_sm;
     __shared__ long long s_produced;
     __shared__ int s_idx;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < kMtN; i += kTapeThreads) mt[i] = v.hdr->mt[i];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int cur = 0;
+    if (tid < kMtN) {
+        mt[0][tid] = v.hdr->mt[tid];
+        out[tid] = mt_temper(mt[0][tid]);
+    }
     int idx = v.hdr->mt_idx;
     const long long first_round = v.hdr->rounds_filled;
     const long long need = (long long)rounds * v.n;  // samples to draw
@@ -173,61 +184,46 @@ __global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView 
     unsigned long long words = 0;
     const int n_pop = 8 * v.d;
     const int bits = 32 - __clz(n_pop);
-    __syncthreads();
-    bool fresh = false;  // `out` holds tempered words of the current block
-    if (tid == 0) {
-        s_sm.begin(n_pop, v.nt);
-    }
+    if (tid == 0) s_sm.begin(n_pop, v.nt);
     __syncthreads();
     while (produced < need) {
         if (idx >= kMtN) {
-            mt_regenerate_lds(mt);
+            mt_next_block(mt[cur], mt[cur ^ 1], out);
+            cur ^= 1;
             idx = 0;
-            fresh = false;
-        }
-        if (!fresh) {
-            for (int i = tid; i < kMtN; i += kTapeThreads) out[i] = mt_temper(mt[i]);
-            fresh = true;
-            __syncthreads();
         }
         if (v.nt == 1) {
             // parallel: word w accepted iff (out[w] >> (32-bits)) < n_pop; sample index = running count
             if (tid == 0) s_idx_end = kMtN;
-            __syncthreads();
-            long long base = produced;
-            for (int w0 = idx; w0 < kMtN; w0 += kTapeThreads) {
-                const int w = w0 + tid;
-                int r = -1;
-                if (w < kMtN) {
-                    const int c = (int)(out[w] >> (32 - bits));
-                    if (c < n_pop) r = c;
-                }
-                const unsigned long long bal = __ballot(r >= 0);
-                const int lane = tid & 63, wv = tid >> 6;
-                if (lane == 0) wave_cnt[wv] = __popcll(bal);
-                __syncthreads();
-                int before = 0, total = 0;
-                for (int q = 0; q < kTapeThreads / 64; ++q) {
-                    if (q < wv) before += wave_cnt[q];
-                    total += wave_cnt[q];
-                }
-                const long long pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
-                if (r >= 0 && pos < need) {
-                    const long long round = first_round + pos / v.n;
-                    const int env = (int)(pos % v.n);
-                    v.tape[((size_t)(round % v.tape_rounds) * v.nt) * v.n + env] = (uint16_t)perimeter_cell(r, v.g);
-                    if (pos == need - 1) s_idx_end = w + 1;
-                }
-                base += total;
-                __syncthreads();
+            int r = -1;
+            if (tid >= idx && tid < kMtN) {
+                const int cnd = (int)(out[tid] >> (32 - bits));
+                if (cnd < n_pop) r = cnd;
             }
+            const unsigned long long bal = __ballot(r >= 0);
+            if (lane == 0) wave_cnt[wv] = __popcll(bal);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < kTapeWaves; ++q) {
+                const int cq = wave_cnt[q];
+                before += q < wv ? cq : 0;
+                total += cq;
+            }
+            const long long pos = produced + before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (r >= 0 && pos < need) {
+                const long long round = first_round + pos / v.n;
+                const int env = (int)(pos % v.n);
+                v.tape[((size_t)(round % v.tape_rounds) * v.nt) * v.n + env] = (uint16_t)perimeter_cell(r, v.g);
+                if (pos == need - 1) s_idx_end = tid + 1;
+            }
+            __syncthreads();
             const int idx_end = s_idx_end;
             words += (unsigned long long)(idx_end - idx);
             idx = idx_end;
-            produced = base < need ? base : need;
-            __syncthreads();
+            produced = produced + total < need ? produced + total : need;
         } else {
-            // general: lane 0 feeds words to the resumable sampler until the block or the job ends
+            // general: thread 0 feeds words to the resumable sampler until the block or the job ends
             if (tid == 0) {
                 long long p = produced;
                 int i = idx;
@@ -253,7 +249,7 @@ __global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView 
         }
     }
     __syncthreads();
-    for (int i = tid; i < kMtN; i += kTapeThreads) v.hdr->mt[i] = mt[i];
+    if (tid < kMtN) v.hdr->mt[tid] = mt[cur][tid];
     if (tid == 0) {
         v.hdr->mt_idx = idx;
         v.hdr->words += words;

@@ -183,7 +183,7 @@ class Squared:
         self.obs_dim = g * g
         self.obs_stride = int(obs_stride) if obs_stride is not None else max(16, _round_up(self.obs_dim, 16))
         self.episode_len = nt * d + 1        # max_ticks steps + the auto-reset row
-        self.tape_rounds = 64
+        self.tape_rounds = 192       # ring capacity: two rollouts of 4 x 96 sends.. (one being consumed + one prefetched)
         self.cfg = _lib.SquaredConfig(num_envs, d, nt, self.obs_stride, self.tape_rounds)
         nbytes = self.L.pfa_squared_state_bytes(C.byref(self.cfg))
         if nbytes == 0:
