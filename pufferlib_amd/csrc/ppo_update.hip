@@ -67,6 +67,18 @@ struct RowMap {  // minibatch row q -> flat env-major experience row (clean_puff
         const long long k = q / horizon, h = q - k * horizon;
         return ((long long)mb + k * nmb) * horizon + h;
     }
+    // Flat row of row r (0..15) of 16-row tile `tile` (wave-uniform).  When bptt_horizon is a multiple of 16 a tile
+    // never straddles a segment, so ONE scalar 32-bit division per tile replaces 16 per-lane 64-bit ones.
+    __device__ __forceinline__ long long tile_row(unsigned tile, int r) const {
+        if ((horizon & 15) == 0) {
+            const unsigned q0 = __builtin_amdgcn_readfirstlane(tile) * 16u;
+            const unsigned k = q0 / (unsigned)horizon, h0 = q0 - k * (unsigned)horizon;
+            return ((long long)mb + (long long)k * nmb) * horizon + h0 + r;
+        }
+        const unsigned q = tile * 16u + (unsigned)r;
+        const unsigned k = q / (unsigned)horizon, h = q - k * (unsigned)horizon;
+        return ((long long)mb + (long long)k * nmb) * horizon + h;
+    }
 };
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -176,7 +188,9 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
     return lo_;
 }
 
-template <int DP>
+// ABL: ablation mask for tools/probe_grad.py (-DPFA_PROBES builds only; the product always runs ABL = 0):
+//   1 skip the loss math   2 skip the backward MFMAs   4 skip the forward MFMAs   8 skip the workgroup reduction
+template <int DP, int ABL = 0>
 __global__ void __launch_bounds__(kGradThreads, 1)
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, pfa_ppo_hparams hp,
                         const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
@@ -193,15 +207,39 @@ __global__ void __launch_bounds__(kGradThreads, 1)
     float *w2bt = w2t + L::kTabFloats;
     const MlpOffsets off = mlp_offsets(DP, a);
 
-    for (int i = threadIdx.x; i < kMT * 64 * KS; i += kGradThreads) {
-        const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64), cc = ln & 15, gg = ln >> 4;
-        w1t[(m * 64 + ln) * W1S + kk] = params[off.w1 + (16 * m + cc) * DP + 4 * kk + gg];
-    }
-    for (int i = threadIdx.x; i < kMT * 64 * 4; i += kGradThreads) {
-        const int r = i & 3, ln = (i >> 2) & 63, m = i >> 8, cc = ln & 15, gg = ln >> 4;
-        b1t[i] = params[off.b1 + 16 * m + 4 * gg + r];
-        w2t[i] = w2v_at(params, off, a, cc, 16 * m + 4 * gg + r);    // A[i=o=cc][k-slot gg] for u = 16m+4gg+r
-        w2bt[i] = w2v_at(params, off, a, 4 * gg + r, 16 * m + cc);   // B[k-slot gg][j=u=16m+cc] for o = 4gg+r
+    // Build the fragment tables.  All global loads of a thread are issued before the first LDS store so they
+    // pipeline (a load -> store -> load chain would serialise ~50 L2 round trips in front of every launch).
+    {
+        constexpr int N1 = kMT * 64 * KS / kGradThreads, N2 = kMT * 64 * 4 / kGradThreads;
+        static_assert(kMT * 64 * KS % kGradThreads == 0 && kMT * 64 * 4 % kGradThreads == 0, "table sizes");
+        float t1[N1], tb[N2], tw[N2], tv[N2];
+#pragma unroll
+        for (int j = 0; j < N1; ++j) {
+            const int i = threadIdx.x + j * kGradThreads;
+            const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64), cc = ln & 15, gg = ln >> 4;
+            t1[j] = params[off.w1 + (16 * m + cc) * DP + 4 * kk + gg];
+        }
+#pragma unroll
+        for (int j = 0; j < N2; ++j) {
+            const int i = threadIdx.x + j * kGradThreads;
+            const int r = i & 3, ln = (i >> 2) & 63, m = i >> 8, cc = ln & 15, gg = ln >> 4;
+            tb[j] = params[off.b1 + 16 * m + 4 * gg + r];
+            tw[j] = w2v_at(params, off, a, cc, 16 * m + 4 * gg + r);    // A[i=o=cc][k-slot gg] for u = 16m+4gg+r
+            tv[j] = w2v_at(params, off, a, 4 * gg + r, 16 * m + cc);    // B[k-slot gg][j=u=16m+cc] for o = 4gg+r
+        }
+#pragma unroll
+        for (int j = 0; j < N1; ++j) {
+            const int i = threadIdx.x + j * kGradThreads;
+            const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64);
+            w1t[(m * 64 + ln) * W1S + kk] = t1[j];
+        }
+#pragma unroll
+        for (int j = 0; j < N2; ++j) {
+            const int i = threadIdx.x + j * kGradThreads;
+            b1t[i] = tb[j];
+            w2t[i] = tw[j];
+            w2bt[i] = tv[j];
+        }
     }
     float bo[4];
 #pragma unroll
@@ -253,7 +291,7 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                 xpre[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok && idx < 16 * V) {
                     const int r = idx / V, c4 = idx - r * V;
-                    xpre[t][j] = *reinterpret_cast<const float4 *>(ex.obs + map.flat(tile * 16 + r) * DP + 4 * c4);
+                    xpre[t][j] = *reinterpret_cast<const float4 *>(ex.obs + map.tile_row((unsigned)tile, r) * DP + 4 * c4);
                 }
             }
         }
@@ -279,7 +317,7 @@ __global__ void __launch_bounds__(kGradThreads, 1)
             // per-row scalars (lane c <-> row c, replicated over the 4 lane groups); consumed after the forward pass
             rs[t] = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (base + t < tiles) {
-                const long long fr = map.flat((base + t) * 16 + c);
+                const long long fr = map.tile_row((unsigned)(base + t), c);
                 rs[t] = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
             }
         }
@@ -295,7 +333,7 @@ __global__ void __launch_bounds__(kGradThreads, 1)
             for (int t = 0; t < kTPI; ++t) h[t][m] = b;
         }
 #pragma unroll
-        for (int k4 = 0; k4 < KS / 4; ++k4) {
+        for (int k4 = 0; k4 < ((ABL & 4) ? 0 : KS / 4); ++k4) {
             float xb[kTPI][4];
 #pragma unroll
             for (int t = 0; t < kTPI; ++t)
@@ -345,7 +383,13 @@ __global__ void __launch_bounds__(kGradThreads, 1)
         f32x4 dout[kTPI];
 #pragma unroll
         for (int t = 0; t < kTPI; ++t) {
-            const LossOut lo = ppo_loss_tile(out[t], rs[t], a, g, hp, adv_mean, adv_den, inv_rows);
+            LossOut lo;
+            if constexpr (ABL & 1) {
+                lo.dout = out[t] * rs[t].weight;
+                lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs[t].adv;
+            } else {
+                lo = ppo_loss_tile(out[t], rs[t], a, g, hp, adv_mean, adv_den, inv_rows);
+            }
             dout[t] = lo.dout;
 #pragma unroll
             for (int r = 0; r < 4; ++r) db2[r] += lo.dout[r];
@@ -376,7 +420,7 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                 for (int r = 0; r < 4; ++r) xa[t][kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
         }
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < ((ABL & 2) ? 0 : 2); ++half) {
             // half of the hidden tile, row-major [row][u - 64*half], for the relu mask and the dW2v contraction
 #pragma unroll
             for (int t = 0; t < kTPI; ++t)
@@ -437,7 +481,7 @@ __global__ void __launch_bounds__(kGradThreads, 1)
         for (int s = 1; s < 16; s <<= 1) stats[i] += __shfl_xor(stats[i], s, 64);
 
     float *red = lds + (wv & 1) * NL::kCount;  // buffer 0: even waves, buffer 1: odd waves
-    for (int turn = 0; turn < kGradWaves / 2; ++turn) {
+    for (int turn = 0; turn < ((ABL & 8) ? 0 : kGradWaves / 2); ++turn) {
         if ((wv >> 1) == turn) {
             const bool first = turn == 0;
 #pragma unroll
@@ -787,3 +831,32 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
         }
     return 0;
 }
+
+#ifdef PFA_PROBES
+// Probe-only entry (tools/probe_grad.py): same launch as pfa_ppo_mlp_grad for obs_stride 64 with an ablation mask.
+extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
+                              const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats, float *grads,
+                              void *workspace, int32_t abl, pfa_stream_t stream) {
+    const int64_t mbs = batch_rows / hp->num_minibatches;
+    const int grid = grad_grid(mbs);
+    RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
+    float *partials = (float *)workspace;
+    constexpr size_t lds_bytes = (size_t)GradLds<64>::kFloats * sizeof(float);
+#define PFA_PROBE_CASE(A)                                                                                              \
+    case A:                                                                                                            \
+        PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A>,                                    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A>), dim3(grid), dim3(kGradThreads), lds_bytes, (hipStream_t)stream, \
+                           *exp, map, (long long)mbs, params, dims->num_actions, *hp, adv_stats, (double)mbs, partials); \
+        break;
+    switch (abl) {
+        PFA_PROBE_CASE(0) PFA_PROBE_CASE(1) PFA_PROBE_CASE(2) PFA_PROBE_CASE(4) PFA_PROBE_CASE(6) PFA_PROBE_CASE(7)
+        PFA_PROBE_CASE(8) PFA_PROBE_CASE(15)
+        default: return -2;
+    }
+#undef PFA_PROBE_CASE
+    PFA_LAUNCH_CHECK();
+    (void)grads;
+    return 0;
+}
+#endif
