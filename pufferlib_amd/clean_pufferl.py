@@ -31,6 +31,7 @@ import numpy as np
 import torch
 
 from . import _lib, utils
+from . import dist as pdist
 from .cleanrl import Policy
 from .models import FlatParams
 from .namespace import namespace
@@ -52,10 +53,7 @@ def make_losses():
 
 
 def _dist():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        return dist, dist.get_rank(), dist.get_world_size()
-    return None, 0, 1
+    return pdist.world()
 
 
 class HipAdam:
@@ -265,6 +263,9 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     policy.noise_seed = int(config.seed)
 
     total_agents = vecenv.num_agents
+    if world > 1:
+        nmb_ = config.batch_size // (_cfg(config, 'minibatch_size', None) or config.batch_size)
+        pdist.check_partition(total_agents, config.batch_size // total_agents, config.bptt_horizon, nmb_)
     experience = Experience(config.batch_size, config.bptt_horizon, _cfg(config, 'minibatch_size', None),
                             vecenv.obs_stride, total_agents, device)
     optimizer = HipAdam(fp, lr=config.learning_rate, eps=1e-5)

