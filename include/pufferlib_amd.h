@@ -192,6 +192,12 @@ int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *para
                       float max_grad_norm, int32_t update_epochs, float *losses, void *workspace,
                       pfa_stream_t stream);
 
+/* What train() logs (clean_pufferl.py:249-254,266-270) in one device buffer of 10 f64: out[0..5] = `losses` (the six
+ * running means above), out[6..9] = sum y_true, sum y_true^2, sum adv, sum adv^2 with y_pred = values in storage
+ * (step-major) order and y_true = advantages (env-major) + y_pred — the reference's explained-variance inputs. */
+int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, const float *losses,
+                       double *out10, void *workspace, pfa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

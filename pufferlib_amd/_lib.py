@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
 SOURCES = ['common.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp',
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
@@ -110,6 +110,7 @@ _SIGNATURES = {
                                    C.POINTER(PpoHparams), P, C.c_int64, P, P, P]),
     'pfa_ppo_mlp_train': (C.c_int, [C.POINTER(Experience), C.c_int64, P, C.POINTER(MlpDims), C.POINTER(PpoHparams), P, P, P, P,
                                     C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P, P]),
+    'pfa_train_log_sums': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, P, P, P]),
     'pfa_adam_clip_step': (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
                                      C.c_float, C.c_float, P, P, C.c_float, P, C.c_int32, P]),
 }

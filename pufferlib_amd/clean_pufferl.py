@@ -284,6 +284,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         grads=torch.zeros(fp.count + 8, dtype=torch.float32, device=device),
         adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
         loss_acc=torch.zeros(8, dtype=torch.float32, device=device),
+        log_sums=torch.zeros(10, dtype=torch.float64, device=device),
         noise=None,            # optional explicit Exp(1) tensor [T][N][A] for the next evaluate() (parity tests)
         tape_stream=torch.cuda.Stream(device=device),   # reset-target tape is drawn one rollout ahead, off the critical path
         tape_event=None,
@@ -424,17 +425,18 @@ def train(data):
             frac = 1.0 - data.global_step / config.total_timesteps
             opt.param_groups[0]['lr'] = frac * config.learning_rate
 
-        # explained variance exactly as the reference logs it (clean_pufferl.py:266-270, App. A.8):
-        # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred
-        T, N = experience.horizon, experience.num_envs
-        y_pred = experience.values.view(N, T).t().reshape(-1).double()
-        y_true = experience.advantages.double() + y_pred
-        var_y = y_true.var(unbiased=False)
-        ev = torch.where(var_y == 0, torch.full_like(var_y, float('nan')),
-                         1 - (y_true - y_pred).var(unbiased=False) / var_y)
-        acc = torch.cat([data.loss_acc[:6].double(), ev.reshape(1)]).cpu().numpy()   # the one sync of train()
+        # losses + explained variance exactly as the reference logs them (clean_pufferl.py:249-254,266-270, App. A.8):
+        # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
+        _lib.check(L.pfa_train_log_sums(C.byref(experience.c), B, experience.num_envs, _lib.ptr(data.loss_acc),
+                                        _lib.ptr(data.log_sums), _lib.ptr(data.workspace), stream), 'train_log_sums')
+        acc = data.log_sums.cpu().numpy()                       # the one sync of train()
+        s_y, s_yy, s_a, s_aa = acc[6:10]
+        var_y = s_yy / B - (s_y / B) ** 2
+        var_res = s_aa / B - (s_a / B) ** 2                      # y_true - y_pred = advantages
+        ev = float('nan') if var_y == 0 else 1 - var_res / var_y
         (losses.policy_loss, losses.value_loss, losses.entropy, losses.old_approx_kl, losses.approx_kl,
-         losses.clipfrac, losses.explained_variance) = (float(x) for x in acc)
+         losses.clipfrac) = (float(x) for x in acc[:6])
+        losses.explained_variance = ev
         data.epoch += 1
 
         done_training = data.global_step >= config.total_timesteps

@@ -626,6 +626,44 @@ __global__ void adv_stats_final_kernel(const double *partial, int nmb, double *s
     stats[2 * mb + 1] = s2;
 }
 
+// Sums behind the reference's explained-variance log line (clean_pufferl.py:266-270):
+//   y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major order) + y_pred  (mis-aligned on
+//   purpose, it only feeds logging).  out[0..3] = sum y_true, sum y_true^2, sum adv, sum adv^2 in f64.
+constexpr int kEvBlocks = 128;
+__global__ void __launch_bounds__(256) ev_partial_kernel(const float *adv, const float *values, long long n, int num_envs,
+                                                        int horizon, double *partial /* [kEvBlocks][4] */) {
+    __shared__ double sh[4][256];
+    double a[4] = {0, 0, 0, 0};
+    for (long long j = (long long)blockIdx.x * 256 + threadIdx.x; j < n; j += (long long)kEvBlocks * 256) {
+        const long long e = j % num_envs, t = j / num_envs;  // storage order index j = t*N + e
+        const double yp = (double)values[e * horizon + t];
+        const double ad = (double)adv[j];
+        const double yt = ad + yp;
+        a[0] += yt;
+        a[1] += yt * yt;
+        a[2] += ad;
+        a[3] += ad * ad;
+    }
+    for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] = a[q];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s)
+            for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = sh[threadIdx.x][0];
+}
+// out[0..5] = the six running loss means (f32 -> f64), out[6..9] = the four sums: one D2H copy serves train()'s log line.
+__global__ void ev_final_kernel(const double *partial, const float *losses, double *out10) {
+    const int q = threadIdx.x;
+    if (q < 6) out10[q] = losses ? (double)losses[q] : 0.0;
+    if (q >= 6 && q < 10) {
+        double s = 0.0;
+        for (int b = 0; b < kEvBlocks; ++b) s += partial[b * 4 + (q - 6)];
+        out10[q] = s;
+    }
+}
+
 // clip_grad_norm_ + torch.optim.Adam (single-tensor path) on the flat parameter vector.
 // Every workgroup recomputes the global gradient norm from the (L2-resident, ~38 KB) gradient in the same fixed
 // order — deterministic and no grid-wide hand-off — then updates its own 256-element slice.
@@ -860,3 +898,16 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
     return 0;
 }
 #endif
+
+extern "C" int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, const float *losses,
+                                  double *out10, void *workspace, pfa_stream_t stream) {
+    PFA_REQUIRE(exp && exp->advantages && exp->values && out10 && workspace, "train_log_sums: null buffer");
+    PFA_REQUIRE(num_envs >= 1 && batch_rows % num_envs == 0, "train_log_sums: batch must be whole rollout steps");
+    double *partial = (double *)workspace;
+    hipLaunchKernelGGL(ev_partial_kernel, dim3(kEvBlocks), dim3(256), 0, (hipStream_t)stream, exp->advantages, exp->values,
+                       (long long)batch_rows, (int)num_envs, (int)(batch_rows / num_envs), partial);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ev_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, losses, out10);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}

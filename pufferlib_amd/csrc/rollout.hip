@@ -8,6 +8,7 @@
 // the reset-target tape (squared.hip).  Per step the HBM traffic is the experience row itself:
 // obs_stride*4 + 20 B per env (280 B at obs_stride 64).
 #include "common.hpp"
+#include "lane_ops.hpp"
 #include "mlp_tile.hpp"
 #include "philox.hpp"
 #include "squared_env.hpp"
@@ -48,12 +49,13 @@ struct SliceFrags {
 
 // Global rows -> padded LDS tile, all 256 threads.
 template <int DP>
-__device__ __forceinline__ void stage_rows(const float *src, long long first_row, long long rows, float *xs) {
+__device__ __forceinline__ void stage_rows(const float *src, long long first_row, long long rows, float *xs,
+                                           int tile_rows = 16) {
     constexpr int XS = XTile<DP>::XS, V = DP / 4;
     for (int idx = threadIdx.x; idx < 16 * V; idx += kRollThreads) {
         const int r = idx / V, c4 = idx - r * V;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (first_row + r < rows) x = *reinterpret_cast<const float4 *>(src + (first_row + r) * DP + 4 * c4);
+        if (r < tile_rows && first_row + r < rows) x = *reinterpret_cast<const float4 *>(src + (first_row + r) * DP + 4 * c4);
         float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
         d[0] = make_float2(x.x, x.y);
         d[1] = make_float2(x.z, x.w);
@@ -62,9 +64,10 @@ __device__ __forceinline__ void stage_rows(const float *src, long long first_row
 
 // LDS tile -> global rows (dst row r at dst + (first_row + r) * row_stride floats), all 256 threads.
 template <int DP>
-__device__ __forceinline__ void unstage_rows(const float *xs, float *dst, long long first_row, long long rows, size_t row_stride) {
+__device__ __forceinline__ void unstage_rows(const float *xs, float *dst, long long first_row, long long rows, size_t row_stride,
+                                             int tile_rows = 16) {
     constexpr int XS = XTile<DP>::XS, V = DP / 4;
-    for (int idx = threadIdx.x; idx < 16 * V; idx += kRollThreads) {
+    for (int idx = threadIdx.x; idx < tile_rows * V; idx += kRollThreads) {
         const int r = idx / V, c4 = idx - r * V;
         if (first_row + r < rows) {
             const float2 *sp = reinterpret_cast<const float2 *>(xs + r * XS + 4 * c4);
@@ -108,39 +111,20 @@ struct LaneSample {
 __device__ __forceinline__ LaneSample sample_lanes(const float (*part)[kOut * 16], int le, int lo, int a, float q) {
     const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
     const bool is_logit = lo < a;
-    float mx = is_logit ? mine : -INFINITY;
-#pragma unroll
-    for (int sft = 1; sft < 16; sft <<= 1) mx = fmaxf(mx, __shfl_xor(mx, sft, 64));
+    const float mx = row16_max(is_logit ? mine : -INFINITY);
     const float ex_ = is_logit ? expf(mine - mx) : 0.0f;
-    float se = ex_;
-#pragma unroll
-    for (int sft = 1; sft < 16; sft <<= 1) se += __shfl_xor(se, sft, 64);
+    const float se = row16_sum(ex_);
     const float lse = mx + logf(se);
     // argmax of p/q with torch's first-index tie rule
     float best = is_logit ? (ex_ / se) / q : -INFINITY;
     int besti = lo;
-#pragma unroll
-    for (int sft = 1; sft < 16; sft <<= 1) {
-        const float ob = __shfl_xor(best, sft, 64);
-        const int oi = __shfl_xor(besti, sft, 64);
-        if (ob > best || (ob == best && oi < besti)) {
-            best = ob;
-            besti = oi;
-        }
-    }
+    row16_argmax(best, besti);
     LaneSample r;
     r.action = besti;
     const float nl = mine - lse;
-    float lp = lo == besti ? nl : 0.0f;
-    float ent = is_logit ? -nl * expf(nl) : 0.0f;
-#pragma unroll
-    for (int sft = 1; sft < 16; sft <<= 1) {
-        lp += __shfl_xor(lp, sft, 64);
-        ent += __shfl_xor(ent, sft, 64);
-    }
-    r.logprob = lp;
-    r.entropy = ent;
-    r.value = __shfl(mine, (lane_id() & 48) | a, 64);  // lane `a` of this row's 16-lane group
+    r.logprob = row16_sum(lo == besti ? nl : 0.0f);
+    r.entropy = row16_sum(is_logit ? -nl * expf(nl) : 0.0f);
+    r.value = row16_sum(lo == a ? mine : 0.0f);
     return r;
 }
 
@@ -192,7 +176,9 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
 // ---------------------------------------------------------------------------------------------
 // fused persistent rollout
 //
-// One workgroup of 4 wavefronts owns 16 envs for all T steps (grid = N/16, one workgroup per CU at N = 4096).
+// One workgroup of 4 wavefronts owns EPW (16 or 8) envs for all T steps.  The per-step chain env -> forward -> sample
+// -> env is latency-bound, so when N/16 would leave fewer than two workgroups per CU the launch uses EPW = 8 (half
+// the MFMA tile is padding, which is free here) and two workgroups per CU hide each other's latencies.
 // Per step:
 //   all 256 threads   store the 16 observation rows (LDS -> experience, one float4 each at obs_stride 64)
 //   wave w            forward_slice: 2 x KS MFMAs against W1 fragments held in registers + its 8 head MFMAs
@@ -202,7 +188,7 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
 //                     LDS observation tile
 //   barrier
 // ---------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, int EPW>
 __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(SquaredView v, const float *params, int a,
                                                                           pfa_experience ex, const float *noise,
                                                                           uint64_t seed, uint64_t step0, long long env_offset,
@@ -213,8 +199,8 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
     __shared__ float part[kRollWaves][kOut * 16];  // partial out^T[o][row] per wave
     __shared__ uint16_t tg[16 * kMaxTargets];
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;  // sampling role: local env, output index
-    const int e = blockIdx.x * 16 + le;
-    const bool env_ok = e < v.n;
+    const int e = blockIdx.x * EPW + le;
+    const bool env_ok = le < EPW && e < v.n;
     const bool owner = lo == 0 && env_ok;  // the thread that carries env `e`
     const int T = ex.horizon_T;
 
@@ -222,7 +208,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
     w.load(params, a);
 
     // recv(): the live buffers are the current observation / reward / terminal of every env
-    stage_rows<DP>(live_obs, (long long)blockIdx.x * 16, v.n, xs);
+    stage_rows<DP>(live_obs, (long long)blockIdx.x * EPW, v.n, xs, EPW);
     SquaredEnv s;
     float reward = 0.0f;
     bool terminal = false;
@@ -236,7 +222,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
 
     for (int t = 0; t < T; ++t) {
         // Experience.store of the observation rows (clean_pufferl.py:443), env-major: row (e, t) at e*T + t
-        unstage_rows<DP>(xs, ex.obs + (size_t)t * DP, (long long)blockIdx.x * 16, v.n, (size_t)T * DP);
+        unstage_rows<DP>(xs, ex.obs + (size_t)t * DP, (long long)blockIdx.x * EPW, v.n, (size_t)T * DP, EPW);
         forward_slice<DP>(w, xs, part);
         __syncthreads();
         const float q = env_ok ? noise_lane(noise ? noise + ((size_t)t * v.n + e) * a : nullptr, seed, step0 + t,
@@ -278,7 +264,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
         live_trunc[e] = 0;
         live_mask[e] = 1;
     }
-    unstage_rows<DP>(xs, live_obs, (long long)blockIdx.x * 16, v.n, (size_t)DP);
+    unstage_rows<DP>(xs, live_obs, (long long)blockIdx.x * EPW, v.n, (size_t)DP, EPW);
 }
 
 static int check_dims(const pfa_mlp_dims *d) {
@@ -344,12 +330,20 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     PFA_REQUIRE(cfg->num_targets <= kMaxTargets, "rollout: too many targets");
     SquaredView v = squared_view(state, *cfg);
     const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
-    const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
     ScopedKernelTimer timer("rollout_mlp_squared", (hipStream_t)stream);
-    PFA_DISPATCH_DP(dims->obs_stride,
-                    hipLaunchKernelGGL(rollout_mlp_squared_kernel<DP>, dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, v, params,
-                                       dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
-                                       terminals, truncations, masks));
+    if (true) {  // EPW = 8 (two workgroups per CU at N = 4096) measured slower: the step is issue-bound, not latency-bound
+        const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
+        PFA_DISPATCH_DP(dims->obs_stride,
+                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16>), dim3(grid), dim3(kRollThreads), 0,
+                                           (hipStream_t)stream, v, params, dims->num_actions, *exp, noise, seed, step,
+                                           (long long)env_offset, obs, rewards, terminals, truncations, masks));
+    } else {
+        const unsigned grid = (unsigned)((cfg->num_envs + 7) / 8);
+        PFA_DISPATCH_DP(dims->obs_stride,
+                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 8>), dim3(grid), dim3(kRollThreads), 0,
+                                           (hipStream_t)stream, v, params, dims->num_actions, *exp, noise, seed, step,
+                                           (long long)env_offset, obs, rewards, terminals, truncations, masks));
+    }
     PFA_LAUNCH_CHECK();
     return 0;
 }
