@@ -26,7 +26,7 @@ namespace pfa {
 
 constexpr int kGradThreads = 256;
 constexpr int kGradWaves = kGradThreads / 64;
-constexpr int kTPI = 2;       // 16-row tiles processed together by one wavefront (independent MFMA chains)
+constexpr int kTPI = 2;       // 16-row tiles in flight per wavefront (the loop body is written for exactly 2)
 constexpr int kNumStats = 8;  // 6 used: pg, v, entropy, old_kl, kl, clipfrac
 
 // LDS map of kernel A (floats).  Per wave and per in-flight tile: X tile, hidden tile, dout tile.  Shared by the
@@ -67,17 +67,18 @@ struct RowMap {  // minibatch row q -> flat env-major experience row (clean_puff
         const long long k = q / horizon, h = q - k * horizon;
         return ((long long)mb + k * nmb) * horizon + h;
     }
-    // Flat row of row r (0..15) of 16-row tile `tile` (wave-uniform).  When bptt_horizon is a multiple of 16 a tile
-    // never straddles a segment, so ONE scalar 32-bit division per tile replaces 16 per-lane 64-bit ones.
-    __device__ __forceinline__ long long tile_row(unsigned tile, int r) const {
-        if ((horizon & 15) == 0) {
-            const unsigned q0 = __builtin_amdgcn_readfirstlane(tile) * 16u;
-            const unsigned k = q0 / (unsigned)horizon, h0 = q0 - k * (unsigned)horizon;
-            return ((long long)mb + (long long)k * nmb) * horizon + h0 + r;
-        }
-        const unsigned q = tile * 16u + (unsigned)r;
+    // 32-bit flat row of minibatch row q (batches stay far below 2^31 rows).
+    __device__ __forceinline__ unsigned row32(unsigned q) const {
         const unsigned k = q / (unsigned)horizon, h = q - k * (unsigned)horizon;
-        return ((long long)mb + (long long)k * nmb) * horizon + h;
+        return ((unsigned)mb + k * (unsigned)nmb) * (unsigned)horizon + h;
+    }
+    // Flat row of row r (0..15) of 16-row tile `tile` (wave-uniform).  When bptt_horizon is a multiple of 16 a tile
+    // never straddles a segment: `first` = row32(16*tile), computed ONCE per tile on the scalar unit, then + r.
+    __device__ __forceinline__ unsigned tile_first(unsigned tile) const {
+        return row32(__builtin_amdgcn_readfirstlane(tile) * 16u);
+    }
+    __device__ __forceinline__ unsigned tile_row(unsigned tile, unsigned first, int r, bool aligned) const {
+        return aligned ? first + (unsigned)r : row32(tile * 16u + (unsigned)r);
     }
 };
 
@@ -107,19 +108,22 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
         if (4 * g + r < a) lmax = fmaxf(lmax, out[r]);
     lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
     lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
-    float se = 0.0f;
+    float ev[4], se = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (4 * g + r < a) se += expf(out[r] - lmax);
+    for (int r = 0; r < 4; ++r) {
+        ev[r] = 4 * g + r < a ? expf(out[r] - lmax) : 0.0f;
+        se += ev[r];
+    }
     se += __shfl_xor(se, 16, 64);
     se += __shfl_xor(se, 32, 64);
     const float lse = lmax + logf(se);
+    const float inv_se = 1.0f / se;
     float nl[4], p[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 4 * g + r;
         nl[r] = out[r] - lse;
-        p[r] = o < a ? expf(nl[r]) : 0.0f;
+        p[r] = ev[r] * inv_se;  // softmax; the exponentials are shared with the log-sum-exp
         if (o < a) ent -= nl[r] * p[r];
         if (o == rs.action) new_logprob = nl[r];
         if (o == a) new_value = out[r];
@@ -280,18 +284,21 @@ __global__ void __launch_bounds__(kGradThreads, 1)
 
     // register prefetch of the next iteration's tiles (HBM latency hides under the current tiles' MFMAs)
     float4 xpre[kTPI][NLD];
+    const bool aligned = (map.horizon & 15) == 0;
     auto prefetch = [&](long long first_tile) {
 #pragma unroll
         for (int t = 0; t < kTPI; ++t) {
             const long long tile = first_tile + t;
             const bool ok = tile < tiles;
+            const unsigned first = ok ? map.tile_first((unsigned)tile) : 0u;
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int idx = lane + 64 * j;
                 xpre[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok && idx < 16 * V) {
                     const int r = idx / V, c4 = idx - r * V;
-                    xpre[t][j] = *reinterpret_cast<const float4 *>(ex.obs + map.tile_row((unsigned)tile, r) * DP + 4 * c4);
+                    const unsigned row = map.tile_row((unsigned)tile, first, r, aligned);
+                    xpre[t][j] = *reinterpret_cast<const float4 *>(ex.obs + (size_t)row * DP + 4 * c4);
                 }
             }
         }
@@ -317,11 +324,10 @@ __global__ void __launch_bounds__(kGradThreads, 1)
             // per-row scalars (lane c <-> row c, replicated over the 4 lane groups); consumed after the forward pass
             rs[t] = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (base + t < tiles) {
-                const long long fr = map.tile_row((unsigned)(base + t), c);
+                const unsigned fr = map.tile_row((unsigned)(base + t), map.tile_first((unsigned)(base + t)), c, aligned);
                 rs[t] = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
             }
         }
-        prefetch(base + wave_count * kTPI);
         wave_lds_fence();
 
         // ---- forward: hidden^T (kTPI x 8 independent accumulator chains) then out^T ---------------------------
@@ -348,47 +354,37 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                     for (int t = 0; t < kTPI; ++t) h[t][m] = mfma16(wq[j], xb[t][j], h[t][m]);
             }
         }
-        f32x4 out[kTPI];
-        {
-            f32x4 o0[kTPI], o1[kTPI];
 #pragma unroll
-            for (int t = 0; t < kTPI; ++t) {
-                o0[t] = f32x4{bo[0], bo[1], bo[2], bo[3]};
-                o1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int m = 0; m < kMT; ++m)
 #pragma unroll
-            for (int m = 0; m < kMT; ++m)
+            for (int t = 0; t < kTPI; ++t)
 #pragma unroll
-                for (int t = 0; t < kTPI; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h[t][m][r] = fmaxf(h[t][m][r], 0.0f);
-                }
+                for (int r = 0; r < 4; ++r) h[t][m][r] = fmaxf(h[t][m][r], 0.0f);
+
+        // The two tiles are staggered from here on so that the VALU-only loss math of one tile sits in the same
+        // scheduling region as MFMA work of the other:  heads(0) | heads(1) + loss(0) | backward(0) + loss(1) | backward(1)
+        auto heads_tile = [&](int t) {
+            f32x4 o0 = f32x4{bo[0], bo[1], bo[2], bo[3]}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int m = 0; m < kMT; m += 2) {
                 const f32x4 wa = *reinterpret_cast<const f32x4 *>(w2t + (m * 64 + lane) * 4);
                 const f32x4 wb = *reinterpret_cast<const f32x4 *>(w2t + ((m + 1) * 64 + lane) * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int t = 0; t < kTPI; ++t) {
-                        o0[t] = mfma16(wa[r], h[t][m][r], o0[t]);
-                        o1[t] = mfma16(wb[r], h[t][m + 1][r], o1[t]);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    o0 = mfma16(wa[r], h[t][m][r], o0);
+                    o1 = mfma16(wb[r], h[t][m + 1][r], o1);
+                }
             }
-#pragma unroll
-            for (int t = 0; t < kTPI; ++t) out[t] = o0[t] + o1[t];  // out^T[o = 4g + r][row = c]
-        }
-
-        // ---- loss and d(loss)/d(out) -----------------------------------------------------------------
+            return o0 + o1;  // out^T[o = 4g + r][row = c]
+        };
         f32x4 dout[kTPI];
-#pragma unroll
-        for (int t = 0; t < kTPI; ++t) {
+        auto loss_tile = [&](int t, const f32x4 &out) {  // loss, d(loss)/d(out), dout tile -> LDS
             LossOut lo;
             if constexpr (ABL & 1) {
-                lo.dout = out[t] * rs[t].weight;
+                lo.dout = out * rs[t].weight;
                 lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs[t].adv;
             } else {
-                lo = ppo_loss_tile(out[t], rs[t], a, g, hp, adv_mean, adv_den, inv_rows);
+                lo = ppo_loss_tile(out, rs[t], a, g, hp, adv_mean, adv_den, inv_rows);
             }
             dout[t] = lo.dout;
 #pragma unroll
@@ -402,66 +398,75 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                 stats[5] += lo.clipped;
             }
             *reinterpret_cast<f32x4 *>(wave_lds + t * L::kTileFloats + 16 * XS + 16 * HS + c * DS + 4 * g) = lo.dout;
-        }
-        wave_lds_fence();
-
-        // ---- backward -----------------------------------------------------------------------------------
-        float dfrag[kTPI][4];   // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c) for the dW2v contraction
-        float xa[kTPI][KT][4];  // A frags of X^T (i = k = 16kt + c, k-slot g <-> row 4g+r) for the dW1 contraction
+        };
+        // Backward of tile t.  `between` runs inside the first half's MFMA region (used to co-schedule the other tile's loss).
+        auto backward_tile = [&](int t, auto &&between) {
+            float *xs = wave_lds + t * L::kTileFloats;
+            float *hsT = xs + 16 * XS;
+            const float *ds = hsT + 16 * HS;
 #pragma unroll
-        for (int t = 0; t < kTPI; ++t) {
-            const float *xs = wave_lds + t * L::kTileFloats;
-            const float *ds = xs + 16 * XS + 16 * HS;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dfrag[t][r] = ds[(4 * g + r) * DS + c];
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xa[t][kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
-        }
-#pragma unroll
-        for (int half = 0; half < ((ABL & 2) ? 0 : 2); ++half) {
-            // half of the hidden tile, row-major [row][u - 64*half], for the relu mask and the dW2v contraction
-#pragma unroll
-            for (int t = 0; t < kTPI; ++t)
+            for (int half = 0; half < ((ABL & 2) ? 0 : 2); ++half) {
+                // half of the hidden tile, row-major [row][u - 64*half], for the relu mask and the dW2v contraction
 #pragma unroll
                 for (int mm = 0; mm < kMT / 2; ++mm)
-                    *reinterpret_cast<f32x4 *>(wave_lds + t * L::kTileFloats + 16 * XS + c * HS + 16 * mm + 4 * g) =
-                        h[t][half * (kMT / 2) + mm];
-            wave_lds_fence();
+                    *reinterpret_cast<f32x4 *>(hsT + c * HS + 16 * mm + 4 * g) = h[t][half * (kMT / 2) + mm];
+                wave_lds_fence();
+                float dfrag[4];   // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c) for the dW2v contraction
+                float xa[KT][4];  // A frags of X^T (i = k = 16kt + c, k-slot g <-> row 4g+r) for the dW1 contraction
 #pragma unroll
-            for (int mm = 0; mm < kMT / 2; ++mm) {
-                const int m = half * (kMT / 2) + mm;
-                // dh[row = 4g+r][u = 16m + c] = sum_o dout[row][o] W2v[o][u]; A = dout^T C-fragment (A = C^T)
-                const f32x4 wb = *reinterpret_cast<const f32x4 *>(w2bt + (m * 64 + lane) * 4);
-                f32x4 dh[kTPI];
-                float hrow[kTPI][4];
+                for (int r = 0; r < 4; ++r) dfrag[r] = ds[(4 * g + r) * DS + c];
 #pragma unroll
-                for (int t = 0; t < kTPI; ++t) dh[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
+                // dh[row = 4g+r][u = 16m + c] = sum_o dout[row][o] W2v[o][u]; A = dout^T C-fragment (A = C^T);
+                // the four hidden tiles of this half are four independent accumulator chains
+                f32x4 dh[kMT / 2];
+                float hrow[kMT / 2][4];
+#pragma unroll
+                for (int mm = 0; mm < kMT / 2; ++mm) {
+                    dh[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hrow[mm][r] = hsT[(4 * g + r) * HS + 16 * mm + c];  // hidden[row=4g+r][u=16m+c]
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int t = 0; t < kTPI; ++t) dh[t] = mfma16(dout[t][r], wb[r], dh[t]);
-#pragma unroll
-                for (int t = 0; t < kTPI; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        hrow[t][r] = wave_lds[t * L::kTileFloats + 16 * XS + (4 * g + r) * HS + 16 * mm + c];
-                        dh[t][r] = hrow[t][r] > 0.0f ? dh[t][r] : 0.0f;  // relu'
-                        db1[m] += dh[t][r];
+                    for (int mm = 0; mm < kMT / 2; ++mm) {
+                        const int m = half * (kMT / 2) + mm;
+                        dh[mm] = mfma16(dout[t][r], w2bt[(m * 64 + lane) * 4 + r], dh[mm]);
                     }
 #pragma unroll
-                for (int t = 0; t < kTPI; ++t) {
+                for (int mm = 0; mm < kMT / 2; ++mm)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dh[mm][r] = hrow[mm][r] > 0.0f ? dh[mm][r] : 0.0f;  // relu'
+                        db1[half * (kMT / 2) + mm] += dh[mm][r];
+                    }
+#pragma unroll
+                for (int mm = 0; mm < kMT / 2; ++mm) {
+                    const int m = half * (kMT / 2) + mm;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                        for (int kt = 0; kt < KT; ++kt) acc_dw1[kt][m] = mfma16(xa[t][kt][r], dh[t][r], acc_dw1[kt][m]);
-                        acc_dw2[m] = mfma16(hrow[t][r], dfrag[t][r], acc_dw2[m]);
+                        for (int kt = 0; kt < KT; ++kt) acc_dw1[kt][m] = mfma16(xa[kt][r], dh[mm][r], acc_dw1[kt][m]);
+                        acc_dw2[m] = mfma16(hrow[mm][r], dfrag[r], acc_dw2[m]);
                     }
                 }
+                if (half == 0) between();
+                wave_lds_fence();
             }
-            wave_lds_fence();
-        }
+        };
+
+        const f32x4 out0 = heads_tile(0);
+        const f32x4 out1 = heads_tile(1);
+        loss_tile(0, out0);
+        wave_lds_fence();
+        backward_tile(0, [&]() { loss_tile(1, out1); });
+        // tile 0's hidden fragments are dead now: their registers take the next pair's X tiles, which have all of
+        // backward(1) to arrive from HBM
+        prefetch(base + wave_count * kTPI);
+        backward_tile(1, []() {});
     }
 
     // ---- reduce the waves' accumulators into one workgroup partial (native order, conflict-free), fixed order -----
