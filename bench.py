@@ -200,7 +200,9 @@ def main():
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        from pufferlib_amd import dist as pdist
         dist.barrier()
+        pdist.finalize_native()
         dist.destroy_process_group()
 
 

@@ -185,12 +185,26 @@ int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float 
 
 /* The whole minibatch loop of one clean_pufferl.train call on ONE rank (clean_pufferl.py:175-258 without the
  * target_kl early exit): update_epochs x num_minibatches x { pfa_ppo_mlp_grad, pfa_adam_clip_step } enqueued from
- * native code (no per-step host work).  opt_step = optimizer steps taken before this call; losses as above. */
+ * native code (no per-step host work).  opt_step = optimizer steps taken before this call; losses as above.
+ * data_parallel != 0: every optimizer step all-reduces the flat bucket [gradient | 8 loss sums] over the RCCL
+ * communicator of pfa_dist_init on `stream` (gradients are pre-divided by the GLOBAL minibatch rows = local rows x
+ * world size; adv_stats must already hold the all-reduced sums) and takes the clip norm after the reduce. */
 int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                       const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                       float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
                       float max_grad_norm, int32_t update_epochs, float *losses, void *workspace,
-                      pfa_stream_t stream);
+                      int32_t data_parallel, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Data parallel over the GPUs of one node (no reference counterpart): one process per GPU, one RCCL communicator
+ * per process, bound at run time (dlopen librccl.so.1).  Rank 0 creates the 128-byte id, the host side broadcasts it
+ * (torch.distributed), every rank calls pfa_dist_init collectively.  Collectives run on the caller's stream.
+ * ------------------------------------------------------------------------------------------ */
+int pfa_dist_unique_id(uint8_t *id128_host);
+int pfa_dist_init(const uint8_t *id128_host, int32_t rank, int32_t world);
+int pfa_dist_finalize(void);
+int pfa_dist_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
+int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
 
 /* What train() logs (clean_pufferl.py:249-254,266-270) in one device buffer of 10 f64: out[0..5] = `losses` (the six
  * running means above), out[6..9] = sum y_true, sum y_true^2, sum adv, sum adv^2 with y_pred = values in storage

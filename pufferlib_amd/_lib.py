@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise ExtensionError(f'hipcc failed on {src}:\n{out.decode()}')
-    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs + ['-ldl']
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise ExtensionError(f'link failed:\n{r.stdout.decode()}')
@@ -109,7 +109,13 @@ _SIGNATURES = {
     'pfa_ppo_mlp_grad': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),
                                    C.POINTER(PpoHparams), P, C.c_int64, P, P, P]),
     'pfa_ppo_mlp_train': (C.c_int, [C.POINTER(Experience), C.c_int64, P, C.POINTER(MlpDims), C.POINTER(PpoHparams), P, P, P, P,
-                                    C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P, P]),
+                                    C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P,
+                                    C.c_int32, P]),
+    'pfa_dist_unique_id': (C.c_int, [P]),
+    'pfa_dist_init': (C.c_int, [P, C.c_int32, C.c_int32]),
+    'pfa_dist_finalize': (C.c_int, []),
+    'pfa_dist_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
+    'pfa_dist_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
     'pfa_train_log_sums': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, P, P, P]),
     'pfa_adam_clip_step': (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
                                      C.c_float, C.c_float, P, P, C.c_float, P, C.c_int32, P]),

@@ -258,8 +258,12 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     vecenv.env_offset = rank * vecenv.num_agents
     vecenv.async_reset(config.seed + vecenv.env_offset)   # clean_pufferl.py:39; env i of rank r gets seed + r*N + i
     fp = policy.adopt(vecenv.obs_stride, device)
+    native_dp = False
     if world > 1:
         dist.broadcast(fp.flat, src=0)
+        native_dp = pdist.init_native()          # RCCL communicator inside the native library, or torch fallback
+    elif _cfg(config, 'force_native_dp', False):
+        native_dp = pdist.init_native(force_single=True)   # 1-rank communicator: exercises the DP code path in tests
     policy.noise_seed = int(config.seed)
 
     total_agents = vecenv.num_agents
@@ -279,7 +283,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         experience=experience, profile=profile, losses=losses, wandb=wandb, global_step=0, epoch=0, stats={},
         msg=msg, last_log_time=0, utilization=utilization,
         # engine state
-        flat_params=fp, rank=rank, world_size=world,
+        flat_params=fp, rank=rank, world_size=world, native_dp=native_dp,
         workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
         grads=torch.zeros(fp.count + 8, dtype=torch.float32, device=device),
         adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
@@ -345,7 +349,9 @@ def evaluate(data):
         experience.step = T
         data.global_step += N * T * data.world_size      # sum(mask) per recv (clean_pufferl.py:90), all ranks
         st = vecenv.episode_stats(reset=True)
-        if data.world_size > 1:
+        if data.native_dp:
+            _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(st), st.numel(), _lib.stream_handle()), 'stats all-reduce')
+        elif data.world_size > 1:
             dist, _, _ = _dist()
             dist.all_reduce(st)
         st = st.cpu().numpy()                            # the one sync of evaluate()
@@ -377,7 +383,9 @@ def train(data):
         if config.norm_adv:
             _lib.check(L.pfa_ppo_adv_stats(C.byref(experience.c), B, C.byref(hp), _lib.ptr(data.adv_stats),
                                            _lib.ptr(data.workspace), stream), 'adv_stats')
-            if world > 1:
+            if data.native_dp:
+                _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(data.adv_stats), data.adv_stats.numel(), stream), 'adv all-reduce')
+            elif world > 1:
                 dist.all_reduce(data.adv_stats)
         data.loss_acc.zero_()
         experience.ptr = 0
@@ -386,16 +394,18 @@ def train(data):
     global_mb_rows = experience.minibatch_size * world
     loss_scale = 1.0 / (global_mb_rows * nmb)
     epochs_run = 0
-    native_loop = world == 1 and config.target_kl is None
+    native_loop = (world == 1 or data.native_dp) and config.target_kl is None
     if native_loop:
-        # single rank, no early exit: the whole epoch x minibatch loop is enqueued by one native call
+        # no early exit: the whole epoch x minibatch loop (incl. the per-step RCCL all-reduce when data parallel) is
+        # enqueued by one native call on the compute stream
         with profile.learn:
             g = opt.param_groups[0]
             _lib.check(L.pfa_ppo_mlp_train(
                 C.byref(experience.c), B, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hp), _lib.ptr(data.adv_stats),
                 _lib.ptr(data.grads), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), opt.step_count, float(g['lr']),
                 float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(config.max_grad_norm),
-                int(config.update_epochs), _lib.ptr(data.loss_acc), _lib.ptr(data.workspace), stream), 'ppo_train')
+                int(config.update_epochs), _lib.ptr(data.loss_acc), _lib.ptr(data.workspace),
+                1 if data.native_dp else 0, stream), 'ppo_train')
             opt.step_count += config.update_epochs * nmb
     for epoch in range(0 if native_loop else config.update_epochs):
         for mb in range(nmb):

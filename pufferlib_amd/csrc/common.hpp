@@ -40,6 +40,11 @@ struct ScopedKernelTimer {  // brackets ONE kernel launch with HIP events on its
 
 #define PFA_LAUNCH_CHECK() PFA_CHECK_HIP(hipGetLastError())
 
+// csrc/dist.cpp: process-wide RCCL communicator (one process per GPU)
+int dist_world();
+bool dist_ready();
+int dist_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream);
+
 constexpr int kWave = 64;
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

@@ -1,0 +1,117 @@
+// dist.cpp — RCCL (librccl.so.1, the "nccl" of ROCm) bound at run time with dlopen, so the library has no link-time
+// dependency on it and a box without RCCL still loads everything else.  One communicator per process (one process per
+// GPU); collectives are enqueued on the caller's HIP stream, i.e. in order with the kernels around them, without the
+// stream hand-off events a framework-side collective needs.  There is no reference counterpart.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "common.hpp"
+
+namespace pfa {
+namespace {
+
+// Minimal RCCL surface (include/rccl/rccl.h): opaque handles and the enum values we use.
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { kNcclSuccess = 0 };
+enum { kNcclFloat32 = 7, kNcclFloat64 = 8 };  // ncclDataType_t
+enum { kNcclSum = 0 };                         // ncclRedOp_t
+
+struct Api {
+    void *handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Api g_api;
+ncclComm_t g_comm = nullptr;
+int g_rank = 0, g_world = 1;
+
+int load_api() {
+    if (g_api.handle) return 0;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    PFA_REQUIRE(h != nullptr, "dist: cannot dlopen librccl.so.1: %s", dlerror());
+    g_api.GetUniqueId = (decltype(g_api.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_api.CommInitRank = (decltype(g_api.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_api.CommDestroy = (decltype(g_api.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_api.AllReduce = (decltype(g_api.AllReduce))dlsym(h, "ncclAllReduce");
+    g_api.GetErrorString = (decltype(g_api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    PFA_REQUIRE(g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce,
+                "dist: librccl is missing a required symbol");
+    g_api.handle = h;
+    return 0;
+}
+
+#define PFA_CHECK_NCCL(expr)                                                                          \
+    do {                                                                                              \
+        int _r = (expr);                                                                              \
+        if (_r != kNcclSuccess) {                                                                     \
+            set_error("%s:%d %s -> rccl error %d (%s)", __FILE__, __LINE__, #expr, _r,                \
+                      g_api.GetErrorString ? g_api.GetErrorString(_r) : "?");                         \
+            return -3;                                                                                \
+        }                                                                                             \
+    } while (0)
+
+}  // namespace
+
+int dist_world() { return g_world; }
+bool dist_ready() { return g_comm != nullptr; }
+
+int dist_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
+    PFA_REQUIRE(g_comm != nullptr, "dist: communicator not initialised");
+    PFA_CHECK_NCCL(g_api.AllReduce(buf, buf, count, f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, g_comm, stream));
+    return 0;
+}
+
+}  // namespace pfa
+
+using namespace pfa;
+
+extern "C" int pfa_dist_unique_id(uint8_t *id128_host) {
+    PFA_REQUIRE(id128_host != nullptr, "dist.unique_id: null buffer");
+    if (int rc = load_api()) return rc;
+    ncclUniqueId id;
+    PFA_CHECK_NCCL(g_api.GetUniqueId(&id));
+    std::memcpy(id128_host, id.internal, 128);
+    return 0;
+}
+
+extern "C" int pfa_dist_init(const uint8_t *id128_host, int32_t rank, int32_t world) {
+    PFA_REQUIRE(id128_host != nullptr && world >= 1 && rank >= 0 && rank < world, "dist.init: bad arguments");
+    if (int rc = load_api()) return rc;
+    if (g_comm) {
+        PFA_CHECK_NCCL(g_api.CommDestroy(g_comm));
+        g_comm = nullptr;
+    }
+    ncclUniqueId id;
+    std::memcpy(id.internal, id128_host, 128);
+    PFA_CHECK_NCCL(g_api.CommInitRank(&g_comm, world, id, rank));
+    g_rank = rank;
+    g_world = world;
+    return 0;
+}
+
+extern "C" int pfa_dist_finalize(void) {
+    if (g_comm) {
+        PFA_CHECK_NCCL(g_api.CommDestroy(g_comm));
+        g_comm = nullptr;
+    }
+    g_world = 1;
+    g_rank = 0;
+    return 0;
+}
+
+extern "C" int pfa_dist_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream) {
+    PFA_REQUIRE(buf && count >= 0, "dist.all_reduce: bad arguments");
+    return dist_all_reduce(buf, (size_t)count, false, (hipStream_t)stream);
+}
+
+extern "C" int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream) {
+    PFA_REQUIRE(buf && count >= 0, "dist.all_reduce: bad arguments");
+    return dist_all_reduce(buf, (size_t)count, true, (hipStream_t)stream);
+}

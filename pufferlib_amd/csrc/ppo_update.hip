@@ -856,21 +856,32 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
                                  const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                                  float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
                                  float max_grad_norm, int32_t update_epochs, float *losses, void *workspace,
-                                 pfa_stream_t stream) {
+                                 int32_t data_parallel, pfa_stream_t stream) {
     if (int rc = check_update_args(exp, batch_rows, dims, hp)) return rc;
     PFA_REQUIRE(update_epochs >= 0 && opt_step >= 0, "ppo.train: bad epoch / step count");
+    PFA_REQUIRE(!data_parallel || dist_ready(), "ppo.train: data_parallel needs pfa_dist_init first");
+    const int world = data_parallel ? dist_world() : 1;
     const int64_t mbs = batch_rows / hp->num_minibatches;
+    const int64_t global_mbs = mbs * world;
     const int64_t count = mlp_offsets(dims->obs_stride, dims->num_actions).count;
-    const float loss_scale = (float)(1.0 / ((double)mbs * hp->num_minibatches));
+    const float loss_scale = (float)(1.0 / ((double)global_mbs * hp->num_minibatches));
     for (int e = 0; e < update_epochs; ++e)
         for (int mb = 0; mb < hp->num_minibatches; ++mb) {
-            if (int rc = pfa_ppo_mlp_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, mbs, grads, workspace, stream)) return rc;
-            ++opt_step;
-            if (int rc = pfa_adam_clip_step(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, opt_step,
-                                            max_grad_norm, 1.0f, grads + count, losses, loss_scale,
-                                            norm_partials_of(workspace, dims->obs_stride),
-                                            (int)((native_count(dims->obs_stride) + 63) / 64), stream))
+            if (int rc = pfa_ppo_mlp_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, global_mbs, grads, workspace, stream))
                 return rc;
+            ++opt_step;
+            if (data_parallel) {
+                // one flat bucket per optimizer step: gradient (already / global rows) + 8 loss sums, on this stream
+                if (int rc = dist_all_reduce(grads, (size_t)count + kNumStats, false, (hipStream_t)stream)) return rc;
+                if (int rc = pfa_adam_clip_step(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, opt_step,
+                                                max_grad_norm, 1.0f, grads + count, losses, loss_scale, nullptr, 0, stream))
+                    return rc;
+            } else if (int rc = pfa_adam_clip_step(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, opt_step,
+                                                   max_grad_norm, 1.0f, grads + count, losses, loss_scale,
+                                                   norm_partials_of(workspace, dims->obs_stride),
+                                                   (int)((native_count(dims->obs_stride) + 63) / 64), stream)) {
+                return rc;
+            }
         }
     return 0;
 }

@@ -76,3 +76,54 @@ def normalisation_from_sums(s1, s2, count):
     mean = s1 / count
     var = max((s2 - s1 * mean) / (count - 1.0), 0.0)
     return mean, math.sqrt(var)
+
+
+_native = dict(ready=False, world=1)
+
+
+def native_ready():
+    return _native['ready']
+
+
+def init_native(force_single=False):
+    """Create this process's RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp) so the optimizer-step
+    all-reduce can be enqueued from native code on the compute stream.  The 128-byte id travels from rank 0 through
+    the already-initialised torch.distributed group.  Returns True when EVERY rank succeeded (agreement by a MIN
+    all-reduce); on any failure all ranks fall back to torch.distributed collectives.  ``PFA_NATIVE_RCCL=0`` disables.
+    ``force_single`` builds a 1-rank communicator without a process group (tests on a single GPU)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from . import _lib
+    if os.environ.get('PFA_NATIVE_RCCL', '1') == '0':
+        return False
+    d, rank, w = world()
+    if w == 1 and not force_single:
+        return False
+    L = _lib.lib()
+    ok = 1
+    ident = np.zeros(128, np.uint8)
+    if rank == 0:
+        if L.pfa_dist_unique_id(ident.ctypes.data_as(C.c_void_p)) != 0:
+            ok = 0
+    if w > 1:
+        t = torch.from_numpy(ident).cuda()
+        d.broadcast(t, src=0)
+        ident = t.cpu().numpy()
+    if ok and L.pfa_dist_init(ident.ctypes.data_as(C.c_void_p), rank, w) != 0:
+        ok = 0
+    if w > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
+        d.all_reduce(flag, op=d.ReduceOp.MIN)
+        ok = int(flag.item())
+        if not ok:
+            L.pfa_dist_finalize()
+    _native.update(ready=bool(ok), world=w)
+    return bool(ok)
+
+
+def finalize_native():
+    from . import _lib
+    if _native['ready']:
+        _lib.lib().pfa_dist_finalize()
+        _native.update(ready=False, world=1)

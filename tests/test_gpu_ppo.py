@@ -222,3 +222,26 @@ def test_philox_actions_match_oracle_at_full_size():
         mism += len(bad)
         ovec.send(dev.astype(np.int64))       # follow the device's actions so later steps stay comparable
     assert mism <= 2, f'{mism} action mismatches in {steps * n} samples (only near-ties in p/q may differ)'
+
+
+def test_native_data_parallel_path_single_rank_equals_plain():
+    """The RCCL-native DP loop (csrc/dist.cpp + pfa_ppo_mlp_train data_parallel=1) with a 1-rank communicator must
+    reproduce the plain single-GPU update bit for bit (all-reduce over one rank is the identity; the clip norm is
+    recomputed from the reduced gradient instead of the reduce kernel's partial sums)."""
+    from pufferlib_amd import clean_pufferl, dist as pdist
+    n, horizon = 256, 64
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    results = []
+    for force in (False, True):
+        vec, pol = _make(n)
+        cfg = _config(n, horizon, n * horizon // 4, 16, 2, n * horizon * 4, hp, force_native_dp=force)
+        data = clean_pufferl.create(cfg, vec, pol)
+        assert data.native_dp == force
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+        results.append((data.flat_params.flat.clone(), dict(data.losses)))
+        pdist.finalize_native()
+    (w0, l0), (w1, l1) = results
+    np.testing.assert_allclose(w1.cpu().numpy(), w0.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    for k in l0:
+        np.testing.assert_allclose(l1[k], l0[k], rtol=1e-5, atol=1e-7)
