@@ -18,6 +18,7 @@
 //   dW1^T[k][u] += X[row][k]^T . dh[row][u]      A from the LDS X tile
 //   dW2v^T[u][o] += hidden[row][u]^T . dout[row][o]   A from the LDS hidden tile, B from the LDS dout tile
 #include <cmath>
+#include <type_traits>
 
 #include "common.hpp"
 #include "mlp_tile.hpp"
@@ -41,8 +42,14 @@ struct GradLds {
     static constexpr int HH = kHidden / 2;    // hidden columns per half
     static constexpr int HS = HH + 4;         // row stride of the half hidden tile (16 B aligned, conflict-free reads)
     static constexpr int DS = 20;             // dout tile row stride
-    static constexpr int kTileFloats = 16 * XS + 16 * HS + 16 * DS;
-    static constexpr int kWaveFloats = kTPI * kTileFloats;
+    static constexpr int HF = kHidden + 4;    // row stride of tile 1's FULL hidden tile
+    // per-wave map: X tiles of both in-flight tiles, tile 0's half hidden tile (rewritten per half), tile 1's full
+    // hidden tile (parked in LDS right after its heads so its 32 registers are free during backward(0)), dout tiles
+    static constexpr int kXs = 0;                       // + t * 16 * XS
+    static constexpr int kHs0 = 2 * 16 * XS;            // tile 0, half
+    static constexpr int kHs1 = kHs0 + 16 * HS;         // tile 1, full
+    static constexpr int kDs = kHs1 + 16 * HF;          // + t * 16 * DS
+    static constexpr int kWaveFloats = kDs + 2 * 16 * DS;
     static constexpr int kW1Floats = kMT * 64 * W1S;
     static constexpr int kTabFloats = kMT * 64 * 4;
     static constexpr int kFloats = kGradWaves * kWaveFloats + kW1Floats + 3 * kTabFloats;
@@ -310,7 +317,7 @@ __global__ void __launch_bounds__(kGradThreads, 1)
         RowScalars rs[kTPI];
 #pragma unroll
         for (int t = 0; t < kTPI; ++t) {
-            float *xs = wave_lds + t * L::kTileFloats;
+            float *xs = wave_lds + L::kXs + t * 16 * XS;
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int idx = lane + 64 * j;
@@ -344,7 +351,7 @@ __global__ void __launch_bounds__(kGradThreads, 1)
 #pragma unroll
             for (int t = 0; t < kTPI; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xb[t][j] = wave_lds[t * L::kTileFloats + c * XS + 4 * (4 * k4 + j) + g];
+                for (int j = 0; j < 4; ++j) xb[t][j] = wave_lds[L::kXs + t * 16 * XS + c * XS + 4 * (4 * k4 + j) + g];
 #pragma unroll
             for (int m = 0; m < kMT; ++m) {
                 const f32x4 wq = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + 4 * k4);
@@ -397,45 +404,52 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                 stats[4] += lo.kl;
                 stats[5] += lo.clipped;
             }
-            *reinterpret_cast<f32x4 *>(wave_lds + t * L::kTileFloats + 16 * XS + 16 * HS + c * DS + 4 * g) = lo.dout;
+            *reinterpret_cast<f32x4 *>(wave_lds + L::kDs + t * 16 * DS + c * DS + 4 * g) = lo.dout;
         };
         // Backward of tile t.  `between` runs inside the first half's MFMA region (used to co-schedule the other tile's loss).
-        auto backward_tile = [&](int t, auto &&between) {
-            float *xs = wave_lds + t * L::kTileFloats;
-            float *hsT = xs + 16 * XS;
-            const float *ds = hsT + 16 * HS;
-#pragma unroll
-            for (int half = 0; half < ((ABL & 2) ? 0 : 2); ++half) {
-                // half of the hidden tile, row-major [row][u - 64*half], for the relu mask and the dW2v contraction
-#pragma unroll
-                for (int mm = 0; mm < kMT / 2; ++mm)
-                    *reinterpret_cast<f32x4 *>(hsT + c * HS + 16 * mm + 4 * g) = h[t][half * (kMT / 2) + mm];
-                wave_lds_fence();
-                float dfrag[4];   // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c) for the dW2v contraction
-                float xa[KT][4];  // A frags of X^T (i = k = 16kt + c, k-slot g <-> row 4g+r) for the dW1 contraction
+        auto backward_tile = [&](auto tconst, auto &&between) {
+            constexpr int t = decltype(tconst)::value;
+            const float *xs = wave_lds + L::kXs + t * 16 * XS;
+            const float *ds = wave_lds + L::kDs + t * 16 * DS;
+            float *hs0 = wave_lds + L::kHs0;
+            const float *hs1 = wave_lds + L::kHs1;
+            // operands that do not depend on the half: loaded once per tile, ahead of every MFMA that uses them
+            float dfrag[4];   // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c) for the dW2v contraction
+            float xa[KT][4];  // A frags of X^T (i = k = 16kt + c, k-slot g <-> row 4g+r) for the dW1 contraction
+            if constexpr (!(ABL & 2)) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dfrag[r] = ds[(4 * g + r) * DS + c];
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
+            }
+#pragma unroll
+            for (int half = 0; half < ((ABL & 2) ? 0 : 2); ++half) {
+                if constexpr (t == 0) {
+                    // tile 0: half of the hidden tile, row-major [row][u - 64*half], for relu' and the dW2v contraction
+#pragma unroll
+                    for (int mm = 0; mm < kMT / 2; ++mm)
+                        *reinterpret_cast<f32x4 *>(hs0 + c * HS + 16 * mm + 4 * g) = h[0][half * (kMT / 2) + mm];
+                    wave_lds_fence();
+                }
                 // dh[row = 4g+r][u = 16m + c] = sum_o dout[row][o] W2v[o][u]; A = dout^T C-fragment (A = C^T);
                 // the four hidden tiles of this half are four independent accumulator chains
-                f32x4 dh[kMT / 2];
+                f32x4 dh[kMT / 2], wb[kMT / 2];
                 float hrow[kMT / 2][4];
 #pragma unroll
                 for (int mm = 0; mm < kMT / 2; ++mm) {
                     dh[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    wb[mm] = *reinterpret_cast<const f32x4 *>(w2bt + ((half * (kMT / 2) + mm) * 64 + lane) * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hrow[mm][r] = hsT[(4 * g + r) * HS + 16 * mm + c];  // hidden[row=4g+r][u=16m+c]
+                    for (int r = 0; r < 4; ++r)  // hidden[row = 4g+r][u = 16m + c]
+                        hrow[mm][r] = t == 0 ? hs0[(4 * g + r) * HS + 16 * mm + c]
+                                             : hs1[(4 * g + r) * L::HF + 16 * (half * (kMT / 2) + mm) + c];
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int mm = 0; mm < kMT / 2; ++mm) {
-                        const int m = half * (kMT / 2) + mm;
-                        dh[mm] = mfma16(dout[t][r], w2bt[(m * 64 + lane) * 4 + r], dh[mm]);
-                    }
+                    for (int mm = 0; mm < kMT / 2; ++mm) dh[mm] = mfma16(dout[t][r], wb[mm][r], dh[mm]);
 #pragma unroll
                 for (int mm = 0; mm < kMT / 2; ++mm)
 #pragma unroll
@@ -454,19 +468,25 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                     }
                 }
                 if (half == 0) between();
-                wave_lds_fence();
+                if constexpr (t == 0) wave_lds_fence();
             }
         };
 
         const f32x4 out0 = heads_tile(0);
         const f32x4 out1 = heads_tile(1);
+        if constexpr (!(ABL & 2)) {  // park tile 1's hidden tile in LDS: frees its 32 registers until backward(1)
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+                *reinterpret_cast<f32x4 *>(wave_lds + L::kHs1 + c * L::HF + 16 * m + 4 * g) = h[1][m];
+        }
         loss_tile(0, out0);
         wave_lds_fence();
-        backward_tile(0, [&]() { loss_tile(1, out1); });
-        // tile 0's hidden fragments are dead now: their registers take the next pair's X tiles, which have all of
-        // backward(1) to arrive from HBM
+        backward_tile(std::integral_constant<int, 0>{}, [&]() { loss_tile(1, out1); });
+        // tile 0's hidden fragments are dead now: the next pair's X tiles take registers and have all of backward(1)
+        // to arrive from HBM
         prefetch(base + wave_count * kTPI);
-        backward_tile(1, []() {});
+        wave_lds_fence();
+        backward_tile(std::integral_constant<int, 1>{}, []() {});
     }
 
     // ---- reduce the waves' accumulators into one workgroup partial (native order, conflict-free), fixed order -----
