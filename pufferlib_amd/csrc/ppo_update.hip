@@ -25,13 +25,16 @@
 
 namespace pfa {
 
-constexpr int kGradThreads = 256;
+constexpr int kGradThreads = 512;
 constexpr int kGradWaves = kGradThreads / 64;
-constexpr int kTPI = 2;       // 16-row tiles in flight per wavefront (the loop body is written for exactly 2)
-constexpr int kNumStats = 8;  // 6 used: pg, v, entropy, old_kl, kl, clipfrac
+constexpr int kGradPairs = kGradWaves / 2;  // (producer, consumer) wavefront pairs per workgroup
+constexpr int kNumStats = 8;                // 6 used: pg, v, entropy, old_kl, kl, clipfrac
 
-// LDS map of kernel A (floats).  Per wave and per in-flight tile: X tile, hidden tile, dout tile.  Shared by the
-// waves: lane-major MFMA fragment tables so every fragment read is one conflict-free ds_read_b128:
+// LDS map of kernel A (floats).  A workgroup is 4 PAIRS of wavefronts; wave p (producer) and wave p+4 (consumer) share a
+// SIMD, so one wave's LDS waits / VALU stretches are covered by the other's MFMAs (two waves per SIMD fit because
+// neither role needs more than ~200 registers: the producer keeps no gradient accumulators, the consumer no forward
+// state).  Per pair: two X tiles (ring), two half-tiles of dh (ring), and the producer's private hidden-half / dout
+// tiles.  Shared by all waves: lane-major MFMA fragment tables, every fragment read one conflict-free ds_read_b128:
 //   w1t[m][lane][KS(+4)] A frags of the forward GEMM: W1[16m + c][4kk + g]
 //   b1t[m][lane][4] accumulator init   w2t[m][lane][4] A frags of the heads   w2bt[m][lane][4] B frags of dh = dout.W2v
 template <int DP>
@@ -40,19 +43,16 @@ struct GradLds {
     static constexpr int KS = DP / 4;
     static constexpr int W1S = KS + 4;        // lane stride of w1t (16 B aligned, spreads 16 lanes over all banks)
     static constexpr int HH = kHidden / 2;    // hidden columns per half
-    static constexpr int HS = HH + 4;         // row stride of the half hidden tile (16 B aligned, conflict-free reads)
+    static constexpr int HS = HH + 4;         // row stride of a half tile (16 B aligned rows, conflict-free reads)
     static constexpr int DS = 20;             // dout tile row stride
-    static constexpr int HF = kHidden + 4;    // row stride of tile 1's FULL hidden tile
-    // per-wave map: X tiles of both in-flight tiles, tile 0's half hidden tile (rewritten per half), tile 1's full
-    // hidden tile (parked in LDS right after its heads so its 32 registers are free during backward(0)), dout tiles
-    static constexpr int kXs = 0;                       // + t * 16 * XS
-    static constexpr int kHs0 = 2 * 16 * XS;            // tile 0, half
-    static constexpr int kHs1 = kHs0 + 16 * HS;         // tile 1, full
-    static constexpr int kDs = kHs1 + 16 * HF;          // + t * 16 * DS
-    static constexpr int kWaveFloats = kDs + 2 * 16 * DS;
+    static constexpr int kXT = 0;                        // + slot * 16 * XS        X tiles (ring of 2)
+    static constexpr int kDH = 2 * 16 * XS;              // + half * 16 * HS        relu'-masked dh half tiles (ring of 2)
+    static constexpr int kHsP = kDH + 2 * 16 * HS;       // producer: hidden half tile [row][u]
+    static constexpr int kDsP = kHsP + 16 * HS;          // producer: dout tile [row][o]
+    static constexpr int kPairFloats = kDsP + 16 * DS;
     static constexpr int kW1Floats = kMT * 64 * W1S;
     static constexpr int kTabFloats = kMT * 64 * 4;
-    static constexpr int kFloats = kGradWaves * kWaveFloats + kW1Floats + 3 * kTabFloats;
+    static constexpr int kFloats = kGradPairs * kPairFloats + kW1Floats + 3 * kTabFloats;
 };
 
 // "Native" layout of one workgroup partial: gradients in MFMA C-fragment order (conflict-free LDS reduction and
@@ -200,9 +200,13 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
 }
 
 // ABL: ablation mask for tools/probe_grad.py (-DPFA_PROBES builds only; the product always runs ABL = 0):
-//   1 skip the loss math   2 skip the backward MFMAs   4 skip the forward MFMAs   8 skip the workgroup reduction
+//   1 skip the loss math   2 skip the consumer's dW1 MFMAs   4 skip the forward MFMAs
+//
+// Schedule of one pair over its tiles j = 0..J-1 (every phase ends in a workgroup barrier, 2 per tile):
+//   phase B_j  producer: stage X(j), forward, heads, loss, first hidden half: dh -> DH[0], dW2v      consumer: dW1 from DH[1] of tile j-1
+//   phase A_j  producer: second hidden half: dh -> DH[1], dW2v; prefetch X(j+1) into registers       consumer: dW1 from DH[0] of tile j
 template <int DP, int ABL = 0>
-__global__ void __launch_bounds__(kGradThreads, 1)
+__global__ void __launch_bounds__(kGradThreads, 2)
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, pfa_ppo_hparams hp,
                         const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
     using L = GradLds<DP>;
@@ -211,15 +215,16 @@ __global__ void __launch_bounds__(kGradThreads, 1)
     constexpr int NLD = (16 * V + 63) / 64;  // float4 loads per lane per tile
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
-    float *wave_lds = lds + wv * L::kWaveFloats;
-    float *w1t = lds + kGradWaves * L::kWaveFloats;
+    const int pair = wv & (kGradPairs - 1);
+    const bool producer = wv < kGradPairs;
+    float *pl = lds + pair * L::kPairFloats;
+    float *w1t = lds + kGradPairs * L::kPairFloats;
     float *b1t = w1t + L::kW1Floats;
     float *w2t = b1t + L::kTabFloats;
     float *w2bt = w2t + L::kTabFloats;
     const MlpOffsets off = mlp_offsets(DP, a);
 
-    // Build the fragment tables.  All global loads of a thread are issued before the first LDS store so they
-    // pipeline (a load -> store -> load chain would serialise ~50 L2 round trips in front of every launch).
+    // Build the fragment tables.  All global loads of a thread are issued before the first LDS store so they pipeline.
     {
         constexpr int N1 = kMT * 64 * KS / kGradThreads, N2 = kMT * 64 * 4 / kGradThreads;
         static_assert(kMT * 64 * KS % kGradThreads == 0 && kMT * 64 * 4 % kGradThreads == 0, "table sizes");
@@ -252,150 +257,129 @@ __global__ void __launch_bounds__(kGradThreads, 1)
             w2bt[i] = tv[j];
         }
     }
-    float bo[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bo[r] = b2v_at(params, off, a, 4 * g + r);
-
-    // advantage normalisation (clean_pufferl.py:211-213): unbiased std over the GLOBAL minibatch
-    float adv_mean = 0.0f, adv_den = 1.0f;
-    if (hp.norm_adv) {
-        const double s1 = adv_stats[2 * map.mb], s2 = adv_stats[2 * map.mb + 1];
-        const double mean = s1 / global_rows;
-        double var = (s2 - s1 * mean) / (global_rows - 1.0);
-        var = var > 0.0 ? var : 0.0;
-        adv_mean = (float)mean;
-        adv_den = (float)sqrt(var) + 1e-8f;
-    }
-    const float inv_rows = (float)(1.0 / global_rows);
-
-    f32x4 acc_dw1[KT][kMT];
-    f32x4 acc_dw2[kMT];
-    float db1[kMT], db2[4], stats[6];
-#pragma unroll
-    for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) acc_dw1[kt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < kMT; ++m) {
-        acc_dw2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-        db1[m] = 0.0f;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) db2[r] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) stats[i] = 0.0f;
 
     const long long tiles = mb_rows / 16;
-    const long long wave_global = (long long)blockIdx.x * kGradWaves + wv;
-    const long long wave_count = (long long)gridDim.x * kGradWaves;
-
-    // register prefetch of the next iteration's tiles (HBM latency hides under the current tiles' MFMAs)
-    float4 xpre[kTPI][NLD];
+    const long long pair_global = (long long)blockIdx.x * kGradPairs + pair;
+    const long long pair_count = (long long)gridDim.x * kGradPairs;
+    const int J = (int)((tiles + pair_count - 1) / pair_count);  // same for every pair: all waves run the same barriers
     const bool aligned = (map.horizon & 15) == 0;
-    auto prefetch = [&](long long first_tile) {
+
+    if (producer) {
+        // ------------------------------------------------------------------------------------------ producer
+        float bo[4];
 #pragma unroll
-        for (int t = 0; t < kTPI; ++t) {
-            const long long tile = first_tile + t;
+        for (int r = 0; r < 4; ++r) bo[r] = b2v_at(params, off, a, 4 * g + r);
+        // advantage normalisation (clean_pufferl.py:211-213): unbiased std over the GLOBAL minibatch
+        float adv_mean = 0.0f, adv_den = 1.0f;
+        if (hp.norm_adv) {
+            const double s1 = adv_stats[2 * map.mb], s2 = adv_stats[2 * map.mb + 1];
+            const double mean = s1 / global_rows;
+            double var = (s2 - s1 * mean) / (global_rows - 1.0);
+            var = var > 0.0 ? var : 0.0;
+            adv_mean = (float)mean;
+            adv_den = (float)sqrt(var) + 1e-8f;
+        }
+        const float inv_rows = (float)(1.0 / global_rows);
+
+        f32x4 acc_dw2[kMT];
+        float db1[kMT], db2[4], stats[6];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+            acc_dw2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            db1[m] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) db2[r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) stats[i] = 0.0f;
+
+        float4 xpre[NLD];  // register prefetch of the next tile's X rows and per-row scalars: issued a whole tile ahead
+        RowScalars rspre;
+        auto prefetch = [&](long long tile) {
             const bool ok = tile < tiles;
             const unsigned first = ok ? map.tile_first((unsigned)tile) : 0u;
+            rspre = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (ok) {  // per-row scalars (lane c <-> row c, replicated over the 4 lane groups)
+                const unsigned fr = map.tile_row((unsigned)tile, first, c, aligned);
+                rspre = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
+            }
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int idx = lane + 64 * j;
-                xpre[t][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                xpre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ok && idx < 16 * V) {
                     const int r = idx / V, c4 = idx - r * V;
                     const unsigned row = map.tile_row((unsigned)tile, first, r, aligned);
-                    xpre[t][j] = *reinterpret_cast<const float4 *>(ex.obs + (size_t)row * DP + 4 * c4);
+                    xpre[j] = *reinterpret_cast<const float4 *>(ex.obs + (size_t)row * DP + 4 * c4);
                 }
             }
-        }
-    };
-    prefetch(wave_global * kTPI);
-    __syncthreads();  // fragment tables ready
+        };
+        prefetch(pair_global);
+        __syncthreads();  // fragment tables ready
 
-    for (long long base = wave_global * kTPI; base < tiles; base += wave_count * kTPI) {
-        RowScalars rs[kTPI];
+        float *hsP = pl + L::kHsP, *dsP = pl + L::kDsP;
+        for (int j = 0; j < J; ++j) {
+            float *xs = pl + L::kXT + (j & 1) * 16 * XS;
+            // ---- phase B: stage X(j), forward, heads, loss, first half --------------------------------------------
 #pragma unroll
-        for (int t = 0; t < kTPI; ++t) {
-            float *xs = wave_lds + L::kXs + t * 16 * XS;
-#pragma unroll
-            for (int j = 0; j < NLD; ++j) {
-                const int idx = lane + 64 * j;
+            for (int q = 0; q < NLD; ++q) {
+                const int idx = lane + 64 * q;
                 if (idx < 16 * V) {
                     const int r = idx / V, c4 = idx - r * V;
                     float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
-                    d[0] = make_float2(xpre[t][j].x, xpre[t][j].y);
-                    d[1] = make_float2(xpre[t][j].z, xpre[t][j].w);
+                    d[0] = make_float2(xpre[q].x, xpre[q].y);
+                    d[1] = make_float2(xpre[q].z, xpre[q].w);
                 }
             }
-            // per-row scalars (lane c <-> row c, replicated over the 4 lane groups); consumed after the forward pass
-            rs[t] = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
-            if (base + t < tiles) {
-                const unsigned fr = map.tile_row((unsigned)(base + t), map.tile_first((unsigned)(base + t)), c, aligned);
-                rs[t] = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
-            }
-        }
-        wave_lds_fence();
+            const RowScalars rs = rspre;
+            prefetch(pair_global + (long long)(j + 1) * pair_count);  // lands during this tile's ~10k cycles
+            wave_lds_fence();
 
-        // ---- forward: hidden^T (kTPI x 8 independent accumulator chains) then out^T ---------------------------
-        f32x4 h[kTPI][kMT];
+            f32x4 h[kMT];
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-            const f32x4 b = *reinterpret_cast<const f32x4 *>(b1t + (m * 64 + lane) * 4);
+            for (int m = 0; m < kMT; ++m) h[m] = *reinterpret_cast<const f32x4 *>(b1t + (m * 64 + lane) * 4);
 #pragma unroll
-            for (int t = 0; t < kTPI; ++t) h[t][m] = b;
-        }
+            for (int k4 = 0; k4 < ((ABL & 4) ? 0 : KS / 4); ++k4) {
+                float xb[4];
 #pragma unroll
-        for (int k4 = 0; k4 < ((ABL & 4) ? 0 : KS / 4); ++k4) {
-            float xb[kTPI][4];
+                for (int q = 0; q < 4; ++q) xb[q] = xs[c * XS + 4 * (4 * k4 + q) + g];
 #pragma unroll
-            for (int t = 0; t < kTPI; ++t)
+                for (int m = 0; m < kMT; ++m) {
+                    const f32x4 wq = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + 4 * k4);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) xb[t][j] = wave_lds[L::kXs + t * 16 * XS + c * XS + 4 * (4 * k4 + j) + g];
-#pragma unroll
-            for (int m = 0; m < kMT; ++m) {
-                const f32x4 wq = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + 4 * k4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < kTPI; ++t) h[t][m] = mfma16(wq[j], xb[t][j], h[t][m]);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < kMT; ++m)
-#pragma unroll
-            for (int t = 0; t < kTPI; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[t][m][r] = fmaxf(h[t][m][r], 0.0f);
-
-        // The two tiles are staggered from here on so that the VALU-only loss math of one tile sits in the same
-        // scheduling region as MFMA work of the other:  heads(0) | heads(1) + loss(0) | backward(0) + loss(1) | backward(1)
-        auto heads_tile = [&](int t) {
-            f32x4 o0 = f32x4{bo[0], bo[1], bo[2], bo[3]}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int m = 0; m < kMT; m += 2) {
-                const f32x4 wa = *reinterpret_cast<const f32x4 *>(w2t + (m * 64 + lane) * 4);
-                const f32x4 wb = *reinterpret_cast<const f32x4 *>(w2t + ((m + 1) * 64 + lane) * 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    o0 = mfma16(wa[r], h[t][m][r], o0);
-                    o1 = mfma16(wb[r], h[t][m + 1][r], o1);
+                    for (int q = 0; q < 4; ++q) h[m] = mfma16(wq[q], xb[q], h[m]);
                 }
             }
-            return o0 + o1;  // out^T[o = 4g + r][row = c]
-        };
-        f32x4 dout[kTPI];
-        auto loss_tile = [&](int t, const f32x4 &out) {  // loss, d(loss)/d(out), dout tile -> LDS
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.0f);
+            f32x4 out;
+            {
+                f32x4 o[4] = {f32x4{bo[0], bo[1], bo[2], bo[3]}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
+                              f32x4{0.f, 0.f, 0.f, 0.f}};  // four independent chains
+#pragma unroll
+                for (int m0 = 0; m0 < kMT; m0 += 4) {
+                    f32x4 w4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const f32x4 *>(w2t + ((m0 + q) * 64 + lane) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = mfma16(w4[q][r], h[m0 + q][r], o[q]);
+                }
+                out = (o[0] + o[1]) + (o[2] + o[3]);  // out^T[o = 4g + r][row = c]
+            }
             LossOut lo;
             if constexpr (ABL & 1) {
-                lo.dout = out * rs[t].weight;
-                lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs[t].adv;
+                lo.dout = out * rs.weight;
+                lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs.adv;
             } else {
-                lo = ppo_loss_tile(out, rs[t], a, g, hp, adv_mean, adv_den, inv_rows);
+                lo = ppo_loss_tile(out, rs, a, g, hp, adv_mean, adv_den, inv_rows);
             }
-            dout[t] = lo.dout;
+            const f32x4 dout = lo.dout;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) db2[r] += lo.dout[r];
+            for (int r = 0; r < 4; ++r) db2[r] += dout[r];
             if (g == 0) {  // one lane group owns the per-row scalars
                 stats[0] += lo.pg;
                 stats[1] += lo.v_loss;
@@ -404,37 +388,20 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                 stats[4] += lo.kl;
                 stats[5] += lo.clipped;
             }
-            *reinterpret_cast<f32x4 *>(wave_lds + L::kDs + t * 16 * DS + c * DS + 4 * g) = lo.dout;
-        };
-        // Backward of tile t.  `between` runs inside the first half's MFMA region (used to co-schedule the other tile's loss).
-        auto backward_tile = [&](auto tconst, auto &&between) {
-            constexpr int t = decltype(tconst)::value;
-            const float *xs = wave_lds + L::kXs + t * 16 * XS;
-            const float *ds = wave_lds + L::kDs + t * 16 * DS;
-            float *hs0 = wave_lds + L::kHs0;
-            const float *hs1 = wave_lds + L::kHs1;
-            // operands that do not depend on the half: loaded once per tile, ahead of every MFMA that uses them
-            float dfrag[4];   // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c) for the dW2v contraction
-            float xa[KT][4];  // A frags of X^T (i = k = 16kt + c, k-slot g <-> row 4g+r) for the dW1 contraction
-            if constexpr (!(ABL & 2)) {
+            *reinterpret_cast<f32x4 *>(dsP + c * DS + 4 * g) = dout;  // dout[row = c][o = 4g..4g+3]
+
+            // one hidden half: hidden half tile -> LDS, dh = dout . W2v (A = dout^T C fragments, A = C^T), relu',
+            // dh half -> DH[half] for the consumer, dW2v += hidden^T . dout
+            auto half_step = [&](int half) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dfrag[r] = ds[(4 * g + r) * DS + c];
+                for (int mm = 0; mm < kMT / 2; ++mm)
+                    *reinterpret_cast<f32x4 *>(hsP + c * HS + 16 * mm + 4 * g) = h[half * (kMT / 2) + mm];
+                wave_lds_fence();
+                float dfrag[4];  // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c)
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
-            }
-#pragma unroll
-            for (int half = 0; half < ((ABL & 2) ? 0 : 2); ++half) {
-                if constexpr (t == 0) {
-                    // tile 0: half of the hidden tile, row-major [row][u - 64*half], for relu' and the dW2v contraction
-#pragma unroll
-                    for (int mm = 0; mm < kMT / 2; ++mm)
-                        *reinterpret_cast<f32x4 *>(hs0 + c * HS + 16 * mm + 4 * g) = h[0][half * (kMT / 2) + mm];
-                    wave_lds_fence();
-                }
-                // dh[row = 4g+r][u = 16m + c] = sum_o dout[row][o] W2v[o][u]; A = dout^T C-fragment (A = C^T);
-                // the four hidden tiles of this half are four independent accumulator chains
+                for (int r = 0; r < 4; ++r) dfrag[r] = dsP[(4 * g + r) * DS + c];
+                float *dhT = pl + L::kDH + half * 16 * HS;
+                // the four hidden tiles of the half are four independent accumulator chains (no dependent-issue stalls)
                 f32x4 dh[kMT / 2], wb[kMT / 2];
                 float hrow[kMT / 2][4];
 #pragma unroll
@@ -442,112 +409,146 @@ __global__ void __launch_bounds__(kGradThreads, 1)
                     dh[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
                     wb[mm] = *reinterpret_cast<const f32x4 *>(w2bt + ((half * (kMT / 2) + mm) * 64 + lane) * 4);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)  // hidden[row = 4g+r][u = 16m + c]
-                        hrow[mm][r] = t == 0 ? hs0[(4 * g + r) * HS + 16 * mm + c]
-                                             : hs1[(4 * g + r) * L::HF + 16 * (half * (kMT / 2) + mm) + c];
+                    for (int r = 0; r < 4; ++r) hrow[mm][r] = hsP[(4 * g + r) * HS + 16 * mm + c];  // hidden[row=4g+r][u=16m+c]
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int mm = 0; mm < kMT / 2; ++mm) dh[mm] = mfma16(dout[t][r], wb[mm][r], dh[mm]);
+                    for (int mm = 0; mm < kMT / 2; ++mm) dh[mm] = mfma16(dout[r], wb[mm][r], dh[mm]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int mm = 0; mm < kMT / 2; ++mm) {
+                        const int m = half * (kMT / 2) + mm;
+                        acc_dw2[m] = mfma16(hrow[mm][r], dfrag[r], acc_dw2[m]);  // independent of dh: fills its latency
+                    }
 #pragma unroll
                 for (int mm = 0; mm < kMT / 2; ++mm)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         dh[mm][r] = hrow[mm][r] > 0.0f ? dh[mm][r] : 0.0f;  // relu'
                         db1[half * (kMT / 2) + mm] += dh[mm][r];
+                        dhT[(4 * g + r) * HS + 16 * mm + c] = dh[mm][r];  // dh[row = 4g+r][u = 16mm + c] of this half
                     }
-#pragma unroll
-                for (int mm = 0; mm < kMT / 2; ++mm) {
-                    const int m = half * (kMT / 2) + mm;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                        for (int kt = 0; kt < KT; ++kt) acc_dw1[kt][m] = mfma16(xa[kt][r], dh[mm][r], acc_dw1[kt][m]);
-                        acc_dw2[m] = mfma16(hrow[mm][r], dfrag[r], acc_dw2[m]);
-                    }
-                }
-                if (half == 0) between();
-                if constexpr (t == 0) wave_lds_fence();
-            }
-        };
-
-        const f32x4 out0 = heads_tile(0);
-        const f32x4 out1 = heads_tile(1);
-        if constexpr (!(ABL & 2)) {  // park tile 1's hidden tile in LDS: frees its 32 registers until backward(1)
-#pragma unroll
-            for (int m = 0; m < kMT; ++m)
-                *reinterpret_cast<f32x4 *>(wave_lds + L::kHs1 + c * L::HF + 16 * m + 4 * g) = h[1][m];
+            };
+            wave_lds_fence();
+            half_step(0);
+            __syncthreads();
+            // ---- phase A: second half; prefetch the next tile ------------------------------------------------------
+            half_step(1);
+            __syncthreads();
         }
-        loss_tile(0, out0);
-        wave_lds_fence();
-        backward_tile(std::integral_constant<int, 0>{}, [&]() { loss_tile(1, out1); });
-        // tile 0's hidden fragments are dead now: the next pair's X tiles take registers and have all of backward(1)
-        // to arrive from HBM
-        prefetch(base + wave_count * kTPI);
-        wave_lds_fence();
-        backward_tile(std::integral_constant<int, 1>{}, []() {});
-    }
+        __syncthreads();  // matches the consumer's trailing phase B_J
 
-    // ---- reduce the waves' accumulators into one workgroup partial (native order, conflict-free), fixed order -----
-    __syncthreads();
+        // ---- epilogue: producers own dW2v, db1, db2v, stats ------------------------------------------------------
 #pragma unroll
-    for (int m = 0; m < kMT; ++m) {
-        db1[m] += __shfl_xor(db1[m], 16, 64);
-        db1[m] += __shfl_xor(db1[m], 32, 64);
-    }
+        for (int m = 0; m < kMT; ++m) {
+            db1[m] += __shfl_xor(db1[m], 16, 64);
+            db1[m] += __shfl_xor(db1[m], 32, 64);
+        }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int s = 1; s < 16; s <<= 1) db2[r] += __shfl_xor(db2[r], s, 64);
+            for (int s = 1; s < 16; s <<= 1) db2[r] += __shfl_xor(db2[r], s, 64);
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+        for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int s = 1; s < 16; s <<= 1) stats[i] += __shfl_xor(stats[i], s, 64);
-
-    float *red = lds + (wv & 1) * NL::kCount;  // buffer 0: even waves, buffer 1: odd waves
-    for (int turn = 0; turn < ((ABL & 8) ? 0 : kGradWaves / 2); ++turn) {
-        if ((wv >> 1) == turn) {
-            const bool first = turn == 0;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+            for (int s = 1; s < 16; s <<= 1) stats[i] += __shfl_xor(stats[i], s, 64);
+        float *red = lds + (pair & 1) * NL::kCount;  // buffer 0: even pairs, buffer 1: odd pairs
+        for (int turn = 0; turn < kGradPairs / 2; ++turn) {
+            if ((pair >> 1) == turn) {
+                const bool first = turn == 0;
 #pragma unroll
                 for (int m = 0; m < kMT; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int idx = NL::kDw1 + ((kt * kMT + m) * 4 + r) * 64 + lane;
-                        red[idx] = (first ? 0.0f : red[idx]) + acc_dw1[kt][m][r];
+                        const int idx = NL::kDw2 + (m * 4 + r) * 64 + lane;
+                        red[idx] = (first ? 0.0f : red[idx]) + acc_dw2[m][r];
                     }
+                if (g == 0) {
 #pragma unroll
-            for (int m = 0; m < kMT; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = NL::kDw2 + (m * 4 + r) * 64 + lane;
-                    red[idx] = (first ? 0.0f : red[idx]) + acc_dw2[m][r];
+                    for (int m = 0; m < kMT; ++m) {
+                        const int idx = NL::kDb1 + 16 * m + c;
+                        red[idx] = (first ? 0.0f : red[idx]) + db1[m];
+                    }
                 }
-            if (g == 0) {
+                if (c == 0) {
 #pragma unroll
-                for (int m = 0; m < kMT; ++m) {
-                    const int idx = NL::kDb1 + 16 * m + c;
-                    red[idx] = (first ? 0.0f : red[idx]) + db1[m];
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = NL::kDb2 + 4 * g + r;
+                        red[idx] = (first ? 0.0f : red[idx]) + db2[r];
+                    }
                 }
-            }
-            if (c == 0) {
+                if (lane == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int idx = NL::kDb2 + 4 * g + r;
-                    red[idx] = (first ? 0.0f : red[idx]) + db2[r];
-                }
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int i = 0; i < kNumStats; ++i) {
-                    const int idx = NL::kStats + i;
-                    red[idx] = (first ? 0.0f : red[idx]) + (i < 6 ? stats[i] : 0.0f);
+                    for (int i = 0; i < kNumStats; ++i) {
+                        const int idx = NL::kStats + i;
+                        red[idx] = (first ? 0.0f : red[idx]) + (i < 6 ? stats[i] : 0.0f);
+                    }
                 }
             }
+            __syncthreads();
         }
+    } else {
+        // ------------------------------------------------------------------------------------------ consumer
+        f32x4 acc_dw1[KT][kMT];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) acc_dw1[kt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();  // fragment tables ready (same barrier as the producers')
+
+        // dW1^T[k][u] += X^T . dh for one hidden half of tile jj: A = X tile (i = k = 16kt + c, k-slot g <-> row 4g+r),
+        // B = masked dh half tile (k-slot g <-> row 4g+r, j = u = 16m + c)
+        auto dw1_half = [&](int jj, int half) {
+            const long long tile = pair_global + (long long)jj * pair_count;
+            if ((ABL & 2) || tile >= tiles) return;
+            const float *xs = pl + L::kXT + (jj & 1) * 16 * XS;
+            const float *dhT = pl + L::kDH + half * 16 * HS;
+            float xa[KT][4];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
+            float dhf[kMT / 2][4];
+#pragma unroll
+            for (int mm = 0; mm < kMT / 2; ++mm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dhf[mm][r] = dhT[(4 * g + r) * HS + 16 * mm + c];
+#pragma unroll
+            for (int mm = 0; mm < kMT / 2; ++mm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt)
+                        acc_dw1[kt][half * (kMT / 2) + mm] = mfma16(xa[kt][r], dhf[mm][r], acc_dw1[kt][half * (kMT / 2) + mm]);
+        };
+        for (int j = 0; j < J; ++j) {
+            if (j > 0) dw1_half(j - 1, 1);  // phase B_j
+            __syncthreads();
+            dw1_half(j, 0);                 // phase A_j
+            __syncthreads();
+        }
+        dw1_half(J - 1, 1);                 // trailing phase B_J
         __syncthreads();
+
+        // ---- epilogue: consumers own dW1 ---------------------------------------------------------------------------
+        float *red = lds + (pair & 1) * NL::kCount;
+        for (int turn = 0; turn < kGradPairs / 2; ++turn) {
+            if ((pair >> 1) == turn) {
+                const bool first = turn == 0;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int idx = NL::kDw1 + ((kt * kMT + m) * 4 + r) * 64 + lane;
+                            red[idx] = (first ? 0.0f : red[idx]) + acc_dw1[kt][m][r];
+                        }
+            }
+            __syncthreads();
+        }
     }
     float *dst = partials + (size_t)blockIdx.x * NL::kCount;
     for (int i = threadIdx.x; i < NL::kCount; i += kGradThreads) dst[i] = lds[i] + lds[NL::kCount + i];
@@ -762,7 +763,7 @@ static double *norm_partials_of(void *workspace, int dp) {  // after the gradien
 
 static int grad_grid(int64_t mb_rows) {
     const int64_t tiles = mb_rows / 16;
-    const int64_t wgs = (tiles + kGradWaves * kTPI - 1) / (kGradWaves * kTPI);
+    const int64_t wgs = (tiles + kGradPairs - 1) / kGradPairs;
     return (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
 }
 
@@ -925,7 +926,6 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
         break;
     switch (abl) {
         PFA_PROBE_CASE(0) PFA_PROBE_CASE(1) PFA_PROBE_CASE(2) PFA_PROBE_CASE(4) PFA_PROBE_CASE(6) PFA_PROBE_CASE(7)
-        PFA_PROBE_CASE(8) PFA_PROBE_CASE(15)
         default: return -2;
     }
 #undef PFA_PROBE_CASE

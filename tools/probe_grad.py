@@ -53,7 +53,27 @@ def main():
                                  C.c_void_p, C.c_int32, C.c_void_p]
     names = {0: 'full', 1: 'no loss math', 2: 'no backward', 4: 'no forward', 6: 'no fwd+bwd (loss, staging, reduce)',
              7: 'staging + reduce only', 8: 'no workgroup reduce', 15: 'staging only'}
-    for abl in (0, 1, 2, 4, 6, 7, 8, 15):
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    # fixed cost vs per-tile cost: shrink the minibatch so every pair gets 1, 2, 4, 8 tiles (grid stays 256 WGs)
+    for tiles_per_pair in (1, 2, 4, 8):
+        rows = 16 * 1024 * tiles_per_pair
+        hp2 = _lib.PpoHparams(.1, .1, .5, .01, 1, 1, B // rows, 16)
+        st2 = torch.tensor([[0.0, float(rows)]] * (B // rows), dtype=torch.float64, device=dev)
+        us = timed(lambda: L.pfa_probe_grad(C.byref(exp), B, 0, params.data_ptr(), C.byref(dims), C.byref(hp2), st2.data_ptr(),
+                                            grads.data_ptr(), ws.data_ptr(), 0, None))
+        print(f'tiles/pair={tiles_per_pair}  rows={rows:7d}  {us:8.1f} us')
+    for abl in (0, 1, 2, 4, 6, 7):
         def run():
             rc = L.pfa_probe_grad(C.byref(exp), B, 1, params.data_ptr(), C.byref(dims), C.byref(hp), stats.data_ptr(),
                                   grads.data_ptr(), ws.data_ptr(), abl, None)
