@@ -245,3 +245,78 @@ def test_native_data_parallel_path_single_rank_equals_plain():
     np.testing.assert_allclose(w1.cpu().numpy(), w0.cpu().numpy(), rtol=1e-6, atol=1e-7)
     for k in l0:
         np.testing.assert_allclose(l1[k], l0[k], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('d,nt,n,horizon,nmb,bptt', [(1, 4, 40, 16, 2, 8), (2, 2, 96, 32, 4, 16), (3, 2, 24, 48, 1, 4)])
+def test_other_grid_sizes_rollout_and_update_vs_oracle(d, nt, n, horizon, nmb, bptt):
+    """obs_stride 16 / 32 / 64 (d = 1, 2, 3), several targets, env counts that are not multiples of 16, one
+    minibatch, short bptt: replay the device rollout's actions on the C oracle (bit-exact env side) and compare the
+    update with the torch-fp32 restatement."""
+    from pufferlib_amd import clean_pufferl
+    from oracle import c_oracle, ppo_torch
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
+    B = n * horizon
+    vec, pol = _make(n, d, nt)
+    torch.manual_seed(d)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    cfg = _config(n, horizon, B // nmb, bptt, 2, B * 10, hp, seed=7)
+    data = clean_pufferl.create(cfg, vec, pol)
+    D = (2 * d + 1) ** 2
+    assert vec.obs_stride == max(16, (D + 15) // 16 * 16)
+    w0 = {k[len('policy.'):]: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    acts = _step_major(exp.actions, n, horizon)
+    obs = _step_major(exp.obs, n, horizon)
+    assert float(np.abs(obs[:, D:]).sum()) == 0.0            # pad columns
+    ovec = c_oracle.SquaredSerial(n, d, nt)
+    ovec.async_reset(7)
+    for t in range(horizon):
+        o, r, dn, _, _, _, _ = ovec.recv()
+        rows = slice(t * n, (t + 1) * n)
+        assert np.array_equal(o.reshape(n, -1), obs[rows, :D]), t
+        assert np.array_equal(r, _step_major(exp.rewards, n, horizon)[rows]), t
+        assert np.array_equal(dn.astype(np.float32), _step_major(exp.dones, n, horizon)[rows]), t
+        ovec.send(acts[rows].astype(np.int64))
+    opol = ppo_torch.Policy(w0)
+    tr = ppo_torch.Trainer(opol, c_oracle.SquaredSerial(n, d, nt), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt,
+                           update_epochs=2, learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3],
+                           vf_coef=hp[4], vf_clip_coef=hp[5], max_grad_norm=hp[6], ent_coef=hp[7],
+                           total_timesteps=B * 10, seed=7)
+    tr.obs = torch.as_tensor(obs[:, :D].copy())
+    tr.actions = acts.astype(np.int64)
+    tr.logprobs = _step_major(exp.logprobs, n, horizon).copy()
+    tr.rewards = _step_major(exp.rewards, n, horizon).copy()
+    tr.dones = _step_major(exp.dones, n, horizon).copy()
+    tr.values = _step_major(exp.values, n, horizon).copy()
+    tr.global_step = data.global_step
+    Lo = tr.train()
+    clean_pufferl.train(data)
+    L = data.losses
+    np.testing.assert_allclose(
+        [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
+        [Lo['policy_loss'], Lo['value_loss'], Lo['entropy'], Lo['old_approx_kl'], Lo['approx_kl'], Lo['clipfrac']],
+        rtol=1e-4, atol=1e-5)
+    sd = pol.state_dict()
+    for k, arr in opol.state_arrays().items():
+        np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=k, **TOL)
+    np.testing.assert_allclose(L.explained_variance, Lo['explained_variance'], rtol=1e-3, atol=1e-4)
+
+
+def test_argument_errors_match_reference_messages():
+    from pufferlib_amd import clean_pufferl
+    vec, pol = _make(16)
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    with pytest.raises(ValueError, match='batch_size must be divisible by minibatch_size'):
+        clean_pufferl.create(_config(16, 32, 100, 4, 1, 10 ** 6, hp), vec, pol)
+    vec, pol = _make(16)
+    with pytest.raises(ValueError, match='minibatch_size must be divisible by bptt_horizon'):
+        clean_pufferl.create(_config(16, 32, 128, 3, 1, 10 ** 6, hp), vec, pol)
+    vec, pol = _make(16)
+    data = clean_pufferl.create(_config(16, 3, 24, 3, 1, 10 ** 6, hp), vec, pol)   # minibatch of 24 rows: not 16-aligned
+    clean_pufferl.evaluate(data)
+    from pufferlib_amd.exceptions import ExtensionError
+    with pytest.raises(ExtensionError, match='multiple of 16'):
+        clean_pufferl.train(data)
