@@ -196,6 +196,46 @@ int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *para
                       int32_t data_parallel, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Recurrent policy — pufferlib.models.LSTMWrapper (models.py:64-111): Default encoder -> nn.LSTM(128,128,1) ->
+ * Default heads, gate order i,f,g,o.  Flat parameter vector = the MLP vector above followed by
+ *   recurrent.weight_ih_l0 [512][128], weight_hh_l0 [512][128], bias_ih_l0 [512], bias_hh_l0 [512].
+ * The plain gate / weight-gradient GEMMs are library calls on the host side this round; these entry points are
+ * everything else (csrc/lstm.hip).  All row-indexed buffers are dense [rows][...] fp32.
+ * ------------------------------------------------------------------------------------------ */
+int pfa_relu(float *x, int64_t n, pfa_stream_t stream);                       /* torch.relu of encode_observations */
+int pfa_relu_grad(float *dx, const float *x, int64_t n, pfa_stream_t stream); /* dx *= (x > 0), x = relu output */
+/* One nn.LSTM cell step given the gate pre-activations [rows][512] (overwritten with the activations i,f,g,o). */
+int pfa_lstm_cell_fwd(float *gates, const float *c_prev, float *c_out, float *h_out, int64_t rows, pfa_stream_t stream);
+/* Its backward: d loss / d h_t = dh + dh2 (heads path + recurrent path, dh2 nullable); dgates = d loss / d
+ * pre-activations; dc holds d loss / d c_t on entry and d loss / d c_{t-1} on exit. */
+int pfa_lstm_cell_bwd(const float *gates_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
+                      float *dc, float *dgates, int64_t rows, pfa_stream_t stream);
+/* Deterministic column sums (bias gradients); workspace >= pfa_colsum_workspace_bytes(cols). */
+size_t pfa_colsum_workspace_bytes(int32_t cols);
+int pfa_colsum(const float *a, int64_t rows, int32_t cols, int64_t ld, float *out, int32_t accumulate, void *workspace,
+               pfa_stream_t stream);
+/* decode_actions on h [rows][128] + sample_logits (rollout mode), same sampler and noise stream as the MLP path. */
+int pfa_lstm_heads_sample(const float *h, int64_t rows, const float *params, const pfa_mlp_dims *dims,
+                          const float *noise, const pfa_noise_key *key, int64_t row_offset, int64_t *actions,
+                          float *logprob, float *entropy, float *value, pfa_stream_t stream);
+/* Experience.store of rollout step t (clean_pufferl.py:436-450) into the env-major buffers. */
+int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_envs, int32_t obs_stride, const float *obs,
+                   const float *rewards, const uint8_t *terminals, const int64_t *actions, const float *logprob,
+                   const float *value, pfa_stream_t stream);
+/* Observation rows of minibatch mb in TIME-MAJOR order (row t*R + k = segment mb + k*nmb, step t). */
+int pfa_gather_obs_time_major(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const pfa_ppo_hparams *hp,
+                              int32_t obs_stride, float *out, pfa_stream_t stream);
+/* decode_actions + PPO loss on the time-major hidden states h [mbs][128] of minibatch mb: dout [mbs][16] (d loss / d the
+ * padded head outputs), dh [mbs][128] (d loss / d h through the heads), loss_sums8 as in pfa_ppo_mlp_grad. */
+size_t pfa_lstm_heads_loss_workspace_bytes(void);
+int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
+                        const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
+                        int64_t global_mb_rows, float *dout, float *dh, float *loss_sums8, void *workspace,
+                        pfa_stream_t stream);
+/* n f64 pieces of sum(g^2) over `count` gradient entries, for pfa_adam_clip_step's norm_partials. */
+int pfa_sumsq_partials(const float *grads, int64_t count, double *partials, int32_t n, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Data parallel over the GPUs of one node (no reference counterpart): one process per GPU, one RCCL communicator
  * per process, bound at run time (dlopen librccl.so.1).  Rank 0 creates the 128-byte id, the host side broadcasts it
  * (torch.distributed), every rank calls pfa_dist_init collectively.  Collectives run on the caller's stream.

@@ -16,8 +16,8 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp',
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip']
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
@@ -111,6 +111,19 @@ _SIGNATURES = {
     'pfa_ppo_mlp_train': (C.c_int, [C.POINTER(Experience), C.c_int64, P, C.POINTER(MlpDims), C.POINTER(PpoHparams), P, P, P, P,
                                     C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P,
                                     C.c_int32, P]),
+    'pfa_relu': (C.c_int, [P, C.c_int64, P]),
+    'pfa_relu_grad': (C.c_int, [P, P, C.c_int64, P]),
+    'pfa_lstm_cell_fwd': (C.c_int, [P, P, P, P, C.c_int64, P]),
+    'pfa_lstm_cell_bwd': (C.c_int, [P, P, P, P, P, P, P, C.c_int64, P]),
+    'pfa_colsum_workspace_bytes': (C.c_size_t, [C.c_int32]),
+    'pfa_colsum': (C.c_int, [P, C.c_int64, C.c_int32, C.c_int64, P, C.c_int32, P, P]),
+    'pfa_lstm_heads_sample': (C.c_int, [P, C.c_int64, P, C.POINTER(MlpDims), P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
+    'pfa_store_step': (C.c_int, [C.POINTER(Experience), C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P]),
+    'pfa_gather_obs_time_major': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, C.POINTER(PpoHparams), C.c_int32, P, P]),
+    'pfa_lstm_heads_loss_workspace_bytes': (C.c_size_t, []),
+    'pfa_lstm_heads_loss': (C.c_int, [P, C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),
+                                      C.POINTER(PpoHparams), P, C.c_int64, P, P, P, P, P]),
+    'pfa_sumsq_partials': (C.c_int, [P, C.c_int64, P, C.c_int32, P]),
     'pfa_dist_unique_id': (C.c_int, [P]),
     'pfa_dist_init': (C.c_int, [P, C.c_int32, C.c_int32]),
     'pfa_dist_finalize': (C.c_int, []),

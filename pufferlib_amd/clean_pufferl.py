@@ -32,7 +32,7 @@ import torch
 
 from . import _lib, utils
 from . import dist as pdist
-from .cleanrl import Policy
+from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
 from .vector import Squared
@@ -250,8 +250,13 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     if not isinstance(vecenv, Squared):
         raise NotImplementedError('pufferlib_amd.clean_pufferl drives pufferlib_amd.vector.Squared vecenvs '
                                   '(device-resident envs); CPU backends are a later row of SURVEY.md §8f')
-    if not isinstance(policy, Policy):
-        policy = Policy(policy, seed=config.seed)     # e.g. the reference's cleanrl.Policy(models.Default)
+    if not isinstance(policy, (Policy, RecurrentPolicy)):
+        from .models import find_lstm
+        if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
+            policy = RecurrentPolicy(getattr(policy, 'policy', policy), seed=config.seed)
+        else:
+            policy = Policy(policy, seed=config.seed)     # e.g. the reference's cleanrl.Policy(models.Default)
+    recurrent = isinstance(policy, RecurrentPolicy)
     dist, rank, world = _dist()
     device = vecenv.device
     vecenv.info_mode = 'lazy'
@@ -273,6 +278,11 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     experience = Experience(config.batch_size, config.bptt_horizon, _cfg(config, 'minibatch_size', None),
                             vecenv.obs_stride, total_agents, device)
     optimizer = HipAdam(fp, lr=config.learning_rate, eps=1e-5)
+    lstm_engine = None
+    if recurrent:
+        from . import lstm as plstm
+        lstm_engine = plstm.Engine(fp, experience, vecenv)
+        experience.lstm_h, experience.lstm_c = lstm_engine.lstm_h, lstm_engine.lstm_c   # clean_pufferl.py:407-412
 
     L = _lib.lib()
     hp = _make_hparams(config, experience)
@@ -283,7 +293,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         experience=experience, profile=profile, losses=losses, wandb=wandb, global_step=0, epoch=0, stats={},
         msg=msg, last_log_time=0, utilization=utilization,
         # engine state
-        flat_params=fp, rank=rank, world_size=world, native_dp=native_dp,
+        flat_params=fp, rank=rank, world_size=world, native_dp=native_dp, lstm_engine=lstm_engine,
         workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
         grads=torch.zeros(fp.count + 8, dtype=torch.float32, device=device),
         adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
@@ -318,6 +328,10 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
+    if data.lstm_engine is not None:
+        with profile.eval_forward:       # recurrent policy: one kernel sequence per step, still no host sync
+            data.lstm_engine.rollout(T, noise, policy.noise_seed, policy.noise_step, vecenv.env_offset)
+        return _finish_evaluate(data, N, T)
     with profile.env:
         main = torch.cuda.current_stream()
         if data.tape_event is not None:
@@ -342,6 +356,12 @@ def evaluate(data):
                 vecenv.ensure_tape(T)
                 data.tape_event = torch.cuda.Event()
                 data.tape_event.record(data.tape_stream)
+    return _finish_evaluate(data, N, T)
+
+
+def _finish_evaluate(data, N, T):
+    profile, experience, vecenv, policy = data.profile, data.experience, data.vecenv, data.policy
+    L = _lib.lib()
     with profile.eval_misc:
         policy.noise_step += T
         data.noise = None
@@ -394,7 +414,23 @@ def train(data):
     global_mb_rows = experience.minibatch_size * world
     loss_scale = 1.0 / (global_mb_rows * nmb)
     epochs_run = 0
-    native_loop = (world == 1 or data.native_dp) and config.target_kl is None
+    if data.lstm_engine is not None:
+        eng = data.lstm_engine
+        for epoch in range(config.update_epochs):
+            eng.state = None                      # lstm_state = None (clean_pufferl.py:176)
+            for mb in range(nmb):
+                with profile.train_forward:
+                    eng.update(mb, hp, data.adv_stats, global_mb_rows, data.grads, B)
+                with profile.learn:
+                    if data.native_dp:
+                        _lib.check(L.pfa_dist_all_reduce_f32(_lib.ptr(data.grads), data.grads.numel(), stream), 'grad all-reduce')
+                    elif world > 1:
+                        dist.all_reduce(data.grads)
+                    eng.clip_adam(data.grads, opt, config.max_grad_norm, data.loss_acc, loss_scale)
+            if config.target_kl is not None:
+                if float(data.grads[fp.count + 4].item()) / global_mb_rows > config.target_kl:
+                    break
+    native_loop = data.lstm_engine is None and (world == 1 or data.native_dp) and config.target_kl is None
     if native_loop:
         # no early exit: the whole epoch x minibatch loop (incl. the per-step RCCL all-reduce when data parallel) is
         # enqueued by one native call on the compute stream
@@ -407,7 +443,7 @@ def train(data):
                 int(config.update_epochs), _lib.ptr(data.loss_acc), _lib.ptr(data.workspace),
                 1 if data.native_dp else 0, stream), 'ppo_train')
             opt.step_count += config.update_epochs * nmb
-    for epoch in range(0 if native_loop else config.update_epochs):
+    for epoch in range(0 if (native_loop or data.lstm_engine is not None) else config.update_epochs):
         for mb in range(nmb):
             with profile.train_forward:
                 _lib.check(L.pfa_ppo_mlp_grad(C.byref(experience.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims),

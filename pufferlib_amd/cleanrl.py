@@ -72,3 +72,70 @@ class Policy(torch.nn.Module):
                                             C.byref(key), 0, _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(entropy),
                                             _lib.ptr(value), _lib.stream_handle()), 'mlp_forward_sample')
         return actions, logprob, entropy, value.unsqueeze(1)
+
+
+class RecurrentPolicy(torch.nn.Module):
+    """frameworks.cleanrl.RecurrentPolicy (pufferlib/frameworks/cleanrl.py:69-93) over the HIP LSTM path.
+
+    ``policy(obs, state)`` (rollout mode) returns (actions, logprob, entropy, value, (h, c)) with state tensors of shape
+    (1, rows, 128) like nn.LSTM.  The training-mode forward lives in pufferlib_amd.clean_pufferl.train."""
+
+    def __init__(self, policy, seed=0):
+        super().__init__()
+        self.policy = policy
+        self.noise_seed = int(seed)
+        self.noise_step = 0
+        self._flat = None
+
+    @property
+    def lstm(self):
+        if hasattr(self.policy, 'recurrent'):
+            return self.policy.recurrent
+        elif hasattr(self.policy, 'lstm'):
+            return self.policy.lstm
+        raise ValueError('Policy must have a subnetwork named lstm or recurrent')
+
+    def adopt(self, obs_stride, device):
+        if (self._flat is None or self._flat.obs_stride != obs_stride
+                or self._flat.flat.device != torch.device(device)):
+            self._flat = FlatParams(self.policy, obs_stride, device)
+        return self._flat
+
+    @property
+    def flat_params(self):
+        return self._flat
+
+    def get_action_and_value(self, x, state=None, action=None, noise=None):
+        return self.forward(x, state=state, action=action, noise=noise)
+
+    def forward(self, x, state=None, action=None, noise=None):
+        if action is not None:
+            raise NotImplementedError('training-mode forward lives in pufferlib_amd.clean_pufferl.train (BPTT path)')
+        from . import lstm as plstm
+        _lib.require_gpu()
+        if not x.is_cuda:
+            x = x.cuda()
+        rows = x.shape[0]
+        x2 = x.reshape(rows, -1)
+        D = x2.shape[1]
+        stride = max(16, (D + 15) // 16 * 16)
+        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) % 16 == 0 and x2.stride(0) <= 128 \
+                and x2.data_ptr() % 16 == 0:
+            stride = x2.stride(0)
+            src = torch.as_strided(x2, (rows, stride), (stride, 1))
+        else:
+            src = torch.zeros(rows, stride, dtype=torch.float32, device=x.device)
+            src[:, :D] = x2.float()
+        fp = self.adopt(stride, x.device)
+        if state is None:
+            h = torch.zeros(rows, 128, device=x.device)
+            c = torch.zeros(rows, 128, device=x.device)
+        else:
+            h, c = state[0][0].contiguous().clone(), state[1][0].contiguous().clone()
+        key = _lib.NoiseKey(self.noise_seed, self.noise_step)
+        if noise is not None:
+            noise = noise.to(device=x.device, dtype=torch.float32).contiguous()
+        else:
+            self.noise_step += 1
+        out = plstm.policy_step(fp, src, h, c, noise, key, 0)
+        return out + ((h.unsqueeze(0), c.unsqueeze(0)),)

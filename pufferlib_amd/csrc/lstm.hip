@@ -1,0 +1,455 @@
+// lstm.hip — kernels of the recurrent policy path: pufferlib.models.LSTMWrapper (pufferlib/models.py:64-111) =
+// Default.encode_observations -> nn.LSTM(128, 128, 1) -> Default.decode_actions, wrapped by
+// frameworks.cleanrl.RecurrentPolicy (frameworks/cleanrl.py:69-93), and its use in clean_pufferl.evaluate
+// (clean_pufferl.py:100-105) and the BPTT minibatch loop of clean_pufferl.train (clean_pufferl.py:186-193).
+//
+// Round-1 structure of this path: the plain dense products ([rows x 128] x [128 x 512] gate GEMMs, the weight
+// gradient GEMMs over all rows of a minibatch) go through the ROCm BLAS the host already has (hipBLASLt/rocBLAS via
+// torch.mm — "library GEMMs for plain GEMMs"); everything that is not a plain GEMM is hand-written here:
+//   lstm_cell_fwd / lstm_cell_bwd      gate nonlinearities + cell/hidden update and their exact derivatives (gate order i,f,g,o)
+//   lstm_heads_sample                   decoder + value head on h, sample_logits with the shared row16 sampler
+//   lstm_heads_loss                     decoder + value head, PPO loss, d loss/d heads, d loss/d h, loss sums
+//   relu / relu' / column sums / experience row store / sum of squares pieces for the clip norm
+// A fused persistent LSTM kernel (gate weights streamed from L2 through MFMA fragments) is the planned replacement.
+#include "common.hpp"
+#include "lane_ops.hpp"
+#include "mlp_tile.hpp"
+#include "sampler.hpp"
+
+namespace pfa {
+
+constexpr int kLstmH = 128;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) relu_kernel(float *x, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = fmaxf(x[i], 0.0f);
+}
+
+// dx *= (x > 0)   (x = relu output)
+__global__ void __launch_bounds__(256) relu_grad_kernel(float *dx, const float *x, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dx[i] = x[i] > 0.0f ? dx[i] : 0.0f;
+}
+
+// gates: [rows][4H] pre-activations in, activations (i,f,g,o) out.  c_prev may alias c_out only if rows do not overlap.
+__global__ void __launch_bounds__(256) lstm_cell_fwd_kernel(float *gates, const float *c_prev, float *c_out, float *h_out,
+                                                           long long rows) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * kLstmH) return;
+    const long long row = idx / kLstmH;
+    const int j = (int)(idx - row * kLstmH);
+    float *gr = gates + row * 4 * kLstmH;
+    const float i = sigmoidf_(gr[j]);
+    const float f = sigmoidf_(gr[kLstmH + j]);
+    const float g = tanhf(gr[2 * kLstmH + j]);
+    const float o = sigmoidf_(gr[3 * kLstmH + j]);
+    const float c = f * c_prev[idx] + i * g;
+    gr[j] = i;
+    gr[kLstmH + j] = f;
+    gr[2 * kLstmH + j] = g;
+    gr[3 * kLstmH + j] = o;
+    c_out[idx] = c;
+    h_out[idx] = o * tanhf(c);
+}
+
+// Backward of one cell step.  gates_act = (i,f,g,o) saved by the forward; dh = d loss / d h_t (heads + recurrent);
+// dc (in/out) = d loss / d c_t from step t+1 on entry, d loss / d c_{t-1} on exit.  dgates = d loss / d pre-activations.
+__global__ void __launch_bounds__(256) lstm_cell_bwd_kernel(const float *gates_act, const float *c_prev, const float *c,
+                                                           const float *dh, const float *dh2, float *dc, float *dgates,
+                                                           long long rows) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * kLstmH) return;
+    const long long row = idx / kLstmH;
+    const int j = (int)(idx - row * kLstmH);
+    const float *ga = gates_act + row * 4 * kLstmH;
+    float *dg = dgates + row * 4 * kLstmH;
+    const float i = ga[j], f = ga[kLstmH + j], g = ga[2 * kLstmH + j], o = ga[3 * kLstmH + j];
+    const float tc = tanhf(c[idx]);
+    const float dhv = dh[idx] + (dh2 ? dh2[idx] : 0.0f);  // heads path + recurrent path
+    const float d_o = dhv * tc;
+    const float d_c = dhv * o * (1.0f - tc * tc) + dc[idx];
+    dg[j] = d_c * g * i * (1.0f - i);
+    dg[kLstmH + j] = d_c * c_prev[idx] * f * (1.0f - f);
+    dg[2 * kLstmH + j] = d_c * i * (1.0f - g * g);
+    dg[3 * kLstmH + j] = d_o * o * (1.0f - o);
+    dc[idx] = d_c * f;
+}
+
+// Deterministic column sums of a [rows][cols] matrix (leading dimension ld): stage 1 per (64-column block, row chunk).
+constexpr int kColChunks = 128;
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float *a, long long rows, int cols, long long ld,
+                                                            float *partial /* [kColChunks][cols] */) {
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, rs = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const long long per = (rows + kColChunks - 1) / kColChunks;
+    const long long lo = (long long)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
+    float s = 0.0f;
+    if (col < cols)
+        for (long long r = lo + rs; r < hi; r += 4) s += a[r * ld + col];
+    sh[rs][cl] = s;
+    __syncthreads();
+    if (rs == 0 && col < cols) partial[(size_t)blockIdx.y * cols + col] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+__global__ void __launch_bounds__(256) colsum_final_kernel(const float *partial, int cols, float *out, int accumulate) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    float s = 0.0f;
+    for (int i = 0; i < kColChunks; ++i) s += partial[(size_t)i * cols + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+// Heads weights of models.Default inside the flat parameter vector, staged in LDS as W2v[16][128(+1)].
+__device__ __forceinline__ void stage_heads(const float *params, int dp, int a, float *w2v /* [16][129] */, float *b2v) {
+    const MlpOffsets off = mlp_offsets(dp, a);
+    for (int i = threadIdx.x; i < kOut * kLstmH; i += blockDim.x) {
+        const int o = i / kLstmH, u = i - o * kLstmH;
+        w2v[o * (kLstmH + 1) + u] = w2v_at(params, off, a, o, u);
+    }
+    for (int i = threadIdx.x; i < kOut; i += blockDim.x) b2v[i] = b2v_at(params, off, a, i);
+}
+
+__device__ __forceinline__ float head_dot(const float *hrow, const float *w2v, const float *b2v, int lo) {
+    float acc = b2v[lo];
+    const float *w = w2v + lo * (kLstmH + 1);
+#pragma unroll 8
+    for (int u = 0; u < kLstmH; ++u) acc = fmaf(hrow[u], w[u], acc);  // k-ordered fma chain, like nn.Linear's fp32 dot
+    return acc;
+}
+
+// policy(obs, state) tail in rollout mode: decode_actions on h + sample_logits.  16 lanes per row, lane lo = output lo.
+__global__ void __launch_bounds__(256) lstm_heads_sample_kernel(const float *h, long long rows, const float *params, int dp,
+                                                               int a, const float *noise, uint64_t seed, uint64_t step,
+                                                               long long row_offset, long long *actions, float *logprob,
+                                                               float *entropy, float *value) {
+    __shared__ float w2v[kOut * (kLstmH + 1)];
+    __shared__ float b2v[kOut];
+    __shared__ float hs[16][kLstmH];
+    stage_heads(params, dp, a, w2v, b2v);
+    const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
+    const long long tiles = (rows + 15) / 16;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * kLstmH; i += 256) {
+            const long long r = tile * 16 + i / kLstmH;
+            hs[i / kLstmH][i % kLstmH] = r < rows ? h[r * kLstmH + i % kLstmH] : 0.0f;
+        }
+        __syncthreads();
+        const long long row = tile * 16 + le;
+        const bool ok = row < rows;
+        const float mine = head_dot(hs[le], w2v, b2v, lo);
+        const float q = ok ? noise_lane(noise ? noise + row * a : nullptr, seed, step, (uint64_t)(row_offset + row), lo, a) : 1.0f;
+        const LaneSample sm = sample_row16(mine, lo, a, q);
+        if (ok && lo == 0) {
+            actions[row] = sm.action;
+            logprob[row] = sm.logprob;
+            if (entropy) entropy[row] = sm.entropy;
+            value[row] = sm.value;
+        }
+    }
+}
+
+// Experience.store of one rollout step (clean_pufferl.py:436-450) into the env-major buffers: row (e, t) at e*T + t.
+__global__ void __launch_bounds__(256) store_step_kernel(pfa_experience ex, int t, int num_envs, int dp, const float *obs,
+                                                        const float *rewards, const uint8_t *terminals, const long long *actions,
+                                                        const float *logprob, const float *value) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int V = dp / 4;
+    if (i < (long long)num_envs * V) {
+        const int e = (int)(i / V), c4 = (int)(i - (long long)e * V);
+        *reinterpret_cast<float4 *>(ex.obs + ((size_t)e * ex.horizon_T + t) * dp + 4 * c4) =
+            *reinterpret_cast<const float4 *>(obs + (size_t)e * dp + 4 * c4);
+    }
+    if (i < num_envs) {
+        const size_t row = (size_t)i * ex.horizon_T + t;
+        ex.rewards[row] = rewards[i];
+        ex.dones[row] = terminals[i] ? 1.0f : 0.0f;
+        ex.actions[row] = (int)actions[i];
+        ex.logprobs[row] = logprob[i];
+        ex.values[row] = value[i];
+    }
+}
+
+// Rows of minibatch `mb` in TIME-MAJOR order: q = t*R + k  ->  flat env-major row (mb + k*nmb)*Th + t
+struct TimeMajorMap {
+    int mb, nmb, horizon;
+    long long R;
+    __device__ __forceinline__ long long flat(long long q) const {
+        const long long t = q / R, k = q - t * R;
+        return ((long long)mb + k * nmb) * horizon + t;
+    }
+};
+
+__global__ void __launch_bounds__(256) gather_obs_tm_kernel(const float *obs, TimeMajorMap map, long long rows, int dp,
+                                                           float *out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int V = dp / 4;
+    if (i >= rows * V) return;
+    const long long q = i / V;
+    const int c4 = (int)(i - q * V);
+    *reinterpret_cast<float4 *>(out + q * dp + 4 * c4) = *reinterpret_cast<const float4 *>(obs + map.flat(q) * dp + 4 * c4);
+}
+
+// decode_actions + PPO loss (clean_pufferl.py:202-238) on the hidden states of one minibatch (time-major rows) and the
+// gradients w.r.t. the 16 padded head outputs and w.r.t. h.  16 lanes per row.  stats_partial: [gridDim.x][8].
+__global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, long long rows, TimeMajorMap map,
+                                                             pfa_experience ex, const float *params, int dp, int a,
+                                                             pfa_ppo_hparams hp, const double *adv_stats, double global_rows,
+                                                             float *dout /* [rows][16] */, float *dh /* [rows][128] */,
+                                                             float *stats_partial) {
+    __shared__ float w2v[kOut * (kLstmH + 1)];
+    __shared__ float b2v[kOut];
+    __shared__ float hs[16][kLstmH];
+    __shared__ float st[16][8];
+    stage_heads(params, dp, a, w2v, b2v);
+    const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
+    float adv_mean = 0.0f, adv_den = 1.0f;
+    if (hp.norm_adv) {
+        const double s1 = adv_stats[2 * map.mb], s2 = adv_stats[2 * map.mb + 1];
+        const double mean = s1 / global_rows;
+        double var = (s2 - s1 * mean) / (global_rows - 1.0);
+        var = var > 0.0 ? var : 0.0;
+        adv_mean = (float)mean;
+        adv_den = (float)sqrt(var) + 1e-8f;
+    }
+    const float inv_rows = (float)(1.0 / global_rows);
+    float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const long long tiles = (rows + 15) / 16;
+    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * kLstmH; i += 256) {
+            const long long r = tile * 16 + i / kLstmH;
+            hs[i / kLstmH][i % kLstmH] = r < rows ? h[r * kLstmH + i % kLstmH] : 0.0f;
+        }
+        __syncthreads();
+        const long long row = tile * 16 + le;
+        const bool ok = row < rows;
+        const long long fr = ok ? map.flat(row) : 0;
+        const float w = ok ? 1.0f : 0.0f;
+        const int action = ex.actions[fr];
+        const float old_logprob = ex.logprobs[fr], old_value = ex.values[fr], adv_raw = ex.advantages[fr], ret = ex.returns[fr];
+        const float mine = head_dot(hs[le], w2v, b2v, lo);
+        // log-softmax over the row's logits
+        const bool is_logit = lo < a;
+        const float mx = row16_max(is_logit ? mine : -INFINITY);
+        const float ev = is_logit ? expf(mine - mx) : 0.0f;
+        const float se = row16_sum(ev);
+        const float lse = mx + logf(se);
+        const float nl = mine - lse;
+        const float p = ev / se;
+        const float ent = row16_sum(is_logit ? -nl * p : 0.0f);
+        const float new_logprob = row16_sum(lo == action ? nl : 0.0f);
+        const float new_value = row16_sum(lo == a ? mine : 0.0f);
+        const float logratio = new_logprob - old_logprob;
+        const float ratio = expf(logratio);
+        const float adv = hp.norm_adv ? (adv_raw - adv_mean) / adv_den : adv_raw;
+        const float lo_c = 1.0f - hp.clip_coef, hi_c = 1.0f + hp.clip_coef;
+        const float pg1 = -adv * ratio, pg2 = -adv * fminf(fmaxf(ratio, lo_c), hi_c);
+        const bool inside = ratio >= lo_c && ratio <= hi_c;
+        float dpg;  // d pg / d ratio: torch.max tie rule + clamp pass-through (see csrc/ppo_update.hip)
+        if (pg1 > pg2) dpg = -adv;
+        else if (pg1 < pg2) dpg = inside ? -adv : 0.0f;
+        else dpg = inside ? -adv : -0.5f * adv;
+        const float scale = inv_rows * w;
+        const float g_lp = dpg * ratio * scale;
+        float v_loss, dv;
+        if (hp.clip_vloss) {
+            const float du = new_value - ret, vl_u = du * du;
+            const float delta = new_value - old_value;
+            const float vcl = old_value + fminf(fmaxf(delta, -hp.vf_clip_coef), hp.vf_clip_coef);
+            const float dc = vcl - ret, vl_c = dc * dc;
+            const bool vin = delta >= -hp.vf_clip_coef && delta <= hp.vf_clip_coef;
+            v_loss = 0.5f * fmaxf(vl_u, vl_c);
+            const float gu = 2.0f * du, gc = vin ? 2.0f * dc : 0.0f;
+            dv = 0.5f * (vl_u > vl_c ? gu : (vl_u < vl_c ? gc : 0.5f * (gu + gc)));
+        } else {
+            const float du = new_value - ret;
+            v_loss = 0.5f * du * du;
+            dv = du;
+        }
+        dv *= hp.vf_coef * scale;
+        float d = 0.0f;
+        if (is_logit) d = g_lp * ((lo == action ? 1.0f : 0.0f) - p) + hp.ent_coef * scale * p * (nl + ent);
+        else if (lo == a) d = dv;
+        if (ok) dout[row * kOut + lo] = d;
+        // d loss / d h[u] = sum_o d_o W2v[o][u]; lane lo owns u = lo, lo+16, ...
+        float dhv[kLstmH / 16];
+#pragma unroll
+        for (int j = 0; j < kLstmH / 16; ++j) dhv[j] = 0.0f;
+        for (int o = 0; o <= a; ++o) {
+            const float d_o = __shfl(d, (lane_id() & 48) | o, 64);
+#pragma unroll
+            for (int j = 0; j < kLstmH / 16; ++j) dhv[j] = fmaf(d_o, w2v[o * (kLstmH + 1) + lo + 16 * j], dhv[j]);
+        }
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < kLstmH / 16; ++j) dh[row * kLstmH + lo + 16 * j] = dhv[j];
+        }
+        if (lo == 0) {
+            acc[0] += fmaxf(pg1, pg2) * w;
+            acc[1] += v_loss * w;
+            acc[2] += ent * w;
+            acc[3] += -logratio * w;
+            acc[4] += ((ratio - 1.0f) - logratio) * w;
+            acc[5] += (fabsf(ratio - 1.0f) > hp.clip_coef ? 1.0f : 0.0f) * w;
+        }
+    }
+    __syncthreads();
+    if (lo == 0)
+        for (int i = 0; i < 8; ++i) st[le][i] = i < 6 ? acc[i] : 0.0f;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float s = 0.0f;
+        for (int e = 0; e < 16; ++e) s += st[e][threadIdx.x];
+        stats_partial[(size_t)blockIdx.x * 8 + threadIdx.x] = s;
+    }
+}
+__global__ void stats_final_kernel(const float *partial, int nblocks, float *out8) {
+    const int i = threadIdx.x;
+    if (i >= 8) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 8 + i];
+    out8[i] = s;
+}
+
+// f64 pieces of sum(g^2) for the clip norm of a large flat gradient (consumed by adam_clip_kernel).
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const float *g, long long count, double *partials) {
+    __shared__ double sh[4];
+    const long long per = (count + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < count ? lo + per : count;
+    double s = 0.0;
+    for (long long i = lo + threadIdx.x; i < hi; i += 256) {
+        const double v = (double)g[i];
+        s += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane_id() == 0) sh[wave_id()] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+static unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace pfa
+
+using namespace pfa;
+
+extern "C" int pfa_relu(float *x, int64_t n, pfa_stream_t stream) {
+    PFA_REQUIRE(x && n >= 0, "relu: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(relu_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_relu_grad(float *dx, const float *x, int64_t n, pfa_stream_t stream) {
+    PFA_REQUIRE(dx && x && n >= 0, "relu_grad: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(relu_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dx, x, (long long)n);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_lstm_cell_fwd(float *gates, const float *c_prev, float *c_out, float *h_out, int64_t rows,
+                                 pfa_stream_t stream) {
+    PFA_REQUIRE(gates && c_prev && c_out && h_out && rows >= 0, "lstm_cell_fwd: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(blocks_for(rows * kLstmH)), dim3(256), 0, (hipStream_t)stream, gates, c_prev,
+                       c_out, h_out, (long long)rows);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_lstm_cell_bwd(const float *gates_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
+                                 float *dc, float *dgates, int64_t rows, pfa_stream_t stream) {
+    PFA_REQUIRE(gates_act && c_prev && c && dh && dc && dgates && rows >= 0, "lstm_cell_bwd: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks_for(rows * kLstmH)), dim3(256), 0, (hipStream_t)stream, gates_act, c_prev,
+                       c, dh, dh2, dc, dgates, (long long)rows);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t pfa_colsum_workspace_bytes(int32_t cols) { return (size_t)kColChunks * (size_t)cols * sizeof(float); }
+
+extern "C" int pfa_colsum(const float *a, int64_t rows, int32_t cols, int64_t ld, float *out, int32_t accumulate, void *workspace,
+                          pfa_stream_t stream) {
+    PFA_REQUIRE(a && out && workspace && rows >= 0 && cols >= 1 && ld >= cols, "colsum: bad arguments");
+    float *partial = (float *)workspace;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, kColChunks), dim3(256), 0, (hipStream_t)stream, a,
+                       (long long)rows, (int)cols, (long long)ld, partial);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, (int)cols, out,
+                       (int)accumulate);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_lstm_heads_sample(const float *h, int64_t rows, const float *params, const pfa_mlp_dims *dims,
+                                     const float *noise, const pfa_noise_key *key, int64_t row_offset, int64_t *actions,
+                                     float *logprob, float *entropy, float *value, pfa_stream_t stream) {
+    PFA_REQUIRE(h && params && dims && actions && logprob && value && rows >= 0, "lstm_heads_sample: bad arguments");
+    PFA_REQUIRE(dims->hidden == kLstmH && dims->num_actions >= 1 && dims->num_actions <= 15, "lstm_heads_sample: bad dims");
+    PFA_REQUIRE(noise || key, "lstm_heads_sample: need a noise tensor or a Philox key");
+    if (rows == 0) return 0;
+    const long long tiles = (rows + 15) / 16;
+    hipLaunchKernelGGL(lstm_heads_sample_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, (hipStream_t)stream, h,
+                       (long long)rows, params, dims->obs_stride, dims->num_actions, noise, key ? key->seed : 0,
+                       key ? key->step : 0, (long long)row_offset, (long long *)actions, logprob, entropy, value);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_envs, int32_t obs_stride, const float *obs,
+                              const float *rewards, const uint8_t *terminals, const int64_t *actions, const float *logprob,
+                              const float *value, pfa_stream_t stream) {
+    PFA_REQUIRE(exp && obs && rewards && terminals && actions && logprob && value, "store_step: null buffer");
+    PFA_REQUIRE(t >= 0 && t < exp->horizon_T && num_envs >= 1 && obs_stride % 4 == 0, "store_step: bad arguments");
+    hipLaunchKernelGGL(store_step_kernel, dim3(blocks_for((long long)num_envs * (obs_stride / 4))), dim3(256), 0,
+                       (hipStream_t)stream, *exp, (int)t, (int)num_envs, (int)obs_stride, obs, rewards, terminals,
+                       (const long long *)actions, logprob, value);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_gather_obs_time_major(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const pfa_ppo_hparams *hp,
+                                         int32_t obs_stride, float *out, pfa_stream_t stream) {
+    PFA_REQUIRE(exp && hp && out && exp->obs, "gather_obs: null buffer");
+    const long long mbs = batch_rows / hp->num_minibatches;
+    TimeMajorMap map{mb, hp->num_minibatches, hp->bptt_horizon, mbs / hp->bptt_horizon};
+    hipLaunchKernelGGL(gather_obs_tm_kernel, dim3(blocks_for(mbs * (obs_stride / 4))), dim3(256), 0, (hipStream_t)stream, exp->obs,
+                       map, mbs, (int)obs_stride, out);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t pfa_lstm_heads_loss_workspace_bytes(void) { return (size_t)1024 * 8 * sizeof(float); }
+
+extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
+                                   const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
+                                   int64_t global_mb_rows, float *dout, float *dh, float *loss_sums8, void *workspace,
+                                   pfa_stream_t stream) {
+    PFA_REQUIRE(h && exp && params && dims && hp && dout && dh && loss_sums8 && workspace, "lstm_heads_loss: null buffer");
+    PFA_REQUIRE(!hp->norm_adv || adv_stats, "lstm_heads_loss: norm_adv needs adv_stats");
+    const long long mbs = batch_rows / hp->num_minibatches;
+    TimeMajorMap map{mb, hp->num_minibatches, hp->bptt_horizon, mbs / hp->bptt_horizon};
+    const long long tiles = (mbs + 15) / 16;
+    const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
+    float *partial = (float *)workspace;
+    hipLaunchKernelGGL(lstm_heads_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, mbs, map, *exp, params,
+                       dims->obs_stride, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, dout, dh, partial);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_sumsq_partials(const float *grads, int64_t count, double *partials, int32_t n, pfa_stream_t stream) {
+    PFA_REQUIRE(grads && partials && count >= 1 && n >= 1 && n <= 4096, "sumsq_partials: bad arguments");
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, grads, (long long)count, partials);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}

@@ -11,6 +11,7 @@
 #include "lane_ops.hpp"
 #include "mlp_tile.hpp"
 #include "philox.hpp"
+#include "sampler.hpp"
 #include "squared_env.hpp"
 
 namespace pfa {
@@ -102,41 +103,10 @@ __device__ __forceinline__ void forward_slice(const SliceFrags<DP> &w, const flo
     for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * 16 + c] = po[r];
 }
 
-// sample_logits for one Discrete head (frameworks/cleanrl.py:25-47), action=None branch, on the 16 lanes of a row:
-//   action = argmax(softmax(logits) / q)  == torch.multinomial(softmax(logits), 1) given its Exp(1) draw q.
-struct LaneSample {
-    int action;
-    float logprob, entropy, value;
-};
+// Sum of the four waves' head partials for (row le, output lo), then sample_row16 (sampler.hpp).
 __device__ __forceinline__ LaneSample sample_lanes(const float (*part)[kOut * 16], int le, int lo, int a, float q) {
     const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
-    const bool is_logit = lo < a;
-    const float mx = row16_max(is_logit ? mine : -INFINITY);
-    const float ex_ = is_logit ? expf(mine - mx) : 0.0f;
-    const float se = row16_sum(ex_);
-    const float lse = mx + logf(se);
-    // argmax of p/q with torch's first-index tie rule
-    float best = is_logit ? (ex_ / se) / q : -INFINITY;
-    int besti = lo;
-    row16_argmax(best, besti);
-    LaneSample r;
-    r.action = besti;
-    const float nl = mine - lse;
-    r.logprob = row16_sum(lo == besti ? nl : 0.0f);
-    r.entropy = row16_sum(is_logit ? -nl * expf(nl) : 0.0f);
-    r.value = row16_sum(lo == a ? mine : 0.0f);
-    return r;
-}
-
-// Exp(1) noise of (row, step, column lo): explicit tensor if given, else the Philox stream (philox.hpp).
-__device__ __forceinline__ float noise_lane(const float *noise_row_ptr, uint64_t seed, uint64_t step, uint64_t row, int lo,
-                                            int a) {
-    if (lo >= a) return 1.0f;
-    if (noise_row_ptr) return noise_row_ptr[lo];
-    const u32x4 w = philox4x32_10((uint32_t)row, (uint32_t)(lo >> 2), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
-                                  (uint32_t)(seed >> 32));
-    const uint32_t wsel = (lo & 3) == 0 ? w.x : (lo & 3) == 1 ? w.y : (lo & 3) == 2 ? w.z : w.w;
-    return -logf(philox_uniform(wsel));
+    return sample_row16(mine, lo, a, q);
 }
 
 // ---------------------------------------------------------------------------------------------

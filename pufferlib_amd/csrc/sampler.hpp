@@ -1,0 +1,47 @@
+// sampler.hpp — sample_logits for one Discrete head (pufferlib/frameworks/cleanrl.py:25-47, action=None branch) on the
+// 16 lanes of a DPP row: lane `lo` holds output `lo` of the row (`mine` = logit for lo < a, value for lo == a).
+//   action = argmax(softmax(logits) / q)  == torch.multinomial(softmax(logits), 1) given its Exp(1) draw q.
+// Shared by the MLP and LSTM policies so every path samples with identical arithmetic.
+#pragma once
+#include "common.hpp"
+#include "lane_ops.hpp"
+#include "philox.hpp"
+
+namespace pfa {
+
+struct LaneSample {
+    int action;
+    float logprob, entropy, value;
+};
+
+__device__ __forceinline__ LaneSample sample_row16(float mine, int lo, int a, float q) {
+    const bool is_logit = lo < a;
+    const float mx = row16_max(is_logit ? mine : -INFINITY);
+    const float ex_ = is_logit ? expf(mine - mx) : 0.0f;
+    const float se = row16_sum(ex_);
+    const float lse = mx + logf(se);
+    // argmax of p/q with torch's first-index tie rule
+    float best = is_logit ? (ex_ / se) / q : -INFINITY;
+    int besti = lo;
+    row16_argmax(best, besti);
+    LaneSample r;
+    r.action = besti;
+    const float nl = mine - lse;
+    r.logprob = row16_sum(lo == besti ? nl : 0.0f);
+    r.entropy = row16_sum(is_logit ? -nl * expf(nl) : 0.0f);
+    r.value = row16_sum(lo == a ? mine : 0.0f);
+    return r;
+}
+
+// Exp(1) noise of (row, step, column lo): explicit tensor if given, else the Philox stream (philox.hpp).
+__device__ __forceinline__ float noise_lane(const float *noise_row_ptr, uint64_t seed, uint64_t step, uint64_t row, int lo,
+                                            int a) {
+    if (lo >= a) return 1.0f;
+    if (noise_row_ptr) return noise_row_ptr[lo];
+    const u32x4 w = philox4x32_10((uint32_t)row, (uint32_t)(lo >> 2), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                                  (uint32_t)(seed >> 32));
+    const uint32_t wsel = (lo & 3) == 0 ? w.x : (lo & 3) == 1 ? w.y : (lo & 3) == 2 ? w.z : w.w;
+    return -logf(philox_uniform(wsel));
+}
+
+}  // namespace pfa

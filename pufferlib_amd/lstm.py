@@ -1,0 +1,190 @@
+"""Host orchestration of the recurrent-policy path (pufferlib.models.LSTMWrapper, models.py:64-111).
+
+Plain dense products are library GEMMs (torch.mm / addmm -> hipBLASLt / rocBLAS, exact fp32); everything else is a
+hand-written kernel behind the C ABI (csrc/lstm.hip).  Structure:
+
+  policy_step      encode_observations -> one nn.LSTM step -> decode_actions + sample_logits        (rollout)
+  Engine.rollout   clean_pufferl.evaluate for a Squared vecenv: T x {policy_step, Experience.store, send}
+  Engine.update    one minibatch of clean_pufferl.train: forward through bptt_horizon steps with the carried, detached
+                   state (clean_pufferl.py:186-191), PPO loss, back-propagation through time, flat gradient
+
+Row order inside a minibatch is TIME-MAJOR (row t*R + k = segment mb + k*nmb at step t) so that every per-step slice is
+a contiguous [R][...] block for the BLAS.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+H = 128
+
+
+def _gates_bias(fp):
+    v = fp.lstm_views
+    return v['bias_ih_l0'] + v['bias_hh_l0']
+
+
+def policy_step(fp, obs, h, c, noise, key, row_offset, bias=None, scratch=None):
+    """One rollout step on ``rows`` observation rows [rows][obs_stride]; h, c [rows][128] are updated in place.
+    Returns (actions int64, logprob, entropy, value[:, None])."""
+    L = _lib.lib()
+    stream = _lib.stream_handle()
+    rows = obs.shape[0]
+    dev = obs.device
+    v = fp.lstm_views
+    bias = _gates_bias(fp) if bias is None else bias
+    if scratch is None:
+        scratch = dict(xe=torch.empty(rows, H, device=dev), gates=torch.empty(rows, 4 * H, device=dev))
+    xe, gates = scratch['xe'], scratch['gates']
+    torch.addmm(fp.views['encoder.bias'], obs, fp.encoder_weight_padded().t(), out=xe)      # Default.encoder
+    _lib.check(L.pfa_relu(_lib.ptr(xe), xe.numel(), stream), 'relu')
+    torch.addmm(bias, xe, v['weight_ih_l0'].t(), out=gates)                                   # nn.LSTM gates
+    gates.addmm_(h, v['weight_hh_l0'].t())
+    _lib.check(L.pfa_lstm_cell_fwd(_lib.ptr(gates), _lib.ptr(c), _lib.ptr(c), _lib.ptr(h), rows, stream), 'lstm_cell_fwd')
+    actions = torch.empty(rows, dtype=torch.int64, device=dev)
+    logprob = torch.empty(rows, device=dev)
+    entropy = torch.empty(rows, device=dev)
+    value = torch.empty(rows, device=dev)
+    _lib.check(L.pfa_lstm_heads_sample(_lib.ptr(h), rows, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(noise), C.byref(key),
+                                       row_offset, _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(entropy), _lib.ptr(value),
+                                       stream), 'lstm_heads_sample')
+    return actions, logprob, entropy, value.unsqueeze(1)
+
+
+class Engine:
+    """Buffers and step functions of the recurrent path for one (vecenv, experience) pair."""
+
+    def __init__(self, fp, experience, vecenv):
+        self.fp, self.exp, self.vec = fp, experience, vecenv
+        dev = fp.flat.device
+        N = vecenv.num_agents
+        self.lstm_h = torch.zeros(1, N, H, device=dev)      # Experience.lstm_h / lstm_c (clean_pufferl.py:407-412)
+        self.lstm_c = torch.zeros(1, N, H, device=dev)
+        self.roll = dict(xe=torch.empty(N, H, device=dev), gates=torch.empty(N, 4 * H, device=dev))
+        M, Th = experience.minibatch_size, experience.bptt_horizon
+        self.M, self.Th, self.R = M, Th, M // Th
+        R = self.R
+        DP = fp.obs_stride
+        self.obs_tm = torch.empty(M, DP, device=dev)
+        self.xe = torch.empty(M, H, device=dev)
+        self.gates = torch.empty(Th, R, 4 * H, device=dev)
+        self.Cs = torch.zeros(Th + 1, R, H, device=dev)
+        self.Hs = torch.zeros(Th + 1, R, H, device=dev)
+        self.dout = torch.empty(M, 16, device=dev)
+        self.dh_heads = torch.empty(M, H, device=dev)
+        self.dG = torch.empty(Th, R, 4 * H, device=dev)
+        self.dC = torch.empty(R, H, device=dev)
+        self.dHrec = torch.empty(R, H, device=dev)
+        self.dxe = torch.empty(M, H, device=dev)
+        self.bsum16 = torch.empty(16, device=dev)
+        L = _lib.lib()
+        self.ws = torch.empty(max(L.pfa_colsum_workspace_bytes(4 * H), L.pfa_lstm_heads_loss_workspace_bytes()),
+                              dtype=torch.uint8, device=dev)
+        self.norm_partials = torch.empty(256, dtype=torch.float64, device=dev)
+        self.state = None      # (h, c) carried from the previous minibatch of this epoch
+
+    # -------------------------------------------------------------------------------------------- rollout
+    def rollout(self, T, noise, key_seed, step0, env_offset):
+        """clean_pufferl.evaluate's loop for a Squared vecenv, one kernel sequence per step (no host sync)."""
+        L = _lib.lib()
+        vec, exp, fp = self.vec, self.exp, self.fp
+        stream = _lib.stream_handle()
+        h, c = self.lstm_h[0], self.lstm_c[0]
+        bias = _gates_bias(fp)
+        N = vec.num_agents
+        for t in range(T):
+            key = _lib.NoiseKey(key_seed, step0 + t)
+            nz = None if noise is None else noise[t]
+            actions, logprob, _, value = policy_step(fp, vec.obs_buf, h, c, nz, key, env_offset, bias=bias, scratch=self.roll)
+            _lib.check(L.pfa_store_step(C.byref(exp.c), t, N, fp.obs_stride, _lib.ptr(vec.obs_buf), _lib.ptr(vec.rewards),
+                                        _lib.ptr(vec.terminals_u8), _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(value),
+                                        stream), 'store_step')
+            vec.ensure_tape(1)
+            _lib.check(L.pfa_squared_send(_lib.ptr(vec.state), C.byref(vec.cfg), _lib.ptr(actions), _lib.ptr(vec.obs_buf),
+                                          _lib.ptr(vec.rewards), _lib.ptr(vec.terminals_u8), _lib.ptr(vec.truncations_u8),
+                                          _lib.ptr(vec.masks_u8), stream), 'send')
+            vec.sends += 1
+
+    # -------------------------------------------------------------------------------------------- update
+    def update(self, mb, hp, adv_stats, global_mb_rows, grads, B):
+        """Forward + loss + BPTT for minibatch `mb`; writes the flat gradient (+8 loss sums) into `grads`."""
+        L = _lib.lib()
+        stream = _lib.stream_handle()
+        fp, exp = self.fp, self.exp
+        M, Th, R = self.M, self.Th, self.R
+        v = fp.lstm_views
+        W_ih, W_hh = v['weight_ih_l0'], v['weight_hh_l0']
+        W1p = fp.encoder_weight_padded()
+        bias = _gates_bias(fp)
+        A = fp.num_actions
+        # ---- forward -----------------------------------------------------------------------------------------------
+        _lib.check(L.pfa_gather_obs_time_major(C.byref(exp.c), B, mb, C.byref(hp), fp.obs_stride, _lib.ptr(self.obs_tm), stream),
+                   'gather_obs')
+        torch.addmm(fp.views['encoder.bias'], self.obs_tm, W1p.t(), out=self.xe)
+        _lib.check(L.pfa_relu(_lib.ptr(self.xe), self.xe.numel(), stream), 'relu')
+        if mb == 0 or self.state is None:      # lstm_state = None at the start of every epoch (clean_pufferl.py:176)
+            self.Hs[0].zero_()
+            self.Cs[0].zero_()
+        else:                                   # carried across minibatches, detached (clean_pufferl.py:188-191)
+            self.Hs[0].copy_(self.state[0])
+            self.Cs[0].copy_(self.state[1])
+        xe_t = self.xe.view(Th, R, H)
+        for t in range(Th):
+            g = self.gates[t]
+            torch.addmm(bias, xe_t[t], W_ih.t(), out=g)
+            g.addmm_(self.Hs[t], W_hh.t())
+            _lib.check(L.pfa_lstm_cell_fwd(_lib.ptr(g), _lib.ptr(self.Cs[t]), _lib.ptr(self.Cs[t + 1]), _lib.ptr(self.Hs[t + 1]), R,
+                                           stream), 'lstm_cell_fwd')
+        self.state = (self.Hs[Th].clone(), self.Cs[Th].clone())
+        h_all = self.Hs[1:].view(M, H)
+        # ---- heads + loss ----------------------------------------------------------------------------------------
+        loss_sums = grads[fp.count:fp.count + 8]
+        _lib.check(L.pfa_lstm_heads_loss(_lib.ptr(h_all), C.byref(exp.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hp),
+                                         _lib.ptr(adv_stats), global_mb_rows, _lib.ptr(self.dout), _lib.ptr(self.dh_heads),
+                                         _lib.ptr(loss_sums), _lib.ptr(self.ws), stream), 'lstm_heads_loss')
+        # ---- back-propagation through time -------------------------------------------------------------------------
+        self.dC.zero_()
+        dh_t = self.dh_heads.view(Th, R, H)
+        for t in range(Th - 1, -1, -1):
+            dh2 = None if t == Th - 1 else self.dHrec
+            _lib.check(L.pfa_lstm_cell_bwd(_lib.ptr(self.gates[t]), _lib.ptr(self.Cs[t]), _lib.ptr(self.Cs[t + 1]), _lib.ptr(dh_t[t]),
+                                           _lib.ptr(dh2), _lib.ptr(self.dC), _lib.ptr(self.dG[t]), R, stream), 'lstm_cell_bwd')
+            if t > 0:
+                torch.mm(self.dG[t], W_hh, out=self.dHrec)          # d loss / d h_{t-1} through the recurrence
+        dG = self.dG.view(M, 4 * H)
+        torch.mm(dG, W_ih, out=self.dxe)                            # d loss / d encoder output
+        _lib.check(L.pfa_relu_grad(_lib.ptr(self.dxe), _lib.ptr(self.xe), self.dxe.numel(), stream), 'relu_grad')
+        # ---- weight gradients (contractions over all rows of the minibatch) ------------------------------------------
+        gv = fp.split(grads[:fp.count])
+        gW1p = fp.encoder_weight_padded(grads[:fp.count])
+        torch.mm(self.dxe.t(), self.obs_tm, out=gW1p)
+        self._colsum(self.dxe, H, gv['encoder.bias'])
+        torch.mm(dG.t(), self.xe, out=gv['recurrent.weight_ih_l0'])
+        torch.mm(dG.t(), self.Hs[:Th].view(M, H), out=gv['recurrent.weight_hh_l0'])
+        self._colsum(dG, 4 * H, gv['recurrent.bias_ih_l0'])
+        gv['recurrent.bias_hh_l0'].copy_(gv['recurrent.bias_ih_l0'])
+        g16 = torch.mm(self.dout.t(), h_all)                        # [16][128]: rows < A decoder, row A value head
+        gv['decoder.weight'].copy_(g16[:A])
+        gv['value_head.weight'].copy_(g16[A:A + 1])
+        self._colsum(self.dout, 16, self.bsum16)
+        gv['decoder.bias'].copy_(self.bsum16[:A])
+        gv['value_head.bias'].copy_(self.bsum16[A:A + 1])
+
+    def _colsum(self, a, cols, out):
+        L = _lib.lib()
+        _lib.check(L.pfa_colsum(_lib.ptr(a), a.shape[0], cols, a.stride(0), _lib.ptr(out), 0, _lib.ptr(self.ws),
+                                _lib.stream_handle()), 'colsum')
+
+    def clip_adam(self, grads, opt, max_grad_norm, loss_acc, loss_scale):
+        L = _lib.lib()
+        stream = _lib.stream_handle()
+        fp = self.fp
+        n = self.norm_partials.numel()
+        _lib.check(L.pfa_sumsq_partials(_lib.ptr(grads), fp.count, _lib.ptr(self.norm_partials), n, stream), 'sumsq')
+        opt.step_count += 1
+        g = opt.param_groups[0]
+        _lib.check(L.pfa_adam_clip_step(_lib.ptr(fp.flat), _lib.ptr(grads), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq),
+                                        fp.count, float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+                                        opt.step_count, float(max_grad_norm), 1.0, C.c_void_p(grads.data_ptr() + 4 * fp.count),
+                                        _lib.ptr(loss_acc), loss_scale, _lib.ptr(self.norm_partials), n, stream), 'adam')

@@ -38,6 +38,40 @@ class Default(nn.Module):
                            'pufferlib_amd.cleanrl.Policy / pufferlib_amd.clean_pufferl (HIP kernels)')
 
 
+class LSTMWrapper(nn.Module):
+    """pufferlib.models.LSTMWrapper (models.py:64-111): policy.encode_observations -> nn.LSTM(128, 128, 1) ->
+    policy.decode_actions; LSTM weights orthogonal (gain 1), biases 0.  Parameter container like ``Default``."""
+
+    def __init__(self, env, policy, input_size=HIDDEN, hidden_size=HIDDEN, num_layers=1):
+        super().__init__()
+        if (input_size, hidden_size, num_layers) != (HIDDEN, HIDDEN, 1):
+            raise ValueError(f'pufferlib_amd.models.LSTMWrapper supports nn.LSTM({HIDDEN}, {HIDDEN}, 1) only')
+        self.obs_shape = env.single_observation_space.shape
+        self.policy = policy
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.recurrent = nn.LSTM(input_size, hidden_size, num_layers)
+        for name, param in self.recurrent.named_parameters():
+            if 'bias' in name:
+                nn.init.constant_(param, 0)
+            elif 'weight' in name:
+                nn.init.orthogonal_(param, 1.0)
+
+    def forward(self, x, state):
+        raise RuntimeError('pufferlib_amd.models.LSTMWrapper is a parameter container: call it through '
+                           'pufferlib_amd.cleanrl.RecurrentPolicy / pufferlib_amd.clean_pufferl (HIP kernels)')
+
+
+LSTM_KEYS = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
+
+
+def find_lstm(module):
+    """The nn.LSTM of a recurrent policy wrapper (ours or the reference's LSTMWrapper: attribute ``recurrent``)."""
+    for m in module.modules():
+        if isinstance(m, nn.LSTM):
+            return m
+    return None
+
+
 MLP_KEYS = ['encoder.weight', 'encoder.bias', 'decoder.weight', 'decoder.bias', 'value_head.weight', 'value_head.bias']
 
 
@@ -66,7 +100,12 @@ class FlatParams:
         self.dims = _lib.MlpDims(int(D), int(obs_stride), int(H), int(A))
         self.obs_dim, self.obs_stride, self.num_actions = int(D), int(obs_stride), int(A)
         DP = self.obs_stride
-        self.count = H * DP + H + A * H + A + H + 1
+        self.mlp_count = H * DP + H + A * H + A + H + 1
+        self.lstm = find_lstm(policy_module)
+        if self.lstm is not None:
+            if (self.lstm.input_size, self.lstm.hidden_size, self.lstm.num_layers) != (H, H, 1) or self.lstm.bidirectional:
+                raise ValueError(f'the recurrent policy must use nn.LSTM({H}, {H}, 1)')
+        self.count = self.mlp_count + (8 * H * H + 8 * H if self.lstm is not None else 0)
         self.flat = torch.zeros(self.count, dtype=torch.float32, device=device)
         o = 0
         self.views = {}
@@ -76,13 +115,37 @@ class FlatParams:
         self.views['decoder.bias'] = self.flat[o:o + A]; o += A
         self.views['value_head.weight'] = self.flat[o:o + H].view(1, H); o += H
         self.views['value_head.bias'] = self.flat[o:o + 1]; o += 1
-        assert o == self.count
+        assert o == self.mlp_count
+        self.lstm_views = self._lstm_views(self.flat)
         with torch.no_grad():
             for name, view in self.views.items():
                 mod, attr = name.split('.')
                 p = getattr(getattr(mlp, mod), attr)
                 view.copy_(p.detach().to(device=device, dtype=torch.float32))
                 p.data = view          # the module now aliases the flat buffer
+            for name, view in self.lstm_views.items():
+                p = getattr(self.lstm, name)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view
+            if self.lstm is not None:
+                self.lstm._flat_weights = [getattr(self.lstm, n) for n in self.lstm._flat_weights_names]
+
+    def _lstm_views(self, flat):
+        if self.lstm is None:
+            return {}
+        H, o = HIDDEN, self.mlp_count
+        v = {}
+        v['weight_ih_l0'] = flat[o:o + 4 * H * H].view(4 * H, H); o += 4 * H * H
+        v['weight_hh_l0'] = flat[o:o + 4 * H * H].view(4 * H, H); o += 4 * H * H
+        v['bias_ih_l0'] = flat[o:o + 4 * H]; o += 4 * H
+        v['bias_hh_l0'] = flat[o:o + 4 * H]; o += 4 * H
+        assert o == self.count
+        return v
+
+    def encoder_weight_padded(self, flat=None):
+        """encoder.weight with its pad columns: [128][obs_stride] contiguous (what the GEMMs use)."""
+        flat = self.flat if flat is None else flat
+        return flat[:HIDDEN * self.obs_stride].view(HIDDEN, self.obs_stride)
 
     def flat_like(self):
         return torch.zeros_like(self.flat)
@@ -98,4 +161,6 @@ class FlatParams:
         out['decoder.bias'] = flat[o:o + A]; o += A
         out['value_head.weight'] = flat[o:o + H].view(1, H); o += H
         out['value_head.bias'] = flat[o:o + 1]
+        for k, v in self._lstm_views(flat).items():
+            out['recurrent.' + k] = v
         return out

@@ -1,0 +1,142 @@
+"""Recurrent policy path (LSTMWrapper) vs the golden outputs of the unmodified reference (tests/golden/ppo_lstm.npz):
+rollout with the recorded multinomial noise, LSTM state carry, BPTT update, two full iterations.  Plus cell kernels vs
+torch autograd.  Tolerances: 1e-5 on activations/advantages, a little looser on weights after 2 x 8 optimizer steps of
+an LSTM (different but fp32-exact summation orders in the BLAS)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def _config(n, horizon, mbs, bptt, epochs, total, hp, **over):
+    from pufferlib_amd import namespace
+    lr, gamma, lam, clip, vf_coef, vf_clip, mgn, ent = hp
+    cfg = dict(env='squared', seed=1, torch_deterministic=True, cpu_offload=False, device='cuda', total_timesteps=total,
+               learning_rate=lr, anneal_lr=True, gamma=gamma, gae_lambda=lam, update_epochs=epochs, norm_adv=True,
+               clip_coef=clip, clip_vloss=True, vf_coef=vf_coef, vf_clip_coef=vf_clip, max_grad_norm=mgn, ent_coef=ent,
+               target_kl=None, batch_size=n * horizon, minibatch_size=mbs, bptt_horizon=bptt, compile=False,
+               checkpoint_interval=0, data_dir='/tmp/pfa_experiments', exp_id='test')
+    cfg.update(over)
+    return namespace(**cfg)
+
+
+def _make(n):
+    from pufferlib_amd import vector, models, cleanrl
+    vec = vector.make(vector.make_squared, num_envs=n, backend=vector.Squared)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+    return vec, pol
+
+
+def _step_major(x, n, t):
+    return x.view(n, t, *x.shape[1:]).transpose(0, 1).reshape(n * t, *x.shape[1:]).cpu().numpy()
+
+
+def test_cell_kernels_match_torch_autograd():
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(0)
+    R, H = 37, 128
+    pre = torch.randn(R, 4 * H, device='cuda', requires_grad=True)
+    c0 = torch.randn(R, H, device='cuda', requires_grad=True)
+    i, f, g, o = pre.chunk(4, dim=1)
+    c1 = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(g)
+    h1 = torch.sigmoid(o) * torch.tanh(c1)
+    dh, dc1 = torch.randn(R, H, device='cuda'), torch.randn(R, H, device='cuda')
+    (h1 * dh).sum().backward(retain_graph=True, inputs=[pre, c0])
+    gpre_h, gc0_h = pre.grad.clone(), c0.grad.clone()
+    pre.grad = None
+    c0.grad = None
+    ((h1 * dh).sum() + (c1 * dc1).sum()).backward(inputs=[pre, c0])
+
+    gates = pre.detach().clone()
+    c_out, h_out = torch.empty(R, H, device='cuda'), torch.empty(R, H, device='cuda')
+    _lib.check(L.pfa_lstm_cell_fwd(_lib.ptr(gates), _lib.ptr(c0.detach()), _lib.ptr(c_out), _lib.ptr(h_out), R, None), 'fwd')
+    np.testing.assert_allclose(c_out.cpu().numpy(), c1.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(h_out.cpu().numpy(), h1.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    dcv = dc1.clone()
+    dgates = torch.empty(R, 4 * H, device='cuda')
+    _lib.check(L.pfa_lstm_cell_bwd(_lib.ptr(gates), _lib.ptr(c0.detach()), _lib.ptr(c_out), _lib.ptr(dh), None, _lib.ptr(dcv),
+                                   _lib.ptr(dgates), R, None), 'bwd')
+    np.testing.assert_allclose(dgates.cpu().numpy(), pre.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dcv.cpu().numpy(), c0.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_colsum_and_relu_grad():
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    a = torch.randn(1000, 512, device='cuda')
+    out = torch.empty(512, device='cuda')
+    ws = torch.empty(L.pfa_colsum_workspace_bytes(512), dtype=torch.uint8, device='cuda')
+    _lib.check(L.pfa_colsum(_lib.ptr(a), 1000, 512, 512, _lib.ptr(out), 0, _lib.ptr(ws), None), 'colsum')
+    np.testing.assert_allclose(out.cpu().numpy(), a.double().sum(0).float().cpu().numpy(), rtol=1e-5, atol=1e-4)
+    x = torch.relu(torch.randn(4096, device='cuda'))
+    dx = torch.randn(4096, device='cuda')
+    want = torch.where(x > 0, dx, torch.zeros_like(dx))
+    _lib.check(L.pfa_relu_grad(_lib.ptr(dx), _lib.ptr(x), 4096, None), 'relu_grad')
+    assert torch.equal(dx, want)
+
+
+def test_create_evaluate_train_replays_golden_lstm(golden_dir):
+    from pufferlib_amd import clean_pufferl
+    g = np.load(os.path.join(golden_dir, 'ppo_lstm.npz'))
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    vec, pol = _make(n)
+    pol.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith('w0.')})
+    data = clean_pufferl.create(_config(n, horizon, mbs, bptt, epochs, total, [float(x) for x in g['hparams']]), vec, pol)
+    exp = data.experience
+    assert exp.lstm_h.shape == (1, n, 128)
+    for it in range(iters):
+        data.noise = torch.as_tensor(g[f'it{it}.noise'])
+        stats, _ = clean_pufferl.evaluate(data)
+        assert np.array_equal(_step_major(exp.actions, n, horizon), g[f'it{it}.actions'].astype(np.int32)), 'actions'
+        assert np.array_equal(_step_major(exp.obs, n, horizon)[:, :49], g[f'it{it}.obs'].astype(np.float32))
+        assert np.array_equal(_step_major(exp.rewards, n, horizon), g[f'it{it}.rewards'])
+        np.testing.assert_allclose(_step_major(exp.logprobs, n, horizon), g[f'it{it}.logprobs'], **TOL)
+        np.testing.assert_allclose(_step_major(exp.values, n, horizon), g[f'it{it}.values'], **TOL)
+        np.testing.assert_allclose(exp.lstm_h.cpu().numpy(), g[f'it{it}.lstm_h'], **TOL)      # state after the rollout,
+        np.testing.assert_allclose(exp.lstm_c.cpu().numpy(), g[f'it{it}.lstm_c'], **TOL)      # never reset on done
+        assert data.global_step == int(g[f'it{it}.global_step'])
+        clean_pufferl.train(data)
+        for m in range(exp.num_minibatches):
+            idx = exp.minibatch_rows_index(m)
+            np.testing.assert_allclose(exp.advantages[idx].cpu().numpy(), g[f'it{it}.advantages'][m], rtol=1e-5, atol=1e-5)
+        L = data.losses
+        got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=2e-4, atol=2e-5)
+        sd = pol.state_dict()
+        for k in sd:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'it{it}.w.{k}'], rtol=5e-5, atol=5e-6, err_msg=k)
+        m_ = data.flat_params.split(data.optimizer.exp_avg)
+        for k, v in m_.items():
+            key = 'policy.' + k if k.startswith('recurrent.') else 'policy.policy.' + k
+            np.testing.assert_allclose(v.cpu().numpy(), g[f'it{it}.m.{key}'], rtol=2e-4, atol=1e-6, err_msg=k)
+
+
+def test_recurrent_policy_protocol_step_matches_fused_engine():
+    """policy(obs, state) through the public wrapper == the engine's rollout step (same kernels, same noise stream)."""
+    from pufferlib_amd import clean_pufferl
+    n, horizon = 32, 8
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    vec, pol = _make(n)
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 4, 1, n * horizon * 4, hp, seed=3), vec, pol)
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    vec2, pol2 = _make(n)
+    pol2.load_state_dict(pol.state_dict())
+    pol2.noise_seed = 3
+    vec2.async_reset(3)
+    state = None
+    acts = []
+    for t in range(horizon):
+        o = vec2.recv()[0]
+        a, lp, ent, val, state = pol2(o, state)
+        acts.append(a.clone())
+        vec2.send(a)
+    assert torch.equal(exp.actions.view(n, horizon).t().reshape(-1).long(), torch.cat(acts))
+    assert torch.equal(state[0], exp.lstm_h) and torch.equal(state[1], exp.lstm_c)
