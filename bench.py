@@ -94,6 +94,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--policy', choices=['mlp', 'lstm'], default='mlp',
+                    help="'lstm' = LSTMWrapper(128) on the same envs (BASELINE configs[2]'s policy; not the headline metric)")
     ap.add_argument('--no-breakdown', action='store_true', help='skip the extra (untimed) per-kernel breakdown pass')
     args = ap.parse_args()
 
@@ -118,7 +120,10 @@ def main():
     per_gpu = NUM_ENVS * HORIZON
     vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=D, num_targets=NT), num_envs=NUM_ENVS,
                       backend=vector.Squared, obs_stride=64)
-    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    if args.policy == 'lstm':
+        pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+    else:
+        pol = cleanrl.Policy(models.Default(vec.driver_env))
     data = clean_pufferl.create(make_config(per_gpu * world * (K + W) * 4), vec, pol)
 
     def barrier():
@@ -173,7 +178,7 @@ def main():
         launches, total_ms = grad_launches, grad_total_ms
         avg_ms = total_ms / max(launches, 1)
         rows_per_launch = per_gpu // NMB
-        achieved = FLOP_PER_ROW_UPDATE * rows_per_launch / (avg_ms * 1e-3) / 1e12
+        achieved = FLOP_PER_ROW_UPDATE * rows_per_launch / (avg_ms * 1e-3) / 1e12 if launches else 0.0
         traffic = None
         pmc = os.path.join(REPO, 'profiles', 'pmc_summary.json')
         if os.path.exists(pmc):
@@ -187,7 +192,7 @@ def main():
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'squared d={D} nt={NT}, {NUM_ENVS} envs/GPU x {HORIZON} steps, obs 49->64 f32 rows, '
-                                   f'MLP 128, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[1]'
+                                   f'{"MLP 128" if args.policy == "mlp" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[1]'
                                    + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': 'ppo_mlp_grad', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
