@@ -44,6 +44,17 @@ size_t pfa_gae_workspace_bytes(int64_t n);
 int pfa_gae_f32(const float *dones, const float *values, const float *rewards, float *advantages,
                 float *returns, int64_t n, float gamma, float gae_lambda, void *workspace,
                 pfa_stream_t stream);
+/* Data-parallel form: the array is one rank's SHARD of the reference's single flat batch (rank-major order).
+ * pass1 writes the shard's affine map {C, D} (f64, device) to shard_map[2]; the caller all-gathers the maps and
+ * folds those of the later shards into carry_in[1] (f64, device) = the advantage of the first element after this
+ * shard; pass2 (same workspace, untouched in between) finishes the scan.  has_next != 0: a later shard exists, the
+ * three input arrays hold n+1 readable elements (element n = the next shard's first row) and the last element is
+ * an interior row; has_next == 0: last shard, advantages[n-1] = 0 and carry_in is ignored. */
+int pfa_gae_shard_pass1(const float *dones, const float *values, const float *rewards, int64_t n, int has_next,
+                        float gamma, float gae_lambda, void *workspace, double *shard_map, pfa_stream_t stream);
+int pfa_gae_shard_pass2(const float *dones, const float *values, const float *rewards, float *advantages,
+                        float *returns, int64_t n, int has_next, float gamma, float gae_lambda,
+                        const void *workspace, const double *carry_in, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Squared vecenv — replaces pufferlib.vector.Serial (vector.py:70-166) over

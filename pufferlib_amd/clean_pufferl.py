@@ -115,9 +115,9 @@ class Experience:
         self.obs = torch.zeros(B, obs_stride, dtype=torch.float32, device=device)
         self.actions = torch.zeros(B, dtype=torch.int32, device=device)
         self.logprobs = torch.zeros(B, dtype=torch.float32, device=device)
-        self.rewards = torch.zeros(B, dtype=torch.float32, device=device)
-        self.dones = torch.zeros(B, dtype=torch.float32, device=device)
-        self.values = torch.zeros(B, dtype=torch.float32, device=device)
+        # one spare element behind rewards/dones/values: the halo row of the data-parallel GAE (next rank's first row)
+        self._rdv = torch.zeros(3, B + 1, dtype=torch.float32, device=device)
+        self.rewards, self.dones, self.values = self._rdv[0, :B], self._rdv[1, :B], self._rdv[2, :B]
         self.advantages = torch.zeros(B, dtype=torch.float32, device=device)
         self.returns = torch.zeros(B, dtype=torch.float32, device=device)
         self.lstm_h = self.lstm_c = None
@@ -383,6 +383,29 @@ def _finish_evaluate(data, N, T):
     return data.stats, infos
 
 
+def _sharded_gae(data, dist, rank, world, stream):
+    """compute_gae over the GLOBAL rank-major flat batch (c_gae.pyx:11-32 crosses env boundaries, so it also crosses
+    shard boundaries): two tiny all-gathers — the first rows (halo of the previous rank) and the shards' affine maps."""
+    config, ex = data.config, data.experience
+    L, B = _lib.lib(), ex.batch_size
+    has_next = int(rank < world - 1)
+    first = ex._rdv[:, 0].contiguous()
+    rows = [torch.empty_like(first) for _ in range(world)]
+    dist.all_gather(rows, first)
+    if has_next:
+        ex._rdv[:, B] = rows[rank + 1]
+    smap = torch.empty(2, dtype=torch.float64, device=ex.device)
+    args = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
+    _lib.check(L.pfa_gae_shard_pass1(*args, B, has_next, float(config.gamma), float(config.gae_lambda),
+                                     _lib.ptr(data.workspace), _lib.ptr(smap), stream), 'gae pass 1')
+    maps = [torch.empty_like(smap) for _ in range(world)]
+    dist.all_gather(maps, smap)
+    carry = pdist.gae_fold_later(maps, rank)
+    _lib.check(L.pfa_gae_shard_pass2(*args, _lib.ptr(ex.advantages), _lib.ptr(ex.returns), B, has_next,
+                                     float(config.gamma), float(config.gae_lambda), _lib.ptr(data.workspace),
+                                     _lib.ptr(carry) if has_next else None, stream), 'gae pass 2')
+
+
 @utils.profile
 def train(data):
     config, profile, experience = data.config, data.profile, data.experience
@@ -397,9 +420,12 @@ def train(data):
 
     with profile.train_misc:
         # compute_gae over the env-major batch (clean_pufferl.py:163-169) + returns (:482)
-        _lib.check(L.pfa_gae_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
-                                 _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
-                                 float(config.gae_lambda), _lib.ptr(data.workspace), stream), 'gae')
+        if world > 1:
+            _sharded_gae(data, dist, rank, world, stream)
+        else:
+            _lib.check(L.pfa_gae_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
+                                     _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
+                                     float(config.gae_lambda), _lib.ptr(data.workspace), stream), 'gae')
         if config.norm_adv:
             _lib.check(L.pfa_ppo_adv_stats(C.byref(experience.c), B, C.byref(hp), _lib.ptr(data.adv_stats),
                                            _lib.ptr(data.workspace), stream), 'adv_stats')
@@ -525,7 +551,7 @@ def save_checkpoint(data):
     model_path = os.path.join(path, model_name)
     if os.path.exists(model_path):
         return model_path
-    torch.save(data.uncompiled_policy.state_dict(), model_path)
+    torch.save(data.uncompiled_policy, model_path)      # whole module, loadable by the reference's eval path
     state = dict(optimizer_state_dict=data.optimizer.state_dict(), global_step=data.global_step,
                  agent_step=data.global_step, update=data.epoch, model_name=model_name, exp_id=config.exp_id)
     state_path = os.path.join(path, 'trainer_state.pt')
@@ -543,8 +569,11 @@ def try_load_checkpoint(data):
         print('No checkpoint found. Assuming new experiment')
         return
     resume = torch.load(trainer_path, weights_only=False)
-    sd = torch.load(os.path.join(path, resume['model_name']), map_location=data.flat_params.flat.device)
-    with torch.no_grad():
+    sd = torch.load(os.path.join(path, resume['model_name']), map_location=data.flat_params.flat.device,
+                    weights_only=False)
+    if isinstance(sd, torch.nn.Module):
+        sd = sd.state_dict()
+    with torch.no_grad():      # copy INTO the views of the flat device buffer the kernels read
         for k, v in data.uncompiled_policy.state_dict().items():
             v.copy_(sd[k])
     data.optimizer.load_state_dict(resume['optimizer_state_dict'])

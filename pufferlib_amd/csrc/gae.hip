@@ -42,7 +42,7 @@ struct GaeItems {
 };
 
 __device__ __forceinline__ void gae_load(const float *dones, const float *values, const float *rewards, long long s,
-                                         long long n, GaeItems &it) {
+                                         long long n, GaeItems &it) {  // n = readable elements (incl. a halo row)
 #pragma unroll
     for (int i = 0; i <= kGaeItems; ++i) {
         const long long t = s + i;
@@ -53,13 +53,14 @@ __device__ __forceinline__ void gae_load(const float *dones, const float *values
     }
 }
 
-__device__ __forceinline__ Affine gae_thread_map(const GaeItems &it, long long s, long long n, float gamma, float lam) {
+__device__ __forceinline__ Affine gae_thread_map(const GaeItems &it, long long s, long long n, float gamma, float lam,
+                                                 bool pin_last) {
     Affine f = {1.0, 0.0};
 #pragma unroll
     for (int i = kGaeItems - 1; i >= 0; --i) {
         const long long t = s + i;
         if (t >= n) continue;  // identity
-        if (t == n - 1) {      // adv[n-1] = 0 whatever follows
+        if (t == n - 1 && pin_last) {  // adv[n-1] = 0 whatever follows
             f = {0.0, 0.0};
             continue;
         }
@@ -92,19 +93,20 @@ __device__ __forceinline__ void block_suffix_scan(Affine &mine, Affine &after, A
 
 __global__ void __launch_bounds__(kGaeThreads) gae_aggregate_kernel(const float *dones, const float *values,
                                                                    const float *rewards, long long n, float gamma,
-                                                                   float lam, Affine *agg) {
+                                                                   float lam, Affine *agg, int halo) {
     __shared__ Affine sh[kGaeThreads / 64];
     const long long s = (long long)blockIdx.x * kGaeBlock + (long long)threadIdx.x * kGaeItems;
     GaeItems it;
-    gae_load(dones, values, rewards, s, n, it);
-    Affine mine = gae_thread_map(it, s, n, gamma, lam), after;
+    gae_load(dones, values, rewards, s, n + halo, it);
+    Affine mine = gae_thread_map(it, s, n, gamma, lam, halo == 0), after;
     block_suffix_scan(mine, after, sh);
     if (threadIdx.x == 0) agg[blockIdx.x] = mine;
 }
 
 __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *dones, const float *values,
                                                                const float *rewards, float *adv, float *ret, long long n,
-                                                               float gamma, float lam, const Affine *agg, int nblocks) {
+                                                               float gamma, float lam, const Affine *agg, int nblocks,
+                                                               const double *carry_in, int halo) {
     __shared__ Affine sh[kGaeThreads / 64];
     __shared__ double s_carry;
     // carry-in of this block = (agg[b+1] o agg[b+2] o ... o agg[nblocks-1])(0), composed in order by wave 0
@@ -122,19 +124,20 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
             const Affine o = shfl_down_affine(f, off);
             if (lane + off < 64) f = compose(f, o);
         }
-        if (lane == 0) s_carry = f.d;  // applied to x = 0
+        // applied to x = the advantage of the element that follows this array (0 unless a later shard exists)
+        if (lane == 0) s_carry = f.c * (carry_in ? *carry_in : 0.0) + f.d;
     }
     const long long s = (long long)blockIdx.x * kGaeBlock + (long long)threadIdx.x * kGaeItems;
     GaeItems it;
-    gae_load(dones, values, rewards, s, n, it);
-    Affine mine = gae_thread_map(it, s, n, gamma, lam), after;
+    gae_load(dones, values, rewards, s, n + halo, it);
+    Affine mine = gae_thread_map(it, s, n, gamma, lam, halo == 0), after;
     block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
     float last = (float)(after.c * s_carry + after.d);  // adv at the first element after this thread's items
 #pragma unroll
     for (int i = kGaeItems - 1; i >= 0; --i) {
         const long long t = s + i;
         if (t >= n) continue;
-        if (t == n - 1) {
+        if (t == n - 1 && halo == 0) {
             last = 0.0f;
         } else {  // the reference's statement order and rounding (c_gae.pyx:27-30)
             // explicit round-to-nearest ops: no FMA contraction, like the reference's x86-64 build
@@ -144,6 +147,28 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
         }
         adv[t] = last;
         if (ret) ret[t] = last + it.v[i];
+    }
+}
+
+// Composition of all block maps of this array = the affine map of the whole shard (data-parallel GAE: rank r's
+// carry-in is (shard_{r+1} o ... o shard_{R-1})(0), so one all-gather of these pairs restores the reference's
+// single flat scan across shard boundaries).
+__global__ void gae_shard_aggregate_kernel(const Affine *agg, int nblocks, double *out2) {
+    const int lane = lane_id();
+    const int per = (nblocks + 63) / 64;
+    Affine f = {1.0, 0.0};
+    for (int i = per - 1; i >= 0; --i) {
+        const int b = lane * per + i;
+        if (b < nblocks) f = compose(agg[b], f);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Affine o = shfl_down_affine(f, off);
+        if (lane + off < 64) f = compose(f, o);
+    }
+    if (lane == 0) {
+        out2[0] = f.c;
+        out2[1] = f.d;
     }
 }
 
@@ -166,10 +191,44 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
     Affine *agg = (Affine *)workspace;
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // both passes
     hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
-                       rewards, (long long)n, gamma, gae_lambda, agg);
+                       rewards, (long long)n, gamma, gae_lambda, agg, 0);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(gae_apply_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb);
+                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb, (const double *)nullptr, 0);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Two-call form for an array that is one SHARD of a longer flat batch (data parallel).  Pass 1 leaves this shard's
+// affine map (C, D) in shard_map[2] (f64, device); the host side all-gathers the maps, folds the LATER shards' maps
+// into carry_in = adv of the first element after this shard, and pass 2 finishes the scan.  has_next != 0 means a
+// later shard exists: the arrays then hold n+1 readable elements, element n being the next shard's first row (its
+// done / value / reward enter this shard's last delta), and the last element is an interior row instead of the
+// pinned adv = 0.
+extern "C" int pfa_gae_shard_pass1(const float *dones, const float *values, const float *rewards, int64_t n, int has_next,
+                                   float gamma, float gae_lambda, void *workspace, double *shard_map,
+                                   pfa_stream_t stream) {
+    PFA_REQUIRE(n >= 1 && dones && values && rewards && workspace && shard_map, "gae_shard: bad arguments");
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
+    Affine *agg = (Affine *)workspace;
+    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
+                       rewards, (long long)n, gamma, gae_lambda, agg, has_next ? 1 : 0);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gae_shard_aggregate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, agg, (int)nb, shard_map);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_gae_shard_pass2(const float *dones, const float *values, const float *rewards, float *advantages,
+                                   float *returns, int64_t n, int has_next, float gamma, float gae_lambda,
+                                   const void *workspace, const double *carry_in, pfa_stream_t stream) {
+    PFA_REQUIRE(n >= 1 && dones && values && rewards && advantages && workspace, "gae_shard: bad arguments");
+    PFA_REQUIRE(!has_next || carry_in, "gae_shard: a shard with a successor needs carry_in");
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    hipLaunchKernelGGL(gae_apply_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       advantages, returns, (long long)n, gamma, gae_lambda, (const Affine *)workspace, (int)nb,
+                       has_next ? carry_in : (const double *)nullptr, has_next ? 1 : 0);
     PFA_LAUNCH_CHECK();
     return 0;
 }

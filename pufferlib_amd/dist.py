@@ -8,6 +8,8 @@ Sharding contract
   * every rank keeps its own env-major experience and applies the reference's minibatch partition locally; because
     ``N * (T / bptt_horizon) % num_minibatches == 0`` (checked) local minibatch m is exactly this rank's share of
     global minibatch m;
+  * GAE is the reference's single scan over the rank-major flat batch: per update two tiny all-gathers (first rows
+    = halo of the previous rank; the shards' affine maps) feed csrc/gae.hip's two-pass shard form;
   * per update ONE all-reduce(SUM) of the per-minibatch advantage sums [nmb][2] (f64) so every rank normalises with the
     global-minibatch mean / unbiased std; per optimizer step ONE all-reduce(SUM) of the flat bucket
     [gradient (already divided by the GLOBAL minibatch rows) | 8 loss sums]; the clip norm is taken after it, so
@@ -76,6 +78,15 @@ def normalisation_from_sums(s1, s2, count):
     mean = s1 / count
     var = max((s2 - s1 * mean) / (count - 1.0), 0.0)
     return mean, math.sqrt(var)
+
+
+def gae_fold_later(maps, rank):
+    """Carry-in of rank's shard = (M_{rank+1} o ... o M_{R-1})(0) where M_q(x) = C_q*x + D_q is shard q's affine map
+    (csrc/gae.hip pass 1).  ``maps`` is a list of R 2-element f64 tensors (or arrays); stays on their device."""
+    x = maps[-1][1] * 0.0
+    for q in range(len(maps) - 1, rank, -1):
+        x = maps[q][0] * x + maps[q][1]
+    return x.reshape(1) if hasattr(x, 'reshape') else x
 
 
 _native = dict(ready=False, world=1)

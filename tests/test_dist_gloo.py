@@ -145,3 +145,61 @@ def test_normalisation_from_sums_matches_torch():
     a = torch.randn(4096, dtype=torch.float64) * 3 + 1
     mean, std = pdist.normalisation_from_sums(float(a.sum()), float((a * a).sum()), a.numel())
     assert abs(mean - float(a.mean())) < 1e-12 and abs(std - float(a.std())) < 1e-10
+
+
+def _gae_shard_worker(rank, world, port, out_dir):
+    """Host protocol of clean_pufferl._sharded_gae over gloo, with the shard scan done in numpy f64 (the device kernels are
+    covered by tests/test_gpu_gae.py): halo all-gather -> shard affine map -> map all-gather -> fold -> apply."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, REPO)
+    from pufferlib_amd import dist as pdist
+    d, _, _ = pdist.init_from_env('gloo')
+    rng = np.random.RandomState(5)
+    n, gamma, lam = 600, 0.99, 0.95
+    dn = (rng.rand(n) < 0.1).astype(np.float64)
+    v, r = rng.randn(n), rng.randn(n)
+    m = n // world
+    lo = rank * m
+    has_next = rank < world - 1
+    first = torch.tensor([r[lo], dn[lo], v[lo]])
+    rows = [torch.empty_like(first) for _ in range(world)]
+    d.all_gather(rows, first)
+    rr, dd, vv = (np.concatenate([x[lo:lo + m], [float(rows[rank + 1][i])] if has_next else []])
+                  for i, x in enumerate((r, dn, v)))
+    coef, delta = np.zeros(m), np.zeros(m)
+    for t in range(m):
+        if t == m - 1 and not has_next:
+            continue                      # pinned: the map x -> 0
+        nnt = 1.0 - dd[t + 1]
+        delta[t] = rr[t + 1] + gamma * vv[t + 1] * nnt - vv[t]
+        coef[t] = gamma * lam * nnt
+    Cq, Dq = 1.0, 0.0
+    for t in range(m - 1, -1, -1):        # compose(f_t, acc)
+        Cq, Dq = coef[t] * Cq, delta[t] + coef[t] * Dq
+    smap = torch.tensor([Cq, Dq], dtype=torch.float64)
+    maps = [torch.empty_like(smap) for _ in range(world)]
+    d.all_gather(maps, smap)
+    x = float(pdist.gae_fold_later(maps, rank)[0])
+    adv = np.zeros(m)
+    for t in range(m - 1, -1, -1):
+        x = delta[t] + coef[t] * x
+        adv[t] = x
+    np.save(os.path.join(out_dir, f'adv{rank}.npy'), adv)
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_sharded_gae_protocol_equals_flat_scan(tmp_path):
+    world = 3
+    mp.spawn(_gae_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f'adv{q}.npy') for q in range(world)])
+    rng = np.random.RandomState(5)
+    n = 600
+    dn = (rng.rand(n) < 0.1).astype(np.float32)
+    v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    sys.path.insert(0, REPO)
+    from oracle import c_oracle
+    # the workers ran in f64 on the un-rounded inputs; compare against the f32 oracle on the rounded ones
+    want = c_oracle.compute_gae(dn, v, r, 0.99, 0.95)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    assert got[-1] == 0.0

@@ -67,3 +67,43 @@ def test_empty_is_noop():
     from pufferlib_amd import _lib
     L = _lib.lib()
     assert L.pfa_gae_f32(None, None, None, None, None, 0, .99, .95, None, None) == 0
+
+
+@pytest.mark.parametrize('n,shards,p_done', [(524288, 8, 0.01), (12288, 3, 0.2), (4100, 2, 0.0), (7, 7, 0.3)])
+def test_sharded_two_pass_equals_flat_scan(n, shards, p_done):
+    """Data-parallel form: R shards of the rank-major flat batch, each run through pfa_gae_shard_pass1/2 with the halo
+    row and the folded carry-in (what clean_pufferl._sharded_gae does over all_gather), reproduce the single scan."""
+    import torch
+    from oracle import c_oracle
+    from pufferlib_amd import _lib, dist as pdist
+    L = _lib.lib()
+    rng = np.random.RandomState(n % 977 + shards)
+    d = (rng.rand(n) < p_done).astype(np.float32)
+    v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    want = c_oracle.compute_gae(d, v, r, 0.99, 0.95)
+    m = n // shards
+    st = _lib.stream_handle()
+    bufs, maps = [], []
+    for q in range(shards):
+        has_next = int(q < shards - 1)
+        sl = slice(q * m, (q + 1) * m + has_next)
+        t = [torch.as_tensor(x[sl].copy()).cuda() for x in (d, v, r)]
+        ws = torch.zeros(max(1, L.pfa_gae_workspace_bytes(m)), dtype=torch.uint8, device='cuda')
+        smap = torch.zeros(2, dtype=torch.float64, device='cuda')
+        _lib.check(L.pfa_gae_shard_pass1(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), m, has_next, 0.99, 0.95,
+                                         _lib.ptr(ws), _lib.ptr(smap), st), 'pass1')
+        bufs.append((t, ws, has_next))
+        maps.append(smap)
+    got = np.empty(n, np.float32)
+    for q, (t, ws, has_next) in enumerate(bufs):
+        carry = pdist.gae_fold_later(maps, q)
+        adv = torch.full((m,), float('nan'), device='cuda')
+        ret = torch.full((m,), float('nan'), device='cuda')
+        _lib.check(L.pfa_gae_shard_pass2(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.ptr(adv), _lib.ptr(ret), m,
+                                         has_next, 0.99, 0.95, _lib.ptr(ws), _lib.ptr(carry) if has_next else None, st),
+                   'pass2')
+        got[q * m:(q + 1) * m] = adv.cpu().numpy()
+        np.testing.assert_allclose(ret.cpu().numpy(), got[q * m:(q + 1) * m] + v[q * m:(q + 1) * m], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert np.abs(got - want).max() <= 8 * np.finfo(np.float32).eps * max(1.0, np.abs(want).max())
+    assert got[-1] == 0.0

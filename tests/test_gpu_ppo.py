@@ -320,3 +320,47 @@ def test_argument_errors_match_reference_messages():
     from pufferlib_amd.exceptions import ExtensionError
     with pytest.raises(ExtensionError, match='multiple of 16'):
         clean_pufferl.train(data)
+
+
+def test_checkpoint_round_trip_resumes_bit_identically(tmp_path):
+    """save_checkpoint / try_load_checkpoint (clean_pufferl.py:509-546): a resumed trainer must continue exactly like
+    the one that never stopped — parameters, Adam moments, step count and lr all live in the flat device buffers."""
+    from pufferlib_amd import clean_pufferl
+    n, horizon = 64, 32
+    hp = [2.5e-3, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        vec, pol = _make(n)
+        cfg = _config(n, horizon, 512, 16, 2, n * horizon * 8, hp, data_dir=str(tmp_path), exp_id='ckpt')
+        return clean_pufferl.create(cfg, vec, pol)
+
+    a = fresh(0)
+    for _ in range(2):
+        clean_pufferl.evaluate(a)
+        clean_pufferl.train(a)
+    path = clean_pufferl.save_checkpoint(a)
+    assert os.path.exists(path) and os.path.exists(tmp_path / 'ckpt' / 'trainer_state.pt')
+    saved = torch.load(path, weights_only=False)                      # whole module, as the reference saves it
+    assert isinstance(saved, torch.nn.Module)
+
+    b = fresh(123)                                                     # different initial weights
+    assert not torch.equal(a.flat_params.flat, b.flat_params.flat)
+    clean_pufferl.try_load_checkpoint(b)
+    assert torch.equal(a.flat_params.flat, b.flat_params.flat)
+    assert torch.equal(a.optimizer.exp_avg, b.optimizer.exp_avg) and torch.equal(a.optimizer.exp_avg_sq, b.optimizer.exp_avg_sq)
+    assert (b.global_step, b.epoch, b.optimizer.step_count) == (a.global_step, a.epoch, a.optimizer.step_count)
+    assert b.optimizer.param_groups[0]['lr'] == a.optimizer.param_groups[0]['lr']
+
+    # same experience + same state -> the next update is bit-identical
+    clean_pufferl.evaluate(a)
+    for name in ('obs', 'actions', 'logprobs', 'advantages', 'returns'):
+        getattr(b.experience, name).copy_(getattr(a.experience, name))
+    b.experience._rdv.copy_(a.experience._rdv)
+    b.experience.ptr, b.experience.step = a.experience.ptr, a.experience.step
+    b.global_step = a.global_step
+    clean_pufferl.train(a)
+    clean_pufferl.train(b)
+    assert torch.equal(a.flat_params.flat, b.flat_params.flat)
+    for k in a.losses:
+        assert a.losses[k] == b.losses[k], k
