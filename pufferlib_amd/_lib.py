@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -125,6 +125,8 @@ _SIGNATURES = {
     'pfa_lstm_heads_loss_workspace_bytes': (C.c_size_t, []),
     'pfa_lstm_heads_loss': (C.c_int, [P, C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),
                                       C.POINTER(PpoHparams), P, C.c_int64, P, P, P, P, P]),
+    'pfa_gemm_tn_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
+    'pfa_gemm_tn_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, P, P]),
     'pfa_sumsq_partials': (C.c_int, [P, C.c_int64, P, C.c_int32, P]),
     'pfa_dist_unique_id': (C.c_int, [P]),
     'pfa_dist_init': (C.c_int, [P, C.c_int32, C.c_int32]),

@@ -1,0 +1,195 @@
+// gemm.hip — fp32 MFMA contractions over the ROW dimension of two row-major activations,
+//   C[mo][no] = sum_k A[k][mo] * B[k][no]        (C = A^T B, k = minibatch rows, 10^5..10^6 of them)
+// i.e. the weight-gradient products autograd forms for nn.Linear / nn.LSTM in the reference's
+// loss.backward() (clean_pufferl.py:244): dW_ih = dG^T xe, dW_hh = dG^T h_prev, dW_enc = dxe^T obs,
+// dW_heads = dout^T h.  The output is tiny (<= 512 x 128) and k is huge, so the work is split over k:
+//   pass 1  WG (tile, split) owns a TM x TN output tile and a contiguous range of k; both operands are staged
+//           k-major through a double-buffered LDS slab (BK = 16 rows) and consumed as v_mfma_f32_16x16x4_f32
+//           fragments (A-op lane (c,g) = A[4kk+g][i0+c], B-op = B[4kk+g][j0+c]); row stride TM+16 floats keeps the
+//           fragment reads conflict-free (bank = 16g + c within a 32-lane half);
+//   pass 2  deterministic sum of the split partials in f64 -> C.
+// Roofline: fp32 MFMA (2*mo*no flop per k row) for the wide products, HBM (reading A and B once) for the
+// 16-row head product.
+#include "common.hpp"
+#include "mlp_tile.hpp"
+
+namespace pfa {
+
+constexpr int kGemmBK = 16;
+constexpr int kGemmThreads = 256;
+
+template <int WR, int WC, int MI, int NI>
+struct GemmTnCfg {
+    static constexpr int TM = WR * MI * 16, TN = WC * NI * 16;
+    // LDS row strides (floats), == 16 mod 32
+    static constexpr int SA = TM % 32 == 0 ? TM + 16 : TM + 32, SB = TN % 32 == 0 ? TN + 16 : TN + 32;
+    static constexpr int kStageFloats = kGemmBK * (SA + SB);
+    static constexpr int kA4 = kGemmBK * TM / 4, kB4 = kGemmBK * TN / 4;  // float4 per stage
+    static constexpr int kLA = (kA4 + kGemmThreads - 1) / kGemmThreads, kLB = (kB4 + kGemmThreads - 1) / kGemmThreads;
+    static_assert(WR * WC * 64 == kGemmThreads, "4 waves");
+};
+
+template <int WR, int WC, int MI, int NI>
+__global__ void __launch_bounds__(kGemmThreads, 2)
+    gemm_tn_partial_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ B, long long ldb, int mo, int no,
+                           long long K, long long k_per_split, float *__restrict__ partial) {
+    using Cfg = GemmTnCfg<WR, WC, MI, NI>;
+    __shared__ float lds[2 * Cfg::kStageFloats];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int wr = wv / WC, wc = wv % WC;
+    const int tiles_n = no / Cfg::TN;
+    const int tile = blockIdx.x, split = blockIdx.y;
+    const int i0 = (tile / tiles_n) * Cfg::TM, j0 = (tile % tiles_n) * Cfg::TN;
+    const long long k_lo = (long long)split * k_per_split;
+    const long long k_hi = k_lo + k_per_split < K ? k_lo + k_per_split : K;
+    const int stages = (int)((k_hi - k_lo + kGemmBK - 1) / kGemmBK);
+
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ra[Cfg::kLA], rb[Cfg::kLB];
+    auto fetch = [&](int s) {
+        const long long kb = k_lo + (long long)s * kGemmBK;
+#pragma unroll
+        for (int q = 0; q < Cfg::kLA; ++q) {
+            const int idx = tid + q * kGemmThreads;
+            const int row = idx / (Cfg::TM / 4), col = (idx % (Cfg::TM / 4)) * 4;
+            const bool ok = idx < Cfg::kA4 && kb + row < k_hi;
+            ra[q] = ok ? *(const float4 *)(A + (kb + row) * lda + i0 + col) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < Cfg::kLB; ++q) {
+            const int idx = tid + q * kGemmThreads;
+            const int row = idx / (Cfg::TN / 4), col = (idx % (Cfg::TN / 4)) * 4;
+            const bool ok = idx < Cfg::kB4 && kb + row < k_hi;
+            rb[q] = ok ? *(const float4 *)(B + (kb + row) * ldb + j0 + col) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+        float *la = lds + buf * Cfg::kStageFloats, *lb = la + kGemmBK * Cfg::SA;
+#pragma unroll
+        for (int q = 0; q < Cfg::kLA; ++q) {
+            const int idx = tid + q * kGemmThreads;
+            if (idx < Cfg::kA4) *(float4 *)(la + (idx / (Cfg::TM / 4)) * Cfg::SA + (idx % (Cfg::TM / 4)) * 4) = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < Cfg::kLB; ++q) {
+            const int idx = tid + q * kGemmThreads;
+            if (idx < Cfg::kB4) *(float4 *)(lb + (idx / (Cfg::TN / 4)) * Cfg::SB + (idx % (Cfg::TN / 4)) * 4) = rb[q];
+        }
+    };
+
+    if (stages > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < stages) fetch(s + 1);  // global loads in flight across this stage's MFMAs
+        const float *la = lds + buf * Cfg::kStageFloats + wr * MI * 16 + c;
+        const float *lb = lds + buf * Cfg::kStageFloats + kGemmBK * Cfg::SA + wc * NI * 16 + c;
+#pragma unroll
+        for (int kk = 0; kk < kGemmBK / 4; ++kk) {
+            float fa[MI], fb[NI];
+#pragma unroll
+            for (int a = 0; a < MI; ++a) fa[a] = la[(4 * kk + g) * Cfg::SA + 16 * a];
+#pragma unroll
+            for (int b = 0; b < NI; ++b) fb[b] = lb[(4 * kk + g) * Cfg::SB + 16 * b];
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+        }
+        if (s + 1 < stages) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    float *out = partial + (size_t)split * mo * no;
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(size_t)(i0 + (wr * MI + a) * 16 + 4 * g + r) * no + j0 + (wc * NI + b) * 16 + c] = acc[a][b][r];
+}
+
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ partial, int splits, int mo, int no,
+                                                            float *__restrict__ C, long long ldc) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= mo * no) return;
+    double s = 0.0;
+    for (int q = 0; q < splits; ++q) s += (double)partial[(size_t)q * mo * no + idx];
+    C[(long long)(idx / no) * ldc + idx % no] = (float)s;
+}
+
+struct GemmTnPlan {
+    int cfg;  // 0: 128x128, 1: 128x64, 2: 16x128
+    int tm, tn, tiles, splits;
+    long long k_per_split;
+};
+
+static bool gemm_tn_plan(int mo, int no, long long K, GemmTnPlan &p) {
+    if (mo % 128 == 0 && no % 128 == 0) {
+        p.cfg = 0, p.tm = 128, p.tn = 128;
+    } else if (mo % 128 == 0 && no % 64 == 0) {
+        p.cfg = 1, p.tm = 128, p.tn = 64;
+    } else if (mo % 16 == 0 && no % 128 == 0) {
+        p.cfg = 2, p.tm = 16, p.tn = 128;
+    } else {
+        return false;
+    }
+    p.tiles = (mo / p.tm) * (no / p.tn);
+    // >= 2 workgroups per CU when k allows it, every split at least 8 slabs deep, split size a multiple of the slab
+    long long want = (512 + p.tiles - 1) / p.tiles;
+    const long long max_splits = (K + 8 * kGemmBK - 1) / (8 * kGemmBK);
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    long long per = (K + want - 1) / want;
+    per = (per + kGemmBK - 1) / kGemmBK * kGemmBK;
+    p.k_per_split = per;
+    p.splits = (int)((K + per - 1) / per);
+    return true;
+}
+
+}  // namespace pfa
+
+using namespace pfa;
+
+extern "C" size_t pfa_gemm_tn_workspace_bytes(int32_t mo, int32_t no, int64_t k) {
+    GemmTnPlan p;
+    if (mo <= 0 || no <= 0 || k <= 0 || !gemm_tn_plan(mo, no, k, p)) return 0;
+    return (size_t)p.splits * mo * no * sizeof(float);
+}
+
+extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t mo,
+                               int32_t no, int64_t k, void *workspace, pfa_stream_t stream) {
+    PFA_REQUIRE(a && b && c && workspace && mo > 0 && no > 0 && k > 0, "gemm_tn: bad arguments");
+    PFA_REQUIRE(lda >= mo && ldb >= no && ldc >= no && lda % 4 == 0 && ldb % 4 == 0, "gemm_tn: row strides must cover the tile and be 16-byte multiples");
+    PFA_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
+    GemmTnPlan p;
+    PFA_REQUIRE(gemm_tn_plan(mo, no, k, p), "gemm_tn: supported shapes are (128a x 128b), (128a x 64b), (16a x 128b)");
+    const dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
+    float *partial = (float *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    ScopedKernelTimer timer("gemm_tn", st);
+    if (p.cfg == 0)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 4>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
+                           mo, no, (long long)k, p.k_per_split, partial);
+    else if (p.cfg == 1)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 2>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
+                           mo, no, (long long)k, p.k_per_split, partial);
+    else
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 4, 1, 2>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
+                           mo, no, (long long)k, p.k_per_split, partial);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no + 255) / 256)), dim3(256), 0, st, partial, p.splits, mo, no, c,
+                       (long long)ldc);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}

@@ -306,12 +306,19 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
         stats_partial[(size_t)blockIdx.x * 8 + threadIdx.x] = s;
     }
 }
-__global__ void stats_final_kernel(const float *partial, int nblocks, float *out8) {
-    const int i = threadIdx.x;
-    if (i >= 8) return;
+// 256 threads: 32 strided chains per statistic, then a fixed-order tree (deterministic).
+__global__ void __launch_bounds__(256) stats_final_kernel(const float *partial, int nblocks, float *out8) {
+    __shared__ float sh[32][8];
+    const int i = threadIdx.x & 7, chain = threadIdx.x >> 3;
     float s = 0.0f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 8 + i];
-    out8[i] = s;
+    for (int b = chain; b < nblocks; b += 32) s += partial[(size_t)b * 8 + i];
+    sh[chain][i] = s;
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        float t = 0.0f;
+        for (int q = 0; q < 32; ++q) t += sh[q][threadIdx.x];
+        out8[threadIdx.x] = t;
+    }
 }
 
 // f64 pieces of sum(g^2) for the clip norm of a large flat gradient (consumed by adam_clip_kernel).
@@ -442,7 +449,7 @@ extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, in
     hipLaunchKernelGGL(lstm_heads_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, mbs, map, *exp, params,
                        dims->obs_stride, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, dout, dh, partial);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8);
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8);
     PFA_LAUNCH_CHECK();
     return 0;
 }

@@ -81,6 +81,10 @@ class Engine:
         L = _lib.lib()
         self.ws = torch.empty(max(L.pfa_colsum_workspace_bytes(4 * H), L.pfa_lstm_heads_loss_workspace_bytes()),
                               dtype=torch.uint8, device=dev)
+        shapes = [(4 * H, H), (H, DP), (16, H)]
+        self.gemm_ws = torch.empty(max(L.pfa_gemm_tn_workspace_bytes(mo, no, M) for mo, no in shapes), dtype=torch.uint8,
+                                   device=dev)
+        self.g16 = torch.empty(16, H, device=dev)
         self.norm_partials = torch.empty(256, dtype=torch.float64, device=dev)
         self.state = None      # (h, c) carried from the previous minibatch of this epoch
 
@@ -158,18 +162,25 @@ class Engine:
         # ---- weight gradients (contractions over all rows of the minibatch) ------------------------------------------
         gv = fp.split(grads[:fp.count])
         gW1p = fp.encoder_weight_padded(grads[:fp.count])
-        torch.mm(self.dxe.t(), self.obs_tm, out=gW1p)
+        self._gemm_tn(self.dxe, self.obs_tm, gW1p)
         self._colsum(self.dxe, H, gv['encoder.bias'])
-        torch.mm(dG.t(), self.xe, out=gv['recurrent.weight_ih_l0'])
-        torch.mm(dG.t(), self.Hs[:Th].view(M, H), out=gv['recurrent.weight_hh_l0'])
+        self._gemm_tn(dG, self.xe, gv['recurrent.weight_ih_l0'])
+        self._gemm_tn(dG, self.Hs[:Th].view(M, H), gv['recurrent.weight_hh_l0'])
         self._colsum(dG, 4 * H, gv['recurrent.bias_ih_l0'])
         gv['recurrent.bias_hh_l0'].copy_(gv['recurrent.bias_ih_l0'])
-        g16 = torch.mm(self.dout.t(), h_all)                        # [16][128]: rows < A decoder, row A value head
+        g16 = self._gemm_tn(self.dout, h_all, self.g16)             # [16][128]: rows < A decoder, row A value head
         gv['decoder.weight'].copy_(g16[:A])
         gv['value_head.weight'].copy_(g16[A:A + 1])
         self._colsum(self.dout, 16, self.bsum16)
         gv['decoder.bias'].copy_(self.bsum16[:A])
         gv['value_head.bias'].copy_(self.bsum16[A:A + 1])
+
+    def _gemm_tn(self, a, b, out):
+        """out[mo][no] = a[k][mo]^T b[k][no] — the weight-gradient contraction over the minibatch rows (csrc/gemm.hip)."""
+        L = _lib.lib()
+        _lib.check(L.pfa_gemm_tn_f32(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), _lib.ptr(out), out.stride(0),
+                                     a.shape[1], b.shape[1], a.shape[0], _lib.ptr(self.gemm_ws), _lib.stream_handle()), 'gemm_tn')
+        return out
 
     def _colsum(self, a, cols, out):
         L = _lib.lib()
