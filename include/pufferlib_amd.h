@@ -229,6 +229,29 @@ int pfa_colsum(const float *a, int64_t rows, int32_t cols, int64_t ld, float *ou
 int pfa_lstm_heads_sample(const float *h, int64_t rows, const float *params, const pfa_mlp_dims *dims,
                           const float *noise, const pfa_noise_key *key, int64_t row_offset, int64_t *actions,
                           float *logprob, float *entropy, float *value, pfa_stream_t stream);
+/* --- fused recurrent policy (csrc/lstm_fused.hip) ---
+ * Flat parameter vector of the recurrent policy = the MLP block above followed by nn.LSTM's weight_ih_l0 [512][128],
+ * weight_hh_l0 [512][128], bias_ih_l0 [512], bias_hh_l0 [512].  pfa_lstm_pack re-tiles [W_ih | W_hh] into the MFMA
+ * fragment order the fused kernels stream from L2 (wpack: pfa_lstm_pack_bytes() bytes, 16-byte aligned); call it
+ * whenever the weights changed. */
+int64_t pfa_lstm_param_count(const pfa_mlp_dims *dims);
+size_t pfa_lstm_pack_bytes(void);
+int pfa_lstm_pack(const float *params, const pfa_mlp_dims *dims, void *wpack, pfa_stream_t stream);
+/* RecurrentPolicy.forward with action=None (frameworks/cleanrl.py:84-93 -> models.py:86-111) on `rows` rows: encode ->
+ * one nn.LSTM step -> decode -> sample_logits.  h, c [rows][128] are the LSTM state, updated in place.  Outputs as in
+ * pfa_mlp_forward_sample. */
+int pfa_lstm_policy_step(const float *obs, int64_t rows, const float *params, const pfa_mlp_dims *dims,
+                         const void *wpack, float *h, float *c, const float *noise, const pfa_noise_key *key,
+                         int64_t row_offset, int64_t *actions, float *logprob, float *entropy, float *value,
+                         pfa_stream_t stream);
+/* clean_pufferl.evaluate's loop (clean_pufferl.py:84-124) for a Squared vecenv and the recurrent policy, one persistent
+ * kernel: arguments as pfa_rollout_mlp_squared plus the packed gate weights and the LSTM state h, c [num_envs][128]
+ * (Experience.lstm_h / lstm_c, clean_pufferl.py:407-412), carried across rollouts and never reset on done. */
+int pfa_rollout_lstm_squared(void *state, const pfa_squared_config *cfg, const float *params,
+                             const pfa_mlp_dims *dims, const void *wpack, float *h, float *c,
+                             const pfa_experience *exp, const float *noise, const pfa_noise_key *key,
+                             int64_t env_offset, float *obs, float *rewards, uint8_t *terminals,
+                             uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 /* Experience.store of rollout step t (clean_pufferl.py:436-450) into the env-major buffers. */
 int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_envs, int32_t obs_stride, const float *obs,
                    const float *rewards, const uint8_t *terminals, const int64_t *actions, const float *logprob,

@@ -1,0 +1,191 @@
+// lstm_tile.hpp — fp32 MFMA building blocks of the recurrent policy (pufferlib.models.LSTMWrapper, models.py:64-111):
+//   xe = relu(obs @ W1^T + b1)                                   Default.encode_observations (models.py:41-50)
+//   gates = [xe | h] @ [W_ih | W_hh]^T + (b_ih + b_hh)           nn.LSTM(128, 128), gate order i, f, g, o
+//   c' = sig(f) c + sig(i) tanh(g);  h' = sig(o) tanh(c')
+//   logits, value = h' @ W2v^T + b2v                             Default.decode_actions (models.py:52-62)
+// for 16-row tiles owned by a 4-wave workgroup.  Like mlp_tile.hpp everything is computed transposed
+// (out^T[col][row] = W[col][:] . in[row][:]) so the weights are the MFMA A operand and a row tile in LDS is the B operand.
+//
+// The gate matrix Wcat = [W_ih | W_hh] (512 x 256 fp32 = 512 KB) does not fit in registers or LDS, so every step
+// streams it from L2 as pre-packed A fragments (lstm_pack_kernel): wave w owns, for every gate q, the hidden units
+// 32w .. 32w+31, i.e. the 8 column tiles ct = 2q + sub, col(w, ct, i) = 128q + 32w + 16sub + i.  After the product
+// lane (c, g) holds for batch row c the four gates of units 32w + 16sub + 4g + r — the cell update is register-local.
+// The contraction index is permuted, k(kq, s, g) = 16kq + 4g + s for k-step 4kq + s, so that one ds_read_b128 of the
+// [row][k] tile and one 16-byte global load of the packed weights feed four consecutive MFMAs.
+#pragma once
+#include "common.hpp"
+#include "mlp_tile.hpp"
+
+namespace pfa {
+
+constexpr int kLH = 128;          // hidden units
+constexpr int kLG = 4 * kLH;      // gate columns
+constexpr int kLK = 2 * kLH;      // contraction length of the gate product: [xe | h]
+constexpr int kXHS = kLK + 4;     // LDS row stride of an [row][xe | h] tile (floats); rows stay 16-byte aligned
+constexpr int kXHTile = 16 * kXHS;
+constexpr int kGatePackFloats = kLG * kLK;
+
+struct LstmOffsets {
+    int w_ih, w_hh, b_ih, b_hh, count;
+};
+__host__ __device__ inline LstmOffsets lstm_offsets(int dp, int a) {
+    LstmOffsets o;
+    o.w_ih = mlp_offsets(dp, a).count;
+    o.w_hh = o.w_ih + kLG * kLH;
+    o.b_ih = o.w_hh + kLG * kLH;
+    o.b_hh = o.b_ih + kLG;
+    o.count = o.b_hh + kLG;
+    return o;
+}
+
+__device__ __forceinline__ int gate_col(int w, int ct, int i) { return 128 * (ct >> 1) + 32 * w + 16 * (ct & 1) + i; }
+
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// Register-resident weights of one wave (everything except the gate matrix).
+template <int DP>
+struct LstmFrags {
+    float w1f[2][DP / 4];  // encoder tiles m = 2w + i: W1[16m + c][4kk + g]
+    float b1f[2][4];       // b1[16m + 4g + r]
+    float w2f[2][4];       // heads, this wave's K slice: W2v[o = c][32w + 16j + 4g + s]
+    float bo[4];           // head bias of outputs 4g + r (wave 0 only, the partials are summed)
+    __device__ __forceinline__ void load(const float *params, int a) {
+        const MlpOffsets off = mlp_offsets(DP, a);
+        const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = 2 * wv + i;
+#pragma unroll
+            for (int kk = 0; kk < DP / 4; ++kk) w1f[i][kk] = params[off.w1 + (16 * m + c) * DP + 4 * kk + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) b1f[i][r] = params[off.b1 + 16 * m + 4 * g + r];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) w2f[j][s] = w2v_at(params, off, a, c, 32 * wv + 16 * j + 4 * g + s);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bo[r] = wv == 0 ? b2v_at(params, off, a, 4 * g + r) : 0.0f;
+    }
+};
+
+// b_ih + b_hh -> LDS [512], all threads of the workgroup (the cell update reads it as float4 per column tile).
+__device__ __forceinline__ void stage_gate_bias(const float *params, int dp, int a, float *gbias) {
+    const LstmOffsets lo = lstm_offsets(dp, a);
+    for (int i = threadIdx.x; i < kLG; i += blockDim.x) gbias[i] = params[lo.b_ih + i] + params[lo.b_hh + i];
+}
+
+// encode_observations for the 16 rows in xs ([16][DP+2]) -> x half of the xh tile; wave w writes units 32w..32w+31.
+template <int DP>
+__device__ __forceinline__ void lstm_encode(const LstmFrags<DP> &w, const float *xs, float *xh) {
+    constexpr int XS = XTile<DP>::XS;
+    const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
+    f32x4 h0 = f32x4{w.b1f[0][0], w.b1f[0][1], w.b1f[0][2], w.b1f[0][3]};
+    f32x4 h1 = f32x4{w.b1f[1][0], w.b1f[1][1], w.b1f[1][2], w.b1f[1][3]};
+#pragma unroll
+    for (int kk = 0; kk < DP / 4; ++kk) {
+        const float b = xs[c * XS + 4 * kk + g];
+        h0 = mfma16(w.w1f[0][kk], b, h0);
+        h1 = mfma16(w.w1f[1][kk], b, h1);
+    }
+    float4 *dst = reinterpret_cast<float4 *>(xh + c * kXHS + 32 * wv + 4 * g);
+    dst[0] = make_float4(fmaxf(h0[0], 0.f), fmaxf(h0[1], 0.f), fmaxf(h0[2], 0.f), fmaxf(h0[3], 0.f));
+    dst[4] = make_float4(fmaxf(h1[0], 0.f), fmaxf(h1[1], 0.f), fmaxf(h1[2], 0.f), fmaxf(h1[3], 0.f));
+}
+
+// First groups of packed gate fragments of this wave; issued early so the L2 latency hides behind the previous phase.
+constexpr int kGatePrefetch = 3;  // groups in flight ahead of the MFMAs (one group = 8 x 1 KB per wave, 32*RT MFMAs)
+__device__ __forceinline__ void gates_prefetch(const float4 *__restrict__ wp, float4 (&abuf)[4][8]) {
+#pragma unroll
+    for (int j = 0; j < kGatePrefetch; ++j)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) abuf[j][ct] = wp[(j * 8 + ct) * 64 + lane_id()];
+}
+
+// gates^T for RT row tiles (tile rt at xh + rt * kXHTile).  wp = this wave's packed fragments [16 kq][8 ct][64 lanes];
+// abuf holds groups 0..kGatePrefetch-1 on entry (gates_prefetch).  The group loop is kept rolled (4 groups per trip, a
+// 4-deep register ring) so the loads stay kGatePrefetch groups ahead instead of being hoisted wholesale.
+template <int RT>
+__device__ __forceinline__ void gates_product(const float4 *__restrict__ wp, const float *xh, float4 (&abuf)[4][8],
+                                              f32x4 (&acc)[RT][8]) {
+    const int lane = lane_id(), c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *brow = xh + c * kXHS + 4 * g;
+#pragma unroll 1
+    for (int it = 0; it < 4; ++it) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kq = 4 * it + j;
+            if (kq + kGatePrefetch < 16) {
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct)
+                    abuf[(j + kGatePrefetch) & 3][ct] = wp[((kq + kGatePrefetch) * 8 + ct) * 64 + lane];
+            }
+            float4 b[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) b[rt] = *reinterpret_cast<const float4 *>(brow + rt * kXHTile + 16 * kq);
+            // s outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {
+                    const float4 a = abuf[j][ct];
+                    const float av = s4 == 0 ? a.x : s4 == 1 ? a.y : s4 == 2 ? a.z : a.w;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) {
+                        const float bv = s4 == 0 ? b[rt].x : s4 == 1 ? b[rt].y : s4 == 2 ? b[rt].z : b[rt].w;
+                        acc[rt][ct] = mfma16(av, bv, acc[rt][ct]);
+                    }
+                }
+        }
+    }
+}
+
+// The cell update on one row tile's gate products (+ the bias from LDS, gbias[512]); cst = c state of units (sub, r).
+// Returns h' and leaves the activations (i, f, g, o) in acc (what the backward pass stores).
+__device__ __forceinline__ void lstm_cell(f32x4 (&acc)[8], const float *gbias, f32x4 (&cst)[2], f32x4 (&hout)[2]) {
+    const int wv = wave_id(), g = lane_id() >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 b = *reinterpret_cast<const float4 *>(gbias + gate_col(wv, ct, 4 * g));
+        acc[ct] += f32x4{b.x, b.y, b.z, b.w};
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float i = sigmoid_f(acc[0 + sub][r]);
+            const float f = sigmoid_f(acc[2 + sub][r]);
+            const float gg = tanhf(acc[4 + sub][r]);
+            const float o = sigmoid_f(acc[6 + sub][r]);
+            const float cn = f * cst[sub][r] + i * gg;
+            acc[0 + sub][r] = i;
+            acc[2 + sub][r] = f;
+            acc[4 + sub][r] = gg;
+            acc[6 + sub][r] = o;
+            cst[sub][r] = cn;
+            hout[sub][r] = o * tanhf(cn);
+        }
+}
+
+// This wave's K slice of decode_actions on the h half of an xh tile -> part[wave][o*16 + row].
+template <int DP>
+__device__ __forceinline__ void lstm_heads(const LstmFrags<DP> &w, const float *xh, float (*part)[kOut * 16]) {
+    const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
+    f32x4 o0 = f32x4{w.bo[0], w.bo[1], w.bo[2], w.bo[3]};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4 b = *reinterpret_cast<const float4 *>(xh + c * kXHS + kLH + 32 * wv + 16 * j + 4 * g);
+        o0 = mfma16(w.w2f[j][0], b.x, o0);
+        o0 = mfma16(w.w2f[j][1], b.y, o0);
+        o0 = mfma16(w.w2f[j][2], b.z, o0);
+        o0 = mfma16(w.w2f[j][3], b.w, o0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * 16 + c] = o0[r];
+}
+
+}  // namespace pfa

@@ -25,30 +25,31 @@ def _gates_bias(fp):
     return v['bias_ih_l0'] + v['bias_hh_l0']
 
 
-def policy_step(fp, obs, h, c, noise, key, row_offset, bias=None, scratch=None):
+def pack_gates(fp, out=None):
+    """[W_ih | W_hh] in the fragment order the fused kernels stream (csrc/lstm_fused.hip); call after the weights changed."""
+    L = _lib.lib()
+    if out is None:
+        out = torch.empty(L.pfa_lstm_pack_bytes() // 4, device=fp.flat.device)
+    _lib.check(L.pfa_lstm_pack(_lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(out), _lib.stream_handle()), 'lstm_pack')
+    return out
+
+
+def policy_step(fp, obs, h, c, noise, key, row_offset, wpack=None):
     """One rollout step on ``rows`` observation rows [rows][obs_stride]; h, c [rows][128] are updated in place.
     Returns (actions int64, logprob, entropy, value[:, None])."""
     L = _lib.lib()
     stream = _lib.stream_handle()
     rows = obs.shape[0]
     dev = obs.device
-    v = fp.lstm_views
-    bias = _gates_bias(fp) if bias is None else bias
-    if scratch is None:
-        scratch = dict(xe=torch.empty(rows, H, device=dev), gates=torch.empty(rows, 4 * H, device=dev))
-    xe, gates = scratch['xe'], scratch['gates']
-    torch.addmm(fp.views['encoder.bias'], obs, fp.encoder_weight_padded().t(), out=xe)      # Default.encoder
-    _lib.check(L.pfa_relu(_lib.ptr(xe), xe.numel(), stream), 'relu')
-    torch.addmm(bias, xe, v['weight_ih_l0'].t(), out=gates)                                   # nn.LSTM gates
-    gates.addmm_(h, v['weight_hh_l0'].t())
-    _lib.check(L.pfa_lstm_cell_fwd(_lib.ptr(gates), _lib.ptr(c), _lib.ptr(c), _lib.ptr(h), rows, stream), 'lstm_cell_fwd')
+    if wpack is None:
+        wpack = pack_gates(fp)
     actions = torch.empty(rows, dtype=torch.int64, device=dev)
     logprob = torch.empty(rows, device=dev)
     entropy = torch.empty(rows, device=dev)
     value = torch.empty(rows, device=dev)
-    _lib.check(L.pfa_lstm_heads_sample(_lib.ptr(h), rows, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(noise), C.byref(key),
-                                       row_offset, _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(entropy), _lib.ptr(value),
-                                       stream), 'lstm_heads_sample')
+    _lib.check(L.pfa_lstm_policy_step(_lib.ptr(obs), rows, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(wpack), _lib.ptr(h),
+                                      _lib.ptr(c), _lib.ptr(noise), C.byref(key), row_offset, _lib.ptr(actions),
+                                      _lib.ptr(logprob), _lib.ptr(entropy), _lib.ptr(value), stream), 'lstm_policy_step')
     return actions, logprob, entropy, value.unsqueeze(1)
 
 
@@ -61,7 +62,7 @@ class Engine:
         N = vecenv.num_agents
         self.lstm_h = torch.zeros(1, N, H, device=dev)      # Experience.lstm_h / lstm_c (clean_pufferl.py:407-412)
         self.lstm_c = torch.zeros(1, N, H, device=dev)
-        self.roll = dict(xe=torch.empty(N, H, device=dev), gates=torch.empty(N, 4 * H, device=dev))
+        self.wpack = torch.empty(_lib.lib().pfa_lstm_pack_bytes() // 4, device=dev)
         M, Th = experience.minibatch_size, experience.bptt_horizon
         self.M, self.Th, self.R = M, Th, M // Th
         R = self.R
@@ -90,17 +91,33 @@ class Engine:
 
     # -------------------------------------------------------------------------------------------- rollout
     def rollout(self, T, noise, key_seed, step0, env_offset):
-        """clean_pufferl.evaluate's loop for a Squared vecenv, one kernel sequence per step (no host sync)."""
+        """clean_pufferl.evaluate's loop for a Squared vecenv: one persistent kernel (csrc/lstm_fused.hip)."""
+        L = _lib.lib()
+        vec, exp, fp = self.vec, self.exp, self.fp
+        assert T == exp.horizon
+        pack_gates(fp, self.wpack)
+        vec.ensure_tape(T)
+        key = _lib.NoiseKey(key_seed, step0)
+        _lib.check(L.pfa_rollout_lstm_squared(_lib.ptr(vec.state), C.byref(vec.cfg), _lib.ptr(fp.flat), C.byref(fp.dims),
+                                              _lib.ptr(self.wpack), _lib.ptr(self.lstm_h), _lib.ptr(self.lstm_c), C.byref(exp.c),
+                                              _lib.ptr(noise), C.byref(key), env_offset, _lib.ptr(vec.obs_buf),
+                                              _lib.ptr(vec.rewards), _lib.ptr(vec.terminals_u8), _lib.ptr(vec.truncations_u8),
+                                              _lib.ptr(vec.masks_u8), _lib.stream_handle()), 'rollout_lstm_squared')
+        vec.sends += T
+
+    def rollout_stepwise(self, T, noise, key_seed, step0, env_offset):
+        """The same rollout through the protocol-level pieces (policy_step / store / send), one launch sequence per step —
+        what a generic vecenv would run; bit-identical to rollout() (tests)."""
         L = _lib.lib()
         vec, exp, fp = self.vec, self.exp, self.fp
         stream = _lib.stream_handle()
         h, c = self.lstm_h[0], self.lstm_c[0]
-        bias = _gates_bias(fp)
         N = vec.num_agents
+        pack_gates(fp, self.wpack)
         for t in range(T):
             key = _lib.NoiseKey(key_seed, step0 + t)
             nz = None if noise is None else noise[t]
-            actions, logprob, _, value = policy_step(fp, vec.obs_buf, h, c, nz, key, env_offset, bias=bias, scratch=self.roll)
+            actions, logprob, _, value = policy_step(fp, vec.obs_buf, h, c, nz, key, env_offset, wpack=self.wpack)
             _lib.check(L.pfa_store_step(C.byref(exp.c), t, N, fp.obs_stride, _lib.ptr(vec.obs_buf), _lib.ptr(vec.rewards),
                                         _lib.ptr(vec.terminals_u8), _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(value),
                                         stream), 'store_step')

@@ -180,3 +180,66 @@ def test_gemm_tn_rejects_unsupported_shapes():
     with pytest.raises(ExtensionError):
         _lib.check(L.pfa_gemm_tn_f32(_lib.ptr(x), 128, _lib.ptr(x), 128, _lib.ptr(x), 128, 24, 100, 64, _lib.ptr(x),
                                      _lib.stream_handle()), 'gemm_tn')
+
+
+def test_fused_lstm_rollout_equals_stepwise_protocol_pieces():
+    """Engine.rollout (one persistent kernel) vs Engine.rollout_stepwise (policy_step / store / send launches): identical
+    experience, env state and LSTM state, bit for bit; 40 envs = a ragged last tile, two rollouts = state carry."""
+    from pufferlib_amd import clean_pufferl
+    n, horizon = 40, 16
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+
+    def run(stepwise):
+        torch.manual_seed(7)
+        vec, pol = _make(n)
+        data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 4, 1, n * horizon * 4, hp, seed=5), vec, pol)
+        eng = data.lstm_engine
+        if stepwise:
+            eng.rollout = eng.rollout_stepwise
+        out = []
+        for _ in range(2):
+            clean_pufferl.evaluate(data)
+            e = data.experience
+            out.append([x.clone() for x in (e.obs, e.actions, e.logprobs, e.values, e.rewards, e.dones, e.lstm_h, e.lstm_c,
+                                            vec.obs_buf, vec.rewards)])
+        return out
+
+    fused, step = run(False), run(True)
+    for a, b in zip(fused, step):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+
+
+def test_lstm_policy_step_matches_torch_modules():
+    """pfa_lstm_policy_step vs nn.Linear / nn.LSTM / Categorical on the same weights (fp32, 1e-5)."""
+    from pufferlib_amd import _lib, lstm as plstm
+    torch.manual_seed(11)
+    n = 50
+    vec, pol = _make(n)
+    with torch.no_grad():                      # the default init zeroes most biases: make every one of them count
+        for name, p in pol.named_parameters():
+            if name.endswith('bias') or 'bias_' in name:
+                p.copy_(torch.randn_like(p) * 0.2)
+    vec.async_reset(1)
+    obs = vec.recv()[0]
+    state = (torch.randn(1, n, 128, device='cuda') * 0.3, torch.randn(1, n, 128, device='cuda') * 0.3)
+    noise = torch.empty(n, 8, device='cuda').exponential_()
+    a, lp, ent, val, (h1, c1) = pol(obs, state, noise=noise)
+    sd = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+    enc_w, enc_b = sd['policy.policy.encoder.weight'], sd['policy.policy.encoder.bias']
+    x = torch.relu(obs.reshape(n, -1)[:, :enc_w.shape[1]].float() @ enc_w.t() + enc_b)
+    lstm = torch.nn.LSTM(128, 128).cuda()
+    lstm.load_state_dict({k.split('recurrent.')[1]: v for k, v in sd.items() if 'recurrent.' in k})
+    with torch.no_grad():
+        y, (h_ref, c_ref) = lstm(x.unsqueeze(0), state)
+    y = y[0]
+    logits = y @ sd['policy.policy.decoder.weight'].t() + sd['policy.policy.decoder.bias']
+    value = y @ sd['policy.policy.value_head.weight'].t() + sd['policy.policy.value_head.bias']
+    np.testing.assert_allclose(h1.cpu().numpy(), h_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c1.cpu().numpy(), c_ref.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(val.cpu().numpy(), value.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    logp = torch.log_softmax(logits, dim=1)
+    want_a = torch.argmax(torch.softmax(logits, 1) / noise, dim=1)
+    assert torch.equal(a, want_a)
+    np.testing.assert_allclose(lp.cpu().numpy(), logp.gather(1, want_a[:, None])[:, 0].cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ent.cpu().numpy(), -(logp * logp.exp()).sum(1).cpu().numpy(), rtol=1e-5, atol=1e-5)
