@@ -252,6 +252,21 @@ int pfa_rollout_lstm_squared(void *state, const pfa_squared_config *cfg, const f
                              const pfa_experience *exp, const float *noise, const pfa_noise_key *key,
                              int64_t env_offset, float *obs, float *rewards, uint8_t *terminals,
                              uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+/* --- the recurrent policy in training mode (csrc/lstm_seq.hip): forward over the `steps` (= bptt_horizon) time steps
+ * of a minibatch of `rows` independent segments and back-propagation through time (clean_pufferl.py:186-193, :244).
+ * Time-major buffers: obs_tm [steps][rows][obs_stride], xe / dh_heads / dxe [steps][rows][128], gates_act / dgates
+ * [steps][rows][512], hs / cs [steps+1][rows][128] (slot 0 = the carried-in state, read; slots 1.. written).
+ * forward keeps what autograd would keep (xe, gate activations i,f,g,o, c_t, h_t).  backward takes d loss / d h_t through
+ * the heads (dh_heads, from pfa_lstm_heads_loss) and produces dgates (d loss / d gate pre-activations), dxe (d loss / d the
+ * encoder pre-activations, relu' applied) and the bias gradients gate_bias_grad [512] (= d b_ih = d b_hh) and
+ * enc_bias_grad [128]; wpack_bwd from pfa_lstm_pack_bwd (same size as wpack). */
+int pfa_lstm_pack_bwd(const float *params, const pfa_mlp_dims *dims, void *wpack_bwd, pfa_stream_t stream);
+int pfa_lstm_seq_forward(const float *obs_tm, int64_t rows, int32_t steps, const float *params, const pfa_mlp_dims *dims,
+                         const void *wpack, float *xe, float *gates_act, float *hs, float *cs, pfa_stream_t stream);
+size_t pfa_lstm_seq_backward_workspace_bytes(int64_t rows);
+int pfa_lstm_seq_backward(const float *gates_act, const float *cs, const float *xe, const float *dh_heads, int64_t rows,
+                          int32_t steps, const void *wpack_bwd, float *dgates, float *dxe, float *gate_bias_grad,
+                          float *enc_bias_grad, void *workspace, pfa_stream_t stream);
 /* Experience.store of rollout step t (clean_pufferl.py:436-450) into the env-major buffers. */
 int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_envs, int32_t obs_stride, const float *obs,
                    const float *rewards, const uint8_t *terminals, const int64_t *actions, const float *logprob,

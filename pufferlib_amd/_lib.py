@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -132,6 +132,10 @@ _SIGNATURES = {
                                        P, P, P, P, P]),
     'pfa_rollout_lstm_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), P, P, P, C.POINTER(Experience),
                                            P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
+    'pfa_lstm_pack_bwd': (C.c_int, [P, C.POINTER(MlpDims), P, P]),
+    'pfa_lstm_seq_forward': (C.c_int, [P, C.c_int64, C.c_int32, P, C.POINTER(MlpDims), P, P, P, P, P, P]),
+    'pfa_lstm_seq_backward_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'pfa_lstm_seq_backward': (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, P, P, P, P, P, P, P]),
     'pfa_gemm_tn_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     'pfa_gemm_tn_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, P, P]),
     'pfa_sumsq_partials': (C.c_int, [P, C.c_int64, P, C.c_int32, P]),

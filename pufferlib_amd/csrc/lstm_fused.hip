@@ -19,8 +19,6 @@
 
 namespace pfa {
 
-constexpr int kLstmThreads = 256;
-
 // dst float4 index ((w*16 + kq)*8 + ct)*64 + lane  <-  Wcat[col(w, ct, c)][16kq + 4g .. +3]
 __global__ void __launch_bounds__(256) lstm_pack_kernel(const float *__restrict__ params, int dp, int a, float4 *__restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -62,69 +60,6 @@ __device__ __forceinline__ void lstm_tile_step(const LstmFrags<DP> &w, const flo
     __syncthreads();
     lstm_heads<DP>(w, L.xh[cur ^ 1], L.part);
     __syncthreads();
-}
-
-// c state <-> global [rows][128] in the cell layout (lane (c, g): row c, units 32w + 16sub + 4g + r).
-__device__ __forceinline__ void load_cstate(const float *cglob, long long row, bool ok, f32x4 (&cst)[2]) {
-    const int wv = wave_id(), g = lane_id() >> 4;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4 *>(cglob + row * kLH + 32 * wv + 16 * sub + 4 * g);
-        cst[sub] = f32x4{v.x, v.y, v.z, v.w};
-    }
-}
-__device__ __forceinline__ void store_cstate(float *cglob, long long row, bool ok, const f32x4 (&cst)[2]) {
-    const int wv = wave_id(), g = lane_id() >> 4;
-    if (!ok) return;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-        *reinterpret_cast<float4 *>(cglob + row * kLH + 32 * wv + 16 * sub + 4 * g) =
-            make_float4(cst[sub][0], cst[sub][1], cst[sub][2], cst[sub][3]);
-}
-// h state: global [rows][128] <-> the h half of an xh tile, all 256 threads.
-__device__ __forceinline__ void load_hstate(const float *hglob, long long first_row, long long rows, float *xh) {
-    for (int idx = threadIdx.x; idx < 16 * (kLH / 4); idx += kLstmThreads) {
-        const int r = idx / (kLH / 4), c4 = idx % (kLH / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (first_row + r < rows) v = *reinterpret_cast<const float4 *>(hglob + (first_row + r) * kLH + 4 * c4);
-        *reinterpret_cast<float4 *>(xh + r * kXHS + kLH + 4 * c4) = v;
-    }
-}
-__device__ __forceinline__ void store_hstate(float *hglob, long long first_row, long long rows, const float *xh) {
-    for (int idx = threadIdx.x; idx < 16 * (kLH / 4); idx += kLstmThreads) {
-        const int r = idx / (kLH / 4), c4 = idx % (kLH / 4);
-        if (first_row + r < rows)
-            *reinterpret_cast<float4 *>(hglob + (first_row + r) * kLH + 4 * c4) =
-                *reinterpret_cast<const float4 *>(xh + r * kXHS + kLH + 4 * c4);
-    }
-}
-
-// Same staging as rollout.hip's stage_rows / unstage_rows (float2 pieces: the xs stride is DP+2).
-template <int DP>
-__device__ __forceinline__ void lstm_stage_obs(const float *src, long long first_row, long long rows, float *xs) {
-    constexpr int XS = XTile<DP>::XS, V = DP / 4;
-    for (int idx = threadIdx.x; idx < 16 * V; idx += kLstmThreads) {
-        const int r = idx / V, c4 = idx - r * V;
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (first_row + r < rows) x = *reinterpret_cast<const float4 *>(src + (first_row + r) * DP + 4 * c4);
-        float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
-        d[0] = make_float2(x.x, x.y);
-        d[1] = make_float2(x.z, x.w);
-    }
-}
-template <int DP>
-__device__ __forceinline__ void lstm_unstage_obs(const float *xs, float *dst, long long first_row, long long rows,
-                                                 size_t row_stride) {
-    constexpr int XS = XTile<DP>::XS, V = DP / 4;
-    for (int idx = threadIdx.x; idx < 16 * V; idx += kLstmThreads) {
-        const int r = idx / V, c4 = idx - r * V;
-        if (first_row + r < rows) {
-            const float2 *sp = reinterpret_cast<const float2 *>(xs + r * XS + 4 * c4);
-            const float2 lo2 = sp[0], hi2 = sp[1];
-            *reinterpret_cast<float4 *>(dst + (size_t)(first_row + r) * row_stride + 4 * c4) = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
-        }
-    }
 }
 
 __device__ __forceinline__ LaneSample lstm_sample(const float (*part)[kOut * 16], int le, int lo, int a, float q) {

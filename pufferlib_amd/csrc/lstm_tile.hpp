@@ -24,6 +24,7 @@ constexpr int kLK = 2 * kLH;      // contraction length of the gate product: [xe
 constexpr int kXHS = kLK + 4;     // LDS row stride of an [row][xe | h] tile (floats); rows stay 16-byte aligned
 constexpr int kXHTile = 16 * kXHS;
 constexpr int kGatePackFloats = kLG * kLK;
+constexpr int kLstmThreads = 256;  // 4 wavefronts per tile workgroup
 
 struct LstmOffsets {
     int w_ih, w_hh, b_ih, b_hh, count;
@@ -77,7 +78,7 @@ __device__ __forceinline__ void stage_gate_bias(const float *params, int dp, int
 
 // encode_observations for the 16 rows in xs ([16][DP+2]) -> x half of the xh tile; wave w writes units 32w..32w+31.
 template <int DP>
-__device__ __forceinline__ void lstm_encode(const LstmFrags<DP> &w, const float *xs, float *xh) {
+__device__ __forceinline__ void lstm_encode(const LstmFrags<DP> &w, const float *xs, float *xh, float *xe_row = nullptr) {
     constexpr int XS = XTile<DP>::XS;
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
     f32x4 h0 = f32x4{w.b1f[0][0], w.b1f[0][1], w.b1f[0][2], w.b1f[0][3]};
@@ -91,6 +92,11 @@ __device__ __forceinline__ void lstm_encode(const LstmFrags<DP> &w, const float 
     float4 *dst = reinterpret_cast<float4 *>(xh + c * kXHS + 32 * wv + 4 * g);
     dst[0] = make_float4(fmaxf(h0[0], 0.f), fmaxf(h0[1], 0.f), fmaxf(h0[2], 0.f), fmaxf(h0[3], 0.f));
     dst[4] = make_float4(fmaxf(h1[0], 0.f), fmaxf(h1[1], 0.f), fmaxf(h1[2], 0.f), fmaxf(h1[3], 0.f));
+    if (xe_row) {  // this lane's row of the [rows][128] encoder output kept for the backward pass
+        float4 *gx = reinterpret_cast<float4 *>(xe_row + 32 * wv + 4 * g);
+        gx[0] = dst[0];
+        gx[4] = dst[4];
+    }
 }
 
 // First groups of packed gate fragments of this wave; issued early so the L2 latency hides behind the previous phase.
@@ -186,6 +192,69 @@ __device__ __forceinline__ void lstm_heads(const LstmFrags<DP> &w, const float *
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * 16 + c] = o0[r];
+}
+
+// c state <-> global [rows][128] in the cell layout (lane (c, g): row c, units 32w + 16sub + 4g + r).
+__device__ __forceinline__ void load_cstate(const float *cglob, long long row, bool ok, f32x4 (&cst)[2]) {
+    const int wv = wave_id(), g = lane_id() >> 4;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) v = *reinterpret_cast<const float4 *>(cglob + row * kLH + 32 * wv + 16 * sub + 4 * g);
+        cst[sub] = f32x4{v.x, v.y, v.z, v.w};
+    }
+}
+__device__ __forceinline__ void store_cstate(float *cglob, long long row, bool ok, const f32x4 (&cst)[2]) {
+    const int wv = wave_id(), g = lane_id() >> 4;
+    if (!ok) return;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+        *reinterpret_cast<float4 *>(cglob + row * kLH + 32 * wv + 16 * sub + 4 * g) =
+            make_float4(cst[sub][0], cst[sub][1], cst[sub][2], cst[sub][3]);
+}
+// h state: global [rows][128] <-> the h half of an xh tile, all 256 threads.
+__device__ __forceinline__ void load_hstate(const float *hglob, long long first_row, long long rows, float *xh) {
+    for (int idx = threadIdx.x; idx < 16 * (kLH / 4); idx += kLstmThreads) {
+        const int r = idx / (kLH / 4), c4 = idx % (kLH / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (first_row + r < rows) v = *reinterpret_cast<const float4 *>(hglob + (first_row + r) * kLH + 4 * c4);
+        *reinterpret_cast<float4 *>(xh + r * kXHS + kLH + 4 * c4) = v;
+    }
+}
+__device__ __forceinline__ void store_hstate(float *hglob, long long first_row, long long rows, const float *xh) {
+    for (int idx = threadIdx.x; idx < 16 * (kLH / 4); idx += kLstmThreads) {
+        const int r = idx / (kLH / 4), c4 = idx % (kLH / 4);
+        if (first_row + r < rows)
+            *reinterpret_cast<float4 *>(hglob + (first_row + r) * kLH + 4 * c4) =
+                *reinterpret_cast<const float4 *>(xh + r * kXHS + kLH + 4 * c4);
+    }
+}
+
+// Same staging as rollout.hip's stage_rows / unstage_rows (float2 pieces: the xs stride is DP+2).
+template <int DP>
+__device__ __forceinline__ void lstm_stage_obs(const float *src, long long first_row, long long rows, float *xs) {
+    constexpr int XS = XTile<DP>::XS, V = DP / 4;
+    for (int idx = threadIdx.x; idx < 16 * V; idx += kLstmThreads) {
+        const int r = idx / V, c4 = idx - r * V;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (first_row + r < rows) x = *reinterpret_cast<const float4 *>(src + (first_row + r) * DP + 4 * c4);
+        float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
+        d[0] = make_float2(x.x, x.y);
+        d[1] = make_float2(x.z, x.w);
+    }
+}
+template <int DP>
+__device__ __forceinline__ void lstm_unstage_obs(const float *xs, float *dst, long long first_row, long long rows,
+                                                 size_t row_stride) {
+    constexpr int XS = XTile<DP>::XS, V = DP / 4;
+    for (int idx = threadIdx.x; idx < 16 * V; idx += kLstmThreads) {
+        const int r = idx / V, c4 = idx - r * V;
+        if (first_row + r < rows) {
+            const float2 *sp = reinterpret_cast<const float2 *>(xs + r * XS + 4 * c4);
+            const float2 lo2 = sp[0], hi2 = sp[1];
+            *reinterpret_cast<float4 *>(dst + (size_t)(first_row + r) * row_stride + 4 * c4) = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
+        }
+    }
 }
 
 }  // namespace pfa

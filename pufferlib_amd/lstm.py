@@ -1,15 +1,15 @@
-"""Host orchestration of the recurrent-policy path (pufferlib.models.LSTMWrapper, models.py:64-111).
+"""Host orchestration of the recurrent-policy path (pufferlib.models.LSTMWrapper, models.py:64-111).  Every product is a
+hand-written fp32 MFMA kernel behind the C ABI; this module only sequences them:
 
-Plain dense products are library GEMMs (torch.mm / addmm -> hipBLASLt / rocBLAS, exact fp32); everything else is a
-hand-written kernel behind the C ABI (csrc/lstm.hip).  Structure:
-
-  policy_step      encode_observations -> one nn.LSTM step -> decode_actions + sample_logits        (rollout)
-  Engine.rollout   clean_pufferl.evaluate for a Squared vecenv: T x {policy_step, Experience.store, send}
-  Engine.update    one minibatch of clean_pufferl.train: forward through bptt_horizon steps with the carried, detached
-                   state (clean_pufferl.py:186-191), PPO loss, back-propagation through time, flat gradient
+  pack_gates       [W_ih | W_hh] -> MFMA fragment order (csrc/lstm_fused.hip), after every weight change
+  policy_step      encode_observations -> one nn.LSTM step -> decode_actions + sample_logits, one kernel   (protocol path)
+  Engine.rollout   clean_pufferl.evaluate for a Squared vecenv: ONE persistent kernel for all T steps (csrc/lstm_fused.hip)
+  Engine.update    one minibatch of clean_pufferl.train: gather -> fused forward over the bptt_horizon steps with the carried,
+                   detached state (clean_pufferl.py:186-191; csrc/lstm_seq.hip) -> heads + PPO loss (csrc/lstm.hip) -> fused
+                   BPTT (csrc/lstm_seq.hip) -> weight-gradient contractions over the rows (csrc/gemm.hip) -> flat gradient
 
 Row order inside a minibatch is TIME-MAJOR (row t*R + k = segment mb + k*nmb at step t) so that every per-step slice is
-a contiguous [R][...] block for the BLAS.
+a contiguous [R][...] block.
 """
 import ctypes as C
 
@@ -18,11 +18,6 @@ import torch
 from . import _lib
 
 H = 128
-
-
-def _gates_bias(fp):
-    v = fp.lstm_views
-    return v['bias_ih_l0'] + v['bias_hh_l0']
 
 
 def pack_gates(fp, out=None):
@@ -63,6 +58,7 @@ class Engine:
         self.lstm_h = torch.zeros(1, N, H, device=dev)      # Experience.lstm_h / lstm_c (clean_pufferl.py:407-412)
         self.lstm_c = torch.zeros(1, N, H, device=dev)
         self.wpack = torch.empty(_lib.lib().pfa_lstm_pack_bytes() // 4, device=dev)
+        self.wpack_bwd = torch.empty_like(self.wpack)
         M, Th = experience.minibatch_size, experience.bptt_horizon
         self.M, self.Th, self.R = M, Th, M // Th
         R = self.R
@@ -75,8 +71,6 @@ class Engine:
         self.dout = torch.empty(M, 16, device=dev)
         self.dh_heads = torch.empty(M, H, device=dev)
         self.dG = torch.empty(Th, R, 4 * H, device=dev)
-        self.dC = torch.empty(R, H, device=dev)
-        self.dHrec = torch.empty(R, H, device=dev)
         self.dxe = torch.empty(M, H, device=dev)
         self.bsum16 = torch.empty(16, device=dev)
         L = _lib.lib()
@@ -86,6 +80,7 @@ class Engine:
         self.gemm_ws = torch.empty(max(L.pfa_gemm_tn_workspace_bytes(mo, no, M) for mo, no in shapes), dtype=torch.uint8,
                                    device=dev)
         self.g16 = torch.empty(16, H, device=dev)
+        self.bwd_ws = torch.empty(L.pfa_lstm_seq_backward_workspace_bytes(R), dtype=torch.uint8, device=dev)
         self.norm_partials = torch.empty(256, dtype=torch.float64, device=dev)
         self.state = None      # (h, c) carried from the previous minibatch of this epoch
 
@@ -134,29 +129,20 @@ class Engine:
         stream = _lib.stream_handle()
         fp, exp = self.fp, self.exp
         M, Th, R = self.M, self.Th, self.R
-        v = fp.lstm_views
-        W_ih, W_hh = v['weight_ih_l0'], v['weight_hh_l0']
-        W1p = fp.encoder_weight_padded()
-        bias = _gates_bias(fp)
         A = fp.num_actions
         # ---- forward -----------------------------------------------------------------------------------------------
         _lib.check(L.pfa_gather_obs_time_major(C.byref(exp.c), B, mb, C.byref(hp), fp.obs_stride, _lib.ptr(self.obs_tm), stream),
                    'gather_obs')
-        torch.addmm(fp.views['encoder.bias'], self.obs_tm, W1p.t(), out=self.xe)
-        _lib.check(L.pfa_relu(_lib.ptr(self.xe), self.xe.numel(), stream), 'relu')
         if mb == 0 or self.state is None:      # lstm_state = None at the start of every epoch (clean_pufferl.py:176)
             self.Hs[0].zero_()
             self.Cs[0].zero_()
         else:                                   # carried across minibatches, detached (clean_pufferl.py:188-191)
             self.Hs[0].copy_(self.state[0])
             self.Cs[0].copy_(self.state[1])
-        xe_t = self.xe.view(Th, R, H)
-        for t in range(Th):
-            g = self.gates[t]
-            torch.addmm(bias, xe_t[t], W_ih.t(), out=g)
-            g.addmm_(self.Hs[t], W_hh.t())
-            _lib.check(L.pfa_lstm_cell_fwd(_lib.ptr(g), _lib.ptr(self.Cs[t]), _lib.ptr(self.Cs[t + 1]), _lib.ptr(self.Hs[t + 1]), R,
-                                           stream), 'lstm_cell_fwd')
+        pack_gates(fp, self.wpack)              # the weights changed in the previous optimizer step
+        _lib.check(L.pfa_lstm_seq_forward(_lib.ptr(self.obs_tm), R, Th, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(self.wpack),
+                                          _lib.ptr(self.xe), _lib.ptr(self.gates), _lib.ptr(self.Hs), _lib.ptr(self.Cs), stream),
+                   'lstm_seq_forward')
         self.state = (self.Hs[Th].clone(), self.Cs[Th].clone())
         h_all = self.Hs[1:].view(M, H)
         # ---- heads + loss ----------------------------------------------------------------------------------------
@@ -164,27 +150,19 @@ class Engine:
         _lib.check(L.pfa_lstm_heads_loss(_lib.ptr(h_all), C.byref(exp.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hp),
                                          _lib.ptr(adv_stats), global_mb_rows, _lib.ptr(self.dout), _lib.ptr(self.dh_heads),
                                          _lib.ptr(loss_sums), _lib.ptr(self.ws), stream), 'lstm_heads_loss')
-        # ---- back-propagation through time -------------------------------------------------------------------------
-        self.dC.zero_()
-        dh_t = self.dh_heads.view(Th, R, H)
-        for t in range(Th - 1, -1, -1):
-            dh2 = None if t == Th - 1 else self.dHrec
-            _lib.check(L.pfa_lstm_cell_bwd(_lib.ptr(self.gates[t]), _lib.ptr(self.Cs[t]), _lib.ptr(self.Cs[t + 1]), _lib.ptr(dh_t[t]),
-                                           _lib.ptr(dh2), _lib.ptr(self.dC), _lib.ptr(self.dG[t]), R, stream), 'lstm_cell_bwd')
-            if t > 0:
-                torch.mm(self.dG[t], W_hh, out=self.dHrec)          # d loss / d h_{t-1} through the recurrence
-        dG = self.dG.view(M, 4 * H)
-        torch.mm(dG, W_ih, out=self.dxe)                            # d loss / d encoder output
-        _lib.check(L.pfa_relu_grad(_lib.ptr(self.dxe), _lib.ptr(self.xe), self.dxe.numel(), stream), 'relu_grad')
-        # ---- weight gradients (contractions over all rows of the minibatch) ------------------------------------------
+        # ---- back-propagation through time (csrc/lstm_seq.hip) + weight gradients (csrc/gemm.hip) ----------------------
         gv = fp.split(grads[:fp.count])
+        _lib.check(L.pfa_lstm_pack_bwd(_lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(self.wpack_bwd), stream), 'lstm_pack_bwd')
+        _lib.check(L.pfa_lstm_seq_backward(_lib.ptr(self.gates), _lib.ptr(self.Cs), _lib.ptr(self.xe), _lib.ptr(self.dh_heads), R, Th,
+                                           _lib.ptr(self.wpack_bwd), _lib.ptr(self.dG), _lib.ptr(self.dxe),
+                                           _lib.ptr(gv['recurrent.bias_ih_l0']), _lib.ptr(gv['encoder.bias']), _lib.ptr(self.bwd_ws),
+                                           stream), 'lstm_seq_backward')
+        gv['recurrent.bias_hh_l0'].copy_(gv['recurrent.bias_ih_l0'])
+        dG = self.dG.view(M, 4 * H)
         gW1p = fp.encoder_weight_padded(grads[:fp.count])
         self._gemm_tn(self.dxe, self.obs_tm, gW1p)
-        self._colsum(self.dxe, H, gv['encoder.bias'])
         self._gemm_tn(dG, self.xe, gv['recurrent.weight_ih_l0'])
         self._gemm_tn(dG, self.Hs[:Th].view(M, H), gv['recurrent.weight_hh_l0'])
-        self._colsum(dG, 4 * H, gv['recurrent.bias_ih_l0'])
-        gv['recurrent.bias_hh_l0'].copy_(gv['recurrent.bias_ih_l0'])
         g16 = self._gemm_tn(self.dout, h_all, self.g16)             # [16][128]: rows < A decoder, row A value head
         gv['decoder.weight'].copy_(g16[:A])
         gv['value_head.weight'].copy_(g16[A:A + 1])

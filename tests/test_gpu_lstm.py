@@ -243,3 +243,75 @@ def test_lstm_policy_step_matches_torch_modules():
     assert torch.equal(a, want_a)
     np.testing.assert_allclose(lp.cpu().numpy(), logp.gather(1, want_a[:, None])[:, 0].cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(ent.cpu().numpy(), -(logp * logp.exp()).sum(1).cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('R,Th', [(40, 5), (64, 16), (7, 3)])
+def test_lstm_seq_forward_backward_match_torch_autograd(R, Th):
+    """pfa_lstm_seq_forward / pfa_lstm_seq_backward vs nn.Linear + nn.LSTM under torch autograd: every kept activation, the
+    state after Th steps, d loss/d gate pre-activations, d loss/d encoder pre-activations and the bias gradients.  Ragged
+    row counts (not a multiple of the 32-row workgroup), nonzero biases, nonzero carried-in state."""
+    from pufferlib_amd import _lib, lstm as plstm
+    L = _lib.lib()
+    torch.manual_seed(R * 100 + Th)
+    vec, pol = _make(16)
+    with torch.no_grad():
+        for name, p in pol.named_parameters():
+            if name.endswith('bias') or 'bias_' in name:
+                p.copy_(torch.randn_like(p) * 0.2)
+    fp = pol.adopt(64, 'cuda')
+    dev = 'cuda'
+    obs = torch.zeros(Th, R, 64, device=dev)
+    obs[:, :, :49] = (torch.rand(Th, R, 49, device=dev) < 0.1).float() + 0.1 * torch.randn(Th, R, 49, device=dev)
+    h0, c0 = 0.3 * torch.randn(R, 128, device=dev), 0.3 * torch.randn(R, 128, device=dev)
+    dh = 0.1 * torch.randn(Th, R, 128, device=dev)                    # d loss / d h_t through the heads
+
+    xe = torch.full((Th, R, 128), float('nan'), device=dev)
+    gates = torch.full((Th, R, 512), float('nan'), device=dev)
+    Hs = torch.full((Th + 1, R, 128), float('nan'), device=dev)
+    Cs = torch.full((Th + 1, R, 128), float('nan'), device=dev)
+    Hs[0], Cs[0] = h0, c0
+    wpack = plstm.pack_gates(fp)
+    st = _lib.stream_handle()
+    _lib.check(L.pfa_lstm_seq_forward(_lib.ptr(obs), R, Th, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(wpack), _lib.ptr(xe),
+                                      _lib.ptr(gates), _lib.ptr(Hs), _lib.ptr(Cs), st), 'fwd')
+    wb = torch.empty_like(wpack)
+    _lib.check(L.pfa_lstm_pack_bwd(_lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(wb), st), 'pack_bwd')
+    dG = torch.full((Th, R, 512), float('nan'), device=dev)
+    dxe = torch.full((Th, R, 128), float('nan'), device=dev)
+    gb, eb = torch.empty(512, device=dev), torch.empty(128, device=dev)
+    ws = torch.empty(L.pfa_lstm_seq_backward_workspace_bytes(R), dtype=torch.uint8, device=dev)
+    _lib.check(L.pfa_lstm_seq_backward(_lib.ptr(gates), _lib.ptr(Cs), _lib.ptr(xe), _lib.ptr(dh), R, Th, _lib.ptr(wb), _lib.ptr(dG),
+                                       _lib.ptr(dxe), _lib.ptr(gb), _lib.ptr(eb), _lib.ptr(ws), st), 'bwd')
+
+    # torch reference in f64
+    sd = {k: v.detach().double() for k, v in pol.state_dict().items()}
+    W1 = sd['policy.policy.encoder.weight']
+    b1 = sd['policy.policy.encoder.bias'].clone().requires_grad_(True)
+    Wih, Whh = sd['policy.recurrent.weight_ih_l0'], sd['policy.recurrent.weight_hh_l0']
+    bih = sd['policy.recurrent.bias_ih_l0'].clone().requires_grad_(True)
+    bhh = sd['policy.recurrent.bias_hh_l0']
+    pre = obs[:, :, :49].double() @ W1.t() + b1
+    pre.retain_grad()
+    x = torch.relu(pre)
+    h, c = h0.double(), c0.double()
+    acts, hs, cs, pres = [], [], [], []
+    for t in range(Th):
+        p = x[t] @ Wih.t() + h @ Whh.t() + bih + bhh
+        p.retain_grad()
+        i, f, g, o = p.chunk(4, 1)
+        i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        acts.append(torch.cat([i, f, g, o], 1)); hs.append(h); cs.append(c); pres.append(p)
+    loss = sum((hs[t] * dh[t].double()).sum() for t in range(Th))
+    loss.backward()
+    tol = dict(rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(xe.cpu().numpy(), x.detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(gates.cpu().numpy(), torch.stack(acts).detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(Hs[1:].cpu().numpy(), torch.stack(hs).detach().cpu().numpy(), **tol)
+    np.testing.assert_allclose(Cs[1:].cpu().numpy(), torch.stack(cs).detach().cpu().numpy(), **tol)
+    assert torch.equal(Hs[0], h0) and torch.equal(Cs[0], c0)
+    np.testing.assert_allclose(dG.cpu().numpy(), torch.stack([p.grad for p in pres]).cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(dxe.cpu().numpy(), pre.grad.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(gb.cpu().numpy(), bih.grad.cpu().numpy(), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(eb.cpu().numpy(), b1.grad.cpu().numpy(), rtol=2e-5, atol=1e-5)
