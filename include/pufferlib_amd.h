@@ -275,12 +275,13 @@ int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_envs, int32
 int pfa_gather_obs_time_major(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const pfa_ppo_hparams *hp,
                               int32_t obs_stride, float *out, pfa_stream_t stream);
 /* decode_actions + PPO loss on the time-major hidden states h [mbs][128] of minibatch mb: dout [mbs][16] (d loss / d the
- * padded head outputs), dh [mbs][128] (d loss / d h through the heads), loss_sums8 as in pfa_ppo_mlp_grad. */
+ * padded head outputs), dh [mbs][128] (d loss / d h through the heads), loss_sums8 as in pfa_ppo_mlp_grad,
+ * head_bias_grad16 (nullable) = column sums of dout = d loss / d (decoder.bias | value_head.bias | padding). */
 size_t pfa_lstm_heads_loss_workspace_bytes(void);
 int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
                         const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
-                        int64_t global_mb_rows, float *dout, float *dh, float *loss_sums8, void *workspace,
-                        pfa_stream_t stream);
+                        int64_t global_mb_rows, float *dout, float *dh, float *loss_sums8, float *head_bias_grad16,
+                        void *workspace, pfa_stream_t stream);
 /* C[mo][no] (row stride ldc) = sum over the k rows of A[k][mo]^T B[k][no]  (A, B row-major activations with row strides
  * lda, ldb; fp32 MFMA, split over k, deterministic f64 reduction of the splits).  These are the weight-gradient
  * contractions autograd performs for nn.Linear / nn.LSTM under loss.backward() (clean_pufferl.py:244).  Supported

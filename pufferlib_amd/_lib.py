@@ -124,7 +124,7 @@ _SIGNATURES = {
     'pfa_gather_obs_time_major': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, C.POINTER(PpoHparams), C.c_int32, P, P]),
     'pfa_lstm_heads_loss_workspace_bytes': (C.c_size_t, []),
     'pfa_lstm_heads_loss': (C.c_int, [P, C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),
-                                      C.POINTER(PpoHparams), P, C.c_int64, P, P, P, P, P]),
+                                      C.POINTER(PpoHparams), P, C.c_int64, P, P, P, P, P, P]),
     'pfa_lstm_param_count': (C.c_int64, [C.POINTER(MlpDims)]),
     'pfa_lstm_pack_bytes': (C.c_size_t, []),
     'pfa_lstm_pack': (C.c_int, [P, C.POINTER(MlpDims), P, P]),

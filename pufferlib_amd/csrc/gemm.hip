@@ -119,13 +119,45 @@ __global__ void __launch_bounds__(kGemmThreads, 2)
                 out[(size_t)(i0 + (wr * MI + a) * 16 + 4 * g + r) * no + j0 + (wc * NI + b) * 16 + c] = acc[a][b][r];
 }
 
+// pass 2: 64 float4 column groups x 4 split quarters per workgroup; each thread sums its quarter of the splits (4 loads in
+// flight), the quarters are combined through LDS in a fixed order -> deterministic, and latency- rather than issue-bound.
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ partial, int splits, int mo, int no,
                                                             float *__restrict__ C, long long ldc) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= mo * no) return;
-    double s = 0.0;
-    for (int q = 0; q < splits; ++q) s += (double)partial[(size_t)q * mo * no + idx];
-    C[(long long)(idx / no) * ldc + idx % no] = (float)s;
+    __shared__ double sh[3][64][4];
+    const int col4 = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int idx4 = blockIdx.x * 64 + col4;  // float4 index into the mo x no output
+    const int total4 = mo * no / 4;
+    const size_t stride4 = (size_t)mo * no / 4;
+    const float4 *p4 = reinterpret_cast<const float4 *>(partial);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (idx4 < total4) {
+        const int per = (splits + 3) / 4;
+        const int lo = quarter * per, hi = lo + per < splits ? lo + per : splits;
+        int q = lo;
+        for (; q + 4 <= hi; q += 4) {
+            const float4 a = p4[(size_t)q * stride4 + idx4], b = p4[(size_t)(q + 1) * stride4 + idx4];
+            const float4 c = p4[(size_t)(q + 2) * stride4 + idx4], d = p4[(size_t)(q + 3) * stride4 + idx4];
+            s0 += ((double)a.x + (double)b.x) + ((double)c.x + (double)d.x);
+            s1 += ((double)a.y + (double)b.y) + ((double)c.y + (double)d.y);
+            s2 += ((double)a.z + (double)b.z) + ((double)c.z + (double)d.z);
+            s3 += ((double)a.w + (double)b.w) + ((double)c.w + (double)d.w);
+        }
+        for (; q < hi; ++q) {
+            const float4 a = p4[(size_t)q * stride4 + idx4];
+            s0 += a.x, s1 += a.y, s2 += a.z, s3 += a.w;
+        }
+    }
+    if (quarter > 0) {
+        sh[quarter - 1][col4][0] = s0, sh[quarter - 1][col4][1] = s1, sh[quarter - 1][col4][2] = s2, sh[quarter - 1][col4][3] = s3;
+    }
+    __syncthreads();
+    if (quarter == 0 && idx4 < total4) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s0 += sh[k][col4][0], s1 += sh[k][col4][1], s2 += sh[k][col4][2], s3 += sh[k][col4][3];
+        const int e = idx4 * 4, i = e / no, j = e % no;  // no % 4 == 0: the four values stay in one row
+        float *out = C + (long long)i * ldc + j;
+        out[0] = (float)s0, out[1] = (float)s1, out[2] = (float)s2, out[3] = (float)s3;
+    }
 }
 
 struct GemmTnPlan {
@@ -188,7 +220,7 @@ extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int6
         hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 4, 1, 2>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
                            mo, no, (long long)k, p.k_per_split, partial);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no + 255) / 256)), dim3(256), 0, st, partial, p.splits, mo, no, c,
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no / 4 + 63) / 64)), dim3(256), 0, st, partial, p.splits, mo, no, c,
                        (long long)ldc);
     PFA_LAUNCH_CHECK();
     return 0;

@@ -19,6 +19,7 @@
 namespace pfa {
 
 constexpr int kLstmH = 128;
+constexpr int kHeadStatCols = 24;  // per-workgroup partials of lstm_heads_loss: 8 loss sums + 16 column sums of dout
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -203,6 +204,8 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
     __shared__ float b2v[kOut];
     __shared__ float hs[16][kLstmH];
     __shared__ float st[16][8];
+    __shared__ float sd[16][16];
+    float dsum = 0.0f;  // this lane's column of sum_rows dout (the head bias gradient)
     stage_heads(params, dp, a, w2v, b2v);
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
     float adv_mean = 0.0f, adv_den = 1.0f;
@@ -273,7 +276,10 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
         float d = 0.0f;
         if (is_logit) d = g_lp * ((lo == action ? 1.0f : 0.0f) - p) + hp.ent_coef * scale * p * (nl + ent);
         else if (lo == a) d = dv;
-        if (ok) dout[row * kOut + lo] = d;
+        if (ok) {
+            dout[row * kOut + lo] = d;
+            dsum += d;
+        }
         // d loss / d h[u] = sum_o d_o W2v[o][u]; lane lo owns u = lo, lo+16, ...
         float dhv[kLstmH / 16];
 #pragma unroll
@@ -299,25 +305,32 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
     __syncthreads();
     if (lo == 0)
         for (int i = 0; i < 8; ++i) st[le][i] = i < 6 ? acc[i] : 0.0f;
+    sd[le][lo] = dsum;
     __syncthreads();
     if (threadIdx.x < 8) {
         float s = 0.0f;
         for (int e = 0; e < 16; ++e) s += st[e][threadIdx.x];
-        stats_partial[(size_t)blockIdx.x * 8 + threadIdx.x] = s;
+        stats_partial[(size_t)blockIdx.x * kHeadStatCols + threadIdx.x] = s;
+    } else if (threadIdx.x >= 16 && threadIdx.x < 32) {
+        float s = 0.0f;
+        for (int e = 0; e < 16; ++e) s += sd[e][threadIdx.x - 16];
+        stats_partial[(size_t)blockIdx.x * kHeadStatCols + 8 + (threadIdx.x - 16)] = s;
     }
 }
-// 256 threads: 32 strided chains per statistic, then a fixed-order tree (deterministic).
-__global__ void __launch_bounds__(256) stats_final_kernel(const float *partial, int nblocks, float *out8) {
-    __shared__ float sh[32][8];
-    const int i = threadIdx.x & 7, chain = threadIdx.x >> 3;
+// 256 threads: 8 strided chains per column (8 loss statistics + 16 head-output column sums), then a fixed-order tree.
+__global__ void __launch_bounds__(256) stats_final_kernel(const float *partial, int nblocks, float *out8, float *out16) {
+    __shared__ float sh[8][32];
+    const int i = threadIdx.x & 31, chain = threadIdx.x >> 5;
     float s = 0.0f;
-    for (int b = chain; b < nblocks; b += 32) s += partial[(size_t)b * 8 + i];
+    if (i < kHeadStatCols)
+        for (int b = chain; b < nblocks; b += 8) s += partial[(size_t)b * kHeadStatCols + i];
     sh[chain][i] = s;
     __syncthreads();
-    if (threadIdx.x < 8) {
+    if (threadIdx.x < kHeadStatCols) {
         float t = 0.0f;
-        for (int q = 0; q < 32; ++q) t += sh[q][threadIdx.x];
-        out8[threadIdx.x] = t;
+        for (int q = 0; q < 8; ++q) t += sh[q][threadIdx.x];
+        if (threadIdx.x < 8) out8[threadIdx.x] = t;
+        else if (out16) out16[threadIdx.x - 8] = t;
     }
 }
 
@@ -433,12 +446,12 @@ extern "C" int pfa_gather_obs_time_major(const pfa_experience *exp, int64_t batc
     return 0;
 }
 
-extern "C" size_t pfa_lstm_heads_loss_workspace_bytes(void) { return (size_t)1024 * 8 * sizeof(float); }
+extern "C" size_t pfa_lstm_heads_loss_workspace_bytes(void) { return (size_t)1024 * kHeadStatCols * sizeof(float); }
 
 extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
                                    const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
-                                   int64_t global_mb_rows, float *dout, float *dh, float *loss_sums8, void *workspace,
-                                   pfa_stream_t stream) {
+                                   int64_t global_mb_rows, float *dout, float *dh, float *loss_sums8, float *head_bias_grad16,
+                                   void *workspace, pfa_stream_t stream) {
     PFA_REQUIRE(h && exp && params && dims && hp && dout && dh && loss_sums8 && workspace, "lstm_heads_loss: null buffer");
     PFA_REQUIRE(!hp->norm_adv || adv_stats, "lstm_heads_loss: norm_adv needs adv_stats");
     const long long mbs = batch_rows / hp->num_minibatches;
@@ -449,7 +462,7 @@ extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, in
     hipLaunchKernelGGL(lstm_heads_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, mbs, map, *exp, params,
                        dims->obs_stride, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, dout, dh, partial);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8);
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8, head_bias_grad16);
     PFA_LAUNCH_CHECK();
     return 0;
 }

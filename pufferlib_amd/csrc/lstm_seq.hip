@@ -286,15 +286,29 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
         }
 }
 
-// out[col] = sum over workgroups of partial[wg][col]; cols < 512 -> gate bias gradient, the rest -> encoder bias gradient
+// out[col] = sum over workgroups of partial[wg][col]; cols < 512 -> gate bias gradient, the rest -> encoder bias gradient.
+// One workgroup per 64 columns: 4 group-quarters x 64 columns, combined through LDS in a fixed order.
 __global__ void __launch_bounds__(256) lstm_bias_final_kernel(const float *__restrict__ partial, int groups, float *__restrict__ gate_bias_grad,
                                                              float *__restrict__ enc_bias_grad) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= kBiasCols) return;
-    float s = 0.0f;
-    for (int i = 0; i < groups; ++i) s += partial[(size_t)i * kBiasCols + col];
-    if (col < kLG) gate_bias_grad[col] = s;
-    else enc_bias_grad[col - kLG] = s;
+    __shared__ float sh[4][64];
+    const int cl = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int per = (groups + 3) / 4;
+    const int lo = quarter * per, hi = lo + per < groups ? lo + per : groups;
+    float s0 = 0.0f, s1 = 0.0f;
+    int i = lo;
+    for (; i + 2 <= hi; i += 2) {
+        s0 += partial[(size_t)i * kBiasCols + col];
+        s1 += partial[(size_t)(i + 1) * kBiasCols + col];
+    }
+    if (i < hi) s0 += partial[(size_t)i * kBiasCols + col];
+    sh[quarter][cl] = s0 + s1;
+    __syncthreads();
+    if (quarter == 0) {
+        const float s = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+        if (col < kLG) gate_bias_grad[col] = s;
+        else enc_bias_grad[col - kLG] = s;
+    }
 }
 
 static int check_seq_dims(const pfa_mlp_dims *d) {
@@ -360,7 +374,7 @@ extern "C" int pfa_lstm_seq_backward(const float *gates_act, const float *cs, co
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(grid), dim3(kLstmThreads), 0, st, gates_act, cs, xe, dh_heads, (long long)rows,
                        (int)steps, (const float4 *)wpack_bwd, dgates, dxe, (float *)workspace);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lstm_bias_final_kernel, dim3((kBiasCols + 255) / 256), dim3(256), 0, st, (const float *)workspace, (int)grid,
+    hipLaunchKernelGGL(lstm_bias_final_kernel, dim3(kBiasCols / 64), dim3(256), 0, st, (const float *)workspace, (int)grid,
                        gate_bias_grad, enc_bias_grad);
     PFA_LAUNCH_CHECK();
     return 0;

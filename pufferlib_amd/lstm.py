@@ -74,7 +74,7 @@ class Engine:
         self.dxe = torch.empty(M, H, device=dev)
         self.bsum16 = torch.empty(16, device=dev)
         L = _lib.lib()
-        self.ws = torch.empty(max(L.pfa_colsum_workspace_bytes(4 * H), L.pfa_lstm_heads_loss_workspace_bytes()),
+        self.ws = torch.empty(L.pfa_lstm_heads_loss_workspace_bytes(),
                               dtype=torch.uint8, device=dev)
         shapes = [(4 * H, H), (H, DP), (16, H)]
         self.gemm_ws = torch.empty(max(L.pfa_gemm_tn_workspace_bytes(mo, no, M) for mo, no in shapes), dtype=torch.uint8,
@@ -149,7 +149,7 @@ class Engine:
         loss_sums = grads[fp.count:fp.count + 8]
         _lib.check(L.pfa_lstm_heads_loss(_lib.ptr(h_all), C.byref(exp.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hp),
                                          _lib.ptr(adv_stats), global_mb_rows, _lib.ptr(self.dout), _lib.ptr(self.dh_heads),
-                                         _lib.ptr(loss_sums), _lib.ptr(self.ws), stream), 'lstm_heads_loss')
+                                         _lib.ptr(loss_sums), _lib.ptr(self.bsum16), _lib.ptr(self.ws), stream), 'lstm_heads_loss')
         # ---- back-propagation through time (csrc/lstm_seq.hip) + weight gradients (csrc/gemm.hip) ----------------------
         gv = fp.split(grads[:fp.count])
         _lib.check(L.pfa_lstm_pack_bwd(_lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(self.wpack_bwd), stream), 'lstm_pack_bwd')
@@ -166,7 +166,6 @@ class Engine:
         g16 = self._gemm_tn(self.dout, h_all, self.g16)             # [16][128]: rows < A decoder, row A value head
         gv['decoder.weight'].copy_(g16[:A])
         gv['value_head.weight'].copy_(g16[A:A + 1])
-        self._colsum(self.dout, 16, self.bsum16)
         gv['decoder.bias'].copy_(self.bsum16[:A])
         gv['value_head.bias'].copy_(self.bsum16[A:A + 1])
 
@@ -176,11 +175,6 @@ class Engine:
         _lib.check(L.pfa_gemm_tn_f32(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), _lib.ptr(out), out.stride(0),
                                      a.shape[1], b.shape[1], a.shape[0], _lib.ptr(self.gemm_ws), _lib.stream_handle()), 'gemm_tn')
         return out
-
-    def _colsum(self, a, cols, out):
-        L = _lib.lib()
-        _lib.check(L.pfa_colsum(_lib.ptr(a), a.shape[0], cols, a.stride(0), _lib.ptr(out), 0, _lib.ptr(self.ws),
-                                _lib.stream_handle()), 'colsum')
 
     def clip_adam(self, grads, opt, max_grad_norm, loss_acc, loss_scale):
         L = _lib.lib()
