@@ -134,6 +134,9 @@ def main():
     for _ in range(W):
         clean_pufferl.evaluate(data)
         clean_pufferl.train(data)
+    # dominant kernel of the update: the fused fwd/loss/bwd kernel (MLP) or the BPTT kernel (LSTM)
+    dominant = 'ppo_mlp_grad' if args.policy == 'mlp' else 'lstm_seq_bwd'
+    L.pfa_timing_select(dominant.encode())
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
     barrier()
@@ -154,7 +157,7 @@ def main():
         _lib.check(L.pfa_timing_read(name.encode(), C.byref(n), C.byref(ms)), 'timing_read')
         return n.value, ms.value
 
-    grad_launches, grad_total_ms = kernel_ms('ppo_mlp_grad')   # HIP events over the timed region, launch stream
+    grad_launches, grad_total_ms = kernel_ms(dominant)   # HIP events over the timed region, launch stream
     breakdown = {}
     if rank == 0 and not args.no_breakdown:
         # separate, untimed pass with every instrumented kernel bracketed by events (the extra event packets cost
@@ -169,7 +172,9 @@ def main():
         barrier()
     if rank == 0 and not args.no_breakdown:
         L.pfa_timing_enable(0)
-        for name in ('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip'):
+        names = (('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
+                 else ('rollout_lstm_squared', 'squared_tape', 'gae', 'lstm_seq_fwd', 'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
+        for name in names:
             n, ms = kernel_ms(name)
             breakdown[name] = dict(launches_per_step=n // KB, ms_per_step=round(ms / KB, 4))
 
@@ -178,12 +183,14 @@ def main():
         launches, total_ms = grad_launches, grad_total_ms
         avg_ms = total_ms / max(launches, 1)
         rows_per_launch = per_gpu // NMB
-        achieved = FLOP_PER_ROW_UPDATE * rows_per_launch / (avg_ms * 1e-3) / 1e12 if launches else 0.0
+        # algorithmic flop per minibatch row: DESIGN.md section 4 (MLP fwd+bwd) / section 7 (BPTT product [dxe | dh] = dG Wcat)
+        flop_row = FLOP_PER_ROW_UPDATE if args.policy == 'mlp' else 2 * 512 * 256
+        achieved = flop_row * rows_per_launch / (avg_ms * 1e-3) / 1e12 if launches else 0.0
         traffic = None
         pmc = os.path.join(REPO, 'profiles', 'pmc_summary.json')
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get('ppo_mlp_grad', {}).get('hbm_bytes_per_launch')
+                traffic = json.load(open(pmc)).get(dominant, {}).get('hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         out = {
@@ -195,10 +202,10 @@ def main():
                                    f'{"MLP 128" if args.policy == "mlp" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[1]'
                                    + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': 'ppo_mlp_grad', 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+            'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
                          'avg_launch_ms': avg_ms, 'launches': launches,
-                         'flop_per_launch': FLOP_PER_ROW_UPDATE * rows_per_launch},
+                         'flop_per_launch': flop_row * rows_per_launch},
             'kernel_ms_per_step': breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:

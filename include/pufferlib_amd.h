@@ -31,6 +31,7 @@ const char *pfa_last_error(void);
  * hipEvents recorded on the launch stream.  pfa_timing_read synchronises on the recorded events and returns
  * the launch count and the summed device time in ms (HOST pointers). */
 int pfa_timing_enable(int mode);
+int pfa_timing_select(const char *kernel); /* the kernel mode 1 times (default "ppo_mlp_grad") */
 int pfa_timing_reset(void);
 int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms_host);
 

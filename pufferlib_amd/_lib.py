@@ -87,6 +87,7 @@ _SIGNATURES = {
     'pfa_version': (C.c_int, []),
     'pfa_last_error': (C.c_char_p, []),
     'pfa_timing_enable': (C.c_int, [C.c_int]),
+    'pfa_timing_select': (C.c_int, [C.c_char_p]),
     'pfa_timing_reset': (C.c_int, []),
     'pfa_timing_read': (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'pfa_gae_workspace_bytes': (C.c_size_t, [C.c_int64]),

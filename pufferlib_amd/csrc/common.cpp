@@ -24,14 +24,15 @@ struct TimedKernel {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
     size_t used = 0;
 };
-static int g_timing = 0;  // 0 off, 1 dominant kernel only, 2 every instrumented kernel
+static int g_timing = 0;  // 0 off, 1 the selected (dominant) kernel only, 2 every instrumented kernel
+static std::string g_selected = "ppo_mlp_grad";
 static std::map<std::string, TimedKernel> g_timed;
 
 bool timing_enabled() { return g_timing != 0; }
 
 // Returns the stop event (to be recorded after the launch) or nullptr when timing is off.
 void *timing_begin(const char *name, hipStream_t stream) {
-    if (g_timing == 0 || (g_timing == 1 && std::strcmp(name, "ppo_mlp_grad") != 0)) return nullptr;
+    if (g_timing == 0 || (g_timing == 1 && g_selected != name)) return nullptr;
     TimedKernel &k = g_timed[name];
     if (k.used == k.pairs.size()) {
         hipEvent_t a, b;
@@ -52,6 +53,11 @@ extern "C" const char *pfa_last_error(void) { return pfa::g_err; }
 
 extern "C" int pfa_timing_enable(int on) {
     pfa::g_timing = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return 0;
+}
+extern "C" int pfa_timing_select(const char *kernel) {
+    if (!kernel || !*kernel) return -2;
+    pfa::g_selected = kernel;
     return 0;
 }
 extern "C" int pfa_timing_reset(void) {
