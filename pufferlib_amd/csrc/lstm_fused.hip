@@ -46,12 +46,15 @@ template <int DP>
 __device__ __forceinline__ void lstm_tile_step(const LstmFrags<DP> &w, const float4 *__restrict__ wp, LstmLds<DP> &L, int cur,
                                                f32x4 (&cst)[2]) {
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
-    float4 abuf[4][8];
-    gates_prefetch(wp, abuf);
+    float4 ring[kGateRing][8];
+    const Stream ws = stream_begin(wp);
+    ring_prefetch<8, kGateRing>(ws, ring);
     lstm_encode<DP>(w, L.xs, L.xh[cur]);
     __syncthreads();
     f32x4 acc[1][8];
-    gates_product<1>(wp, L.xh[cur], abuf, acc);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) acc[0][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stream_product<16, 8, 1, kXHTile, kGateRing>(ws, L.xh[cur] + c * kXHS + 4 * g, ring, acc, NoSide{});
     f32x4 hn[2];
     lstm_cell(acc[0], L.gbias, cst, hn);
     float4 *dst = reinterpret_cast<float4 *>(L.xh[cur ^ 1] + c * kXHS + kLH + 32 * wv + 4 * g);
@@ -80,7 +83,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_policy_step_kernel(const fl
     LstmFrags<DP> w;
     w.load(params, a);
     stage_gate_bias(params, DP, a, L.gbias);
-    const float4 *wp = wpack + (size_t)wave_id() * 16 * 8 * 64;
+    const float4 *wp = wpack + (size_t)__builtin_amdgcn_readfirstlane(wave_id()) * 16 * 8 * 64;  // wave-uniform: SGPR base + lane offset
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
     const int c = lane_id() & 15;
     const long long tiles = (rows + 15) / 16;
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(kLstmThreads) rollout_lstm_squared_kernel(Squa
     LstmFrags<DP> w;
     w.load(params, a);
     stage_gate_bias(params, DP, a, L.gbias);
-    const float4 *wp = wpack + (size_t)wave_id() * 16 * 8 * 64;
+    const float4 *wp = wpack + (size_t)__builtin_amdgcn_readfirstlane(wave_id()) * 16 * 8 * 64;  // wave-uniform: SGPR base + lane offset
 
     lstm_stage_obs<DP>(live_obs, first, v.n, L.xs);
     load_hstate(h, first, v.n, L.xh[0]);

@@ -54,8 +54,9 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
     w.load(params, a);
     stage_gate_bias(params, DP, a, L.gbias);
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
-    const float4 *wp = wpack + (size_t)wv * 16 * 8 * 64;
+    const float4 *wp = wpack + (size_t)__builtin_amdgcn_readfirstlane(wv) * 16 * 8 * 64;
     const long long first = (long long)blockIdx.x * kSeqRows;
+    const int uoff = 32 * wv + 4 * g;
     f32x4 cst[kSeqRT][2];
 #pragma unroll
     for (int rt = 0; rt < kSeqRT; ++rt) {
@@ -64,10 +65,28 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
         lstm_stage_obs<DP>(obs_tm, first + 16 * rt, R, L.xs[rt]);
     }
     __syncthreads();
+
+    // What step t keeps for the backward pass leaves the registers during step t+1's gate product, two stores per
+    // weight group (stream_product's side slot): per row tile 8 gate-activation float4, 2 of h_t, 2 of c_t.
+    constexpr int kPend = 12;
+    float4 pend[kSeqRT][kPend];
+    auto flush = [&](int k, int tp) {  // store #k (0 .. 2*kPend-1) of step tp
+        const int rt = k / kPend, j = k % kPend;
+        const long long row = first + 16 * rt + c;
+        if (row >= R) return;
+        if (j < 8)
+            *reinterpret_cast<float4 *>(gates_act + ((size_t)tp * R + row) * kLG + 128 * (j >> 1) + 16 * (j & 1) + uoff) = pend[rt][j];
+        else if (j < 10)
+            *reinterpret_cast<float4 *>(Hs + ((size_t)(tp + 1) * R + row) * kLH + 16 * (j - 8) + uoff) = pend[rt][j];
+        else
+            *reinterpret_cast<float4 *>(Cs + ((size_t)(tp + 1) * R + row) * kLH + 16 * (j - 10) + uoff) = pend[rt][j];
+    };
+
     for (int t = 0; t < Th; ++t) {
         const int cur = t & 1;
-        float4 abuf[4][8];
-        gates_prefetch(wp, abuf);
+        float4 ring[kGateRing][8];
+        const Stream ws = stream_begin(wp);
+        ring_prefetch<8, kGateRing>(ws, ring);
 #pragma unroll
         for (int rt = 0; rt < kSeqRT; ++rt) {
             const long long row = first + 16 * rt + c;
@@ -82,32 +101,36 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
             for (int q = 0; q < NX; ++q) {
                 const int idx = threadIdx.x + q * kLstmThreads;
                 const long long row = first + idx / V;
-                nx[q] = (idx < kSeqRows * V && row < R) ? *reinterpret_cast<const float4 *>(obs_tm + ((size_t)(t + 1) * R + row) * DP + 4 * (idx % V))
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                nx[q] = (idx < kSeqRows * V && row < R)
+                            ? *reinterpret_cast<const float4 *>(obs_tm + ((size_t)(t + 1) * R + row) * DP + 4 * (idx % V))
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
         f32x4 acc[kSeqRT][8];
-        gates_product<kSeqRT>(wp, L.xh[cur][0], abuf, acc);
+#pragma unroll
+        for (int rt = 0; rt < kSeqRT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool have_pend = t > 0;
+        stream_product<16, 8, kSeqRT, kXHTile, kGateRing>(ws, L.xh[cur][0] + c * kXHS + 4 * g, ring, acc, [&](int gq) {
+            if (have_pend && 2 * gq + 1 < kSeqRT * kPend) {
+                flush(2 * gq, t - 1);
+                flush(2 * gq + 1, t - 1);
+            }
+        });
 #pragma unroll
         for (int rt = 0; rt < kSeqRT; ++rt) {
             f32x4 hn[2];
             lstm_cell(acc[rt], L.gbias, cst[rt], hn);
-            float4 *dst = reinterpret_cast<float4 *>(L.xh[cur ^ 1][rt] + c * kXHS + kLH + 32 * wv + 4 * g);
+            float4 *dst = reinterpret_cast<float4 *>(L.xh[cur ^ 1][rt] + c * kXHS + kLH + uoff);
             dst[0] = make_float4(hn[0][0], hn[0][1], hn[0][2], hn[0][3]);
             dst[4] = make_float4(hn[1][0], hn[1][1], hn[1][2], hn[1][3]);
-            const long long row = first + 16 * rt + c;
-            if (row < R) {
-                float4 *ga = reinterpret_cast<float4 *>(gates_act + ((size_t)t * R + row) * kLG + 32 * wv + 4 * g);
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct)  // column 128q + 32w + 16sub + 4g + r, ct = 2q + sub
-                    ga[(128 * (ct >> 1) + 16 * (ct & 1)) / 4] = make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
-                float4 *hp = reinterpret_cast<float4 *>(Hs + ((size_t)(t + 1) * R + row) * kLH + 32 * wv + 4 * g);
-                float4 *cp = reinterpret_cast<float4 *>(Cs + ((size_t)(t + 1) * R + row) * kLH + 32 * wv + 4 * g);
+            for (int ct = 0; ct < 8; ++ct) pend[rt][ct] = make_float4(acc[rt][ct][0], acc[rt][ct][1], acc[rt][ct][2], acc[rt][ct][3]);
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-                    hp[4 * sub] = make_float4(hn[sub][0], hn[sub][1], hn[sub][2], hn[sub][3]);
-                    cp[4 * sub] = make_float4(cst[rt][sub][0], cst[rt][sub][1], cst[rt][sub][2], cst[rt][sub][3]);
-                }
+            for (int sub = 0; sub < 2; ++sub) {
+                pend[rt][8 + sub] = make_float4(hn[sub][0], hn[sub][1], hn[sub][2], hn[sub][3]);
+                pend[rt][10 + sub] = make_float4(cst[rt][sub][0], cst[rt][sub][1], cst[rt][sub][2], cst[rt][sub][3]);
             }
         }
         if (t + 1 < Th) {
@@ -124,6 +147,8 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int k = 0; k < kSeqRT * kPend; ++k) flush(k, Th - 1);
 }
 
 // dst float4 index ((w*32 + cq)*4 + kt)*64 + lane  <-  { Wcat[16cq + 4g + s][k(w, kt, c)] : s = 0..3 },
@@ -152,38 +177,69 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
     __shared__ SeqBwdLds L;
     seq_stagger(stagger);
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
-    const float4 *wp = wpack_bwd + (size_t)wv * 32 * 4 * 64;
+    const float4 *wp = wpack_bwd + (size_t)__builtin_amdgcn_readfirstlane(wv) * 32 * 4 * 64;
     const long long first = (long long)blockIdx.x * kSeqRows;
     const int uoff = 32 * wv + 4 * g;  // this lane's units: uoff + 16 sub + r
+    constexpr int kBwdRing = 8;        // 4 fragments per group: keep 7 groups (3 us) of the stream in flight
 
-    f32x4 dc[kSeqRT][2], dhrec[kSeqRT][2], bsum[8], xsum[2];
+    f32x4 dc[kSeqRT][2], dhrec[kSeqRT][2], xsum[2];
+    float bcol0 = 0.0f, bcol1 = 0.0f;  // column sums of dG (gate bias gradient) for columns tid and tid + 256
 #pragma unroll
     for (int rt = 0; rt < kSeqRT; ++rt)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) dc[rt][sub] = dhrec[rt][sub] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bsum[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     xsum[0] = xsum[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Inputs of the cell backward of one step, per row tile: 8 gate activations (q, sub), c_{t-1} (2), dh_heads (2); the
+    // encoder output xe (2) masks dxe after the product.  Step t-1's set is fetched during step t's product, one load per
+    // weight group (stream_product's side slot); c_t is last step's c_{t-1}.
+    constexpr int kIn = 12;
+    float4 in[kSeqRT][kIn], xv[kSeqRT][2], ccur[kSeqRT][2];
+    auto fetch = [&](int k, int tt) {  // load #k (0 .. 2*kIn-1) of step tt
+        const int rt = k / kIn, j = k % kIn;
+        const long long row = first + 16 * rt + c;
+        if (row >= R) {
+            in[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            return;
+        }
+        const size_t tr = (size_t)tt * R + row;
+        if (j < 8)
+            in[rt][j] = *reinterpret_cast<const float4 *>(gates_act + tr * kLG + 128 * (j >> 1) + 16 * (j & 1) + uoff);
+        else if (j < 10)
+            in[rt][j] = *reinterpret_cast<const float4 *>(Cs + tr * kLH + 16 * (j - 8) + uoff);  // c_{tt-1}
+        else
+            in[rt][j] = *reinterpret_cast<const float4 *>(dh_heads + tr * kLH + 16 * (j - 10) + uoff);
+    };
+    auto fetch_x = [&](int k, int tt) {  // load #k (0..3) of xe at step tt
+        const int rt = k >> 1, sub = k & 1;
+        const long long row = first + 16 * rt + c;
+        xv[rt][sub] = row < R ? *reinterpret_cast<const float4 *>(xe + ((size_t)tt * R + row) * kLH + 16 * sub + uoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+#pragma unroll
+    for (int k = 0; k < kSeqRT * kIn; ++k) fetch(k, Th - 1);
+#pragma unroll
+    for (int rt = 0; rt < kSeqRT; ++rt)
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const long long row = first + 16 * rt + c;
+            ccur[rt][sub] = row < R ? *reinterpret_cast<const float4 *>(Cs + ((size_t)Th * R + row) * kLH + 16 * sub + uoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+
     for (int t = Th - 1; t >= 0; --t) {
+        float4 ring[kBwdRing][4];
+        const Stream ws = stream_begin(wp);
+        ring_prefetch<4, kBwdRing>(ws, ring);  // ahead of this step's stores in the memory queue
         // ---- cell backward, elementwise on (row c, units uoff + 16 sub + r) ------------------------------------
 #pragma unroll
         for (int rt = 0; rt < kSeqRT; ++rt) {
             const long long row = first + 16 * rt + c;
             const bool ok = row < R;
-            const size_t tr = (size_t)t * R + (ok ? row : 0);
-            const float4 *ga = reinterpret_cast<const float4 *>(gates_act + tr * kLG + uoff);
-            const float4 *cpv = reinterpret_cast<const float4 *>(Cs + tr * kLH + uoff);                     // c_{t-1}
-            const float4 *cnv = reinterpret_cast<const float4 *>(Cs + ((size_t)(t + 1) * R + (ok ? row : 0)) * kLH + uoff);  // c_t
-            const float4 *dhv = reinterpret_cast<const float4 *>(dh_heads + tr * kLH + uoff);
-            float4 *dgo = reinterpret_cast<float4 *>(dG + tr * kLG + uoff);
+            float4 *dgo = reinterpret_cast<float4 *>(dG + ((size_t)t * R + (ok ? row : 0)) * kLG + uoff);
             float *dgl = L.dg[rt] + c * kDGS + uoff;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 vi = ok ? ga[(0 + 16 * sub) / 4] : z, vf = ok ? ga[(128 + 16 * sub) / 4] : z;
-                const float4 vg = ok ? ga[(256 + 16 * sub) / 4] : z, vo = ok ? ga[(384 + 16 * sub) / 4] : z;
-                const float4 vcp = ok ? cpv[4 * sub] : z, vcn = ok ? cnv[4 * sub] : z, vdh = ok ? dhv[4 * sub] : z;
+                const float4 vi = in[rt][0 + sub], vf = in[rt][2 + sub], vg = in[rt][4 + sub], vo = in[rt][6 + sub];
+                const float4 vcp = in[rt][8 + sub], vcn = ccur[rt][sub], vdh = in[rt][10 + sub];
                 const float ai[4] = {vi.x, vi.y, vi.z, vi.w}, af[4] = {vf.x, vf.y, vf.z, vf.w};
                 const float ag[4] = {vg.x, vg.y, vg.z, vg.w}, ao[4] = {vo.x, vo.y, vo.z, vo.w};
                 const float acp[4] = {vcp.x, vcp.y, vcp.z, vcp.w}, acn[4] = {vcn.x, vcn.y, vcn.z, vcn.w};
@@ -201,10 +257,6 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
                     go[r] = d_o * ao[r] * (1.0f - ao[r]);
                     dc[rt][sub][r] = d_c * af[r];
                 }
-                bsum[0 + sub] += gi;
-                bsum[2 + sub] += gf;
-                bsum[4 + sub] += gg;
-                bsum[6 + sub] += go;
                 const float4 fi = make_float4(gi[0], gi[1], gi[2], gi[3]), ff = make_float4(gf[0], gf[1], gf[2], gf[3]);
                 const float4 fg = make_float4(gg[0], gg[1], gg[2], gg[3]), fo = make_float4(go[0], go[1], go[2], go[3]);
                 *reinterpret_cast<float4 *>(dgl + 0 + 16 * sub) = fi;
@@ -217,83 +269,55 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
                     dgo[(256 + 16 * sub) / 4] = fg;
                     dgo[(384 + 16 * sub) / 4] = fo;
                 }
+                ccur[rt][sub] = vcp;  // c_{t-1} is the next iteration's c_t
             }
         }
         __syncthreads();
-        // ---- [dxe | dh_{t-1}]^T = Wcat^T dG^T -----------------------------------------------------------------------
+        // ---- [dxe | dh_{t-1}]^T = Wcat^T dG^T, with next step's inputs streaming in ---------------------------------
         f32x4 acc[kSeqRT][4];
 #pragma unroll
         for (int rt = 0; rt < kSeqRT; ++rt)
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) acc[rt][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float4 abuf[4][4];
-#pragma unroll
-        for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) abuf[j][kt] = wp[(j * 4 + kt) * 64 + lane];
-        const float *brow = L.dg[0] + c * kDGS + 4 * g;
-#pragma unroll 1
-        for (int it = 0; it < 8; ++it) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cq = 4 * it + j;
-                if (cq + 3 < 32) {
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) abuf[(j + 3) & 3][kt] = wp[((cq + 3) * 4 + kt) * 64 + lane];
-                }
-                float4 b[kSeqRT];
-#pragma unroll
-                for (int rt = 0; rt < kSeqRT; ++rt) b[rt] = *reinterpret_cast<const float4 *>(brow + rt * kDGTile + 16 * cq);
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int kt = 0; kt < 4; ++kt) {
-                        const float4 av4 = abuf[j][kt];
-                        const float av = s4 == 0 ? av4.x : s4 == 1 ? av4.y : s4 == 2 ? av4.z : av4.w;
-#pragma unroll
-                        for (int rt = 0; rt < kSeqRT; ++rt) {
-                            const float bv = s4 == 0 ? b[rt].x : s4 == 1 ? b[rt].y : s4 == 2 ? b[rt].z : b[rt].w;
-                            acc[rt][kt] = mfma16(av, bv, acc[rt][kt]);
-                        }
-                    }
-            }
-        }
+        const bool more = t > 0;
+        stream_product<32, 4, kSeqRT, kDGTile, kBwdRing>(ws, L.dg[0] + c * kDGS + 4 * g, ring, acc, [&](int gq) {
+            if (gq < 4) fetch_x(gq, t);
+            else if (more && gq - 4 < kSeqRT * kIn) fetch(gq - 4, t - 1);
+            // gate bias gradient: row gq of the 32-row dG tile, two columns per thread (rows past R hold zeros)
+            const float *drow = L.dg[gq >> 4] + (gq & 15) * kDGS + threadIdx.x;
+            bcol0 += drow[0];
+            bcol1 += drow[256];
+        });
         // ---- outputs: dxe (with relu') to global, dh_{t-1} stays in registers ------------------------------------------
 #pragma unroll
         for (int rt = 0; rt < kSeqRT; ++rt) {
             const long long row = first + 16 * rt + c;
             const bool ok = row < R;
-            const size_t tr = (size_t)t * R + (ok ? row : 0);
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 dhrec[rt][sub] = acc[rt][2 + sub];
-                const float4 xv = ok ? *reinterpret_cast<const float4 *>(xe + tr * kLH + uoff + 16 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 x4 = xv[rt][sub];
                 f32x4 d = acc[rt][sub];
-                d[0] = xv.x > 0.0f ? d[0] : 0.0f;
-                d[1] = xv.y > 0.0f ? d[1] : 0.0f;
-                d[2] = xv.z > 0.0f ? d[2] : 0.0f;
-                d[3] = xv.w > 0.0f ? d[3] : 0.0f;
+                d[0] = x4.x > 0.0f ? d[0] : 0.0f;
+                d[1] = x4.y > 0.0f ? d[1] : 0.0f;
+                d[2] = x4.z > 0.0f ? d[2] : 0.0f;
+                d[3] = x4.w > 0.0f ? d[3] : 0.0f;
                 xsum[sub] += d;
-                if (ok) *reinterpret_cast<float4 *>(dxe + tr * kLH + uoff + 16 * sub) = make_float4(d[0], d[1], d[2], d[3]);
+                if (ok) *reinterpret_cast<float4 *>(dxe + ((size_t)t * R + row) * kLH + uoff + 16 * sub) = make_float4(d[0], d[1], d[2], d[3]);
             }
         }
         __syncthreads();  // every wave is done with the dG tile before the next step overwrites it
     }
 
-    // ---- per-workgroup column sums (bias gradients): reduce over the 16 row lanes, lane c == 0 writes ----------------------
+    // ---- per-workgroup column sums (bias gradients) ---------------------------------------------------------------------
     float *bp = bias_partial + (size_t)blockIdx.x * kBiasCols;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float s = row16_sum(bsum[ct][r]);
-            if (c == 0) bp[128 * (ct >> 1) + 16 * (ct & 1) + uoff + r] = s;
-        }
+    bp[threadIdx.x] = bcol0;
+    bp[threadIdx.x + 256] = bcol1;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float s = row16_sum(xsum[sub][r]);
+            const float s = row16_sum(xsum[sub][r]);  // over the 16 row lanes; lane c == 0 writes
             if (c == 0) bp[kLG + 16 * sub + uoff + r] = s;
         }
 }

@@ -99,56 +99,82 @@ __device__ __forceinline__ void lstm_encode(const LstmFrags<DP> &w, const float 
     }
 }
 
-// First groups of packed gate fragments of this wave; issued early so the L2 latency hides behind the previous phase.
-constexpr int kGatePrefetch = 3;  // groups in flight ahead of the MFMAs (one group = 8 x 1 KB per wave, 32*RT MFMAs)
-__device__ __forceinline__ void gates_prefetch(const float4 *__restrict__ wp, float4 (&abuf)[4][8]) {
-#pragma unroll
-    for (int j = 0; j < kGatePrefetch; ++j)
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) abuf[j][ct] = wp[(j * 8 + ct) * 64 + lane_id()];
+// ---------------------------------------------------------------------------------------------
+// Streaming product: acc[rt][a] += sum over G groups and 4 k-steps of  A(gq, a, s) * B(rt, gq, s)
+//   A: packed fragments streamed from L2, float4 (= 4 k-steps) per lane at wp[(gq*NA + a)*64 + lane];
+//   B: LDS tile rows, float4 at brow + rt*BT + 16*gq  (brow already includes the lane's row and 4g offset).
+// The weight stream runs D-1 groups ahead through a D-deep register ring (ring_prefetch issues the first D-1 groups; call
+// it early so their L2 latency hides behind the preceding phase).  `side(gq)` runs once per group right after that group's
+// weight loads are issued: callers spread their own global loads / stores over the product with it, which is how memory
+// phases overlap the MFMAs inside one instruction stream (gfx9 retires loads and stores through ONE in-order vmcnt, so a
+// burst of stores in front of the ring would stall it; a few per group, D-1 groups of slack, does not).
+// The loop is fully unrolled with a scheduling barrier per group so the compiler neither hoists the stream wholesale
+// (register blow-up) nor sinks the side operations.
+// ---------------------------------------------------------------------------------------------
+// One fragment of the packed stream: wave-uniform base (SGPR pair) + compile-time byte offset + 32-bit lane offset, so
+// the load uses the scalar-base addressing form and no per-load 64-bit address registers.
+struct Stream {
+    const char *base;  // wave-uniform
+    unsigned loff;     // lane * 16
+};
+// Call once per step: the lane offset is laundered through an empty asm so the 128 per-fragment addresses are formed
+// where they are used (scalar base + immediate) instead of being hoisted out of the step loop into 256 registers.
+__device__ __forceinline__ Stream stream_begin(const float4 *__restrict__ wp) {
+    unsigned loff = (unsigned)lane_id() * 16u;
+    asm volatile("" : "+v"(loff));
+    return {reinterpret_cast<const char *>(wp), loff};
+}
+__device__ __forceinline__ float4 stream_ld(const Stream &st, int frag) {
+    return *reinterpret_cast<const float4 *>(st.base + (size_t)frag * 1024 + st.loff);
 }
 
-// gates^T for RT row tiles (tile rt at xh + rt * kXHTile).  wp = this wave's packed fragments [16 kq][8 ct][64 lanes];
-// abuf holds groups 0..kGatePrefetch-1 on entry (gates_prefetch).  The group loop is kept rolled (4 groups per trip, a
-// 4-deep register ring) so the loads stay kGatePrefetch groups ahead instead of being hoisted wholesale.
-template <int RT>
-__device__ __forceinline__ void gates_product(const float4 *__restrict__ wp, const float *xh, float4 (&abuf)[4][8],
-                                              f32x4 (&acc)[RT][8]) {
-    const int lane = lane_id(), c = lane & 15, g = lane >> 4;
+template <int NA, int D>
+__device__ __forceinline__ void ring_prefetch(const Stream &wp, float4 (&ring)[D][NA]) {
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int j = 0; j < D - 1; ++j)
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct) acc[rt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float *brow = xh + c * kXHS + 4 * g;
-#pragma unroll 1
-    for (int it = 0; it < 4; ++it) {
+        for (int a = 0; a < NA; ++a) ring[j][a] = stream_ld(wp, j * NA + a);
+}
+
+__device__ __forceinline__ float f4_at(const float4 &v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+
+template <int G, int NA, int RT, int BT, int D, class Side>
+__device__ __forceinline__ void stream_product(const Stream &wp, const float *brow, float4 (&ring)[D][NA],
+                                               f32x4 (&acc)[RT][NA], Side &&side) {
+    static_assert((D & (D - 1)) == 0, "ring depth must be a power of two");
+    float4 bc[RT], bn[RT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kq = 4 * it + j;
-            if (kq + kGatePrefetch < 16) {
+    for (int rt = 0; rt < RT; ++rt) bc[rt] = *reinterpret_cast<const float4 *>(brow + rt * BT);
 #pragma unroll
-                for (int ct = 0; ct < 8; ++ct)
-                    abuf[(j + kGatePrefetch) & 3][ct] = wp[((kq + kGatePrefetch) * 8 + ct) * 64 + lane];
-            }
-            float4 b[RT];
+    for (int gq = 0; gq < G; ++gq) {
+        if (gq + D - 1 < G) {
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) b[rt] = *reinterpret_cast<const float4 *>(brow + rt * kXHTile + 16 * kq);
-            // s outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int ct = 0; ct < 8; ++ct) {
-                    const float4 a = abuf[j][ct];
-                    const float av = s4 == 0 ? a.x : s4 == 1 ? a.y : s4 == 2 ? a.z : a.w;
-#pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) {
-                        const float bv = s4 == 0 ? b[rt].x : s4 == 1 ? b[rt].y : s4 == 2 ? b[rt].z : b[rt].w;
-                        acc[rt][ct] = mfma16(av, bv, acc[rt][ct]);
-                    }
-                }
+            for (int a = 0; a < NA; ++a) ring[(gq + D - 1) & (D - 1)][a] = stream_ld(wp, (gq + D - 1) * NA + a);
         }
+        side(gq);
+        if (gq + 1 < G) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) bn[rt] = *reinterpret_cast<const float4 *>(brow + rt * BT + 16 * (gq + 1));
+        }
+        // s outermost: consecutive MFMAs hit different accumulators (no back-to-back dependent issue)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt][a] = mfma16(f4_at(ring[gq & (D - 1)][a], s4), f4_at(bc[rt], s4), acc[rt][a]);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) bc[rt] = bn[rt];
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+struct NoSide {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+
+constexpr int kGateRing = 4;  // ring depth of the forward gate product (8 fragments per group)
 
 // The cell update on one row tile's gate products (+ the bias from LDS, gbias[512]); cst = c state of units (sub, r).
 // Returns h' and leaves the activations (i, f, g, o) in acc (what the backward pass stores).
