@@ -290,6 +290,10 @@ int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch
 size_t pfa_gemm_tn_workspace_bytes(int32_t mo, int32_t no, int64_t k);
 int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t mo,
                     int32_t no, int64_t k, void *workspace, pfa_stream_t stream);
+/* Scatter into the flat gradient vector (MLP block + LSTM block layout): g16 [16][128] = dout^T h (rows < A ->
+ * decoder.weight, row A -> value_head.weight), bsum16 = column sums of dout (-> decoder.bias, value_head.bias), and
+ * d bias_hh_l0 = d bias_ih_l0 (already in place). */
+int pfa_lstm_finish_grads(float *grads, const pfa_mlp_dims *dims, const float *g16, const float *bsum16, pfa_stream_t stream);
 /* n f64 pieces of sum(g^2) over `count` gradient entries, for pfa_adam_clip_step's norm_partials. */
 int pfa_sumsq_partials(const float *grads, int64_t count, double *partials, int32_t n, pfa_stream_t stream);
 

@@ -13,6 +13,7 @@
 // A fused persistent LSTM kernel (gate weights streamed from L2 through MFMA fragments) is the planned replacement.
 #include "common.hpp"
 #include "lane_ops.hpp"
+#include "lstm_tile.hpp"
 #include "mlp_tile.hpp"
 #include "sampler.hpp"
 
@@ -317,18 +318,18 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
         stats_partial[(size_t)blockIdx.x * kHeadStatCols + 8 + (threadIdx.x - 16)] = s;
     }
 }
-// 256 threads: 8 strided chains per column (8 loss statistics + 16 head-output column sums), then a fixed-order tree.
-__global__ void __launch_bounds__(256) stats_final_kernel(const float *partial, int nblocks, float *out8, float *out16) {
-    __shared__ float sh[8][32];
+// 1024 threads: 32 strided chains per column (8 loss statistics + 16 head-output column sums), then a fixed-order tree.
+__global__ void __launch_bounds__(1024) stats_final_kernel(const float *partial, int nblocks, float *out8, float *out16) {
+    __shared__ float sh[32][32];
     const int i = threadIdx.x & 31, chain = threadIdx.x >> 5;
     float s = 0.0f;
     if (i < kHeadStatCols)
-        for (int b = chain; b < nblocks; b += 8) s += partial[(size_t)b * kHeadStatCols + i];
+        for (int b = chain; b < nblocks; b += 32) s += partial[(size_t)b * kHeadStatCols + i];
     sh[chain][i] = s;
     __syncthreads();
     if (threadIdx.x < kHeadStatCols) {
         float t = 0.0f;
-        for (int q = 0; q < 8; ++q) t += sh[q][threadIdx.x];
+        for (int q = 0; q < 32; ++q) t += sh[q][threadIdx.x];
         if (threadIdx.x < 8) out8[threadIdx.x] = t;
         else if (out16) out16[threadIdx.x - 8] = t;
     }
@@ -349,6 +350,19 @@ __global__ void __launch_bounds__(256) sumsq_partial_kernel(const float *g, long
     if (lane_id() == 0) sh[wave_id()] = s;
     __syncthreads();
     if (threadIdx.x == 0) partials[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// Scatter of the small gradient pieces into the flat gradient vector, one launch: heads product g16 [16][128] (rows < A
+// decoder.weight, row A value_head.weight), head bias sums [16], and d b_hh = d b_ih.
+__global__ void __launch_bounds__(256) lstm_finish_grads_kernel(float *grads, int dp, int a, const float *g16, const float *bsum16) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const MlpOffsets off = mlp_offsets(dp, a);
+    const LstmOffsets lo = lstm_offsets(dp, a);
+    if (idx < a * kLstmH) grads[off.w2 + idx] = g16[idx];
+    if (idx < kLstmH) grads[off.wv + idx] = g16[a * kLstmH + idx];
+    if (idx < a) grads[off.b2 + idx] = bsum16[idx];
+    if (idx == 0) grads[off.bv] = bsum16[a];
+    if (idx < kLG) grads[lo.b_hh + idx] = grads[lo.b_ih + idx];
 }
 
 static unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
@@ -462,7 +476,17 @@ extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, in
     hipLaunchKernelGGL(lstm_heads_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, mbs, map, *exp, params,
                        dims->obs_stride, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, dout, dh, partial);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8, head_bias_grad16);
+    hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8, head_bias_grad16);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_lstm_finish_grads(float *grads, const pfa_mlp_dims *dims, const float *g16, const float *bsum16,
+                                     pfa_stream_t stream) {
+    PFA_REQUIRE(grads && dims && g16 && bsum16, "lstm_finish_grads: null buffer");
+    PFA_REQUIRE(dims->num_actions >= 1 && dims->num_actions <= 15, "lstm_finish_grads: num_actions must be in 1..15");
+    hipLaunchKernelGGL(lstm_finish_grads_kernel, dim3(16 * kLstmH / 256), dim3(256), 0, (hipStream_t)stream, grads, dims->obs_stride,
+                       dims->num_actions, g16, bsum16);
     PFA_LAUNCH_CHECK();
     return 0;
 }

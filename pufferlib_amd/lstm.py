@@ -82,7 +82,7 @@ class Engine:
         self.g16 = torch.empty(16, H, device=dev)
         self.bwd_ws = torch.empty(L.pfa_lstm_seq_backward_workspace_bytes(R), dtype=torch.uint8, device=dev)
         self.norm_partials = torch.empty(256, dtype=torch.float64, device=dev)
-        self.state = None      # (h, c) carried from the previous minibatch of this epoch
+        self.state = None      # truthy once slot Th of Hs/Cs holds the previous minibatch's final state (this epoch)
 
     # -------------------------------------------------------------------------------------------- rollout
     def rollout(self, T, noise, key_seed, step0, env_offset):
@@ -129,21 +129,20 @@ class Engine:
         stream = _lib.stream_handle()
         fp, exp = self.fp, self.exp
         M, Th, R = self.M, self.Th, self.R
-        A = fp.num_actions
         # ---- forward -----------------------------------------------------------------------------------------------
         _lib.check(L.pfa_gather_obs_time_major(C.byref(exp.c), B, mb, C.byref(hp), fp.obs_stride, _lib.ptr(self.obs_tm), stream),
                    'gather_obs')
         if mb == 0 or self.state is None:      # lstm_state = None at the start of every epoch (clean_pufferl.py:176)
             self.Hs[0].zero_()
             self.Cs[0].zero_()
-        else:                                   # carried across minibatches, detached (clean_pufferl.py:188-191)
-            self.Hs[0].copy_(self.state[0])
-            self.Cs[0].copy_(self.state[1])
+        else:                                   # carried across minibatches, detached (clean_pufferl.py:188-191):
+            self.Hs[0].copy_(self.Hs[Th])       # the previous minibatch's final state is still in slot Th
+            self.Cs[0].copy_(self.Cs[Th])
         pack_gates(fp, self.wpack)              # the weights changed in the previous optimizer step
         _lib.check(L.pfa_lstm_seq_forward(_lib.ptr(self.obs_tm), R, Th, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(self.wpack),
                                           _lib.ptr(self.xe), _lib.ptr(self.gates), _lib.ptr(self.Hs), _lib.ptr(self.Cs), stream),
                    'lstm_seq_forward')
-        self.state = (self.Hs[Th].clone(), self.Cs[Th].clone())
+        self.state = True
         h_all = self.Hs[1:].view(M, H)
         # ---- heads + loss ----------------------------------------------------------------------------------------
         loss_sums = grads[fp.count:fp.count + 8]
@@ -157,17 +156,14 @@ class Engine:
                                            _lib.ptr(self.wpack_bwd), _lib.ptr(self.dG), _lib.ptr(self.dxe),
                                            _lib.ptr(gv['recurrent.bias_ih_l0']), _lib.ptr(gv['encoder.bias']), _lib.ptr(self.bwd_ws),
                                            stream), 'lstm_seq_backward')
-        gv['recurrent.bias_hh_l0'].copy_(gv['recurrent.bias_ih_l0'])
         dG = self.dG.view(M, 4 * H)
         gW1p = fp.encoder_weight_padded(grads[:fp.count])
         self._gemm_tn(self.dxe, self.obs_tm, gW1p)
         self._gemm_tn(dG, self.xe, gv['recurrent.weight_ih_l0'])
         self._gemm_tn(dG, self.Hs[:Th].view(M, H), gv['recurrent.weight_hh_l0'])
-        g16 = self._gemm_tn(self.dout, h_all, self.g16)             # [16][128]: rows < A decoder, row A value head
-        gv['decoder.weight'].copy_(g16[:A])
-        gv['value_head.weight'].copy_(g16[A:A + 1])
-        gv['decoder.bias'].copy_(self.bsum16[:A])
-        gv['value_head.bias'].copy_(self.bsum16[A:A + 1])
+        self._gemm_tn(self.dout, h_all, self.g16)                   # [16][128]: rows < A decoder, row A value head
+        _lib.check(L.pfa_lstm_finish_grads(_lib.ptr(grads), C.byref(fp.dims), _lib.ptr(self.g16), _lib.ptr(self.bsum16), stream),
+                   'lstm_finish_grads')
 
     def _gemm_tn(self, a, b, out):
         """out[mo][no] = a[k][mo]^T b[k][no] — the weight-gradient contraction over the minibatch rows (csrc/gemm.hip)."""
