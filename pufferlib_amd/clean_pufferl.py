@@ -328,10 +328,6 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
-    if data.lstm_engine is not None:
-        with profile.eval_forward:       # recurrent policy: one kernel sequence per step, still no host sync
-            data.lstm_engine.rollout(T, noise, policy.noise_seed, policy.noise_step, vecenv.env_offset)
-        return _finish_evaluate(data, N, T)
     with profile.env:
         main = torch.cuda.current_stream()
         if data.tape_event is not None:
@@ -339,12 +335,15 @@ def evaluate(data):
         vecenv.ensure_tape(T)                    # no-op when the prefetch covered it
         start_point = torch.cuda.Event()
         start_point.record(main)                 # everything before this rollout (incl. the rollout before it) is done
-    with profile.eval_forward:
-        _lib.check(L.pfa_rollout_mlp_squared(
-            _lib.ptr(vecenv.state), C.byref(vecenv.cfg), _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(experience.c),
-            _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
-            _lib.ptr(vecenv.terminals_u8), _lib.ptr(vecenv.truncations_u8), _lib.ptr(vecenv.masks_u8),
-            _lib.stream_handle()), 'rollout')
+    with profile.eval_forward:           # one persistent kernel for all T steps, either policy
+        if data.lstm_engine is not None:
+            data.lstm_engine.rollout(T, noise, policy.noise_seed, policy.noise_step, vecenv.env_offset)
+        else:
+            _lib.check(L.pfa_rollout_mlp_squared(
+                _lib.ptr(vecenv.state), C.byref(vecenv.cfg), _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(experience.c),
+                _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
+                _lib.ptr(vecenv.terminals_u8), _lib.ptr(vecenv.truncations_u8), _lib.ptr(vecenv.masks_u8),
+                _lib.stream_handle()), 'rollout')
     with profile.env:
         vecenv.sends += T
         # The tape does not depend on actions: draw the NEXT rollout's reset rounds on the side stream while THIS

@@ -86,19 +86,18 @@ class Engine:
 
     # -------------------------------------------------------------------------------------------- rollout
     def rollout(self, T, noise, key_seed, step0, env_offset):
-        """clean_pufferl.evaluate's loop for a Squared vecenv: one persistent kernel (csrc/lstm_fused.hip)."""
+        """clean_pufferl.evaluate's loop for a Squared vecenv: one persistent kernel (csrc/lstm_fused.hip).  The caller has
+        made sure the reset-target tape holds the rounds of these T sends and accounts for them afterwards."""
         L = _lib.lib()
         vec, exp, fp = self.vec, self.exp, self.fp
         assert T == exp.horizon
         pack_gates(fp, self.wpack)
-        vec.ensure_tape(T)
         key = _lib.NoiseKey(key_seed, step0)
         _lib.check(L.pfa_rollout_lstm_squared(_lib.ptr(vec.state), C.byref(vec.cfg), _lib.ptr(fp.flat), C.byref(fp.dims),
                                               _lib.ptr(self.wpack), _lib.ptr(self.lstm_h), _lib.ptr(self.lstm_c), C.byref(exp.c),
                                               _lib.ptr(noise), C.byref(key), env_offset, _lib.ptr(vec.obs_buf),
                                               _lib.ptr(vec.rewards), _lib.ptr(vec.terminals_u8), _lib.ptr(vec.truncations_u8),
                                               _lib.ptr(vec.masks_u8), _lib.stream_handle()), 'rollout_lstm_squared')
-        vec.sends += T
 
     def rollout_stepwise(self, T, noise, key_seed, step0, env_offset):
         """The same rollout through the protocol-level pieces (policy_step / store / send), one launch sequence per step —
@@ -121,6 +120,7 @@ class Engine:
                                           _lib.ptr(vec.rewards), _lib.ptr(vec.terminals_u8), _lib.ptr(vec.truncations_u8),
                                           _lib.ptr(vec.masks_u8), stream), 'send')
             vec.sends += 1
+        vec.sends -= T      # the caller (clean_pufferl.evaluate) accounts for the T sends of a rollout
 
     # -------------------------------------------------------------------------------------------- update
     def update(self, mb, hp, adv_stats, global_mb_rows, grads, B):
