@@ -272,6 +272,15 @@ int pfa_lstm_seq_backward(const float *gates_act, const float *cs, const float *
 int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_envs, int32_t obs_stride, const float *obs,
                    const float *rewards, const uint8_t *terminals, const int64_t *actions, const float *logprob,
                    const float *value, pfa_stream_t stream);
+/* Experience.store for rows arriving in ANY order from a host vecenv (clean_pufferl.py:436-450), fused with
+ * sort_training_data (:452-464): batch row i (mask[i] != 0; mask nullable = all) of env slot env_ids[i] (nullable = i; unique
+ * within a call; 0 <= id < num_slots) is written to its sorted position env_id*T + counters[env_id]++ of the env-major
+ * buffers.  counters: int32 [num_slots] rows held per env (zero it when a rollout starts); stored_dropped: int32 [2]
+ * running totals of rows stored / rows dropped because their env already held T rows or the id was out of range. */
+int pfa_store_rows(const pfa_experience *exp, int32_t rows, int32_t num_slots, int32_t obs_stride, const float *obs,
+                   const float *rewards, const uint8_t *dones, const int64_t *actions, const float *logprob,
+                   const float *value, const int32_t *env_ids, const uint8_t *mask, int32_t *counters,
+                   int32_t *stored_dropped, pfa_stream_t stream);
 /* Observation rows of minibatch mb in TIME-MAJOR order (row t*R + k = segment mb + k*nmb, step t). */
 int pfa_gather_obs_time_major(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const pfa_ppo_hparams *hp,
                               int32_t obs_stride, float *out, pfa_stream_t stream);

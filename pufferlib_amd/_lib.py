@@ -122,6 +122,7 @@ _SIGNATURES = {
     'pfa_colsum': (C.c_int, [P, C.c_int64, C.c_int32, C.c_int64, P, C.c_int32, P, P]),
     'pfa_lstm_heads_sample': (C.c_int, [P, C.c_int64, P, C.POINTER(MlpDims), P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
     'pfa_store_step': (C.c_int, [C.POINTER(Experience), C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P]),
+    'pfa_store_rows': (C.c_int, [C.POINTER(Experience), C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P, P, P, P, P]),
     'pfa_gather_obs_time_major': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, C.POINTER(PpoHparams), C.c_int32, P, P]),
     'pfa_lstm_heads_loss_workspace_bytes': (C.c_size_t, []),
     'pfa_lstm_heads_loss': (C.c_int, [P, C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),

@@ -247,9 +247,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     n_params = sum(p.numel() for p in policy.parameters())
     msg = f'Model Size: {n_params} parameters'
 
-    if not isinstance(vecenv, Squared):
-        raise NotImplementedError('pufferlib_amd.clean_pufferl drives pufferlib_amd.vector.Squared vecenvs '
-                                  '(device-resident envs); CPU backends are a later row of SURVEY.md §8f')
+    host_mode = not isinstance(vecenv, Squared)       # any backend speaking the reference's recv/send protocol on the host
     if not isinstance(policy, (Policy, RecurrentPolicy)):
         from .models import find_lstm
         if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
@@ -258,11 +256,21 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
             policy = Policy(policy, seed=config.seed)     # e.g. the reference's cleanrl.Policy(models.Default)
     recurrent = isinstance(policy, RecurrentPolicy)
     dist, rank, world = _dist()
-    device = vecenv.device
-    vecenv.info_mode = 'lazy'
-    vecenv.env_offset = rank * vecenv.num_agents
-    vecenv.async_reset(config.seed + vecenv.env_offset)   # clean_pufferl.py:39; env i of rank r gets seed + r*N + i
-    fp = policy.adopt(vecenv.obs_stride, device)
+    env_offset = rank * vecenv.num_agents
+    host_bridge = None
+    if host_mode:
+        from . import hostpath
+        _lib.require_gpu()
+        device = torch.device('cuda', torch.cuda.current_device())
+        obs_stride = hostpath.obs_stride_for(int(np.prod(vecenv.single_observation_space.shape)))
+        host_bridge = hostpath.HostBridge(vecenv, obs_stride, device)
+    else:
+        device = vecenv.device
+        obs_stride = vecenv.obs_stride
+        vecenv.info_mode = 'lazy'
+        vecenv.env_offset = env_offset
+    vecenv.async_reset(config.seed + env_offset)          # clean_pufferl.py:39; env i of rank r gets seed + r*N + i
+    fp = policy.adopt(obs_stride, device)
     native_dp = False
     if world > 1:
         dist.broadcast(fp.flat, src=0)
@@ -276,7 +284,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         nmb_ = config.batch_size // (_cfg(config, 'minibatch_size', None) or config.batch_size)
         pdist.check_partition(total_agents, config.batch_size // total_agents, config.bptt_horizon, nmb_)
     experience = Experience(config.batch_size, config.bptt_horizon, _cfg(config, 'minibatch_size', None),
-                            vecenv.obs_stride, total_agents, device)
+                            obs_stride, total_agents, device)
     optimizer = HipAdam(fp, lr=config.learning_rate, eps=1e-5)
     lstm_engine = None
     if recurrent:
@@ -294,6 +302,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         msg=msg, last_log_time=0, utilization=utilization,
         # engine state
         flat_params=fp, rank=rank, world_size=world, native_dp=native_dp, lstm_engine=lstm_engine,
+        env_offset=env_offset, host_bridge=host_bridge,
         workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
         grads=torch.zeros(fp.count + 8, dtype=torch.float32, device=device),
         adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
@@ -317,6 +326,9 @@ def evaluate(data):
     config, profile, experience, vecenv = data.config, data.profile, data.experience, data.vecenv
     L = _lib.lib()
     fp = data.flat_params
+    if data.host_bridge is not None:      # host vecenv: the reference's recv/forward/store/send loop (hostpath.py)
+        from . import hostpath
+        return hostpath.evaluate(data)
     T, N = experience.horizon, vecenv.num_agents
     with profile.eval_misc:
         policy = data.policy

@@ -174,6 +174,56 @@ __global__ void __launch_bounds__(256) store_step_kernel(pfa_experience ex, int 
     }
 }
 
+// Experience.store for ARBITRARY arrival order (clean_pufferl.py:436-450) fused with sort_training_data (:452-464): the
+// reference appends rows as they arrive and later sorts them by (env_id, step); here row i of the batch goes straight to
+// its sorted position env_id*T + (rows this env has contributed so far).  16 rows per workgroup; rows with mask == 0
+// are skipped, rows of an env that already holds T rows are dropped and counted.  env_ids must be unique within a call.
+__global__ void __launch_bounds__(256) store_rows_kernel(pfa_experience ex, int rows, int num_slots, int dp, const float *obs,
+                                                        const float *rewards, const uint8_t *dones, const long long *actions,
+                                                        const float *logprob, const float *value, const int *env_ids,
+                                                        const uint8_t *mask, int *counters, int *stored_dropped) {
+    __shared__ int s_t[16], s_slot[16];
+    const int r0 = blockIdx.x * 16;
+    if (threadIdx.x < 16) {
+        const int i = r0 + threadIdx.x;
+        int t = -1, slot = 0;
+        if (i < rows && (!mask || mask[i])) {
+            slot = env_ids ? env_ids[i] : i;
+            if (slot >= 0 && slot < num_slots) {
+                t = counters[slot];
+                if (t >= ex.horizon_T) {
+                    t = -1;
+                    atomicAdd(stored_dropped + 1, 1);
+                }
+            } else {
+                atomicAdd(stored_dropped + 1, 1);
+            }
+        }
+        s_t[threadIdx.x] = t;
+        s_slot[threadIdx.x] = slot;
+    }
+    __syncthreads();
+    const int V = dp / 4;
+    for (int idx = threadIdx.x; idx < 16 * V; idx += 256) {
+        const int rl = idx / V, c4 = idx - rl * V;
+        const int t = s_t[rl];
+        if (t < 0) continue;
+        *reinterpret_cast<float4 *>(ex.obs + ((size_t)s_slot[rl] * ex.horizon_T + t) * dp + 4 * c4) =
+            *reinterpret_cast<const float4 *>(obs + (size_t)(r0 + rl) * dp + 4 * c4);
+    }
+    if (threadIdx.x < 16 && s_t[threadIdx.x] >= 0) {
+        const int i = r0 + threadIdx.x, slot = s_slot[threadIdx.x], t = s_t[threadIdx.x];
+        const size_t row = (size_t)slot * ex.horizon_T + t;
+        ex.rewards[row] = rewards[i];
+        ex.dones[row] = dones[i] ? 1.0f : 0.0f;
+        ex.actions[row] = (int)actions[i];
+        ex.logprobs[row] = logprob[i];
+        ex.values[row] = value[i];
+        counters[slot] = t + 1;
+        atomicAdd(stored_dropped, 1);
+    }
+}
+
 // Rows of minibatch `mb` in TIME-MAJOR order: q = t*R + k  ->  flat env-major row (mb + k*nmb)*Th + t
 struct TimeMajorMap {
     int mb, nmb, horizon;
@@ -445,6 +495,20 @@ extern "C" int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_
     hipLaunchKernelGGL(store_step_kernel, dim3(blocks_for((long long)num_envs * (obs_stride / 4))), dim3(256), 0,
                        (hipStream_t)stream, *exp, (int)t, (int)num_envs, (int)obs_stride, obs, rewards, terminals,
                        (const long long *)actions, logprob, value);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_store_rows(const pfa_experience *exp, int32_t rows, int32_t num_slots, int32_t obs_stride, const float *obs,
+                              const float *rewards, const uint8_t *dones, const int64_t *actions, const float *logprob,
+                              const float *value, const int32_t *env_ids, const uint8_t *mask, int32_t *counters,
+                              int32_t *stored_dropped, pfa_stream_t stream) {
+    PFA_REQUIRE(exp && obs && rewards && dones && actions && logprob && value && counters && stored_dropped, "store_rows: null buffer");
+    PFA_REQUIRE(rows >= 0 && num_slots >= 1 && obs_stride >= 4 && obs_stride % 4 == 0 && exp->horizon_T >= 1, "store_rows: bad arguments");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(store_rows_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, *exp, (int)rows,
+                       (int)num_slots, (int)obs_stride, obs, rewards, dones, (const long long *)actions, logprob, value, env_ids, mask,
+                       counters, stored_dropped);
     PFA_LAUNCH_CHECK();
     return 0;
 }

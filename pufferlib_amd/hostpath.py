@@ -1,0 +1,173 @@
+"""Rollout against a HOST vecenv: any backend that speaks the reference's protocol —
+``pufferlib.vector.Serial`` / ``Multiprocessing`` over arbitrary CPU envs, async EnvPool batches — feeds the device-resident
+trainer.  The loop is the reference's (clean_pufferl.py:84-124):
+
+    recv() -> [pinned staging, async H2D] -> policy forward + sample on device -> Experience.store on device
+           -> actions D2H (the one sync per step, the host env needs them) -> send()
+
+What differs from the reference: ``Experience.store`` + ``sort_training_data`` (clean_pufferl.py:436-464) are one kernel
+(``pfa_store_rows``): every arriving row is written straight to its sorted position ``env_id*T + rows_so_far[env_id]`` of the
+env-major device buffers, so out-of-order ``env_id`` batches need no sort and the update path is the same as for the
+device-resident envs.  Rows of a batch are ordered by ``env_id`` before they are staged; the reference's backends hand out
+contiguous ``env_id`` slices (vector.py:158-162, :395-398), for which the Philox noise row of an agent is its global index —
+the same stream the fused device rollout uses, so both paths sample identical actions.
+"""
+import ctypes as C
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+from . import _lib, utils
+
+_STRIDES = (16, 32, 64, 96, 128)
+
+
+def obs_stride_for(obs_dim):
+    for s in _STRIDES:
+        if obs_dim <= s:
+            return s
+    raise NotImplementedError(f'flat observation of {obs_dim} floats: the MLP/LSTM kernels take rows of up to 128 floats')
+
+
+class HostBridge:
+    """Pinned staging buffers of one host vecenv and their device mirrors."""
+
+    def __init__(self, vecenv, obs_stride, device):
+        space = vecenv.single_observation_space
+        self.obs_dim = int(np.prod(space.shape))
+        self.obs_stride = obs_stride
+        self.total_agents = int(vecenv.num_agents)
+        n = int(getattr(vecenv, 'agents_per_batch', self.total_agents))
+        self.max_rows = n
+        pin = dict(pin_memory=True)
+        self.obs_pin = torch.zeros(n, obs_stride, dtype=torch.float32, **pin)
+        self.rew_pin = torch.zeros(n, dtype=torch.float32, **pin)
+        self.done_pin = torch.zeros(n, dtype=torch.uint8, **pin)
+        self.mask_pin = torch.zeros(n, dtype=torch.uint8, **pin)
+        self.ids_pin = torch.zeros(n, dtype=torch.int32, **pin)
+        self.act_pin = torch.zeros(n, dtype=torch.int64, **pin)
+        self.obs = torch.zeros(n, obs_stride, dtype=torch.float32, device=device)
+        self.rew = torch.zeros(n, dtype=torch.float32, device=device)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=device)
+        self.mask = torch.zeros(n, dtype=torch.uint8, device=device)
+        self.ids = torch.zeros(n, dtype=torch.int32, device=device)
+        self.ids64 = torch.zeros(n, dtype=torch.int64, device=device)
+        self.counters = torch.zeros(self.total_agents, dtype=torch.int32, device=device)
+        self.stored_dropped = torch.zeros(2, dtype=torch.int32, device=device)
+
+    def upload(self, o, r, d, env_id, mask):
+        """Stage one recv() (numpy arrays, any row order) and start its H2D copies.  Returns (rows, order) with
+        ``order`` the permutation that sorts the rows by env_id (None when they already are)."""
+        env_id = np.asarray(env_id)
+        n = len(env_id)
+        if n > self.max_rows:
+            raise ValueError(f'recv() returned {n} rows, vecenv advertised {self.max_rows} agents per batch')
+        order = None
+        if n > 1 and np.any(env_id[1:] < env_id[:-1]):
+            order = np.argsort(env_id, kind='stable')
+        pick = (lambda x: x[order]) if order is not None else (lambda x: x)
+        flat = np.asarray(o).reshape(n, -1)
+        if flat.shape[1] != self.obs_dim:
+            raise ValueError(f'observation rows of {flat.shape[1]} values, expected {self.obs_dim}')
+        self.obs_pin.numpy()[:n, :self.obs_dim] = pick(flat)          # .float() of models.Default (models.py:50)
+        self.rew_pin.numpy()[:n] = pick(np.asarray(r))
+        self.done_pin.numpy()[:n] = pick(np.asarray(d)).astype(np.uint8)
+        self.mask_pin.numpy()[:n] = pick(np.asarray(mask)).astype(np.uint8)
+        self.ids_pin.numpy()[:n] = pick(env_id)
+        for dev, host in ((self.obs, self.obs_pin), (self.rew, self.rew_pin), (self.done, self.done_pin),
+                          (self.mask, self.mask_pin), (self.ids, self.ids_pin)):
+            dev[:n].copy_(host[:n], non_blocking=True)
+        return n, order
+
+    def download_actions(self, actions_dev, n, order):
+        """Device actions (env_id order) -> host numpy in the row order recv() used.  Synchronises."""
+        self.act_pin[:n].copy_(actions_dev[:n], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        a = self.act_pin.numpy()[:n]
+        if order is None:
+            return a.copy()
+        out = np.empty_like(a)
+        out[order] = a
+        return out
+
+
+def evaluate(data):
+    """clean_pufferl.evaluate (clean_pufferl.py:76-154) for a host vecenv."""
+    config, profile, experience, vecenv, policy = data.config, data.profile, data.experience, data.vecenv, data.policy
+    L = _lib.lib()
+    fp, bridge = data.flat_params, data.host_bridge
+    A = fp.num_actions
+    stream = _lib.stream_handle()
+    infos = defaultdict(list)
+    bridge.counters.zero_()
+    bridge.stored_dropped.zero_()
+    sent_rows = 0
+    recvs = 0
+    eng = data.lstm_engine
+    while sent_rows < experience.batch_size:                       # `while not experience.full` (clean_pufferl.py:84)
+        with profile.env:
+            o, r, d, t, info, env_id, mask = vecenv.recv()
+        with profile.eval_misc:
+            n, order = bridge.upload(o, r, d, env_id, mask)
+            nmask = int(np.sum(mask))
+            data.global_step += nmask * data.world_size             # clean_pufferl.py:90, all ranks
+        with profile.eval_forward:
+            key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
+            row0 = data.env_offset + int(bridge.ids_pin[0]) if n else data.env_offset
+            noise = None
+            if data.noise is not None:                               # explicit Exp(1) draws [recv][agent][A] (parity tests)
+                bridge.ids64[:n].copy_(bridge.ids[:n])
+                noise = data.noise[recvs].to(device=bridge.obs.device, dtype=torch.float32).index_select(0, bridge.ids64[:n]).contiguous()
+            actions = torch.empty(n, dtype=torch.int64, device=bridge.obs.device)
+            logprob = torch.empty(n, device=bridge.obs.device)
+            value = torch.empty(n, device=bridge.obs.device)
+            if eng is None:
+                _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(bridge.obs), n, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(noise),
+                                                    C.byref(key), row0, _lib.ptr(actions), _lib.ptr(logprob), None, _lib.ptr(value),
+                                                    stream), 'forward_sample')
+            else:                                                    # state rows of these agents (clean_pufferl.py:100-105)
+                from . import lstm as plstm
+                bridge.ids64[:n].copy_(bridge.ids[:n])
+                idx = bridge.ids64[:n]
+                h, c = eng.lstm_h[0].index_select(0, idx), eng.lstm_c[0].index_select(0, idx)
+                if recvs == 0:
+                    plstm.pack_gates(fp, eng.wpack)
+                _lib.check(L.pfa_lstm_policy_step(_lib.ptr(bridge.obs), n, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(eng.wpack),
+                                                  _lib.ptr(h), _lib.ptr(c), _lib.ptr(noise), C.byref(key), row0, _lib.ptr(actions),
+                                                  _lib.ptr(logprob), None, _lib.ptr(value), stream), 'lstm_policy_step')
+                eng.lstm_h[0].index_copy_(0, idx, h)
+                eng.lstm_c[0].index_copy_(0, idx, c)
+            policy.noise_step += 1
+        with profile.eval_misc:
+            _lib.check(L.pfa_store_rows(C.byref(experience.c), n, bridge.total_agents, fp.obs_stride, _lib.ptr(bridge.obs),
+                                        _lib.ptr(bridge.rew), _lib.ptr(bridge.done), _lib.ptr(actions), _lib.ptr(logprob),
+                                        _lib.ptr(value), _lib.ptr(bridge.ids), _lib.ptr(bridge.mask), _lib.ptr(bridge.counters),
+                                        _lib.ptr(bridge.stored_dropped), stream), 'store_rows')
+            actions_np = bridge.download_actions(actions, n, order)
+            sent_rows += nmask
+            recvs += 1
+            for i in info:                                           # clean_pufferl.py:110-113
+                for k, v in utils.unroll_nested_dict(i):
+                    infos[k].append(v)
+        with profile.env:
+            vecenv.send(actions_np)
+
+    with profile.eval_misc:
+        stored, dropped = (int(x) for x in bridge.stored_dropped.cpu().numpy())
+        if stored != experience.batch_size or dropped:
+            raise RuntimeError(f'host rollout stored {stored} of {experience.batch_size} rows and dropped {dropped}: every agent '
+                               'must contribute batch_size / num_agents rows per rollout (env-major experience layout)')
+        data.noise = None
+        experience.ptr = experience.batch_size
+        experience.step = experience.horizon
+        data.stats = {}
+        for k, v in infos.items():                                   # clean_pufferl.py:127-137
+            if '_map' in k and data.wandb is not None:
+                data.stats[f'Media/{k}'] = data.wandb.Image(v[0])
+                continue
+            try:
+                data.stats[k] = np.mean(v)
+            except Exception:
+                continue
+    return data.stats, infos

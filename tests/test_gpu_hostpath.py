@@ -1,0 +1,125 @@
+"""Host-vecenv rollout path (pufferlib_amd/hostpath.py): a CPU vecenv speaking the reference's
+recv/send protocol feeds the device trainer.  With the C oracle's SquaredSerial as that CPU vecenv the whole
+create -> evaluate -> train loop must reproduce the device-resident Squared path bit for bit (same envs, same policy kernel,
+same Philox rows), whatever order the rows of a batch arrive in."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+pytestmark = pytest.mark.gpu
+
+HP = [2.5e-3, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+
+
+def _run(kind, recurrent, n=48, horizon=16, iters=2, order='natural'):
+    from pufferlib_amd import clean_pufferl, cleanrl, models, vector
+    from host_vecenv import HostSquared
+    from test_gpu_ppo import _config
+    torch.manual_seed(3)
+    if kind == 'device':
+        vec = vector.make(vector.make_squared, num_envs=n, backend=vector.Squared)
+    else:
+        vec = HostSquared(n, order=order)
+    base = models.Default(vec.driver_env)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base)) if recurrent else cleanrl.Policy(base)
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 8, 2, n * horizon * 8, HP, seed=11), vec, pol)
+    out = []
+    for _ in range(iters):
+        stats, _ = clean_pufferl.evaluate(data)
+        e = data.experience
+        snap = [x.clone() for x in (e.obs, e.actions, e.logprobs, e.values, e.rewards, e.dones)]
+        clean_pufferl.train(data)
+        out.append((snap, dict(stats), data.flat_params.flat.clone(), dict(data.losses), data.global_step))
+    return out
+
+
+@pytest.mark.parametrize('recurrent', [False, True])
+@pytest.mark.parametrize('order', ['natural', 'reversed', 'shuffled'])
+def test_host_vecenv_rollout_equals_device_resident_path(recurrent, order):
+    dev = _run('device', recurrent)
+    host = _run('host', recurrent, order=order)
+    for (sd, std, wd, ld, gd), (sh, sth, wh, lh, gh) in zip(dev, host):
+        for x, y in zip(sd, sh):
+            assert torch.equal(x, y)
+        assert gd == gh
+        assert set(std) == set(sth)
+        for k in std:
+            assert abs(std[k] - sth[k]) < 1e-12, k
+        assert torch.equal(wd, wh)
+        for k in ld:
+            assert ld[k] == lh[k] or (ld[k] != ld[k] and lh[k] != lh[k]), k
+
+
+def test_store_rows_places_rows_by_env_and_counts_drops():
+    from pufferlib_amd import _lib, clean_pufferl
+    L = _lib.lib()
+    N, T, DP = 5, 3, 16
+    exp = clean_pufferl.Experience(N * T, T, None, DP, N, 'cuda')
+    counters = torch.zeros(N, dtype=torch.int32, device='cuda')
+    sd = torch.zeros(2, dtype=torch.int32, device='cuda')
+    rng = np.random.RandomState(0)
+    want_obs = np.zeros((N, T, DP), np.float32)
+    held = [0] * N
+    for step in range(T + 1):                                        # one step too many: every row of it must be dropped
+        ids = rng.permutation(N).astype(np.int32)
+        mask = np.ones(N, np.uint8)
+        if step == 0:
+            mask[2] = 0                                               # masked row: not stored, its env lags one step behind
+        obs = rng.randn(N, DP).astype(np.float32)
+        t = lambda a, dt=None: torch.as_tensor(a if dt is None else a.astype(dt)).cuda()
+        rew, done = rng.randn(N).astype(np.float32), (rng.rand(N) < 0.5).astype(np.uint8)
+        act, lp, val = rng.randint(0, 8, N).astype(np.int64), rng.randn(N).astype(np.float32), rng.randn(N).astype(np.float32)
+        args = [t(obs), t(rew), t(done), t(act), t(lp), t(val), t(ids), t(mask)]
+        _lib.check(L.pfa_store_rows(C.byref(exp.c), N, N, DP, *[_lib.ptr(a) for a in args], _lib.ptr(counters), _lib.ptr(sd), None),
+                   'store_rows')
+        torch.cuda.synchronize()
+        for i in range(N):
+            e = int(ids[i])
+            if mask[i] and held[e] < T:
+                want_obs[e, held[e]] = obs[i]
+                held[e] += 1
+    assert np.array_equal(exp.obs.view(N, T, DP).cpu().numpy(), want_obs)
+    assert counters.cpu().tolist() == held == [T] * N
+    stored, dropped = sd.cpu().tolist()
+    assert stored == N * T and dropped == N - 1                       # the lagging env used the extra step, the others were dropped
+
+
+def test_create_rejects_wide_observations():
+    from pufferlib_amd import hostpath
+    assert hostpath.obs_stride_for(49) == 64 and hostpath.obs_stride_for(128) == 128
+    with pytest.raises(NotImplementedError):
+        hostpath.obs_stride_for(129)
+
+
+def test_host_path_throughput_report(capsys):
+    """Not a pass/fail bound: prints the end-to-end rate of the host path (C oracle envs on one host core + PCIe both ways
+    per step + device policy/update) so DESIGN.md can quote it next to the device-resident rate."""
+    import time
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from host_vecenv import HostSquared
+    from test_gpu_ppo import _config
+    n, horizon = 4096, 32
+    vec = HostSquared(n)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 4, 16, 2, n * horizon * 64, HP, seed=1), vec, pol)
+    for _ in range(2):
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 5
+    for _ in range(iters):
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    p = data.profile
+    with capsys.disabled():
+        print(f'\n[host path] {n} envs x {horizon} steps: {iters * n * horizon / dt / 1e6:.2f} M env steps/s '
+              f'(env {p.env.elapsed:.2f}s, forward {p.eval_forward.elapsed:.2f}s, misc {p.eval_misc.elapsed:.2f}s of {dt:.2f}s)')
+    assert data.global_step == (iters + 2) * n * horizon
