@@ -1,0 +1,70 @@
+"""Host-side logic that needs no GPU: flat parameter layout vs the native offsets, obs stride selection, experience
+shape checks, the rollout noise-row contract of the host path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+
+def _policy(recurrent):
+    from pufferlib_amd import cleanrl, models, vector
+    env = vector.make_squared()
+    base = models.Default(env)
+    return cleanrl.RecurrentPolicy(models.LSTMWrapper(env, base)) if recurrent else cleanrl.Policy(base)
+
+
+@pytest.mark.parametrize('recurrent', [False, True])
+def test_flat_params_layout_matches_native_offsets(recurrent):
+    from pufferlib_amd import _lib
+    from pufferlib_amd.models import FlatParams
+    pol = _policy(recurrent)
+    before = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+    fp = FlatParams(pol.policy, 64, 'cpu')
+    L = _lib.lib()
+    n_native = L.pfa_lstm_param_count(C.byref(fp.dims)) if recurrent else L.pfa_mlp_param_count(C.byref(fp.dims))
+    assert fp.count == n_native == fp.flat.numel()
+    # the module's parameters are now views of the flat buffer, values unchanged, pad columns zero
+    for k, v in pol.state_dict().items():
+        assert torch.equal(v, before[k]), k
+        assert v.untyped_storage().data_ptr() == fp.flat.untyped_storage().data_ptr(), k
+    w1p = fp.encoder_weight_padded()
+    assert w1p.shape == (128, 64) and torch.count_nonzero(w1p[:, 49:]) == 0
+    # writing through the flat buffer is visible through the module (what the Adam kernel relies on)
+    fp.flat.add_(1.0)
+    for k, v in pol.state_dict().items():
+        assert torch.allclose(v, before[k] + 1.0), k
+    # split() of another flat vector has the same shapes
+    g = fp.split(torch.zeros_like(fp.flat))
+    assert {k: tuple(v.shape) for k, v in g.items()} == {k.split('policy.')[-1] if not recurrent else
+                                                         (k[len('policy.'):] if 'recurrent' in k else k[len('policy.policy.'):]): tuple(v.shape)
+                                                         for k, v in before.items()}
+
+
+def test_obs_stride_selection():
+    from pufferlib_amd import hostpath
+    assert [hostpath.obs_stride_for(d) for d in (1, 16, 17, 49, 64, 65, 96, 97, 128)] == [16, 16, 32, 64, 64, 96, 96, 128, 128]
+    with pytest.raises(NotImplementedError):
+        hostpath.obs_stride_for(129)
+
+
+def test_experience_shape_checks_raise_before_touching_the_gpu():
+    from pufferlib_amd.clean_pufferl import Experience
+    with pytest.raises(ValueError):
+        Experience(1000, 16, 300, 64, 10, 'cpu')       # batch not divisible by minibatch
+    with pytest.raises(ValueError):
+        Experience(1024, 16, 24, 64, 16, 'cpu')        # minibatch not divisible by bptt_horizon
+    with pytest.raises(ValueError):
+        Experience(1024, 16, 256, 64, 48, 'cpu')       # batch not divisible by the env count
+    with pytest.raises(ValueError):
+        Experience(16 * 24, 16, 128, 64, 16, 'cpu')    # rows per env not a whole number of bptt segments
+
+
+def test_gae_fold_later_composes_affine_maps_in_order():
+    from pufferlib_amd import dist as pdist
+    maps = [torch.tensor([0.5, 1.0], dtype=torch.float64), torch.tensor([2.0, -1.0], dtype=torch.float64),
+            torch.tensor([0.25, 4.0], dtype=torch.float64)]
+    # rank 0: M1(M2(0)) = 2*4 - 1 = 7;  rank 1: M2(0) = 4;  rank 2: nothing follows
+    assert float(pdist.gae_fold_later(maps, 0)[0]) == 7.0
+    assert float(pdist.gae_fold_later(maps, 1)[0]) == 4.0
+    assert float(pdist.gae_fold_later(maps, 2)[0]) == 0.0
