@@ -118,7 +118,7 @@ typedef struct {
 int64_t pfa_mlp_param_count(const pfa_mlp_dims *dims);
 
 /* Philox4x32-10 action-noise stream: key=(seed lo, seed hi), counter=(row, column/4, step lo, step hi),
- * row = global env index (env_offset + local env), so the stream is invariant to how envs are sharded. */
+ * row = global env index (env_offset + local env), so the NOISE stream is invariant to how envs are sharded (env reset streams are per process, like the reference's). */
 typedef struct {
     uint64_t seed;
     uint64_t step; /* rollout step counter (monotonic across rollouts) */

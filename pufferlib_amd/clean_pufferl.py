@@ -394,23 +394,29 @@ def _finish_evaluate(data, N, T):
     return data.stats, infos
 
 
+def _all_gather_small(dist, x, rank, world):
+    """all_gather of a tiny tensor as one all-reduce(SUM) of a zero-padded [world, ...] buffer: exact (every slot has one
+    non-zero contributor) and available for device tensors on every backend (gloo has no device all_gather)."""
+    buf = torch.zeros((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+    buf[rank] = x
+    dist.all_reduce(buf)
+    return buf
+
+
 def _sharded_gae(data, dist, rank, world, stream):
     """compute_gae over the GLOBAL rank-major flat batch (c_gae.pyx:11-32 crosses env boundaries, so it also crosses
-    shard boundaries): two tiny all-gathers — the first rows (halo of the previous rank) and the shards' affine maps."""
+    shard boundaries): two tiny exchanges — the first rows (halo of the previous rank) and the shards' affine maps."""
     config, ex = data.config, data.experience
     L, B = _lib.lib(), ex.batch_size
     has_next = int(rank < world - 1)
-    first = ex._rdv[:, 0].contiguous()
-    rows = [torch.empty_like(first) for _ in range(world)]
-    dist.all_gather(rows, first)
+    rows = _all_gather_small(dist, ex._rdv[:, 0].contiguous(), rank, world)
     if has_next:
         ex._rdv[:, B] = rows[rank + 1]
     smap = torch.empty(2, dtype=torch.float64, device=ex.device)
     args = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
     _lib.check(L.pfa_gae_shard_pass1(*args, B, has_next, float(config.gamma), float(config.gae_lambda),
                                      _lib.ptr(data.workspace), _lib.ptr(smap), stream), 'gae pass 1')
-    maps = [torch.empty_like(smap) for _ in range(world)]
-    dist.all_gather(maps, smap)
+    maps = _all_gather_small(dist, smap, rank, world)
     carry = pdist.gae_fold_later(maps, rank)
     _lib.check(L.pfa_gae_shard_pass2(*args, _lib.ptr(ex.advantages), _lib.ptr(ex.returns), B, has_next,
                                      float(config.gamma), float(config.gae_lambda), _lib.ptr(data.workspace),

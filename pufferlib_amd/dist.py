@@ -3,8 +3,10 @@
 CPU tests.
 
 Sharding contract
-  * rank r of R owns global envs [r*N, (r+1)*N): seeds ``seed + global index`` (vector.py:639-641 semantics), Philox
-    noise rows = global env index, so trajectories do not depend on how envs are spread over ranks;
+  * rank r of R owns global envs [r*N, (r+1)*N): seeds ``seed + global index`` (vector.py:639-641 semantics) and Philox
+    noise rows = global env index.  A rank is one reference PROCESS (SURVEY config C5): the reset-target stream of
+    ``random.sample`` is process-global in the reference, so after their first episode the envs of a rank follow that
+    rank's own stream — a rank is not a slice of one big process;
   * every rank keeps its own env-major experience and applies the reference's minibatch partition locally; because
     ``N * (T / bptt_horizon) % num_minibatches == 0`` (checked) local minibatch m is exactly this rank's share of
     global minibatch m;
