@@ -109,8 +109,15 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local_rank}'))
+        # PFA_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than ranks (ranks then share
+        # devices); the driver's runs use the default: nccl (= RCCL), one rank per GPU
+        backend = os.environ.get('PFA_DIST_BACKEND', 'nccl')
+        dev_index = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(dev_index)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{dev_index}'))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
 
