@@ -211,8 +211,9 @@ int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *para
  * Recurrent policy — pufferlib.models.LSTMWrapper (models.py:64-111): Default encoder -> nn.LSTM(128,128,1) ->
  * Default heads, gate order i,f,g,o.  Flat parameter vector = the MLP vector above followed by
  *   recurrent.weight_ih_l0 [512][128], weight_hh_l0 [512][128], bias_ih_l0 [512], bias_hh_l0 [512].
- * The plain gate / weight-gradient GEMMs are library calls on the host side this round; these entry points are
- * everything else (csrc/lstm.hip).  All row-indexed buffers are dense [rows][...] fp32.
+ * Every product runs on the fused MFMA kernels declared further down (pfa_lstm_pack / pfa_rollout_lstm_squared /
+ * pfa_lstm_policy_step / pfa_lstm_seq_forward / pfa_lstm_seq_backward / pfa_gemm_tn_f32); the entry points up to
+ * pfa_lstm_heads_sample are the step-wise pieces (csrc/lstm.hip).  All row-indexed buffers are dense [rows][...] fp32.
  * ------------------------------------------------------------------------------------------ */
 int pfa_relu(float *x, int64_t n, pfa_stream_t stream);                       /* torch.relu of encode_observations */
 int pfa_relu_grad(float *dx, const float *x, int64_t n, pfa_stream_t stream); /* dx *= (x > 0), x = relu output */

@@ -3,14 +3,14 @@
 // frameworks.cleanrl.RecurrentPolicy (frameworks/cleanrl.py:69-93), and its use in clean_pufferl.evaluate
 // (clean_pufferl.py:100-105) and the BPTT minibatch loop of clean_pufferl.train (clean_pufferl.py:186-193).
 //
-// Round-1 structure of this path: the plain dense products ([rows x 128] x [128 x 512] gate GEMMs, the weight
-// gradient GEMMs over all rows of a minibatch) go through the ROCm BLAS the host already has (hipBLASLt/rocBLAS via
-// torch.mm — "library GEMMs for plain GEMMs"); everything that is not a plain GEMM is hand-written here:
+// The products of this path are the fused MFMA kernels of lstm_fused.hip (rollout), lstm_seq.hip (training forward / BPTT) and
+// gemm.hip (weight gradients).  This file holds the rest:
+//   lstm_heads_loss                     decoder + value head, PPO loss, d loss/d heads, d loss/d h, loss sums, head bias gradient
+//   gather_obs_time_major / store_rows / store_step / finish_grads / sumsq pieces for the clip norm
+// and the step-wise pieces the fused kernels replaced, kept as protocol-level entry points and test anchors:
 //   lstm_cell_fwd / lstm_cell_bwd      gate nonlinearities + cell/hidden update and their exact derivatives (gate order i,f,g,o)
 //   lstm_heads_sample                   decoder + value head on h, sample_logits with the shared row16 sampler
-//   lstm_heads_loss                     decoder + value head, PPO loss, d loss/d heads, d loss/d h, loss sums
-//   relu / relu' / column sums / experience row store / sum of squares pieces for the clip norm
-// A fused persistent LSTM kernel (gate weights streamed from L2 through MFMA fragments) is the planned replacement.
+//   relu / relu' / column sums
 #include "common.hpp"
 #include "lane_ops.hpp"
 #include "lstm_tile.hpp"

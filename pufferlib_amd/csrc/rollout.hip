@@ -301,19 +301,13 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     SquaredView v = squared_view(state, *cfg);
     const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
     ScopedKernelTimer timer("rollout_mlp_squared", (hipStream_t)stream);
-    if (true) {  // EPW = 8 (two workgroups per CU at N = 4096) measured slower: the step is issue-bound, not latency-bound
-        const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
-        PFA_DISPATCH_DP(dims->obs_stride,
-                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16>), dim3(grid), dim3(kRollThreads), 0,
-                                           (hipStream_t)stream, v, params, dims->num_actions, *exp, noise, seed, step,
-                                           (long long)env_offset, obs, rewards, terminals, truncations, masks));
-    } else {
-        const unsigned grid = (unsigned)((cfg->num_envs + 7) / 8);
-        PFA_DISPATCH_DP(dims->obs_stride,
-                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 8>), dim3(grid), dim3(kRollThreads), 0,
-                                           (hipStream_t)stream, v, params, dims->num_actions, *exp, noise, seed, step,
-                                           (long long)env_offset, obs, rewards, terminals, truncations, masks));
-    }
+    // 16 envs per workgroup.  An 8-env variant (two workgroups per CU at N = 4096) measured slower: the step is issue-bound,
+    // not latency-bound.
+    const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
+    PFA_DISPATCH_DP(dims->obs_stride,
+                    hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, v,
+                                       params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
+                                       terminals, truncations, masks));
     PFA_LAUNCH_CHECK();
     return 0;
 }
