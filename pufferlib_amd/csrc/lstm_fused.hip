@@ -42,13 +42,16 @@ struct LstmLds {
 
 // One policy step on the tile: xs (obs) + xh[cur] (h in its h half) + cst -> h' into xh[cur^1], c' in cst, head partials
 // in part.  Contains three workgroup barriers; the caller must barrier before reading part / rewriting xs.
-template <int DP>
+// `after_prefetch()` runs right after the first weight groups are requested: global STORES of the caller go there, behind
+// the loads in the in-order memory queue, so the weight ring never waits for a store acknowledgement.
+template <int DP, class AfterPrefetch>
 __device__ __forceinline__ void lstm_tile_step(const LstmFrags<DP> &w, const float4 *__restrict__ wp, LstmLds<DP> &L, int cur,
-                                               f32x4 (&cst)[2]) {
+                                               f32x4 (&cst)[2], AfterPrefetch &&after_prefetch) {
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
     float4 ring[kGateRing][8];
     const Stream ws = stream_begin(wp);
     ring_prefetch<8, kGateRing>(ws, ring);
+    after_prefetch();
     lstm_encode<DP>(w, L.xs, L.xh[cur]);
     __syncthreads();
     f32x4 acc[1][8];
@@ -94,7 +97,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_policy_step_kernel(const fl
         f32x4 cst[2];
         load_cstate(cell, tile * 16 + c, tile * 16 + c < rows, cst);
         __syncthreads();
-        lstm_tile_step<DP>(w, wp, L, 0, cst);
+        lstm_tile_step<DP>(w, wp, L, 0, cst, [] {});
         store_cstate(cell, tile * 16 + c, tile * 16 + c < rows, cst);
         store_hstate(h, tile * 16, rows, L.xh[1]);
         const long long row = tile * 16 + le;
@@ -153,8 +156,9 @@ __global__ void __launch_bounds__(kLstmThreads) rollout_lstm_squared_kernel(Squa
 
     for (int t = 0; t < T; ++t) {
         const int cur = t & 1;
-        lstm_unstage_obs<DP>(L.xs, ex.obs + (size_t)t * DP, first, v.n, (size_t)T * DP);
-        lstm_tile_step<DP>(w, wp, L, cur, cst);
+        // Experience.store of the observation rows (clean_pufferl.py:443), env-major: row (e, t) at e*T + t
+        lstm_tile_step<DP>(w, wp, L, cur, cst,
+                           [&] { lstm_unstage_obs<DP>(L.xs, ex.obs + (size_t)t * DP, first, v.n, (size_t)T * DP); });
         const float q = env_ok ? noise_lane(noise ? noise + ((size_t)t * v.n + e) * a : nullptr, seed, step0 + t,
                                             (uint64_t)(env_offset + e), lo, a)
                                : 1.0f;
