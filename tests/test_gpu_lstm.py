@@ -245,7 +245,7 @@ def test_lstm_policy_step_matches_torch_modules():
     np.testing.assert_allclose(ent.cpu().numpy(), -(logp * logp.exp()).sum(1).cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.parametrize('R,Th', [(40, 5), (64, 16), (7, 3)])
+@pytest.mark.parametrize('R,Th', [(40, 5), (64, 16), (7, 3), (8192, 16)])    # last: one full-size minibatch (BASELINE configs[1])
 def test_lstm_seq_forward_backward_match_torch_autograd(R, Th):
     """pfa_lstm_seq_forward / pfa_lstm_seq_backward vs nn.Linear + nn.LSTM under torch autograd: every kept activation, the
     state after Th steps, d loss/d gate pre-activations, d loss/d encoder pre-activations and the bias gradients.  Ragged
