@@ -31,10 +31,10 @@ constexpr int kGradPairs = kGradWaves / 2;  // (producer, consumer) wavefront pa
 constexpr int kNumStats = 8;                // 6 used: pg, v, entropy, old_kl, kl, clipfrac
 
 // LDS map of kernel A (floats).  A workgroup is 4 PAIRS of wavefronts; wave p (producer) and wave p+4 (consumer) share a
-// SIMD, so one wave's LDS waits / VALU stretches are covered by the other's MFMAs (two waves per SIMD fit because
-// neither role needs more than ~200 registers: the producer keeps no gradient accumulators, the consumer no forward
-// state).  Per pair: two X tiles (ring), two half-tiles of dh (ring), and the producer's private hidden-half / dout
-// tiles.  Shared by all waves: lane-major MFMA fragment tables, every fragment read one conflict-free ds_read_b128:
+// SIMD, so one wave's LDS waits / VALU stretches (the loss math) are covered by the other's MFMAs (two waves per SIMD fit
+// because neither role needs more than ~230 registers: the producer keeps no dW1 accumulators, the consumer no forward
+// state).  Per pair: two X tiles (ring), the hidden tile and the dout tile of the tile in flight between the two waves.
+// Shared by all waves: lane-major MFMA fragment tables, every fragment read one conflict-free ds_read_b128:
 //   w1t[m][lane][KS(+4)] A frags of the forward GEMM: W1[16m + c][4kk + g]
 //   b1t[m][lane][4] accumulator init   w2t[m][lane][4] A frags of the heads   w2bt[m][lane][4] B frags of dh = dout.W2v
 template <int DP>
@@ -42,14 +42,12 @@ struct GradLds {
     static constexpr int XS = XTile<DP>::XS;
     static constexpr int KS = DP / 4;
     static constexpr int W1S = KS + 4;        // lane stride of w1t (16 B aligned, spreads 16 lanes over all banks)
-    static constexpr int HH = kHidden / 2;    // hidden columns per half
-    static constexpr int HS = HH + 4;         // row stride of a half tile (16 B aligned rows, conflict-free reads)
+    static constexpr int HS = kHidden + 4;    // row stride of the hidden tile (16 B aligned rows, conflict-free reads)
     static constexpr int DS = 20;             // dout tile row stride
     static constexpr int kXT = 0;                        // + slot * 16 * XS        X tiles (ring of 2)
-    static constexpr int kDH = 2 * 16 * XS;              // + half * 16 * HS        relu'-masked dh half tiles (ring of 2)
-    static constexpr int kHsP = kDH + 2 * 16 * HS;       // producer: hidden half tile [row][u]
-    static constexpr int kDsP = kHsP + 16 * HS;          // producer: dout tile [row][o]
-    static constexpr int kPairFloats = kDsP + 16 * DS;
+    static constexpr int kHT = 2 * 16 * XS;              // hidden tile [row][u] (post-relu) of the published tile
+    static constexpr int kDT = kHT + 16 * HS;            // dout tile [row][o] of the published tile
+    static constexpr int kPairFloats = kDT + 16 * DS;
     static constexpr int kW1Floats = kMT * 64 * W1S;
     static constexpr int kTabFloats = kMT * 64 * 4;
     static constexpr int kFloats = kGradPairs * kPairFloats + kW1Floats + 3 * kTabFloats;
@@ -202,9 +200,12 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
 // ABL: ablation mask for tools/probe_grad.py (-DPFA_PROBES builds only; the product always runs ABL = 0):
 //   1 skip the loss math   2 skip the consumer's dW1 MFMAs   4 skip the forward MFMAs
 //
-// Schedule of one pair over its tiles j = 0..J-1 (every phase ends in a workgroup barrier, 2 per tile):
-//   phase B_j  producer: stage X(j), forward, heads, loss, first hidden half: dh -> DH[0], dW2v      consumer: dW1 from DH[1] of tile j-1
-//   phase A_j  producer: second hidden half: dh -> DH[1], dW2v; prefetch X(j+1) into registers       consumer: dW1 from DH[0] of tile j
+// Schedule of one pair over its tiles j = 0..J-1 (two workgroup barriers per tile, alpha_j and beta_j):
+//   producer   stage X(j), forward, heads, loss        | alpha_j | hidden(j), dout(j) -> LDS | beta_j | dW2v(j) from LDS ...
+//   consumer   dh(j-1) = dout.W2v, relu', db1, dW1(j-1)  | alpha_j |                           | beta_j | dh(j), ... 
+// i.e. the consumer's whole share of tile j (160 MFMAs) runs under the producer's forward + loss of tile j+1 (192 MFMAs + the
+// VALU-heavy loss).  alpha_j: the consumer is done reading hidden/dout(j-1), so they may be overwritten; beta_j: published.
+// dh's C fragment (rows 4g+r, column u = c) IS the B fragment dW1 = X^T dh needs, so the consumer never stages dh.
 template <int DP, int ABL = 0>
 __global__ void __launch_bounds__(kGradThreads, 2)
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, pfa_ppo_hparams hp,
@@ -282,12 +283,9 @@ __global__ void __launch_bounds__(kGradThreads, 2)
         const float inv_rows = (float)(1.0 / global_rows);
 
         f32x4 acc_dw2[kMT];
-        float db1[kMT], db2[4], stats[6];
+        float db2[4], stats[6];
 #pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-            acc_dw2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            db1[m] = 0.0f;
-        }
+        for (int m = 0; m < kMT; ++m) acc_dw2[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) db2[r] = 0.0f;
 #pragma unroll
@@ -317,10 +315,10 @@ __global__ void __launch_bounds__(kGradThreads, 2)
         prefetch(pair_global);
         __syncthreads();  // fragment tables ready
 
-        float *hsP = pl + L::kHsP, *dsP = pl + L::kDsP;
+        float *hsP = pl + L::kHT, *dsP = pl + L::kDT;
         for (int j = 0; j < J; ++j) {
             float *xs = pl + L::kXT + (j & 1) * 16 * XS;
-            // ---- phase B: stage X(j), forward, heads, loss, first half --------------------------------------------
+            // ---- stage X(j), forward, heads, loss (registers + this tile's X slot only) ------------------------------
 #pragma unroll
             for (int q = 0; q < NLD; ++q) {
                 const int idx = lane + 64 * q;
@@ -388,64 +386,35 @@ __global__ void __launch_bounds__(kGradThreads, 2)
                 stats[4] += lo.kl;
                 stats[5] += lo.clipped;
             }
-            *reinterpret_cast<f32x4 *>(dsP + c * DS + 4 * g) = dout;  // dout[row = c][o = 4g..4g+3]
-
-            // one hidden half: hidden half tile -> LDS, dh = dout . W2v (A = dout^T C fragments, A = C^T), relu',
-            // dh half -> DH[half] for the consumer, dW2v += hidden^T . dout
-            auto half_step = [&](int half) {
+            __syncthreads();  // alpha_j: the consumer has finished with hidden/dout of tile j-1
+            // ---- publish hidden(j) [row][u] and dout(j) [row][o] ------------------------------------------------------
 #pragma unroll
-                for (int mm = 0; mm < kMT / 2; ++mm)
-                    *reinterpret_cast<f32x4 *>(hsP + c * HS + 16 * mm + 4 * g) = h[half * (kMT / 2) + mm];
-                wave_lds_fence();
+            for (int m = 0; m < kMT; ++m) *reinterpret_cast<f32x4 *>(hsP + c * HS + 16 * m + 4 * g) = h[m];
+            *reinterpret_cast<f32x4 *>(dsP + c * DS + 4 * g) = dout;  // dout[row = c][o = 4g..4g+3]
+            __syncthreads();  // beta_j
+            // ---- dW2v^T[u][o] += hidden^T . dout, both operands back from LDS in A/B fragment order -----------------------
+            if (!(ABL & 2)) {
                 float dfrag[4];  // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dfrag[r] = dsP[(4 * g + r) * DS + c];
-                float *dhT = pl + L::kDH + half * 16 * HS;
-                // the four hidden tiles of the half are four independent accumulator chains (no dependent-issue stalls)
-                f32x4 dh[kMT / 2], wb[kMT / 2];
-                float hrow[kMT / 2][4];
 #pragma unroll
-                for (int mm = 0; mm < kMT / 2; ++mm) {
-                    dh[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    wb[mm] = *reinterpret_cast<const f32x4 *>(w2bt + ((half * (kMT / 2) + mm) * 64 + lane) * 4);
+                for (int m0 = 0; m0 < kMT; m0 += 4) {  // four independent accumulator chains at a time
+                    float hrow[4][4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hrow[mm][r] = hsP[(4 * g + r) * HS + 16 * mm + c];  // hidden[row=4g+r][u=16m+c]
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hrow[q][r] = hsP[(4 * g + r) * HS + 16 * (m0 + q) + c];  // hidden[row=4g+r][u=16m+c]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc_dw2[m0 + q] = mfma16(hrow[q][r], dfrag[r], acc_dw2[m0 + q]);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mm = 0; mm < kMT / 2; ++mm) dh[mm] = mfma16(dout[r], wb[mm][r], dh[mm]);
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int mm = 0; mm < kMT / 2; ++mm) {
-                        const int m = half * (kMT / 2) + mm;
-                        acc_dw2[m] = mfma16(hrow[mm][r], dfrag[r], acc_dw2[m]);  // independent of dh: fills its latency
-                    }
-#pragma unroll
-                for (int mm = 0; mm < kMT / 2; ++mm)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        dh[mm][r] = hrow[mm][r] > 0.0f ? dh[mm][r] : 0.0f;  // relu'
-                        db1[half * (kMT / 2) + mm] += dh[mm][r];
-                        dhT[(4 * g + r) * HS + 16 * mm + c] = dh[mm][r];  // dh[row = 4g+r][u = 16mm + c] of this half
-                    }
-            };
-            wave_lds_fence();
-            half_step(0);
-            __syncthreads();
-            // ---- phase A: second half; prefetch the next tile ------------------------------------------------------
-            half_step(1);
-            __syncthreads();
+            }
         }
-        __syncthreads();  // matches the consumer's trailing phase B_J
+        __syncthreads();  // alpha_J: matches the consumer's trailing barrier pair
+        __syncthreads();  // beta_J
 
-        // ---- epilogue: producers own dW2v, db1, db2v, stats ------------------------------------------------------
-#pragma unroll
-        for (int m = 0; m < kMT; ++m) {
-            db1[m] += __shfl_xor(db1[m], 16, 64);
-            db1[m] += __shfl_xor(db1[m], 32, 64);
-        }
+        // ---- epilogue: producers own dW2v, db2v, stats --------------------------------------------------------------
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -465,13 +434,6 @@ __global__ void __launch_bounds__(kGradThreads, 2)
                         const int idx = NL::kDw2 + (m * 4 + r) * 64 + lane;
                         red[idx] = (first ? 0.0f : red[idx]) + acc_dw2[m][r];
                     }
-                if (g == 0) {
-#pragma unroll
-                    for (int m = 0; m < kMT; ++m) {
-                        const int idx = NL::kDb1 + 16 * m + c;
-                        red[idx] = (first ? 0.0f : red[idx]) + db1[m];
-                    }
-                }
                 if (c == 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -498,41 +460,68 @@ __global__ void __launch_bounds__(kGradThreads, 2)
             for (int m = 0; m < kMT; ++m) acc_dw1[kt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
         __syncthreads();  // fragment tables ready (same barrier as the producers')
 
-        // dW1^T[k][u] += X^T . dh for one hidden half of tile jj: A = X tile (i = k = 16kt + c, k-slot g <-> row 4g+r),
-        // B = masked dh half tile (k-slot g <-> row 4g+r, j = u = 16m + c)
-        auto dw1_half = [&](int jj, int half) {
+        float db1[kMT];
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) db1[m] = 0.0f;
+        const float *hsP = pl + L::kHT, *dsP = pl + L::kDT;
+        // The consumer's share of tile jj from the published hidden/dout tiles and the tile's X slot:
+        //   dh[row][u] = dout . W2v   (A = dout[row = c][o = 4g + r], B = w2bt fragments), relu' from the hidden tile, db1,
+        //   dW1^T[k][u] += X^T . dh   (A = X tile: i = k = 16kt + c, k-slot g <-> row 4g+r;  B = dh's own C fragment)
+        auto backward_tile = [&](int jj) {
             const long long tile = pair_global + (long long)jj * pair_count;
             if ((ABL & 2) || tile >= tiles) return;
             const float *xs = pl + L::kXT + (jj & 1) * 16 * XS;
-            const float *dhT = pl + L::kDH + half * 16 * HS;
+            const f32x4 dout = *reinterpret_cast<const f32x4 *>(dsP + c * DS + 4 * g);
             float xa[KT][4];
 #pragma unroll
             for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
-            float dhf[kMT / 2][4];
 #pragma unroll
-            for (int mm = 0; mm < kMT / 2; ++mm)
+            for (int m0 = 0; m0 < kMT; m0 += 4) {  // four hidden tiles = four independent accumulator chains
+                f32x4 dh[4], wb[4];
+                float hrow[4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dhf[mm][r] = dhT[(4 * g + r) * HS + 16 * mm + c];
+                for (int q = 0; q < 4; ++q) {
+                    dh[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    wb[q] = *reinterpret_cast<const f32x4 *>(w2bt + ((m0 + q) * 64 + lane) * 4);
 #pragma unroll
-            for (int mm = 0; mm < kMT / 2; ++mm)
+                    for (int r = 0; r < 4; ++r) hrow[q][r] = hsP[(4 * g + r) * HS + 16 * (m0 + q) + c];  // hidden[row=4g+r][u=16m+c]
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int kt = 0; kt < KT; ++kt)
-                        acc_dw1[kt][half * (kMT / 2) + mm] = mfma16(xa[kt][r], dhf[mm][r], acc_dw1[kt][half * (kMT / 2) + mm]);
+                    for (int q = 0; q < 4; ++q) dh[q] = mfma16(dout[r], wb[q][r], dh[q]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dh[q][r] = hrow[q][r] > 0.0f ? dh[q][r] : 0.0f;  // relu'
+                        db1[m0 + q] += dh[q][r];
+                    }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int kt = 0; kt < KT; ++kt) acc_dw1[kt][m0 + q] = mfma16(xa[kt][r], dh[q][r], acc_dw1[kt][m0 + q]);
+            }
         };
         for (int j = 0; j < J; ++j) {
-            if (j > 0) dw1_half(j - 1, 1);  // phase B_j
-            __syncthreads();
-            dw1_half(j, 0);                 // phase A_j
-            __syncthreads();
+            if (j > 0) backward_tile(j - 1);
+            __syncthreads();  // alpha_j
+            __syncthreads();  // beta_j
         }
-        dw1_half(J - 1, 1);                 // trailing phase B_J
+        backward_tile(J - 1);
+        __syncthreads();  // alpha_J / beta_J: same barrier count as the producers
         __syncthreads();
 
-        // ---- epilogue: consumers own dW1 ---------------------------------------------------------------------------
+        // ---- epilogue: consumers own dW1 and db1 --------------------------------------------------------------------
+#pragma unroll
+        for (int m = 0; m < kMT; ++m) {
+            db1[m] += __shfl_xor(db1[m], 16, 64);
+            db1[m] += __shfl_xor(db1[m], 32, 64);
+        }
         float *red = lds + (pair & 1) * NL::kCount;
         for (int turn = 0; turn < kGradPairs / 2; ++turn) {
             if ((pair >> 1) == turn) {
@@ -546,6 +535,13 @@ __global__ void __launch_bounds__(kGradThreads, 2)
                             const int idx = NL::kDw1 + ((kt * kMT + m) * 4 + r) * 64 + lane;
                             red[idx] = (first ? 0.0f : red[idx]) + acc_dw1[kt][m][r];
                         }
+                if (g == 0) {
+#pragma unroll
+                    for (int m = 0; m < kMT; ++m) {
+                        const int idx = NL::kDb1 + 16 * m + c;
+                        red[idx] = (first ? 0.0f : red[idx]) + db1[m];
+                    }
+                }
             }
             __syncthreads();
         }
