@@ -296,7 +296,8 @@ int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch
 /* C[mo][no] (row stride ldc) = sum over the k rows of A[k][mo]^T B[k][no]  (A, B row-major activations with row strides
  * lda, ldb; fp32 MFMA, split over k, deterministic f64 reduction of the splits).  These are the weight-gradient
  * contractions autograd performs for nn.Linear / nn.LSTM under loss.backward() (clean_pufferl.py:244).  Supported
- * (mo, no): multiples of (128,128), (128,64) or (16,128).  workspace >= pfa_gemm_tn_workspace_bytes (0 = unsupported). */
+ * (mo, no): mo a multiple of 128 with no a multiple of 16, or mo a multiple of 16 with no a multiple of 128.
+ * workspace >= pfa_gemm_tn_workspace_bytes (0 = unsupported). */
 size_t pfa_gemm_tn_workspace_bytes(int32_t mo, int32_t no, int64_t k);
 int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t mo,
                     int32_t no, int64_t k, void *workspace, pfa_stream_t stream);

@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__rest
 }
 
 struct GemmTnPlan {
-    int cfg;  // 0: 128x128, 1: 128x64, 2: 16x128
+    int cfg;  // 0: 128x128, 1: 128x64, 2: 16x128, 3: 128x32, 4: 128x16
     int tm, tn, tiles, splits;
     long long k_per_split;
 };
@@ -171,6 +171,10 @@ static bool gemm_tn_plan(int mo, int no, long long K, GemmTnPlan &p) {
         p.cfg = 0, p.tm = 128, p.tn = 128;
     } else if (mo % 128 == 0 && no % 64 == 0) {
         p.cfg = 1, p.tm = 128, p.tn = 64;
+    } else if (mo % 128 == 0 && no % 32 == 0) {
+        p.cfg = 3, p.tm = 128, p.tn = 32;
+    } else if (mo % 128 == 0 && no % 16 == 0) {
+        p.cfg = 4, p.tm = 128, p.tn = 16;
     } else if (mo % 16 == 0 && no % 128 == 0) {
         p.cfg = 2, p.tm = 16, p.tn = 128;
     } else {
@@ -205,7 +209,7 @@ extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int6
     PFA_REQUIRE(lda >= mo && ldb >= no && ldc >= no && lda % 4 == 0 && ldb % 4 == 0, "gemm_tn: row strides must cover the tile and be 16-byte multiples");
     PFA_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
     GemmTnPlan p;
-    PFA_REQUIRE(gemm_tn_plan(mo, no, k, p), "gemm_tn: supported shapes are (128a x 128b), (128a x 64b), (16a x 128b)");
+    PFA_REQUIRE(gemm_tn_plan(mo, no, k, p), "gemm_tn: supported shapes are (128a x 16b) and (16a x 128b)");
     const dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
     float *partial = (float *)workspace;
     hipStream_t st = (hipStream_t)stream;
@@ -215,6 +219,12 @@ extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int6
                            mo, no, (long long)k, p.k_per_split, partial);
     else if (p.cfg == 1)
         hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 2>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
+                           mo, no, (long long)k, p.k_per_split, partial);
+    else if (p.cfg == 3)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 1>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
+                           mo, no, (long long)k, p.k_per_split, partial);
+    else if (p.cfg == 4)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 1, 2, 1>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
                            mo, no, (long long)k, p.k_per_split, partial);
     else
         hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 4, 1, 2>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,

@@ -143,7 +143,8 @@ def test_recurrent_policy_protocol_step_matches_fused_engine():
 
 
 @pytest.mark.parametrize('mo,no,k,pad', [(512, 128, 131072, 0), (128, 64, 8192, 0), (16, 128, 4099, 0), (128, 128, 37, 0),
-                                          (256, 256, 1000, 32), (16, 128, 131072, 0)])
+                                          (256, 256, 1000, 32), (16, 128, 131072, 0), (128, 32, 5000, 0), (128, 16, 777, 16),
+                                          (128, 96, 2048, 0)])
 def test_gemm_tn_matches_f64_contraction(mo, no, k, pad):
     """C = A^T B over the k rows (csrc/gemm.hip) vs the same contraction in f64; ragged k and padded row strides."""
     import ctypes as C
@@ -175,7 +176,7 @@ def test_gemm_tn_rejects_unsupported_shapes():
     from pufferlib_amd import _lib
     from pufferlib_amd.exceptions import ExtensionError
     L = _lib.lib()
-    assert L.pfa_gemm_tn_workspace_bytes(24, 100, 64) == 0
+    assert L.pfa_gemm_tn_workspace_bytes(24, 100, 64) == 0 and L.pfa_gemm_tn_workspace_bytes(64, 64, 64) == 0
     x = torch.zeros(64, 128, device='cuda')
     with pytest.raises(ExtensionError):
         _lib.check(L.pfa_gemm_tn_f32(_lib.ptr(x), 128, _lib.ptr(x), 128, _lib.ptr(x), 128, 24, 100, 64, _lib.ptr(x),
@@ -315,3 +316,46 @@ def test_lstm_seq_forward_backward_match_torch_autograd(R, Th):
     np.testing.assert_allclose(dxe.cpu().numpy(), pre.grad.cpu().numpy(), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(gb.cpu().numpy(), bih.grad.cpu().numpy(), rtol=2e-5, atol=1e-5)
     np.testing.assert_allclose(eb.cpu().numpy(), b1.grad.cpu().numpy(), rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('d,nt', [(1, 1), (2, 2), (4, 3)])
+def test_recurrent_policy_trains_on_other_grid_sizes(d, nt):
+    """obs 3x3 / 5x5 / 9x9 -> row strides 16 / 32 / 96: every fused recurrent kernel and the weight-gradient contraction
+    have those instantiations; the update is compared with the torch-fp32 oracle trainer on the same rollout."""
+    from pufferlib_amd import clean_pufferl, cleanrl, models, vector
+    from oracle import c_oracle, ppo_torch
+    n, horizon, nmb, bptt = 32, 16, 2, 8
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
+    B = n * horizon
+    torch.manual_seed(d)
+    vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=d, num_targets=nt), num_envs=n, backend=vector.Squared)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    cfg = _config(n, horizon, B // nmb, bptt, 2, B * 10, hp, seed=7)
+    data = clean_pufferl.create(cfg, vec, pol)
+    D = (2 * d + 1) ** 2
+    assert vec.obs_stride == max(16, (D + 15) // 16 * 16)
+    opol = ppo_torch.Policy.from_reference_state_dict({k: v.detach().cpu().clone() for k, v in pol.state_dict().items()})
+    assert opol.recurrent
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    tr = ppo_torch.Trainer(opol, c_oracle.SquaredSerial(n, d, nt), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt,
+                           update_epochs=2, learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3],
+                           vf_coef=hp[4], vf_clip_coef=hp[5], max_grad_norm=hp[6], ent_coef=hp[7],
+                           total_timesteps=B * 10, seed=7)
+    tr.obs = torch.as_tensor(_step_major(exp.obs, n, horizon)[:, :D].copy())
+    tr.actions = _step_major(exp.actions, n, horizon).astype(np.int64)
+    tr.logprobs = _step_major(exp.logprobs, n, horizon).copy()
+    tr.rewards = _step_major(exp.rewards, n, horizon).copy()
+    tr.dones = _step_major(exp.dones, n, horizon).copy()
+    tr.values = _step_major(exp.values, n, horizon).copy()
+    tr.global_step = data.global_step
+    tr.train()
+    clean_pufferl.train(data)
+    want = opol.state_arrays()                      # short names: 'encoder.weight', ..., 'weight_ih_l0', ...
+    sd = pol.state_dict()
+    for k, w in want.items():
+        full = ('policy.recurrent.' if k.endswith('_l0') else 'policy.policy.') + k
+        np.testing.assert_allclose(sd[full].cpu().numpy(), w, rtol=1e-4, atol=2e-6, err_msg=k)
