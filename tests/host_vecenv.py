@@ -41,3 +41,43 @@ class HostSquared:
 
     def close(self):
         pass
+
+
+class HostSquaredPool:
+    """EnvPool-style host vecenv (vector.py:218-447 semantics in miniature): `workers` independent groups of envs, each
+    recv() hands out ONE group's rows (agents_per_batch = num_envs / workers < num_agents), send() steps that group only,
+    groups take turns.  Each group is its own C-oracle SquaredSerial, i.e. has its own `random` stream like a worker process."""
+
+    def __init__(self, num_envs, workers=2, distance_to_target=3, num_targets=1):
+        from oracle import c_oracle
+        from pufferlib_amd import vector
+        assert num_envs % workers == 0
+        self.per = num_envs // workers
+        self.groups = [c_oracle.SquaredSerial(self.per, distance_to_target, num_targets) for _ in range(workers)]
+        self.driver_env = vector.SquaredSpec(distance_to_target, num_targets)
+        self.single_observation_space = self.driver_env.single_observation_space
+        self.single_action_space = self.driver_env.single_action_space
+        self.num_envs = self.num_agents = num_envs
+        self.agents_per_batch = self.per
+        self.emulated = True
+        self.turn = 0
+        self.seed = None
+
+    def async_reset(self, seed=42):
+        self.seed = seed
+        for w, g in enumerate(self.groups):
+            g.async_reset(seed + w * self.per)          # make_seeds: env i gets seed + i (vector.py:639-641)
+        self.turn = 0
+
+    def recv(self):
+        w = self.turn
+        o, r, d, t, infos, ids, mask = self.groups[w].recv()
+        infos = [{k: v for k, v in i.items() if not k.startswith('_')} for i in infos]
+        return o.copy(), r.copy(), d.copy(), t.copy(), infos, ids + w * self.per, mask.copy()
+
+    def send(self, actions):
+        self.groups[self.turn].send(np.asarray(actions, np.int64))
+        self.turn = (self.turn + 1) % len(self.groups)
+
+    def close(self):
+        pass

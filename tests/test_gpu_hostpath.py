@@ -123,3 +123,44 @@ def test_host_path_throughput_report(capsys):
         print(f'\n[host path] {n} envs x {horizon} steps: {iters * n * horizon / dt / 1e6:.2f} M env steps/s '
               f'(env {p.env.elapsed:.2f}s, forward {p.eval_forward.elapsed:.2f}s, misc {p.eval_misc.elapsed:.2f}s of {dt:.2f}s)')
     assert data.global_step == (iters + 2) * n * horizon
+
+
+@pytest.mark.parametrize('recurrent', [False, True])
+def test_envpool_batches_smaller_than_the_env_count(recurrent):
+    """agents_per_batch < num_agents: groups of envs take turns (async EnvPool), so a rollout needs workers*T recvs and every
+    recv carries a different env_id range.  Each env's rows must land in its own env-major slot: replaying the stored
+    actions of a group on a fresh oracle group reproduces the stored observations / rewards / dones, and (recurrent) the
+    LSTM state rows advanced only with their own group."""
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from host_vecenv import HostSquaredPool
+    from oracle import c_oracle
+    from test_gpu_ppo import _config
+    n, workers, horizon = 48, 3, 8
+    per = n // workers
+    torch.manual_seed(1)
+    vec = HostSquaredPool(n, workers)
+    base = models.Default(vec.driver_env)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base)) if recurrent else cleanrl.Policy(base)
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 4, 1, n * horizon * 8, HP, seed=9), vec, pol)
+    assert data.host_bridge.max_rows == per
+    for it in range(2):
+        clean_pufferl.evaluate(data)
+        e = data.experience
+        assert data.global_step == (it + 1) * n * horizon
+        obs = e.obs.view(n, horizon, -1)[:, :, :49].cpu().numpy()
+        acts, rew, done = (x.view(n, horizon).cpu().numpy() for x in (e.actions, e.rewards, e.dones))
+        if it == 0:                                   # replay from reset: group w = envs [w*per, (w+1)*per), seed 9 + w*per
+            for w in range(workers):
+                ref = c_oracle.SquaredSerial(per, 3, 1)
+                ref.async_reset(9 + w * per)
+                rows = slice(w * per, (w + 1) * per)
+                for t in range(horizon):
+                    o, r, d, _, _, _, _ = ref.recv()
+                    assert np.array_equal(o.reshape(per, -1), obs[rows, t]), (w, t)
+                    assert np.array_equal(r, rew[rows, t]) and np.array_equal(d.astype(np.float32), done[rows, t]), (w, t)
+                    ref.send(acts[rows, t].astype(np.int64))
+        clean_pufferl.train(data)
+        assert torch.isfinite(data.flat_params.flat).all()
+    if recurrent:
+        h = data.lstm_engine.lstm_h[0]
+        assert torch.isfinite(h).all() and float(h.abs().sum()) > 0
