@@ -206,7 +206,7 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
 // i.e. the consumer's whole share of tile j (160 MFMAs) runs under the producer's forward + loss of tile j+1 (192 MFMAs + the
 // VALU-heavy loss).  alpha_j: the consumer is done reading hidden/dout(j-1), so they may be overwritten; beta_j: published.
 // dh's C fragment (rows 4g+r, column u = c) IS the B fragment dW1 = X^T dh needs, so the consumer never stages dh.
-template <int DP, int ABL = 0>
+template <int DP, int ABL = 0, int KKU = DP / 4>
 __global__ void __launch_bounds__(kGradThreads, 2)
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, pfa_ppo_hparams hp,
                         const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
@@ -337,15 +337,17 @@ __global__ void __launch_bounds__(kGradThreads, 2)
 #pragma unroll
             for (int m = 0; m < kMT; ++m) h[m] = *reinterpret_cast<const f32x4 *>(b1t + (m * 64 + lane) * 4);
 #pragma unroll
-            for (int k4 = 0; k4 < ((ABL & 4) ? 0 : KS / 4); ++k4) {
+            for (int k4 = 0; k4 < ((ABL & 4) ? 0 : (KKU + 3) / 4); ++k4) {
                 float xb[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) xb[q] = xs[c * XS + 4 * (4 * k4 + q) + g];
+                // KKU = ceil(obs_dim / 4) k-steps carry data; the rest is zero padding in X and in W1 and is not issued
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) {
                     const f32x4 wq = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + 4 * k4);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) h[m] = mfma16(wq[q], xb[q], h[m]);
+                    for (int q = 0; q < 4; ++q)
+                        if (4 * k4 + q < KKU) h[m] = mfma16(wq[q], xb[q], h[m]);
                 }
             }
 #pragma unroll
@@ -812,29 +814,35 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     const int grid = grad_grid(mbs);
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
-#define PFA_LAUNCH_GRAD(DPV)                                                                                               \
+#define PFA_LAUNCH_GRAD_K(DPV, KKUV)                                                                                       \
     {                                                                                                                      \
         constexpr size_t lds_bytes = (size_t)GradLds<DPV>::kFloats * sizeof(float);                                        \
         static_assert((size_t)2 * NativeLayout<DPV>::kCount * sizeof(float) <= lds_bytes,                                   \
                       "the two reduction buffers must fit in the tile/table area");                                       \
         static bool attr_set = false;                                                                                      \
         if (!attr_set) {                                                                                                   \
-            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV>,                                      \
+            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV, 0, KKUV>,                             \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
             attr_set = true;                                                                                               \
         }                                                                                                                  \
-        hipLaunchKernelGGL(ppo_mlp_grad_kernel<DPV>, dim3(grid), dim3(kGradThreads), lds_bytes, (hipStream_t)stream, *exp,  \
-                           map, (long long)mbs, params, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, partials); \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV>), dim3(grid), dim3(kGradThreads), lds_bytes,                  \
+                           (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions, *hp, adv_stats,       \
+                           (double)global_mb_rows, partials);                                                              \
     }
+#define PFA_LAUNCH_GRAD(DPV) PFA_LAUNCH_GRAD_K(DPV, DPV / 4)
     {
         ScopedKernelTimer timer("ppo_mlp_grad", (hipStream_t)stream);
         switch (dims->obs_stride) {
             case 16: PFA_LAUNCH_GRAD(16) break;
             case 32: PFA_LAUNCH_GRAD(32) break;
-            default: PFA_LAUNCH_GRAD(64) break;
+            default:
+                if ((dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)   // 7x7 grid: 3 of 16 k-steps are pure padding
+                else PFA_LAUNCH_GRAD(64)
+                break;
         }
     }
 #undef PFA_LAUNCH_GRAD
+#undef PFA_LAUNCH_GRAD_K
     PFA_LAUNCH_CHECK();
     ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
     double *normp = norm_partials_of(workspace, dims->obs_stride);
