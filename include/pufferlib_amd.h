@@ -161,6 +161,29 @@ int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cfg, const fl
                             uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Stochastic vecenv (a second ocean env family on device) — replaces pufferlib.vector.Serial
+ * (vector.py:70-166) over ocean.environment.make_stochastic (ocean/environment.py:61-64; horizon 100) =
+ * GymnasiumPufferEnv + EpisodeStats + ocean.Stochastic (ocean.py:529-582).  No randomness: state = (tick, count of
+ * action 0); observation always [0.0] in rows of 16 floats; reward = f32(1 - (p - count/tick)^2) when the action moves
+ * the action-0 fraction towards p, else 0.  `state` >= pfa_stochastic_state_bytes(num_envs); live buffers as Squared.
+ * episode_stats: out4 = {episodes, sum return, sum length, sum score} (f64).
+ * ------------------------------------------------------------------------------------------ */
+size_t pfa_stochastic_state_bytes(int32_t num_envs);
+int pfa_stochastic_async_reset(void *state, int32_t num_envs, float *obs, float *rewards, uint8_t *terminals,
+                               uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_stochastic_send(void *state, int32_t num_envs, double p, int32_t horizon, const int64_t *actions, float *obs,
+                        float *rewards, uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_stochastic_episode_stats(void *state, int32_t num_envs, double *out4, int32_t reset, pfa_stream_t stream);
+int pfa_stochastic_last_infos(void *state, int32_t num_envs, uint8_t *finished, double *episode_return,
+                              int32_t *episode_length, double *score, pfa_stream_t stream);
+/* clean_pufferl.evaluate's loop for a Stochastic vecenv and the MLP policy, one persistent kernel (as
+ * pfa_rollout_mlp_squared). */
+int pfa_rollout_mlp_stochastic(void *state, int32_t num_envs, double p, int32_t horizon, const float *params,
+                               const pfa_mlp_dims *dims, const pfa_experience *exp, const float *noise,
+                               const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards,
+                               uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * PPO update — the minibatch loop of clean_pufferl.train (clean_pufferl.py:175-258).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {

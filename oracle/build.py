@@ -17,8 +17,8 @@ def build_oracle(force=False):
             and os.path.getmtime(out) >= max(os.path.getmtime(src),
                                              os.path.getmtime(os.path.join(HERE, 'puffer_oracle.h')))):
         return out
-    subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-ffp-contract=off', '-Wall',
-                           src, '-o', out])
+    subprocess.check_call(['gcc', '-O2', '-fPIC', '-shared', '-ffp-contract=off', '-fno-builtin-pow', '-Wall',
+                           src, '-o', out, '-lm'])
     return out
 
 

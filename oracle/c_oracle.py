@@ -12,9 +12,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_build', 'libpuffer_oracle.so')
-        if not os.path.exists(path):
-            path = _build.build_oracle()
+        path = _build.build_oracle()      # no-op when oracle/_build/libpuffer_oracle.so is newer than its sources
         L = C.CDLL(path)
         L.po_squared_create.restype = C.c_void_p
         L.po_squared_create.argtypes = [C.c_int, C.c_int, C.c_int]
@@ -32,6 +30,20 @@ def lib():
         L.po_squared_targets.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.po_squared_stream_pos.restype = C.c_uint64
         L.po_squared_stream_pos.argtypes = [C.c_void_p]
+        L.po_stochastic_create.restype = C.c_void_p
+        L.po_stochastic_create.argtypes = [C.c_int, C.c_double, C.c_int]
+        L.po_stochastic_free.argtypes = [C.c_void_p]
+        L.po_stochastic_async_reset.argtypes = [C.c_void_p, C.c_int64]
+        L.po_stochastic_send.argtypes = [C.c_void_p, C.c_void_p]
+        for name, rt in (('observations', C.c_float), ('rewards', C.c_float), ('terminals', C.c_uint8), ('truncations', C.c_uint8),
+                         ('masks', C.c_uint8), ('info_env', C.c_int32), ('info_return', C.c_double), ('info_length', C.c_int32),
+                         ('info_score', C.c_double)):
+            f = getattr(L, 'po_stochastic_' + name)
+            f.restype = C.POINTER(rt)
+            f.argtypes = [C.c_void_p]
+        L.po_stochastic_num_infos.argtypes = [C.c_void_p]
+        L.po_stochastic_reward.restype = C.c_double
+        L.po_stochastic_reward.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.po_compute_gae.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float]
         L.po_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.po_mt_seed.argtypes = [C.c_void_p, C.c_uint64]
@@ -147,3 +159,60 @@ def philox4x32_10(ctr, key):
     out = np.empty(4, dtype=np.uint32)
     lib().po_philox4x32_10(c.ctypes.data, k.ctypes.data, out.ctypes.data)
     return out
+
+
+class StochasticSerial:
+    """``pufferlib.vector.Serial`` over ``make_stochastic`` envs (ocean/environment.py:61-64: horizon 100), restated in C.
+    Same protocol and buffer aliasing as SquaredSerial."""
+
+    def __init__(self, num_envs, p=0.7, horizon=100):
+        self.L = lib()
+        self.num_envs = num_envs
+        self.p, self.horizon = p, horizon
+        self.h = self.L.po_stochastic_create(num_envs, p, horizon)
+        n = num_envs
+        as_arr = np.ctypeslib.as_array
+        self.observations = as_arr(self.L.po_stochastic_observations(self.h), (n, 1))
+        self.rewards = as_arr(self.L.po_stochastic_rewards(self.h), (n,))
+        self.terminals = as_arr(self.L.po_stochastic_terminals(self.h), (n,)).view(bool)
+        self.truncations = as_arr(self.L.po_stochastic_truncations(self.h), (n,)).view(bool)
+        self.masks = as_arr(self.L.po_stochastic_masks(self.h), (n,)).view(bool)
+        self.agent_ids = np.arange(n)
+        self.infos = []
+
+    def __del__(self):
+        try:
+            self.L.po_stochastic_free(self.h)
+        except Exception:
+            pass
+
+    def _infos(self):
+        k = self.L.po_stochastic_num_infos(self.h)
+        if k == 0:
+            return []
+        env = np.ctypeslib.as_array(self.L.po_stochastic_info_env(self.h), (k,))
+        ret = np.ctypeslib.as_array(self.L.po_stochastic_info_return(self.h), (k,))
+        ln = np.ctypeslib.as_array(self.L.po_stochastic_info_length(self.h), (k,))
+        sc = np.ctypeslib.as_array(self.L.po_stochastic_info_score(self.h), (k,))
+        return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i]), _env=int(env[i]))
+                for i in range(k)]
+
+    def async_reset(self, seed=42):
+        self.L.po_stochastic_async_reset(self.h, int(seed))
+        self.infos = self._infos()
+
+    def send(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions), dtype=np.int64)
+        assert a.shape == (self.num_envs,)
+        self.L.po_stochastic_send(self.h, a.ctypes.data)
+        self.infos = self._infos()
+
+    def recv(self):
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)
+
+
+def stochastic_reward(p, tick, count, action):
+    """(reward, proximity) of ocean.Stochastic.step (ocean.py:566-580) in the C restatement."""
+    prox = C.c_double(0.0)
+    r = lib().po_stochastic_reward(float(p), int(tick), int(count), int(action), C.byref(prox))
+    return r, prox.value

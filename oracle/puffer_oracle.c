@@ -5,6 +5,7 @@
  */
 #include "puffer_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -302,6 +303,122 @@ void po_squared_targets(const po_squared_vec *v, int env, int *out_cells) {
     for (int t = 0; t < v->nt; t++) out_cells[t] = t < v->envs[env].n_remaining ? v->envs[env].targets[t] : -1;
 }
 uint64_t po_squared_stream_pos(const po_squared_vec *v) { return v->rng.count; }
+
+/* ======================================================================================== */
+/* Serial(make_stochastic) — ocean.py:529-582, emulation.py:169-228, postprocess.py:18-54        */
+/* ======================================================================================== */
+typedef struct {
+    int tick, count, done;
+    double ep_return; /* python sum() of the episode's rewards, in order */
+    int ep_length;
+} st_env;
+
+struct po_stochastic_vec {
+    int n, horizon, n_infos;
+    double p;
+    st_env *envs;
+    float *obs, *rewards;
+    uint8_t *terminals, *truncations, *masks;
+    int32_t *info_env, *info_len;
+    double *info_ret, *info_score;
+};
+
+po_stochastic_vec *po_stochastic_create(int num_envs, double p, int horizon) {
+    po_stochastic_vec *v = (po_stochastic_vec *)calloc(1, sizeof(*v));
+    v->n = num_envs;
+    v->p = p;
+    v->horizon = horizon;
+    v->envs = (st_env *)calloc((size_t)num_envs, sizeof(st_env));
+    v->obs = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->rewards = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->terminals = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->truncations = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->masks = (uint8_t *)malloc((size_t)num_envs);
+    memset(v->masks, 1, (size_t)num_envs);
+    v->info_env = (int32_t *)calloc((size_t)num_envs, sizeof(int32_t));
+    v->info_len = (int32_t *)calloc((size_t)num_envs, sizeof(int32_t));
+    v->info_ret = (double *)calloc((size_t)num_envs, sizeof(double));
+    v->info_score = (double *)calloc((size_t)num_envs, sizeof(double));
+    for (int i = 0; i < num_envs; i++) v->envs[i].done = 1;
+    return v;
+}
+
+void po_stochastic_free(po_stochastic_vec *v) {
+    if (!v) return;
+    free(v->envs); free(v->obs); free(v->rewards); free(v->terminals); free(v->truncations); free(v->masks);
+    free(v->info_env); free(v->info_len); free(v->info_ret); free(v->info_score); free(v);
+}
+
+/* ocean.py:551-560 reset + emulation.py:169-192 + postprocess.py:18-20: observation [0.], nothing else to draw */
+static void st_reset(po_stochastic_vec *v, int i) {
+    st_env *e = &v->envs[i];
+    e->tick = e->count = 0;
+    e->done = 0;
+    e->ep_return = 0.0;
+    e->ep_length = 0;
+    v->obs[i] = 0.0f;
+    v->rewards[i] = 0.0f;
+    v->terminals[i] = 0;
+    v->truncations[i] = 0;
+    v->masks[i] = 1;
+}
+
+/* ocean.py:562-582 */
+double po_stochastic_reward(double p, int tick, int count, int action, double *proximity_out) {
+    const double atn0_frac = (double)count / (double)tick;           /* python int / int */
+    const double proximity = 1.0 - pow(p - atn0_frac, 2.0);          /* float ** 2 -> libm pow (CPython float_pow) */
+    if (proximity_out) *proximity_out = proximity;
+    return ((action == 0 && atn0_frac < p) || (action == 1 && atn0_frac >= p)) ? proximity : 0.0;
+}
+
+void po_stochastic_async_reset(po_stochastic_vec *v, int64_t seed) {
+    (void)seed; /* reset(seed) only seeds the global RNGs, which this env never uses */
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) st_reset(v, i);
+}
+
+void po_stochastic_send(po_stochastic_vec *v, const int64_t *actions) {
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) {
+        st_env *e = &v->envs[i];
+        if (e->done) { /* vector.py:147-149: action ignored, reset row */
+            st_reset(v, i);
+            continue;
+        }
+        const int a = (int)actions[i];
+        e->tick += 1;
+        e->count += a == 0;
+        double prox;
+        const double reward = po_stochastic_reward(v->p, e->tick, e->count, a, &prox);
+        const int terminal = e->tick == v->horizon;
+        e->ep_return += reward;                 /* postprocess.py:31, summed in order at the end (:38) */
+        e->ep_length += 1;
+        v->obs[i] = 0.0f;
+        v->rewards[i] = (float)reward;          /* emulation.py:219 buf.rewards[0] = reward */
+        v->terminals[i] = (uint8_t)terminal;
+        v->truncations[i] = 0;
+        v->masks[i] = 1;
+        e->done = terminal;                     /* emulation.py:226 */
+        if (terminal) {
+            const int k = v->n_infos++;
+            v->info_env[k] = i;
+            v->info_ret[k] = e->ep_return;
+            v->info_len[k] = e->ep_length;
+            v->info_score[k] = prox;
+        }
+    }
+}
+
+const float *po_stochastic_observations(const po_stochastic_vec *v) { return v->obs; }
+const float *po_stochastic_rewards(const po_stochastic_vec *v) { return v->rewards; }
+const uint8_t *po_stochastic_terminals(const po_stochastic_vec *v) { return v->terminals; }
+const uint8_t *po_stochastic_truncations(const po_stochastic_vec *v) { return v->truncations; }
+const uint8_t *po_stochastic_masks(const po_stochastic_vec *v) { return v->masks; }
+int po_stochastic_num_infos(const po_stochastic_vec *v) { return v->n_infos; }
+const int32_t *po_stochastic_info_env(const po_stochastic_vec *v) { return v->info_env; }
+const double *po_stochastic_info_return(const po_stochastic_vec *v) { return v->info_ret; }
+const int32_t *po_stochastic_info_length(const po_stochastic_vec *v) { return v->info_len; }
+const double *po_stochastic_info_score(const po_stochastic_vec *v) { return v->info_score; }
 
 /* ======================================================================================== */
 /* GAE — c_gae.pyx:11-32                                                                      */

@@ -64,6 +64,29 @@ void po_squared_targets(const po_squared_vec *v, int env, int *out_cells /* [num
 /* word position of the shared stream (number of 32-bit outputs consumed since the last seeding) */
 uint64_t po_squared_stream_pos(const po_squared_vec *v);
 
+/* ---- Serial vecenv of ocean Stochastic --------------------------------------------------- */
+/* vector.py:78-162 Serial over make_stochastic (ocean/environment.py:61-64: horizon fixed to 100) = GymnasiumPufferEnv
+ * (emulation.py:169-228) over EpisodeStats (postprocess.py:18-54) over ocean.Stochastic (ocean.py:529-582).  The env has no
+ * randomness: reward = 1 - (p - count/tick)**2 (python float arithmetic, cast to f32 by the buffer write) when the action
+ * moves the running action-0 fraction towards p, else 0; observation is always [0.0]. */
+typedef struct po_stochastic_vec po_stochastic_vec;
+po_stochastic_vec *po_stochastic_create(int num_envs, double p, int horizon);
+void po_stochastic_free(po_stochastic_vec *v);
+void po_stochastic_async_reset(po_stochastic_vec *v, int64_t seed);
+void po_stochastic_send(po_stochastic_vec *v, const int64_t *actions);
+const float *po_stochastic_observations(const po_stochastic_vec *v); /* [N][1] */
+const float *po_stochastic_rewards(const po_stochastic_vec *v);
+const uint8_t *po_stochastic_terminals(const po_stochastic_vec *v);
+const uint8_t *po_stochastic_truncations(const po_stochastic_vec *v);
+const uint8_t *po_stochastic_masks(const po_stochastic_vec *v);
+int po_stochastic_num_infos(const po_stochastic_vec *v);
+const int32_t *po_stochastic_info_env(const po_stochastic_vec *v);
+const double *po_stochastic_info_return(const po_stochastic_vec *v);
+const int32_t *po_stochastic_info_length(const po_stochastic_vec *v);
+const double *po_stochastic_info_score(const po_stochastic_vec *v);
+/* the reward ocean.Stochastic.step returns after `tick` steps of which `count` were action 0, the last one `action` */
+double po_stochastic_reward(double p, int tick, int count, int action, double *proximity_out);
+
 /* ---- GAE ---------------------------------------------------------------------------------- */
 /* c_gae.pyx:11-32 */
 void po_compute_gae(const float *dones, const float *values, const float *rewards,

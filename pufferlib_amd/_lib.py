@@ -16,8 +16,8 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp',
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip']
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
@@ -107,6 +107,13 @@ _SIGNATURES = {
                                          P, P, P, P, P]),
     'pfa_rollout_mlp_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), C.POINTER(Experience),
                                           P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
+    'pfa_stochastic_state_bytes': (C.c_size_t, [C.c_int32]),
+    'pfa_stochastic_async_reset': (C.c_int, [P, C.c_int32, P, P, P, P, P, P]),
+    'pfa_stochastic_send': (C.c_int, [P, C.c_int32, C.c_double, C.c_int32, P, P, P, P, P, P, P]),
+    'pfa_stochastic_episode_stats': (C.c_int, [P, C.c_int32, P, C.c_int32, P]),
+    'pfa_stochastic_last_infos': (C.c_int, [P, C.c_int32, P, P, P, P, P]),
+    'pfa_rollout_mlp_stochastic': (C.c_int, [P, C.c_int32, C.c_double, C.c_int32, P, C.POINTER(MlpDims), C.POINTER(Experience),
+                                             P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
     'pfa_ppo_workspace_bytes': (C.c_size_t, [C.POINTER(MlpDims), C.c_int64, C.POINTER(PpoHparams)]),
     'pfa_ppo_adv_stats': (C.c_int, [C.POINTER(Experience), C.c_int64, C.POINTER(PpoHparams), P, P, P]),
     'pfa_ppo_mlp_grad': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),

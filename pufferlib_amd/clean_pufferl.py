@@ -35,7 +35,7 @@ from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
-from .vector import Squared
+from .vector import Squared, Stochastic
 
 
 def seed_everything(seed, torch_deterministic=True):
@@ -247,7 +247,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     n_params = sum(p.numel() for p in policy.parameters())
     msg = f'Model Size: {n_params} parameters'
 
-    host_mode = not isinstance(vecenv, Squared)       # any backend speaking the reference's recv/send protocol on the host
+    host_mode = not isinstance(vecenv, (Squared, Stochastic))   # anything else speaks the recv/send protocol on the host
     if not isinstance(policy, (Policy, RecurrentPolicy)):
         from .models import find_lstm
         if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
@@ -255,6 +255,9 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         else:
             policy = Policy(policy, seed=config.seed)     # e.g. the reference's cleanrl.Policy(models.Default)
     recurrent = isinstance(policy, RecurrentPolicy)
+    if recurrent and isinstance(vecenv, Stochastic):
+        raise NotImplementedError('the device-resident Stochastic vecenv has a fused rollout for the MLP policy only '
+                                  '(ocean.Stochastic: "do not use a policy with memory", ocean.py:534)')
     dist, rank, world = _dist()
     env_offset = rank * vecenv.num_agents
     host_bridge = None
@@ -340,6 +343,10 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
+    if isinstance(vecenv, Stochastic):    # no reset tape: the env draws no random numbers
+        with profile.eval_forward:
+            vecenv.fused_rollout_mlp(fp, experience, noise, key, _lib.stream_handle())
+        return _finish_evaluate(data, N, T)
     with profile.env:
         main = torch.cuda.current_stream()
         if data.tape_event is not None:

@@ -1,0 +1,107 @@
+// rollout_tile.hpp — the policy-forward + sampling tile code shared by every rollout kernel of the MLP policy
+// (frameworks/cleanrl.py:60-66 Policy.forward with action=None = models.py:41-62 + cleanrl.py:25-47): the standalone
+// forward (rollout.hip), the fused Squared rollout (rollout.hip) and the fused Stochastic rollout (stochastic.hip) run exactly
+// this code, so the protocol path and every fused rollout give bit-identical numbers.
+#pragma once
+#include "common.hpp"
+#include "lane_ops.hpp"
+#include "mlp_tile.hpp"
+#include "philox.hpp"
+#include "sampler.hpp"
+
+namespace pfa {
+
+// ---------------------------------------------------------------------------------------------
+// Shared by the standalone forward and the fused rollout: a 256-thread workgroup (4 wavefronts) owns one
+// 16-row tile.  Wave w computes hidden tiles m in {2w, 2w+1} and its K-slice of the heads; after a barrier
+// thread (le, lo) = (tid/16, tid%16) owns output `lo` of row `le`.  Both kernels run exactly this code, so
+// policy(obs) through the protocol and the fused rollout give bit-identical numbers.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRollThreads = 256;
+constexpr int kRollWaves = 4;
+constexpr int kMW = kMT / kRollWaves;  // hidden tiles per wave
+
+template <int DP>
+struct SliceFrags {
+    float w1f[kMW][DP / 4], b1f[kMW][4], w2f[kMW][4], bo[4];
+    __device__ __forceinline__ void load(const float *params, int a) {
+        const MlpOffsets off = mlp_offsets(DP, a);
+        const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
+#pragma unroll
+        for (int i = 0; i < kMW; ++i) {
+            const int m = kMW * wv + i;
+#pragma unroll
+            for (int kk = 0; kk < DP / 4; ++kk) w1f[i][kk] = params[off.w1 + (16 * m + c) * DP + 4 * kk + g];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                b1f[i][r] = params[off.b1 + 16 * m + 4 * g + r];
+                w2f[i][r] = w2v_at(params, off, a, c, 16 * m + 4 * g + r);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bo[r] = wv == 0 ? b2v_at(params, off, a, 4 * g + r) : 0.0f;
+    }
+};
+
+// Global rows -> padded LDS tile, all 256 threads.
+template <int DP>
+__device__ __forceinline__ void stage_rows(const float *src, long long first_row, long long rows, float *xs,
+                                           int tile_rows = 16) {
+    constexpr int XS = XTile<DP>::XS, V = DP / 4;
+    for (int idx = threadIdx.x; idx < 16 * V; idx += kRollThreads) {
+        const int r = idx / V, c4 = idx - r * V;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < tile_rows && first_row + r < rows) x = *reinterpret_cast<const float4 *>(src + (first_row + r) * DP + 4 * c4);
+        float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
+        d[0] = make_float2(x.x, x.y);
+        d[1] = make_float2(x.z, x.w);
+    }
+}
+
+// LDS tile -> global rows (dst row r at dst + (first_row + r) * row_stride floats), all 256 threads.
+template <int DP>
+__device__ __forceinline__ void unstage_rows(const float *xs, float *dst, long long first_row, long long rows, size_t row_stride,
+                                             int tile_rows = 16) {
+    constexpr int XS = XTile<DP>::XS, V = DP / 4;
+    for (int idx = threadIdx.x; idx < tile_rows * V; idx += kRollThreads) {
+        const int r = idx / V, c4 = idx - r * V;
+        if (first_row + r < rows) {
+            const float2 *sp = reinterpret_cast<const float2 *>(xs + r * XS + 4 * c4);
+            const float2 lo2 = sp[0], hi2 = sp[1];
+            *reinterpret_cast<float4 *>(dst + (size_t)(first_row + r) * row_stride + 4 * c4) = make_float4(lo2.x, lo2.y, hi2.x, hi2.y);
+        }
+    }
+}
+
+// This wave's slice of models.Default.forward (models.py:41-62) for the 16 rows in xs -> part[wave][o*16 + row].
+template <int DP>
+__device__ __forceinline__ void forward_slice(const SliceFrags<DP> &w, const float *xs, float (*part)[kOut * 16]) {
+    constexpr int XS = XTile<DP>::XS;
+    const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
+    f32x4 h[kMW];
+#pragma unroll
+    for (int i = 0; i < kMW; ++i) h[i] = f32x4{w.b1f[i][0], w.b1f[i][1], w.b1f[i][2], w.b1f[i][3]};
+#pragma unroll
+    for (int kk = 0; kk < DP / 4; ++kk) {
+        const float b = xs[c * XS + 4 * kk + g];
+#pragma unroll
+        for (int i = 0; i < kMW; ++i) h[i] = mfma16(w.w1f[i][kk], b, h[i]);
+    }
+    f32x4 o0 = f32x4{w.bo[0], w.bo[1], w.bo[2], w.bo[3]}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        o0 = mfma16(w.w2f[0][r], fmaxf(h[0][r], 0.0f), o0);
+        o1 = mfma16(w.w2f[1][r], fmaxf(h[1][r], 0.0f), o1);
+    }
+    const f32x4 po = o0 + o1;  // partial out^T[o = 4g + r][row = c]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * 16 + c] = po[r];
+}
+
+// Sum of the four waves' head partials for (row le, output lo), then sample_row16 (sampler.hpp).
+__device__ __forceinline__ LaneSample sample_lanes(const float (*part)[kOut * 16], int le, int lo, int a, float q) {
+    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+    return sample_row16(mine, lo, a, q);
+}
+
+}  // namespace pfa

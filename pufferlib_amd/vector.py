@@ -305,6 +305,171 @@ class Squared:
         return int(out.item())
 
 
+def make_stochastic(p=0.7, horizon=100, **kwargs):
+    """Env creator token with the signature of ocean.environment.make_stochastic (ocean/environment.py:61-64).  The
+    reference's creator ignores its ``horizon`` argument and always builds Stochastic(horizon=100); so does this one."""
+    return StochasticSpec(p)
+
+
+class StochasticSpec:
+    """What ``driver_env`` exposes to policies and clean_pufferl for ocean.Stochastic (ocean.py:543-549)."""
+
+    def __init__(self, p=0.7):
+        self.p = float(p)
+        self.horizon = 100
+        self.single_observation_space = spaces.Box(low=0, high=1, shape=(1,), dtype=np.float32)
+        self.single_action_space = spaces.Discrete(2)
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+        self.num_agents = 1
+        self.render_mode = 'ansi'
+        self.emulated = namespace(observation_dtype=np.dtype(np.float32),
+                                  emulated_observation_dtype=np.dtype((np.float32, (1,))))
+        self.done = True
+
+    def render(self):
+        return ''
+
+    def close(self):
+        pass
+
+
+class Stochastic:
+    """Device-resident vecenv of N ocean Stochastic envs (csrc/stochastic.hip) — the second env family behind the
+    backend protocol; same live-buffer conventions and ``info_mode`` as ``Squared``.  The env draws no random numbers, so
+    there is no reset tape and seeds only matter to the policy's noise rows."""
+    reset = reset
+    step = step
+    obs_stride = 16
+
+    @property
+    def num_envs(self):
+        return self.agents_per_batch
+
+    def __init__(self, env_creators, env_args, env_kwargs, num_envs, info_mode='sync', env_offset=0, device=None, **kwargs):
+        import inspect
+        import torch
+        for k in kwargs:
+            if k not in ('num_workers', 'batch_size', 'zero_copy', 'backend'):
+                raise APIUsageError(f'Invalid argument: {k}')
+        if len(env_creators) != num_envs:
+            raise APIUsageError('env_creators must be a list of length num_envs')
+        ps = set()
+        for c, a, k in zip(env_creators, env_args, env_kwargs):
+            if 'stochastic' not in getattr(c, '__name__', '').lower():
+                raise APIUsageError('pufferlib_amd.vector.Stochastic only hosts ocean make_stochastic envs on device '
+                                    f'(got creator {getattr(c, "__name__", c)!r})')
+            p = 0.7
+            try:
+                sig = inspect.signature(c)
+                if 'p' in sig.parameters and sig.parameters['p'].default is not inspect._empty:
+                    p = sig.parameters['p'].default
+            except (TypeError, ValueError):
+                pass
+            if len(a) > 0:
+                p = a[0]
+            ps.add(float(k.get('p', p)))
+        if len(ps) != 1:
+            raise APIUsageError(f'obs/atn space mismatch: all envs must share one Stochastic configuration, got p in {ps}')
+        self.driver_env = StochasticSpec(ps.pop())
+        self.p, self.horizon = self.driver_env.p, self.driver_env.horizon
+        _lib.require_gpu()
+        self.L = _lib.lib()
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.emulated = self.driver_env.emulated
+        self.agents_per_env = [1] * num_envs
+        self.agents_per_batch = self.num_agents = num_envs
+        self.single_observation_space = self.driver_env.single_observation_space
+        self.single_action_space = self.driver_env.single_action_space
+        self.action_space = spaces.MultiDiscrete([2] * num_envs)
+        self.observation_space = spaces.Box(low=0, high=1, shape=(num_envs, 1), dtype=np.float32)
+        self.agent_ids = np.arange(num_envs)
+        self.initialized = False
+        self.flag = RESET
+        self.info_mode = info_mode
+        self.env_offset = int(env_offset)
+        self.obs_dim = 1
+        self.episode_len = self.horizon + 1
+        dev = self.device
+        self.state = torch.zeros(self.L.pfa_stochastic_state_bytes(num_envs), dtype=torch.uint8, device=dev)
+        self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.float32, device=dev)
+        self.observations = self.obs_buf[:, :1]
+        self.rewards = torch.zeros(num_envs, dtype=torch.float32, device=dev)
+        self.terminals_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self.truncations_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self.masks_u8 = torch.ones(num_envs, dtype=torch.uint8, device=dev)
+        self.terminals = self.terminals_u8.view(torch.bool)
+        self.truncations = self.truncations_u8.view(torch.bool)
+        self.masks = self.masks_u8.view(torch.bool)
+        self._actions = torch.zeros(num_envs, dtype=torch.int64, device=dev)
+        self._fin = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self._fin_ret = torch.zeros(num_envs, dtype=torch.float64, device=dev)
+        self._fin_len = torch.zeros(num_envs, dtype=torch.int32, device=dev)
+        self._fin_score = torch.zeros(num_envs, dtype=torch.float64, device=dev)
+        self._stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.infos = []
+        self.sends = 0
+
+    def _live(self):
+        return (_lib.ptr(self.obs_buf), _lib.ptr(self.rewards), _lib.ptr(self.terminals_u8), _lib.ptr(self.truncations_u8),
+                _lib.ptr(self.masks_u8))
+
+    def async_reset(self, seed=42):
+        self.flag = RECV
+        make_seeds(seed, self.num_agents)           # validated like Serial does; the env itself ignores seeds
+        _lib.check(self.L.pfa_stochastic_async_reset(_lib.ptr(self.state), self.num_agents, *self._live(), _lib.stream_handle()),
+                   'async_reset')
+        self.sends = 0
+        self.infos = []
+
+    def send(self, actions):
+        import torch
+        send_precheck(self, actions)
+        if not torch.is_tensor(actions):
+            a = np.asarray(actions)
+            if not self.initialized and not self.action_space.contains(a):
+                raise APIUsageError('Actions do not match action space')
+            actions = torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64))
+        elif not self.initialized:
+            if actions.shape != (self.num_agents,) or actions.dtype not in (torch.int64, torch.int32):
+                raise APIUsageError('Actions do not match action space')
+        self.initialized = True
+        self._actions.copy_(actions.reshape(-1), non_blocking=True)
+        _lib.check(self.L.pfa_stochastic_send(_lib.ptr(self.state), self.num_agents, self.p, self.horizon, _lib.ptr(self._actions),
+                                              *self._live(), _lib.stream_handle()), 'send')
+        self.sends += 1
+        self.infos = self._collect_infos() if self.info_mode == 'sync' else []
+
+    def recv(self):
+        recv_precheck(self)
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)
+
+    def close(self):
+        self.flag = CLOSE
+
+    def _collect_infos(self):
+        if self.sends % self.episode_len != self.horizon:      # every env finishes on the same sends
+            return []
+        _lib.check(self.L.pfa_stochastic_last_infos(_lib.ptr(self.state), self.num_agents, _lib.ptr(self._fin), _lib.ptr(self._fin_ret),
+                                                    _lib.ptr(self._fin_len), _lib.ptr(self._fin_score), _lib.stream_handle()),
+                   'last_infos')
+        fin = self._fin.cpu().numpy().astype(bool)
+        ret, ln, sc = self._fin_ret.cpu().numpy(), self._fin_len.cpu().numpy(), self._fin_score.cpu().numpy()
+        return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i])) for i in np.nonzero(fin)[0]]
+
+    def episode_stats(self, reset=True):
+        _lib.check(self.L.pfa_stochastic_episode_stats(_lib.ptr(self.state), self.num_agents, _lib.ptr(self._stats), 1 if reset else 0,
+                                                       _lib.stream_handle()), 'episode_stats')
+        return self._stats
+
+    def fused_rollout_mlp(self, fp, experience, noise, key, stream):
+        """clean_pufferl.evaluate's T-step loop as one persistent kernel (csrc/stochastic.hip)."""
+        _lib.check(self.L.pfa_rollout_mlp_stochastic(_lib.ptr(self.state), self.num_agents, self.p, self.horizon, _lib.ptr(fp.flat),
+                                                     C.byref(fp.dims), C.byref(experience.c), _lib.ptr(noise), C.byref(key),
+                                                     self.env_offset, *self._live(), stream), 'rollout_stochastic')
+        self.sends += experience.horizon
+
+
 def make(env_creator_or_creators, env_args=None, env_kwargs=None, backend=Squared, num_envs=1, **kwargs):
     """pufferlib.vector.make (vector.py:577-637): same argument validation and error messages."""
     if num_envs < 1:

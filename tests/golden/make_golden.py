@@ -12,6 +12,7 @@ Fixtures written (all small, committed):
   gae.npz            c_gae.compute_gae (c_gae.pyx:11-32) on KAT / random / boundary inputs
   squared_<tag>.npz  pufferlib.vector.Serial over ocean make_squared (vector.py:70-166,
                      ocean.py:406-513, emulation.py:124-234, postprocess.py:8-54): lock-step trajectories
+  stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
 """
@@ -92,6 +93,38 @@ def gen_squared(tag, num_envs, d, nt, seed, steps):
         actions=np.stack(acts).astype(np.int8), infos=np.array(info_rows, np.float64).reshape(-1, 5),
         targets=np.stack(targets))
     print(f'squared_{tag}.npz', obs.shape, 'infos', len(info_rows))
+
+
+def gen_stochastic(num_envs=6, p=0.7, seed=3, steps=230):
+    """pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582; horizon is fixed to 100 by
+    ocean/environment.py:61-64): deterministic env, no RNG — rewards are python-float arithmetic cast to f32."""
+    import pufferlib.vector
+    import pufferlib.environments.ocean as ocean
+    vec = pufferlib.vector.make(ocean.env_creator('stochastic'), env_kwargs=dict(p=p), num_envs=num_envs,
+                                backend=pufferlib.vector.Serial)
+    rng = np.random.RandomState(77)
+    vec.async_reset(seed)
+    obs, rew, term, trunc, acts, info_rows = [], [], [], [], [], []
+
+    def snap(k):
+        o, r, te, tr, infos, ids, masks = vec.recv()
+        assert masks.all() and (ids == np.arange(num_envs)).all()
+        obs.append(o.copy()); rew.append(r.copy()); term.append(te.copy()); trunc.append(tr.copy())
+        for j, i in enumerate(infos):
+            info_rows.append((k, j, i['episode_return'], i['episode_length'], i['score']))
+
+    snap(0)
+    bias = rng.rand(num_envs)            # every env plays action 0 with its own probability
+    for k in range(1, steps + 1):
+        a = (rng.rand(num_envs) >= bias).astype(np.int64)
+        acts.append(a)
+        vec.send(a)
+        snap(k)
+    np.savez_compressed(os.path.join(HERE, 'stochastic.npz'), config=np.array([num_envs, seed, steps], np.int64),
+                        p=np.array([p]), obs=np.stack(obs), rewards=np.stack(rew), terminals=np.stack(term),
+                        truncations=np.stack(trunc), actions=np.stack(acts).astype(np.int8),
+                        infos=np.array(info_rows, np.float64).reshape(-1, 5))
+    print('stochastic.npz', np.stack(obs).shape, 'infos', len(info_rows))
 
 
 def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
@@ -207,5 +240,6 @@ if __name__ == '__main__':
     gen_squared('d2t2', 16, 2, 2, 7, 40)       # n=16: pool path with 2 draws
     gen_squared('d4t3', 16, 4, 3, 3, 60)       # n=32 > 21: set-rejection sampling
     gen_squared('d3t1_big', 700, 3, 1, 4090, 12)  # crosses several MT19937 regenerations per reset round
+    gen_stochastic()
     gen_ppo('mlp', use_rnn=False)
     gen_ppo('lstm', use_rnn=True)

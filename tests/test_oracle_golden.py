@@ -150,3 +150,41 @@ def test_ppo_replay_matches_reference(golden_dir, tag):
             np.testing.assert_allclose(m[name], g[f'it{it}.m.' + key], rtol=1e-4, atol=1e-7, err_msg=name)
             np.testing.assert_allclose(v[name], g[f'it{it}.v.' + key], rtol=1e-4, atol=1e-9, err_msg=name)
         assert abs(tr.opt.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-15
+
+
+def test_stochastic_oracle_replays_reference_trajectory(golden_dir):
+    """ocean.Stochastic under Serial + GymnasiumPufferEnv + EpisodeStats (tests/golden/stochastic.npz from the unmodified
+    reference): observations, f32 rewards, terminals, auto-reset rows and the episode infos, bit for bit."""
+    from oracle import c_oracle
+    g = np.load(os.path.join(golden_dir, 'stochastic.npz'))
+    n, seed, steps = (int(x) for x in g['config'])
+    vec = c_oracle.StochasticSerial(n, float(g['p'][0]), 100)
+    vec.async_reset(seed)
+    infos = []
+    for k in range(steps + 1):
+        o, r, te, tr, info, ids, m = vec.recv()
+        assert np.array_equal(o, g['obs'][k]) and np.array_equal(r, g['rewards'][k]), k
+        assert np.array_equal(te, g['terminals'][k]) and np.array_equal(tr, g['truncations'][k]) and m.all(), k
+        for j, i in enumerate(info):
+            infos.append((k, j, i['episode_return'], i['episode_length'], i['score']))
+        if k < steps:
+            vec.send(g['actions'][k].astype(np.int64))
+    assert np.array_equal(np.array(infos, np.float64).reshape(-1, 5), g['infos'])      # f64 sums in the same order
+    assert len(infos) == 12
+
+
+def test_stochastic_reward_formula_every_state():
+    """The C restatement (libm pow, like CPython's float ** 2) vs the python expression of ocean.py:571-576 for every
+    reachable (tick, count, action) of a 100-step episode and a few p."""
+    from oracle import c_oracle
+    for p in (0.7, 0.75, 0.5, 1 / 3):
+        for tick in range(1, 101):
+            for count in range(0, tick + 1):
+                frac = count / tick
+                prox = 1 - (p - frac) ** 2
+                for a in (0, 1):
+                    if (a == 0 and count == 0) or (a == 1 and count == tick):
+                        continue                                   # unreachable: the last action is counted
+                    want = prox if ((a == 0 and frac < p) or (a == 1 and frac >= p)) else 0
+                    got, gp = c_oracle.stochastic_reward(p, tick, count, a)
+                    assert got == want and gp == prox, (p, tick, count, a)
