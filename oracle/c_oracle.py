@@ -30,6 +30,20 @@ def lib():
         L.po_squared_targets.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.po_squared_stream_pos.restype = C.c_uint64
         L.po_squared_stream_pos.argtypes = [C.c_void_p]
+        L.po_mt_seed_numpy.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_memory_create.restype = C.c_void_p
+        L.po_memory_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.po_memory_free.argtypes = [C.c_void_p]
+        L.po_memory_async_reset.argtypes = [C.c_void_p, C.c_int64]
+        L.po_memory_send.argtypes = [C.c_void_p, C.c_void_p]
+        L.po_memory_solution.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        for name, rt in (('observations', C.c_float), ('rewards', C.c_float), ('terminals', C.c_uint8), ('truncations', C.c_uint8),
+                         ('masks', C.c_uint8), ('info_env', C.c_int32), ('info_return', C.c_double), ('info_length', C.c_int32),
+                         ('info_score', C.c_double)):
+            f = getattr(L, 'po_memory_' + name)
+            f.restype = C.POINTER(rt)
+            f.argtypes = [C.c_void_p]
+        L.po_memory_num_infos.argtypes = [C.c_void_p]
         L.po_stochastic_create.restype = C.c_void_p
         L.po_stochastic_create.argtypes = [C.c_int, C.c_double, C.c_int]
         L.po_stochastic_free.argtypes = [C.c_void_p]
@@ -216,3 +230,59 @@ def stochastic_reward(p, tick, count, action):
     prox = C.c_double(0.0)
     r = lib().po_stochastic_reward(float(p), int(tick), int(count), int(action), C.byref(prox))
     return r, prox.value
+
+
+class MemorySerial:
+    """``pufferlib.vector.Serial`` over ``make_memory`` envs (ocean/environment.py:41-44), restated in C (numpy's global legacy
+    stream included).  Same protocol and buffer aliasing as SquaredSerial."""
+
+    def __init__(self, num_envs, mem_length=2, mem_delay=2):
+        self.L = lib()
+        self.num_envs = num_envs
+        self.mem_length, self.mem_delay, self.horizon = mem_length, mem_delay, 2 * mem_length + mem_delay
+        self.h = self.L.po_memory_create(num_envs, mem_length, mem_delay)
+        assert self.h, 'horizon out of range'
+        n = num_envs
+        as_arr = np.ctypeslib.as_array
+        self.observations = as_arr(self.L.po_memory_observations(self.h), (n, 1))
+        self.rewards = as_arr(self.L.po_memory_rewards(self.h), (n,))
+        self.terminals = as_arr(self.L.po_memory_terminals(self.h), (n,)).view(bool)
+        self.truncations = as_arr(self.L.po_memory_truncations(self.h), (n,)).view(bool)
+        self.masks = as_arr(self.L.po_memory_masks(self.h), (n,)).view(bool)
+        self.agent_ids = np.arange(n)
+        self.infos = []
+
+    def __del__(self):
+        try:
+            self.L.po_memory_free(self.h)
+        except Exception:
+            pass
+
+    def _infos(self):
+        k = self.L.po_memory_num_infos(self.h)
+        if k == 0:
+            return []
+        env = np.ctypeslib.as_array(self.L.po_memory_info_env(self.h), (k,))
+        ret = np.ctypeslib.as_array(self.L.po_memory_info_return(self.h), (k,))
+        ln = np.ctypeslib.as_array(self.L.po_memory_info_length(self.h), (k,))
+        sc = np.ctypeslib.as_array(self.L.po_memory_info_score(self.h), (k,))
+        return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i]), _env=int(env[i]))
+                for i in range(k)]
+
+    def async_reset(self, seed=42):
+        self.L.po_memory_async_reset(self.h, int(seed))
+        self.infos = self._infos()
+
+    def send(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions), dtype=np.int64)
+        assert a.shape == (self.num_envs,)
+        self.L.po_memory_send(self.h, a.ctypes.data)
+        self.infos = self._infos()
+
+    def recv(self):
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)
+
+    def solution(self, env):
+        out = (C.c_float * self.horizon)()
+        self.L.po_memory_solution(self.h, env, out)
+        return np.array(out[:], np.float32)

@@ -305,6 +305,143 @@ void po_squared_targets(const po_squared_vec *v, int env, int *out_cells) {
 uint64_t po_squared_stream_pos(const po_squared_vec *v) { return v->rng.count; }
 
 /* ======================================================================================== */
+/* numpy legacy seeding + Serial(make_memory) — ocean.py:65-123                                 */
+/* ======================================================================================== */
+void po_mt_seed_numpy(po_mt_t *g, uint32_t seed) { /* numpy/random/src/mt19937/mt19937.c: mt19937_seed = init_genrand */
+    g->mt[0] = seed;
+    for (int i = 1; i < 624; i++) g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+    g->idx = 624;
+    g->count = 0;
+}
+
+#define PO_MEM_MAXH 64
+typedef struct {
+    int tick, done, ep_length;
+    float solution[PO_MEM_MAXH], submission[PO_MEM_MAXH];
+    double ep_return;
+} mem_env;
+
+struct po_memory_vec {
+    int n, L, D, H, n_infos;
+    po_mt_t rng; /* np.random's global state */
+    mem_env *envs;
+    float *obs, *rewards;
+    uint8_t *terminals, *truncations, *masks;
+    int32_t *info_env, *info_len;
+    double *info_ret, *info_score;
+};
+
+po_memory_vec *po_memory_create(int num_envs, int mem_length, int mem_delay) {
+    po_memory_vec *v = (po_memory_vec *)calloc(1, sizeof(*v));
+    v->n = num_envs;
+    v->L = mem_length;
+    v->D = mem_delay;
+    v->H = 2 * mem_length + mem_delay; /* ocean.py:83 */
+    if (v->H > PO_MEM_MAXH || v->H < 2) { free(v); return NULL; }
+    v->envs = (mem_env *)calloc((size_t)num_envs, sizeof(mem_env));
+    v->obs = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->rewards = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->terminals = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->truncations = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->masks = (uint8_t *)malloc((size_t)num_envs);
+    memset(v->masks, 1, (size_t)num_envs);
+    v->info_env = (int32_t *)calloc((size_t)num_envs, sizeof(int32_t));
+    v->info_len = (int32_t *)calloc((size_t)num_envs, sizeof(int32_t));
+    v->info_ret = (double *)calloc((size_t)num_envs, sizeof(double));
+    v->info_score = (double *)calloc((size_t)num_envs, sizeof(double));
+    for (int i = 0; i < num_envs; i++) v->envs[i].done = 1;
+    po_mt_seed_numpy(&v->rng, 0);
+    return v;
+}
+
+void po_memory_free(po_memory_vec *v) {
+    if (!v) return;
+    free(v->envs); free(v->obs); free(v->rewards); free(v->terminals); free(v->truncations); free(v->masks);
+    free(v->info_env); free(v->info_len); free(v->info_ret); free(v->info_score); free(v);
+}
+
+/* ocean.py:90-100 reset + emulation.py:169-192 + postprocess.py:18-20 */
+static void mem_reset(po_memory_vec *v, int i, int has_seed, int64_t seed) {
+    mem_env *e = &v->envs[i];
+    if (has_seed) po_mt_seed_numpy(&v->rng, (uint32_t)seed); /* np.random.seed(seed), ocean.py:92-93 */
+    /* np.random.randint(0, 2, size=horizon): range 1 -> mask 1, one 32-bit word per element, never rejected */
+    for (int j = 0; j < v->H; j++) e->solution[j] = (float)(po_mt_u32(&v->rng) & 1u);
+    for (int j = v->H - (v->L + v->D); j < v->H; j++) e->solution[j] = -1.0f; /* ocean.py:96 */
+    for (int j = 0; j < v->H; j++) e->submission[j] = -1.0f;
+    e->tick = 1;
+    e->done = 0;
+    e->ep_return = 0.0;
+    e->ep_length = 0;
+    v->obs[i] = e->solution[0];
+    v->rewards[i] = 0.0f;
+    v->terminals[i] = 0;
+    v->truncations[i] = 0;
+    v->masks[i] = 1;
+}
+
+void po_memory_async_reset(po_memory_vec *v, int64_t seed) {
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) mem_reset(v, i, 1, seed + i); /* vector.py:129-130 */
+}
+
+/* ocean.py:102-123 */
+void po_memory_send(po_memory_vec *v, const int64_t *actions) {
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) {
+        mem_env *e = &v->envs[i];
+        if (e->done) { /* vector.py:147-149: action ignored, unseeded reset draws from the shared stream */
+            mem_reset(v, i, 0, 0);
+            continue;
+        }
+        const int a = (int)actions[i];
+        float ob = 0.0f;
+        double reward = 0.0;
+        if (e->tick < v->L) {
+            ob = e->solution[e->tick];
+            reward = a == 0 ? 1.0 : 0.0;
+        }
+        if (e->tick >= v->L + v->D) {
+            const int idx = e->tick - v->L - v->D;
+            reward = (float)a == e->solution[idx] ? 1.0 : 0.0;
+            e->submission[e->tick] = (float)a;
+        }
+        e->tick += 1;
+        const int terminal = e->tick == v->H;
+        e->ep_return += reward;
+        e->ep_length += 1;
+        v->obs[i] = ob;
+        v->rewards[i] = (float)reward;
+        v->terminals[i] = (uint8_t)terminal;
+        v->truncations[i] = 0;
+        v->masks[i] = 1;
+        e->done = terminal;
+        if (terminal) {
+            int ok = 1; /* np.all(solution[:L] == submission[-L:]), ocean.py:120-121 */
+            for (int j = 0; j < v->L; j++) ok &= e->solution[j] == e->submission[v->H - v->L + j];
+            const int k = v->n_infos++;
+            v->info_env[k] = i;
+            v->info_ret[k] = e->ep_return;
+            v->info_len[k] = e->ep_length;
+            v->info_score[k] = (double)ok;
+        }
+    }
+}
+
+const float *po_memory_observations(const po_memory_vec *v) { return v->obs; }
+const float *po_memory_rewards(const po_memory_vec *v) { return v->rewards; }
+const uint8_t *po_memory_terminals(const po_memory_vec *v) { return v->terminals; }
+const uint8_t *po_memory_truncations(const po_memory_vec *v) { return v->truncations; }
+const uint8_t *po_memory_masks(const po_memory_vec *v) { return v->masks; }
+int po_memory_num_infos(const po_memory_vec *v) { return v->n_infos; }
+const int32_t *po_memory_info_env(const po_memory_vec *v) { return v->info_env; }
+const double *po_memory_info_return(const po_memory_vec *v) { return v->info_ret; }
+const int32_t *po_memory_info_length(const po_memory_vec *v) { return v->info_len; }
+const double *po_memory_info_score(const po_memory_vec *v) { return v->info_score; }
+void po_memory_solution(const po_memory_vec *v, int env, float *out) {
+    for (int j = 0; j < v->H; j++) out[j] = v->envs[env].solution[j];
+}
+
+/* ======================================================================================== */
 /* Serial(make_stochastic) — ocean.py:529-582, emulation.py:169-228, postprocess.py:18-54        */
 /* ======================================================================================== */
 typedef struct {

@@ -64,6 +64,32 @@ void po_squared_targets(const po_squared_vec *v, int env, int *out_cells /* [num
 /* word position of the shared stream (number of 32-bit outputs consumed since the last seeding) */
 uint64_t po_squared_stream_pos(const po_squared_vec *v);
 
+/* ---- numpy legacy RandomState on MT19937 (numpy/random/mtrand + _legacy: seed(int) = init_genrand; randint over a
+ * 32-bit range = masked rejection on genrand_uint32).  Third-party arithmetic restated; checked against numpy itself. */
+void po_mt_seed_numpy(po_mt_t *g, uint32_t seed);          /* np.random.seed(int) */
+
+/* ---- Serial vecenv of ocean Memory ---------------------------------------------------------- */
+/* vector.py:78-162 Serial over make_memory (ocean/environment.py:41-44) = GymnasiumPufferEnv + EpisodeStats over
+ * ocean.Memory (ocean.py:65-123).  reset(seed) seeds numpy's PROCESS-GLOBAL generator when a seed is given (async_reset:
+ * seed + i per env) and always draws solution = np.random.randint(0, 2, size=horizon) from it, so after async_reset every
+ * env shares the stream left by the last env. */
+typedef struct po_memory_vec po_memory_vec;
+po_memory_vec *po_memory_create(int num_envs, int mem_length, int mem_delay);
+void po_memory_free(po_memory_vec *v);
+void po_memory_async_reset(po_memory_vec *v, int64_t seed);
+void po_memory_send(po_memory_vec *v, const int64_t *actions);
+const float *po_memory_observations(const po_memory_vec *v); /* [N][1] */
+const float *po_memory_rewards(const po_memory_vec *v);
+const uint8_t *po_memory_terminals(const po_memory_vec *v);
+const uint8_t *po_memory_truncations(const po_memory_vec *v);
+const uint8_t *po_memory_masks(const po_memory_vec *v);
+int po_memory_num_infos(const po_memory_vec *v);
+const int32_t *po_memory_info_env(const po_memory_vec *v);
+const double *po_memory_info_return(const po_memory_vec *v);
+const int32_t *po_memory_info_length(const po_memory_vec *v);
+const double *po_memory_info_score(const po_memory_vec *v);
+void po_memory_solution(const po_memory_vec *v, int env, float *out /* [horizon] */);
+
 /* ---- Serial vecenv of ocean Stochastic --------------------------------------------------- */
 /* vector.py:78-162 Serial over make_stochastic (ocean/environment.py:61-64: horizon fixed to 100) = GymnasiumPufferEnv
  * (emulation.py:169-228) over EpisodeStats (postprocess.py:18-54) over ocean.Stochastic (ocean.py:529-582).  The env has no

@@ -12,6 +12,7 @@ Fixtures written (all small, committed):
   gae.npz            c_gae.compute_gae (c_gae.pyx:11-32) on KAT / random / boundary inputs
   squared_<tag>.npz  pufferlib.vector.Serial over ocean make_squared (vector.py:70-166,
                      ocean.py:406-513, emulation.py:124-234, postprocess.py:8-54): lock-step trajectories
+  memory_<tag>.npz   pufferlib.vector.Serial over ocean make_memory (ocean.py:65-123): numpy's global legacy stream
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
@@ -125,6 +126,44 @@ def gen_stochastic(num_envs=6, p=0.7, seed=3, steps=230):
                         truncations=np.stack(trunc), actions=np.stack(acts).astype(np.int8),
                         infos=np.array(info_rows, np.float64).reshape(-1, 5))
     print('stochastic.npz', np.stack(obs).shape, 'infos', len(info_rows))
+
+
+def gen_memory(tag, num_envs, mem_length, mem_delay, seed, steps):
+    """pufferlib.vector.Serial over ocean make_memory (ocean.py:65-123): every reset draws np.random.randint(0, 2, horizon) from
+    numpy's process-global legacy stream (seeded per env at async_reset, shared afterwards)."""
+    import pufferlib.vector
+    import pufferlib.environments.ocean as ocean
+    vec = pufferlib.vector.make(ocean.env_creator('memory'), env_kwargs=dict(mem_length=mem_length, mem_delay=mem_delay),
+                                num_envs=num_envs, backend=pufferlib.vector.Serial)
+    rng = np.random.RandomState(500 + seed)       # a private generator: must not touch the global stream under test
+    vec.async_reset(seed)
+    obs, rew, term, trunc, acts, info_rows, sols = [], [], [], [], [], [], []
+
+    def snap(k):
+        o, r, te, tr, infos, ids, masks = vec.recv()
+        assert masks.all() and (ids == np.arange(num_envs)).all()
+        obs.append(o.copy()); rew.append(r.copy()); term.append(te.copy()); trunc.append(tr.copy())
+        for j, i in enumerate(infos):
+            info_rows.append((k, j, i['episode_return'], i['episode_length'], float(i['score'])))
+        sols.append(np.stack([env.env.env.solution.copy() for env in vec.envs]))
+
+    snap(0)
+    for k in range(1, steps + 1):
+        # half of the envs echo the remembered digits at the right time, so scores of both kinds appear
+        a = rng.randint(0, 2, size=num_envs)
+        for e, env in enumerate(vec.envs[::2]):
+            m = env.env.env
+            if not env.done and m.tick >= m.mem_length + m.mem_delay:
+                a[2 * e] = int(m.solution[m.tick - m.mem_length - m.mem_delay])
+        acts.append(a)
+        vec.send(a)
+        snap(k)
+    np.savez_compressed(os.path.join(HERE, f'memory_{tag}.npz'),
+                        config=np.array([num_envs, mem_length, mem_delay, seed, steps], np.int64), obs=np.stack(obs),
+                        rewards=np.stack(rew), terminals=np.stack(term), truncations=np.stack(trunc),
+                        actions=np.stack(acts).astype(np.int8), infos=np.array(info_rows, np.float64).reshape(-1, 5),
+                        solutions=np.stack(sols).astype(np.int8))
+    print(f'memory_{tag}.npz', np.stack(obs).shape, 'infos', len(info_rows))
 
 
 def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
@@ -241,5 +280,7 @@ if __name__ == '__main__':
     gen_squared('d4t3', 16, 4, 3, 3, 60)       # n=32 > 21: set-rejection sampling
     gen_squared('d3t1_big', 700, 3, 1, 4090, 12)  # crosses several MT19937 regenerations per reset round
     gen_stochastic()
+    gen_memory('l2d2', 5, 2, 2, 11, 40)
+    gen_memory('l3d1', 130, 3, 1, 4090, 30)    # 130 x 7 words per reset round: crosses MT19937 blocks
     gen_ppo('mlp', use_rnn=False)
     gen_ppo('lstm', use_rnn=True)

@@ -188,3 +188,39 @@ def test_stochastic_reward_formula_every_state():
                     want = prox if ((a == 0 and frac < p) or (a == 1 and frac >= p)) else 0
                     got, gp = c_oracle.stochastic_reward(p, tick, count, a)
                     assert got == want and gp == prox, (p, tick, count, a)
+
+
+@pytest.mark.parametrize('tag', ['l2d2', 'l3d1'])
+def test_memory_oracle_replays_reference_trajectory(golden_dir, tag):
+    """ocean.Memory under Serial (tests/golden/memory_<tag>.npz from the unmodified reference): the solutions drawn from
+    numpy's global legacy stream (per-env seeding at async_reset, shared stream afterwards, MT19937 block crossings),
+    observations, rewards, terminals, auto-reset rows and episode infos, bit for bit."""
+    from oracle import c_oracle
+    g = np.load(os.path.join(golden_dir, f'memory_{tag}.npz'))
+    n, L, D, seed, steps = (int(x) for x in g['config'])
+    vec = c_oracle.MemorySerial(n, L, D)
+    vec.async_reset(seed)
+    infos = []
+    for k in range(steps + 1):
+        o, r, te, tr, info, ids, m = vec.recv()
+        assert np.array_equal(o, g['obs'][k]) and np.array_equal(r, g['rewards'][k]), k
+        assert np.array_equal(te, g['terminals'][k]) and not tr.any() and m.all(), k
+        assert np.array_equal(np.stack([vec.solution(e) for e in range(n)]).astype(np.int8), g['solutions'][k]), k
+        for j, i in enumerate(info):
+            infos.append((k, j, i['episode_return'], i['episode_length'], i['score']))
+        if k < steps:
+            vec.send(g['actions'][k].astype(np.int64))
+    assert np.array_equal(np.array(infos, np.float64).reshape(-1, 5), g['infos'])
+
+
+def test_numpy_legacy_stream_restatement_matches_numpy():
+    """po_mt_seed_numpy + genrand == np.random.RandomState(seed).randint(0, 2, size) (masked rejection, one word per draw)."""
+    from oracle import c_oracle
+    import ctypes as C
+    L = c_oracle.lib()
+    for seed in (0, 1, 42, 4219, 2 ** 32 - 1):
+        st = (C.c_uint8 * 4096)()          # po_mt_t is ~2.5 KB
+        L.po_mt_seed_numpy(st, seed)
+        want = np.random.RandomState(seed).randint(0, 2, size=2000)
+        got = np.array([L.po_mt_u32(st) & 1 for _ in range(2000)])
+        assert np.array_equal(got, want), seed
