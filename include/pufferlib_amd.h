@@ -184,6 +184,32 @@ int pfa_rollout_mlp_stochastic(void *state, int32_t num_envs, double p, int32_t 
                                uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Memory vecenv (the env family that needs the recurrent policy) — replaces pufferlib.vector.Serial over
+ * ocean.environment.make_memory (ocean/environment.py:41-44) = GymnasiumPufferEnv + EpisodeStats + ocean.Memory
+ * (ocean.py:65-123).  Every reset draws np.random.randint(0, 2, size=2L+D) from numpy's process-global legacy MT19937
+ * (seeded per env at async_reset, shared afterwards); the stream is action-independent and is drawn ahead into a tape
+ * (pfa_memory_fill_tape) like Squared's.  Observation rows of 16 floats (1 real column), 2 actions.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t num_envs;
+    int32_t mem_length;  /* L, 1..16 */
+    int32_t mem_delay;   /* D >= 0; horizon = 2L + D */
+    int32_t tape_rounds; /* ring capacity in reset rounds */
+} pfa_memory_config;
+size_t pfa_memory_state_bytes(const pfa_memory_config *cfg);
+int pfa_memory_async_reset(void *state, const pfa_memory_config *cfg, int64_t seed, float *obs, float *rewards,
+                           uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_memory_fill_tape(void *state, const pfa_memory_config *cfg, int32_t rounds, pfa_stream_t stream);
+int pfa_memory_send(void *state, const pfa_memory_config *cfg, const int64_t *actions, float *obs, float *rewards,
+                    uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_memory_episode_stats(void *state, const pfa_memory_config *cfg, double *out4, int32_t reset, pfa_stream_t stream);
+int pfa_memory_last_infos(void *state, const pfa_memory_config *cfg, uint8_t *finished, double *episode_return,
+                          int32_t *episode_length, double *score, pfa_stream_t stream);
+/* test introspection: bit j of bits[e] = solution[j] of env e; *underrun != 0 if a reset ever found the tape empty */
+int pfa_memory_debug_solutions(void *state, const pfa_memory_config *cfg, uint32_t *bits, int32_t *underrun,
+                               pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * PPO update — the minibatch loop of clean_pufferl.train (clean_pufferl.py:175-258).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {

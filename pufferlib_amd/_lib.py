@@ -16,8 +16,8 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp',
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip']
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
@@ -59,6 +59,10 @@ def build(force=False, verbose=False):
 class SquaredConfig(C.Structure):
     _fields_ = [('num_envs', C.c_int32), ('distance_to_target', C.c_int32), ('num_targets', C.c_int32),
                 ('obs_stride', C.c_int32), ('tape_rounds', C.c_int32)]
+
+
+class MemoryConfig(C.Structure):
+    _fields_ = [('num_envs', C.c_int32), ('mem_length', C.c_int32), ('mem_delay', C.c_int32), ('tape_rounds', C.c_int32)]
 
 
 class MlpDims(C.Structure):
@@ -114,6 +118,13 @@ _SIGNATURES = {
     'pfa_stochastic_last_infos': (C.c_int, [P, C.c_int32, P, P, P, P, P]),
     'pfa_rollout_mlp_stochastic': (C.c_int, [P, C.c_int32, C.c_double, C.c_int32, P, C.POINTER(MlpDims), C.POINTER(Experience),
                                              P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
+    'pfa_memory_state_bytes': (C.c_size_t, [C.POINTER(MemoryConfig)]),
+    'pfa_memory_async_reset': (C.c_int, [P, C.POINTER(MemoryConfig), C.c_int64, P, P, P, P, P, P]),
+    'pfa_memory_fill_tape': (C.c_int, [P, C.POINTER(MemoryConfig), C.c_int32, P]),
+    'pfa_memory_send': (C.c_int, [P, C.POINTER(MemoryConfig), P, P, P, P, P, P, P]),
+    'pfa_memory_episode_stats': (C.c_int, [P, C.POINTER(MemoryConfig), P, C.c_int32, P]),
+    'pfa_memory_last_infos': (C.c_int, [P, C.POINTER(MemoryConfig), P, P, P, P, P]),
+    'pfa_memory_debug_solutions': (C.c_int, [P, C.POINTER(MemoryConfig), P, P, P]),
     'pfa_ppo_workspace_bytes': (C.c_size_t, [C.POINTER(MlpDims), C.c_int64, C.POINTER(PpoHparams)]),
     'pfa_ppo_adv_stats': (C.c_int, [C.POINTER(Experience), C.c_int64, C.POINTER(PpoHparams), P, P, P]),
     'pfa_ppo_mlp_grad': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),

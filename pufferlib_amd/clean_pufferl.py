@@ -35,7 +35,7 @@ from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
-from .vector import Squared, Stochastic
+from .vector import Memory, Squared, Stochastic
 
 
 def seed_everything(seed, torch_deterministic=True):
@@ -247,7 +247,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     n_params = sum(p.numel() for p in policy.parameters())
     msg = f'Model Size: {n_params} parameters'
 
-    host_mode = not isinstance(vecenv, (Squared, Stochastic))   # anything else speaks the recv/send protocol on the host
+    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory))   # anything else speaks the recv/send protocol on the host
     if not isinstance(policy, (Policy, RecurrentPolicy)):
         from .models import find_lstm
         if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
@@ -343,6 +343,10 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
+    if isinstance(vecenv, Memory):        # no fused kernel for this env: protocol-level pieces, still no host sync per step
+        with profile.eval_forward:
+            _rollout_stepwise(data, noise, T, N)
+        return _finish_evaluate(data, N, T)
     if isinstance(vecenv, Stochastic):    # no reset tape: the env draws no random numbers
         with profile.eval_forward:
             vecenv.fused_rollout_mlp(fp, experience, noise, key, _lib.stream_handle())
@@ -375,6 +379,38 @@ def evaluate(data):
                 data.tape_event = torch.cuda.Event()
                 data.tape_event.record(data.tape_stream)
     return _finish_evaluate(data, N, T)
+
+
+def _rollout_stepwise(data, noise, T, N):
+    """clean_pufferl.evaluate's loop (clean_pufferl.py:84-124) for a device vecenv without a fused rollout kernel: per step
+    policy forward + sample (one kernel, MLP or recurrent), Experience.store (one kernel), vecenv.device_send (one kernel)."""
+    L = _lib.lib()
+    vecenv, policy, fp, exp = data.vecenv, data.policy, data.flat_params, data.experience
+    stream = _lib.stream_handle()
+    dev = vecenv.device
+    eng = data.lstm_engine
+    if eng is not None:
+        from . import lstm as plstm
+        plstm.pack_gates(fp, eng.wpack)
+    actions = torch.empty(N, dtype=torch.int64, device=dev)
+    logprob = torch.empty(N, device=dev)
+    value = torch.empty(N, device=dev)
+    for t in range(T):
+        key = _lib.NoiseKey(policy.noise_seed, policy.noise_step + t)
+        nz = None if noise is None else noise[t]
+        if eng is None:
+            _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(vecenv.obs_buf), N, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(nz),
+                                                C.byref(key), vecenv.env_offset, _lib.ptr(actions), _lib.ptr(logprob), None,
+                                                _lib.ptr(value), stream), 'forward_sample')
+        else:
+            _lib.check(L.pfa_lstm_policy_step(_lib.ptr(vecenv.obs_buf), N, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(eng.wpack),
+                                              _lib.ptr(eng.lstm_h), _lib.ptr(eng.lstm_c), _lib.ptr(nz), C.byref(key),
+                                              vecenv.env_offset, _lib.ptr(actions), _lib.ptr(logprob), None, _lib.ptr(value),
+                                              stream), 'lstm_policy_step')
+        _lib.check(L.pfa_store_step(C.byref(exp.c), t, N, fp.obs_stride, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
+                                    _lib.ptr(vecenv.terminals_u8), _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(value), stream),
+                   'store_step')
+        vecenv.device_send(actions)
 
 
 def _finish_evaluate(data, N, T):

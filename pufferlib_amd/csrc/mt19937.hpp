@@ -69,4 +69,29 @@ __device__ inline void mt_regenerate_strided(uint32_t *mt, size_t stride) {
     }
 }
 
+// Workgroup-parallel regeneration (>= 624 threads): three dependency waves separated by barriers.
+// new_[.] = next MT block computed from old_[.]; out[.] = tempered new_.  All threads; ends with a barrier.
+__device__ __forceinline__ void mt_next_block(const uint32_t *old_, uint32_t *new_, uint32_t *out) {
+    const int t = threadIdx.x;
+    if (t < 227) {  // kk in [0,227): old words only
+        const uint32_t x = mt_twist(old_[t], old_[t + 1], old_[t + kMtM]);
+        new_[t] = x;
+        out[t] = mt_temper(x);
+    }
+    __syncthreads();
+    if (t >= 227 && t < 454) {  // kk in [227,454): new [0,227)
+        const uint32_t x = mt_twist(old_[t], old_[t + 1], new_[t - 227]);
+        new_[t] = x;
+        out[t] = mt_temper(x);
+    }
+    __syncthreads();
+    if (t >= 454 && t < kMtN) {  // kk in [454,624): new [227,397); kk = 623 wraps to new[0]
+        const uint32_t x = mt_twist(old_[t], t + 1 < kMtN ? old_[t + 1] : new_[0], new_[t - 227]);
+        new_[t] = x;
+        out[t] = mt_temper(x);
+    }
+    __syncthreads();
+}
+
+
 }  // namespace pfa

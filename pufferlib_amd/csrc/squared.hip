@@ -140,29 +140,6 @@ __global__ void __launch_bounds__(256) squared_seed_kernel(SquaredView v, long l
 constexpr int kTapeThreads = 640;
 constexpr int kTapeWaves = kTapeThreads / 64;
 
-// new_[.] = next MT block computed from old_[.]; out[.] = tempered new_.  All threads; ends with a barrier.
-__device__ __forceinline__ void mt_next_block(const uint32_t *old_, uint32_t *new_, uint32_t *out) {
-    const int t = threadIdx.x;
-    if (t < 227) {  // kk in [0,227): old words only
-        const uint32_t x = mt_twist(old_[t], old_[t + 1], old_[t + kMtM]);
-        new_[t] = x;
-        out[t] = mt_temper(x);
-    }
-    __syncthreads();
-    if (t >= 227 && t < 454) {  // kk in [227,454): new [0,227)
-        const uint32_t x = mt_twist(old_[t], old_[t + 1], new_[t - 227]);
-        new_[t] = x;
-        out[t] = mt_temper(x);
-    }
-    __syncthreads();
-    if (t >= 454 && t < kMtN) {  // kk in [454,624): new [227,397); kk = 623 wraps to new[0]
-        const uint32_t x = mt_twist(old_[t], t + 1 < kMtN ? old_[t + 1] : new_[0], new_[t - 227]);
-        new_[t] = x;
-        out[t] = mt_temper(x);
-    }
-    __syncthreads();
-}
-
 __global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView v, int rounds) {
     __shared__ uint32_t mt[2][kMtN];
     __shared__ uint32_t out[kMtN];

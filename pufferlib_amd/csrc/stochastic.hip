@@ -10,6 +10,7 @@
 // the last proximity.  Kernels: async_reset, send (protocol path), episode statistics, and the fused persistent rollout
 // with the MLP policy (same tile code as every other rollout, rollout_tile.hpp; observation row stride 16).
 #include "common.hpp"
+#include "episode_fin.hpp"
 #include "rollout_tile.hpp"
 
 namespace pfa {
@@ -20,12 +21,7 @@ struct StochasticEnv {
     int tick, count, done, ep_length;
     double ep_return;
 };
-// Per-env accumulators of finished episodes since the last statistics read, and the last send()'s finished episode.
-struct StochasticFin {
-    double sum_return, sum_length, sum_score;
-    double last_return, last_score;
-    int finished, last_fin, last_length, pad;
-};
+using StochasticFin = EpisodeFin;  // episode_fin.hpp
 struct StochasticView {
     StochasticEnv *env;
     StochasticFin *fin;
@@ -74,17 +70,6 @@ __device__ __forceinline__ bool stochastic_step(StochasticEnv &s, int action, do
     return terminal;
 }
 
-__device__ __forceinline__ void stochastic_account(StochasticFin &f, double ret, int len, double score) {
-    f.sum_return += ret;
-    f.sum_length += (double)len;
-    f.sum_score += score;
-    f.finished += 1;
-    f.last_fin = 1;
-    f.last_return = ret;
-    f.last_length = len;
-    f.last_score = score;
-}
-
 __global__ void __launch_bounds__(256) stochastic_reset_kernel(StochasticView v, float *obs, float *rewards, uint8_t *terminals,
                                                               uint8_t *truncations, uint8_t *masks) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -118,7 +103,7 @@ __global__ void __launch_bounds__(256) stochastic_send_kernel(StochasticView v, 
     } else {
         double fr, fs;
         int fl;
-        if (stochastic_step(s, (int)actions[e], p, horizon, r, t, fr, fl, fs)) stochastic_account(v.fin[e], fr, fl, fs);
+        if (stochastic_step(s, (int)actions[e], p, horizon, r, t, fr, fl, fs)) episode_account(v.fin[e], fr, fl, fs);
     }
     v.env[e] = s;
     obs[(size_t)e * kStoDP] = 0.0f;
@@ -126,42 +111,6 @@ __global__ void __launch_bounds__(256) stochastic_send_kernel(StochasticView v, 
     terminals[e] = t ? 1 : 0;
     truncations[e] = 0;
     masks[e] = 1;
-}
-
-// out4 = {episodes finished, sum of returns, sum of lengths, sum of scores} since the last reset of the accumulators;
-// single workgroup, fixed-order f64 sums (deterministic).
-__global__ void __launch_bounds__(256) stochastic_stats_kernel(StochasticView v, double *out4, int reset) {
-    __shared__ double sh[4][256];
-    double a[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int e = threadIdx.x; e < v.n; e += 256) {
-        StochasticFin &f = v.fin[e];
-        a[0] += (double)f.finished;
-        a[1] += f.sum_return;
-        a[2] += f.sum_length;
-        a[3] += f.sum_score;
-        if (reset) {
-            f.finished = 0;
-            f.sum_return = f.sum_length = f.sum_score = 0.0;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sh[k][threadIdx.x] = a[k];
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        double s = 0.0;
-        for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
-        out4[threadIdx.x] = s;
-    }
-}
-
-__global__ void __launch_bounds__(256) stochastic_infos_kernel(StochasticView v, uint8_t *fin, double *ret, int *len, double *score) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= v.n) return;
-    const StochasticFin &f = v.fin[e];
-    fin[e] = f.last_fin ? 1 : 0;
-    ret[e] = f.last_return;
-    len[e] = f.last_length;
-    score[e] = f.last_score;
 }
 
 // Fused persistent rollout, structure of rollout_mlp_squared_kernel (rollout.hip): 16 envs per 4-wave workgroup, env state
@@ -215,7 +164,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_stochastic_kernel(St
             } else {
                 double fr, fs;
                 int fl;
-                if (stochastic_step(s, sm.action, p, horizon_env, reward, terminal, fr, fl, fs)) stochastic_account(v.fin[e], fr, fl, fs);
+                if (stochastic_step(s, sm.action, p, horizon_env, reward, terminal, fr, fl, fs)) episode_account(v.fin[e], fr, fl, fs);
             }
             // the observation never changes: xs row le stays [0, 0, ...]
         }
@@ -259,8 +208,8 @@ extern "C" int pfa_stochastic_send(void *state, int32_t num_envs, double p, int3
 
 extern "C" int pfa_stochastic_episode_stats(void *state, int32_t num_envs, double *out4, int32_t reset, pfa_stream_t stream) {
     PFA_REQUIRE(state && num_envs >= 1 && out4, "stochastic.episode_stats: bad arguments");
-    hipLaunchKernelGGL(stochastic_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stochastic_view(state, num_envs), out4,
-                       (int)reset);
+    hipLaunchKernelGGL(episode_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stochastic_view(state, num_envs).fin,
+                       (int)num_envs, out4, (int)reset);
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -268,8 +217,8 @@ extern "C" int pfa_stochastic_episode_stats(void *state, int32_t num_envs, doubl
 extern "C" int pfa_stochastic_last_infos(void *state, int32_t num_envs, uint8_t *finished, double *episode_return,
                                          int32_t *episode_length, double *score, pfa_stream_t stream) {
     PFA_REQUIRE(state && num_envs >= 1 && finished && episode_return && episode_length && score, "stochastic.last_infos: bad arguments");
-    hipLaunchKernelGGL(stochastic_infos_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       stochastic_view(state, num_envs), finished, episode_return, (int *)episode_length, score);
+    hipLaunchKernelGGL(episode_infos_kernel, dim3((unsigned)((num_envs + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       stochastic_view(state, num_envs).fin, (int)num_envs, finished, episode_return, (int *)episode_length, score);
     PFA_LAUNCH_CHECK();
     return 0;
 }

@@ -470,6 +470,204 @@ class Stochastic:
         self.sends += experience.horizon
 
 
+def make_memory(mem_length=2, mem_delay=2, **kwargs):
+    """Env creator token with the signature of ocean.environment.make_memory (ocean/environment.py:41-44)."""
+    return MemorySpec(mem_length, mem_delay)
+
+
+class MemorySpec:
+    """What ``driver_env`` exposes to policies and clean_pufferl for ocean.Memory (ocean.py:80-88)."""
+
+    def __init__(self, mem_length=2, mem_delay=2):
+        self.mem_length, self.mem_delay = int(mem_length), int(mem_delay)
+        self.horizon = 2 * self.mem_length + self.mem_delay
+        self.single_observation_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float32)
+        self.single_action_space = spaces.Discrete(2)
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+        self.num_agents = 1
+        self.render_mode = 'ansi'
+        self.emulated = namespace(observation_dtype=np.dtype(np.float32),
+                                  emulated_observation_dtype=np.dtype((np.float32, (1,))))
+        self.done = True
+
+    def render(self):
+        return ''
+
+    def close(self):
+        pass
+
+
+class Memory:
+    """Device-resident vecenv of N ocean Memory envs (csrc/memory.hip) — the env family that needs the recurrent policy.
+    Same live-buffer conventions and ``info_mode`` as ``Squared``; the solutions of future episodes come from the tape the
+    backend keeps ahead of the sends (numpy's process-global legacy stream, which does not depend on actions).  There is no
+    fused rollout kernel for this env: clean_pufferl.evaluate steps it through ``device_send`` (no host sync per step)."""
+    reset = reset
+    step = step
+    obs_stride = 16
+
+    @property
+    def num_envs(self):
+        return self.agents_per_batch
+
+    def __init__(self, env_creators, env_args, env_kwargs, num_envs, info_mode='sync', env_offset=0, device=None, **kwargs):
+        import inspect
+        import torch
+        for k in kwargs:
+            if k not in ('num_workers', 'batch_size', 'zero_copy', 'backend'):
+                raise APIUsageError(f'Invalid argument: {k}')
+        if len(env_creators) != num_envs:
+            raise APIUsageError('env_creators must be a list of length num_envs')
+        specs = set()
+        for c, a, k in zip(env_creators, env_args, env_kwargs):
+            if 'memory' not in getattr(c, '__name__', '').lower():
+                raise APIUsageError('pufferlib_amd.vector.Memory only hosts ocean make_memory envs on device '
+                                    f'(got creator {getattr(c, "__name__", c)!r})')
+            vals = dict(mem_length=2, mem_delay=2)
+            try:
+                sig = inspect.signature(c)
+                for name in vals:
+                    if name in sig.parameters and sig.parameters[name].default is not inspect._empty:
+                        vals[name] = sig.parameters[name].default
+            except (TypeError, ValueError):
+                pass
+            for i, name in enumerate(('mem_length', 'mem_delay')):
+                if len(a) > i:
+                    vals[name] = a[i]
+                vals[name] = k.get(name, vals[name])
+            specs.add((int(vals['mem_length']), int(vals['mem_delay'])))
+        if len(specs) != 1:
+            raise APIUsageError(f'obs/atn space mismatch: all envs must share one Memory configuration, got {specs}')
+        L_, D_ = specs.pop()
+        self.driver_env = MemorySpec(L_, D_)
+        self.horizon = self.driver_env.horizon
+        _lib.require_gpu()
+        self.L = _lib.lib()
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.emulated = self.driver_env.emulated
+        self.agents_per_env = [1] * num_envs
+        self.agents_per_batch = self.num_agents = num_envs
+        self.single_observation_space = self.driver_env.single_observation_space
+        self.single_action_space = self.driver_env.single_action_space
+        self.action_space = spaces.MultiDiscrete([2] * num_envs)
+        self.observation_space = spaces.Box(low=-1, high=1, shape=(num_envs, 1), dtype=np.float32)
+        self.agent_ids = np.arange(num_envs)
+        self.initialized = False
+        self.flag = RESET
+        self.info_mode = info_mode
+        self.env_offset = int(env_offset)
+        self.obs_dim = 1
+        self.episode_len = self.horizon          # H - 1 steps + the auto-reset row
+        self.tape_rounds = 256
+        self.cfg = _lib.MemoryConfig(num_envs, L_, D_, self.tape_rounds)
+        nbytes = self.L.pfa_memory_state_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise APIUsageError(self.L.pfa_last_error().decode())
+        dev = self.device
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.float32, device=dev)
+        self.observations = self.obs_buf[:, :1]
+        self.rewards = torch.zeros(num_envs, dtype=torch.float32, device=dev)
+        self.terminals_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self.truncations_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self.masks_u8 = torch.ones(num_envs, dtype=torch.uint8, device=dev)
+        self.terminals = self.terminals_u8.view(torch.bool)
+        self.truncations = self.truncations_u8.view(torch.bool)
+        self.masks = self.masks_u8.view(torch.bool)
+        self._actions = torch.zeros(num_envs, dtype=torch.int64, device=dev)
+        self._fin = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self._fin_ret = torch.zeros(num_envs, dtype=torch.float64, device=dev)
+        self._fin_len = torch.zeros(num_envs, dtype=torch.int32, device=dev)
+        self._fin_score = torch.zeros(num_envs, dtype=torch.float64, device=dev)
+        self._stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self.infos = []
+        self.sends = 0
+        self.rounds_filled = 0
+
+    def _live(self):
+        return (_lib.ptr(self.obs_buf), _lib.ptr(self.rewards), _lib.ptr(self.terminals_u8), _lib.ptr(self.truncations_u8),
+                _lib.ptr(self.masks_u8))
+
+    def _rounds_needed(self, upto_send):
+        """Reset rounds consumed by sends 1..upto_send: every env resets on sends k*horizon."""
+        return upto_send // self.episode_len
+
+    def ensure_tape(self, extra_sends):
+        need = self._rounds_needed(self.sends + extra_sends)
+        if need - self._rounds_needed(self.sends) > self.tape_rounds:
+            raise APIUsageError(f'{extra_sends} sends need more reset rounds than the tape holds ({self.tape_rounds})')
+        if need > self.rounds_filled:
+            _lib.check(self.L.pfa_memory_fill_tape(_lib.ptr(self.state), C.byref(self.cfg), need - self.rounds_filled,
+                                                   _lib.stream_handle()), 'fill_tape')
+            self.rounds_filled = need
+
+    def async_reset(self, seed=42):
+        self.flag = RECV
+        seeds = make_seeds(seed, self.num_agents)
+        if any(s != seeds[0] + i for i, s in enumerate(seeds)):
+            raise APIUsageError('pufferlib_amd.vector.Memory needs consecutive seeds (seed + env index)')
+        _lib.check(self.L.pfa_memory_async_reset(_lib.ptr(self.state), C.byref(self.cfg), int(seeds[0]), *self._live(),
+                                                 _lib.stream_handle()), 'async_reset')
+        self.sends = 0
+        self.rounds_filled = 0
+        self.infos = []
+
+    def device_send(self, actions):
+        """send() for a device int64 tensor of actions, no protocol bookkeeping and no host sync (rollout loops)."""
+        self.ensure_tape(1)
+        _lib.check(self.L.pfa_memory_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(actions), *self._live(),
+                                          _lib.stream_handle()), 'send')
+        self.sends += 1
+
+    def send(self, actions):
+        import torch
+        send_precheck(self, actions)
+        if not torch.is_tensor(actions):
+            a = np.asarray(actions)
+            if not self.initialized and not self.action_space.contains(a):
+                raise APIUsageError('Actions do not match action space')
+            actions = torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64))
+        elif not self.initialized:
+            if actions.shape != (self.num_agents,) or actions.dtype not in (torch.int64, torch.int32):
+                raise APIUsageError('Actions do not match action space')
+        self.initialized = True
+        self._actions.copy_(actions.reshape(-1), non_blocking=True)
+        self.device_send(self._actions)
+        self.infos = self._collect_infos() if self.info_mode == 'sync' else []
+
+    def recv(self):
+        recv_precheck(self)
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)
+
+    def close(self):
+        self.flag = CLOSE
+
+    def _collect_infos(self):
+        if self.sends % self.episode_len != self.episode_len - 1:      # every env finishes on the same sends
+            return []
+        _lib.check(self.L.pfa_memory_last_infos(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._fin), _lib.ptr(self._fin_ret),
+                                                _lib.ptr(self._fin_len), _lib.ptr(self._fin_score), _lib.stream_handle()),
+                   'last_infos')
+        fin = self._fin.cpu().numpy().astype(bool)
+        ret, ln, sc = self._fin_ret.cpu().numpy(), self._fin_len.cpu().numpy(), self._fin_score.cpu().numpy()
+        return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i])) for i in np.nonzero(fin)[0]]
+
+    def episode_stats(self, reset=True):
+        _lib.check(self.L.pfa_memory_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._stats), 1 if reset else 0,
+                                                   _lib.stream_handle()), 'episode_stats')
+        return self._stats
+
+    def debug_solutions(self):
+        """(solution digits per env as a bit mask, tape underrun flag) — test introspection."""
+        import torch
+        bits = torch.zeros(self.num_agents, dtype=torch.int32, device=self.device)
+        under = torch.zeros(1, dtype=torch.int32, device=self.device)
+        _lib.check(self.L.pfa_memory_debug_solutions(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(bits), _lib.ptr(under),
+                                                     _lib.stream_handle()), 'debug_solutions')
+        return bits.cpu().numpy(), int(under.item())
+
+
 def make(env_creator_or_creators, env_args=None, env_kwargs=None, backend=Squared, num_envs=1, **kwargs):
     """pufferlib.vector.make (vector.py:577-637): same argument validation and error messages."""
     if num_envs < 1:
