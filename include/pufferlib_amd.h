@@ -210,6 +210,23 @@ int pfa_memory_debug_solutions(void *state, const pfa_memory_config *cfg, uint32
                                pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Bandit vecenv — replaces pufferlib.vector.Serial over ocean.environment.make_bandit
+ * (ocean/environment.py:33-37) = GymnasiumPufferEnv + EpisodeStats + ocean.Bandit (ocean.py:8-63).  Every episode is
+ * one step; reward = f32(((action == solution) + noise[e]) * reward_scale) in f64 arithmetic.  `solution` and the per-env
+ * `noise` table (f64 [num_envs], device; NULL = reward_noise 0) are what numpy's legacy generator yields after
+ * seed(42): the host side draws them with numpy itself.  Observation rows of 16 floats, first column 1.0.
+ * ------------------------------------------------------------------------------------------ */
+size_t pfa_bandit_state_bytes(int32_t num_envs);
+int pfa_bandit_async_reset(void *state, int32_t num_envs, float *obs, float *rewards, uint8_t *terminals,
+                           uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_bandit_send(void *state, int32_t num_envs, int32_t solution, double reward_scale, const double *noise,
+                    const int64_t *actions, float *obs, float *rewards, uint8_t *terminals, uint8_t *truncations,
+                    uint8_t *masks, pfa_stream_t stream);
+int pfa_bandit_episode_stats(void *state, int32_t num_envs, double *out4, int32_t reset, pfa_stream_t stream);
+int pfa_bandit_last_infos(void *state, int32_t num_envs, uint8_t *finished, double *episode_return,
+                          int32_t *episode_length, double *score, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * PPO update — the minibatch loop of clean_pufferl.train (clean_pufferl.py:175-258).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {

@@ -31,6 +31,23 @@ def lib():
         L.po_squared_stream_pos.restype = C.c_uint64
         L.po_squared_stream_pos.argtypes = [C.c_void_p]
         L.po_mt_seed_numpy.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_np_seed.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_np_randint.restype = C.c_uint32
+        L.po_np_randint.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_np_randn.restype = C.c_double
+        L.po_np_randn.argtypes = [C.c_void_p]
+        L.po_bandit_create.restype = C.c_void_p
+        L.po_bandit_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+        L.po_bandit_free.argtypes = [C.c_void_p]
+        L.po_bandit_async_reset.argtypes = [C.c_void_p, C.c_int64]
+        L.po_bandit_send.argtypes = [C.c_void_p, C.c_void_p]
+        for name, rt in (('observations', C.c_float), ('rewards', C.c_float), ('terminals', C.c_uint8), ('masks', C.c_uint8),
+                         ('info_return', C.c_double), ('info_score', C.c_double)):
+            f = getattr(L, 'po_bandit_' + name)
+            f.restype = C.POINTER(rt)
+            f.argtypes = [C.c_void_p]
+        L.po_bandit_num_infos.argtypes = [C.c_void_p]
+        L.po_bandit_solution.argtypes = [C.c_void_p]
         L.po_memory_create.restype = C.c_void_p
         L.po_memory_create.argtypes = [C.c_int, C.c_int, C.c_int]
         L.po_memory_free.argtypes = [C.c_void_p]
@@ -286,3 +303,53 @@ class MemorySerial:
         out = (C.c_float * self.horizon)()
         self.L.po_memory_solution(self.h, env, out)
         return np.array(out[:], np.float32)
+
+
+class BanditSerial:
+    """``pufferlib.vector.Serial`` over ``make_bandit`` envs (ocean/environment.py:33-37), restated in C incl. numpy's legacy
+    randint / gauss on the process-global generator."""
+
+    def __init__(self, num_envs, num_actions=10, reward_scale=1, reward_noise=1):
+        self.L = lib()
+        self.num_envs = num_envs
+        self.h = self.L.po_bandit_create(num_envs, num_actions, float(reward_scale), float(reward_noise))
+        n = num_envs
+        as_arr = np.ctypeslib.as_array
+        self.observations = as_arr(self.L.po_bandit_observations(self.h), (n, 1))
+        self.rewards = as_arr(self.L.po_bandit_rewards(self.h), (n,))
+        self.terminals = as_arr(self.L.po_bandit_terminals(self.h), (n,)).view(bool)
+        self.truncations = np.zeros(n, bool)
+        self.masks = as_arr(self.L.po_bandit_masks(self.h), (n,)).view(bool)
+        self.agent_ids = np.arange(n)
+        self.infos = []
+
+    def __del__(self):
+        try:
+            self.L.po_bandit_free(self.h)
+        except Exception:
+            pass
+
+    def _infos(self):
+        k = self.L.po_bandit_num_infos(self.h)
+        if k == 0:
+            return []
+        ret = np.ctypeslib.as_array(self.L.po_bandit_info_return(self.h), (k,))
+        sc = np.ctypeslib.as_array(self.L.po_bandit_info_score(self.h), (k,))
+        return [dict(episode_return=float(ret[i]), episode_length=1, score=float(sc[i])) for i in range(k)]
+
+    @property
+    def solution(self):
+        return self.L.po_bandit_solution(self.h)
+
+    def async_reset(self, seed=42):
+        self.L.po_bandit_async_reset(self.h, int(seed))
+        self.infos = []
+
+    def send(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions), dtype=np.int64)
+        assert a.shape == (self.num_envs,)
+        self.L.po_bandit_send(self.h, a.ctypes.data)
+        self.infos = self._infos()
+
+    def recv(self):
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)

@@ -314,6 +314,123 @@ void po_mt_seed_numpy(po_mt_t *g, uint32_t seed) { /* numpy/random/src/mt19937/m
     g->count = 0;
 }
 
+void po_np_seed(po_np_state *s, uint32_t seed) {
+    po_mt_seed_numpy(&s->mt, seed);
+    s->has_gauss = 0; /* _legacy_seeding clears the cached gaussian */
+    s->gauss = 0.0;
+}
+
+uint32_t po_np_randint(po_np_state *s, uint32_t n) { /* _bounded_integers: masked rejection, range n - 1 */
+    const uint32_t rng = n - 1;
+    if (rng == 0) return 0;
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    uint32_t v;
+    while ((v = po_mt_u32(&s->mt) & mask) > rng) {}
+    return v;
+}
+
+static double np_double(po_np_state *s) { /* mt19937_next_double */
+    const uint32_t a = po_mt_u32(&s->mt) >> 5, b = po_mt_u32(&s->mt) >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+
+double po_np_randn(po_np_state *s) { /* legacy_gauss */
+    if (s->has_gauss) {
+        const double t = s->gauss;
+        s->has_gauss = 0;
+        s->gauss = 0.0;
+        return t;
+    }
+    double f, x1, x2, r2;
+    do {
+        x1 = 2.0 * np_double(s) - 1.0;
+        x2 = 2.0 * np_double(s) - 1.0;
+        r2 = x1 * x1 + x2 * x2;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = sqrt(-2.0 * log(r2) / r2);
+    s->gauss = f * x1;
+    s->has_gauss = 1;
+    return f * x2;
+}
+
+/* ---- Serial(make_bandit) — ocean.py:8-63 ---- */
+struct po_bandit_vec {
+    int n, num_actions, n_infos, solution;
+    double scale, noise;
+    po_np_state rng; /* np.random's global state */
+    int *done;
+    float *obs, *rewards;
+    uint8_t *terminals, *masks;
+    double *info_ret, *info_score;
+};
+
+po_bandit_vec *po_bandit_create(int num_envs, int num_actions, double reward_scale, double reward_noise) {
+    po_bandit_vec *v = (po_bandit_vec *)calloc(1, sizeof(*v));
+    v->n = num_envs;
+    v->num_actions = num_actions;
+    v->scale = reward_scale;
+    v->noise = reward_noise;
+    v->done = (int *)calloc((size_t)num_envs, sizeof(int));
+    v->obs = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->rewards = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->terminals = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->masks = (uint8_t *)malloc((size_t)num_envs);
+    memset(v->masks, 1, (size_t)num_envs);
+    v->info_ret = (double *)calloc((size_t)num_envs, sizeof(double));
+    v->info_score = (double *)calloc((size_t)num_envs, sizeof(double));
+    po_np_seed(&v->rng, 0);
+    return v;
+}
+void po_bandit_free(po_bandit_vec *v) {
+    if (!v) return;
+    free(v->done); free(v->obs); free(v->rewards); free(v->terminals); free(v->masks); free(v->info_ret); free(v->info_score);
+    free(v);
+}
+static void bandit_reset(po_bandit_vec *v, int i) { /* ocean.py:33-44: the seed argument is replaced by hard_fixed_seed = 42 */
+    po_np_seed(&v->rng, 42);
+    v->solution = (int)po_np_randint(&v->rng, (uint32_t)v->num_actions);
+    v->done[i] = 0;
+    v->obs[i] = 1.0f;
+    v->rewards[i] = 0.0f;
+    v->terminals[i] = 0;
+    v->masks[i] = 1;
+}
+void po_bandit_async_reset(po_bandit_vec *v, int64_t seed) {
+    (void)seed;
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) bandit_reset(v, i);
+}
+void po_bandit_send(po_bandit_vec *v, const int64_t *actions) { /* ocean.py:46-63 */
+    v->n_infos = 0;
+    for (int i = 0; i < v->n; i++) {
+        if (v->done[i]) {
+            bandit_reset(v, i);
+            continue;
+        }
+        const int correct = (int)actions[i] == v->solution;
+        double noise = 0.0;
+        if (v->noise != 0.0) noise = po_np_randn(&v->rng) * v->scale;
+        const double reward = ((double)correct + noise) * v->scale;
+        v->obs[i] = 1.0f;
+        v->rewards[i] = (float)reward;
+        v->terminals[i] = 1;
+        v->masks[i] = 1;
+        v->done[i] = 1;
+        const int k = v->n_infos++;
+        v->info_ret[k] = reward;      /* sum([reward]) */
+        v->info_score[k] = (double)correct;
+    }
+}
+const float *po_bandit_observations(const po_bandit_vec *v) { return v->obs; }
+const float *po_bandit_rewards(const po_bandit_vec *v) { return v->rewards; }
+const uint8_t *po_bandit_terminals(const po_bandit_vec *v) { return v->terminals; }
+const uint8_t *po_bandit_masks(const po_bandit_vec *v) { return v->masks; }
+int po_bandit_num_infos(const po_bandit_vec *v) { return v->n_infos; }
+const double *po_bandit_info_return(const po_bandit_vec *v) { return v->info_ret; }
+const double *po_bandit_info_score(const po_bandit_vec *v) { return v->info_score; }
+int po_bandit_solution(const po_bandit_vec *v) { return v->solution; }
+
 #define PO_MEM_MAXH 64
 typedef struct {
     int tick, done, ep_length;

@@ -68,6 +68,36 @@ uint64_t po_squared_stream_pos(const po_squared_vec *v);
  * 32-bit range = masked rejection on genrand_uint32).  Third-party arithmetic restated; checked against numpy itself. */
 void po_mt_seed_numpy(po_mt_t *g, uint32_t seed);          /* np.random.seed(int) */
 
+/* numpy legacy helpers on the same generator: rk_double (53-bit) and legacy_gauss (polar Box-Muller with a cached second
+ * value; numpy/random/src/legacy/legacy-distributions.c), randint over [0, n) with masked rejection. */
+typedef struct {
+    po_mt_t mt;
+    int has_gauss;
+    double gauss;
+} po_np_state;
+void po_np_seed(po_np_state *s, uint32_t seed);            /* np.random.seed(int): also drops the cached gaussian */
+uint32_t po_np_randint(po_np_state *s, uint32_t n);        /* np.random.randint(0, n), n <= 2**32 */
+double po_np_randn(po_np_state *s);                        /* np.random.randn() */
+
+/* ---- Serial vecenv of ocean Bandit ----------------------------------------------------------- */
+/* vector.py:78-162 Serial over make_bandit (ocean/environment.py:33-37) = GymnasiumPufferEnv + EpisodeStats over
+ * ocean.Bandit (ocean.py:8-63): every reset reseeds numpy's global generator with hard_fixed_seed = 42 and draws
+ * solution_idx = randint(0, num_actions); a step returns ((action == solution) + randn() * reward_scale) * reward_scale
+ * (noise only if reward_noise != 0) and always terminates. */
+typedef struct po_bandit_vec po_bandit_vec;
+po_bandit_vec *po_bandit_create(int num_envs, int num_actions, double reward_scale, double reward_noise);
+void po_bandit_free(po_bandit_vec *v);
+void po_bandit_async_reset(po_bandit_vec *v, int64_t seed);
+void po_bandit_send(po_bandit_vec *v, const int64_t *actions);
+const float *po_bandit_observations(const po_bandit_vec *v); /* [N][1] */
+const float *po_bandit_rewards(const po_bandit_vec *v);
+const uint8_t *po_bandit_terminals(const po_bandit_vec *v);
+const uint8_t *po_bandit_masks(const po_bandit_vec *v);
+int po_bandit_num_infos(const po_bandit_vec *v);
+const double *po_bandit_info_return(const po_bandit_vec *v);
+const double *po_bandit_info_score(const po_bandit_vec *v);
+int po_bandit_solution(const po_bandit_vec *v);
+
 /* ---- Serial vecenv of ocean Memory ---------------------------------------------------------- */
 /* vector.py:78-162 Serial over make_memory (ocean/environment.py:41-44) = GymnasiumPufferEnv + EpisodeStats over
  * ocean.Memory (ocean.py:65-123).  reset(seed) seeds numpy's PROCESS-GLOBAL generator when a seed is given (async_reset:

@@ -35,7 +35,7 @@ from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
-from .vector import Memory, Squared, Stochastic
+from .vector import Bandit, Memory, Squared, Stochastic
 
 
 def seed_everything(seed, torch_deterministic=True):
@@ -247,7 +247,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     n_params = sum(p.numel() for p in policy.parameters())
     msg = f'Model Size: {n_params} parameters'
 
-    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory))   # anything else speaks the recv/send protocol on the host
+    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory, Bandit))   # anything else speaks the recv/send protocol on the host
     if not isinstance(policy, (Policy, RecurrentPolicy)):
         from .models import find_lstm
         if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
@@ -343,7 +343,7 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
-    if isinstance(vecenv, Memory):        # no fused kernel for this env: protocol-level pieces, still no host sync per step
+    if isinstance(vecenv, (Memory, Bandit)):   # no fused kernel for these envs: protocol-level pieces, still no host sync per step
         with profile.eval_forward:
             _rollout_stepwise(data, noise, T, N)
         return _finish_evaluate(data, N, T)

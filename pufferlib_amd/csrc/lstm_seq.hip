@@ -11,8 +11,6 @@
 //                         [dxe_t | dh_{t-1}]^T = Wcat^T dG_t^T on MFMA; relu' applied to dxe; dh_{t-1}, dc stay in
 //                         registers.  Also accumulates the bias gradients (column sums of dG and dxe) per workgroup.
 // Roofline: fp32 MFMA, 2*256*512 flop per row and step in each direction (+ 2*64*128 for the encoder forward).
-#include <cstdlib>
-
 #include "common.hpp"
 #include "lane_ops.hpp"
 #include "lstm_tile.hpp"
@@ -26,14 +24,6 @@ constexpr int kDGS = kLG + 4;             // LDS row stride of a dG tile (floats
 constexpr int kDGTile = 16 * kDGS;
 constexpr int kBiasCols = kLG + kLH;      // per-workgroup partial column sums: dG (512) then dxe (128)
 
-// Every workgroup runs the same compute phase / memory phase cycle per step; launched together they stay in lock-step
-// and the whole chip alternates between saturating HBM and idling it.  A one-off start delay of (group index mod 8) *
-// `units` * 64 cycles spreads the phases so that memory phases of some workgroups overlap the MFMA phases of others.
-__device__ __forceinline__ void seq_stagger(int units) {
-    const int n = (int)((blockIdx.x >> 3) & 7) * units;
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-}
-
 template <int DP>
 struct SeqFwdLds {
     float xs[kSeqRT][XTile<DP>::kFloats];
@@ -46,10 +36,9 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
                                                                    const float *__restrict__ params, int a,
                                                                    const float4 *__restrict__ wpack, float *__restrict__ xe,
                                                                    float *__restrict__ gates_act, float *__restrict__ Hs,
-                                                                   float *__restrict__ Cs, int stagger) {
+                                                                   float *__restrict__ Cs) {
     constexpr int V = DP / 4;
     __shared__ SeqFwdLds<DP> L;
-    seq_stagger(stagger);
     LstmFrags<DP> w;
     w.load(params, a);
     stage_gate_bias(params, DP, a, L.gbias);
@@ -173,9 +162,8 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
                                                                    const float *__restrict__ xe, const float *__restrict__ dh_heads,
                                                                    long long R, int Th, const float4 *__restrict__ wpack_bwd,
                                                                    float *__restrict__ dG, float *__restrict__ dxe,
-                                                                   float *__restrict__ bias_partial, int stagger) {
+                                                                   float *__restrict__ bias_partial) {
     __shared__ SeqBwdLds L;
-    seq_stagger(stagger);
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
     const float4 *wp = wpack_bwd + (size_t)__builtin_amdgcn_readfirstlane(wv) * 32 * 4 * 64;
     const long long first = (long long)blockIdx.x * kSeqRows;
@@ -356,17 +344,6 @@ static int check_seq_dims(const pfa_mlp_dims *d) {
     return 0;
 }
 
-// start-delay unit (x 64 cycles per phase slot); PFA_LSTM_STAGGER_FWD / _BWD override the defaults (0 disables)
-static int seq_stagger_units(int bwd) {
-    static int cached[2] = {-1, -1};
-    if (cached[bwd] < 0) {
-        const char *e = getenv(bwd ? "PFA_LSTM_STAGGER_BWD" : "PFA_LSTM_STAGGER_FWD");
-        cached[bwd] = e ? atoi(e) : 0;
-        if (cached[bwd] < 0) cached[bwd] = 0;
-    }
-    return cached[bwd];
-}
-
 #define PFA_SEQ_DISPATCH_DP(dp, CALL)             \
     switch (dp) {                                 \
         case 16: { constexpr int DP = 16; CALL; } break;   \
@@ -399,7 +376,7 @@ extern "C" int pfa_lstm_seq_forward(const float *obs_tm, int64_t rows, int32_t s
     PFA_SEQ_DISPATCH_DP(dims->obs_stride,
                         hipLaunchKernelGGL(lstm_seq_fwd_kernel<DP>, dim3(grid), dim3(kLstmThreads), 0, (hipStream_t)stream, obs_tm,
                                            (long long)rows, (int)steps, params, dims->num_actions, (const float4 *)wpack, xe,
-                                           gates_act, hs, cs, seq_stagger_units(0)));
+                                           gates_act, hs, cs));
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -419,7 +396,7 @@ extern "C" int pfa_lstm_seq_backward(const float *gates_act, const float *cs, co
     hipStream_t st = (hipStream_t)stream;
     ScopedKernelTimer timer("lstm_seq_bwd", st);
     hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(grid), dim3(kLstmThreads), 0, st, gates_act, cs, xe, dh_heads, (long long)rows,
-                       (int)steps, (const float4 *)wpack_bwd, dgates, dxe, (float *)workspace, seq_stagger_units(1));
+                       (int)steps, (const float4 *)wpack_bwd, dgates, dxe, (float *)workspace);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(lstm_bias_final_kernel, dim3(kBiasCols / 64), dim3(256), 0, st, (const float *)workspace, (int)grid,
                        gate_bias_grad, enc_bias_grad);

@@ -305,20 +305,12 @@ class Squared:
         return int(out.item())
 
 
-def make_stochastic(p=0.7, horizon=100, **kwargs):
-    """Env creator token with the signature of ocean.environment.make_stochastic (ocean/environment.py:61-64).  The
-    reference's creator ignores its ``horizon`` argument and always builds Stochastic(horizon=100); so does this one."""
-    return StochasticSpec(p)
+class _SimpleSpec:
+    """What ``driver_env`` exposes to policies (models.py:26-37) and clean_pufferl for a one-value-observation ocean env."""
 
-
-class StochasticSpec:
-    """What ``driver_env`` exposes to policies and clean_pufferl for ocean.Stochastic (ocean.py:543-549)."""
-
-    def __init__(self, p=0.7):
-        self.p = float(p)
-        self.horizon = 100
-        self.single_observation_space = spaces.Box(low=0, high=1, shape=(1,), dtype=np.float32)
-        self.single_action_space = spaces.Discrete(2)
+    def __init__(self, low, high, num_actions):
+        self.single_observation_space = spaces.Box(low=low, high=high, shape=(1,), dtype=np.float32)
+        self.single_action_space = spaces.Discrete(num_actions)
         self.observation_space = self.single_observation_space
         self.action_space = self.single_action_space
         self.num_agents = 1
@@ -334,238 +326,75 @@ class StochasticSpec:
         pass
 
 
-class Stochastic:
-    """Device-resident vecenv of N ocean Stochastic envs (csrc/stochastic.hip) — the second env family behind the
-    backend protocol; same live-buffer conventions and ``info_mode`` as ``Squared``.  The env draws no random numbers, so
-    there is no reset tape and seeds only matter to the policy's noise rows."""
-    reset = reset
-    step = step
-    obs_stride = 16
-
-    @property
-    def num_envs(self):
-        return self.agents_per_batch
-
-    def __init__(self, env_creators, env_args, env_kwargs, num_envs, info_mode='sync', env_offset=0, device=None, **kwargs):
-        import inspect
-        import torch
-        for k in kwargs:
-            if k not in ('num_workers', 'batch_size', 'zero_copy', 'backend'):
-                raise APIUsageError(f'Invalid argument: {k}')
-        if len(env_creators) != num_envs:
-            raise APIUsageError('env_creators must be a list of length num_envs')
-        ps = set()
-        for c, a, k in zip(env_creators, env_args, env_kwargs):
-            if 'stochastic' not in getattr(c, '__name__', '').lower():
-                raise APIUsageError('pufferlib_amd.vector.Stochastic only hosts ocean make_stochastic envs on device '
-                                    f'(got creator {getattr(c, "__name__", c)!r})')
-            p = 0.7
-            try:
-                sig = inspect.signature(c)
-                if 'p' in sig.parameters and sig.parameters['p'].default is not inspect._empty:
-                    p = sig.parameters['p'].default
-            except (TypeError, ValueError):
-                pass
-            if len(a) > 0:
-                p = a[0]
-            ps.add(float(k.get('p', p)))
-        if len(ps) != 1:
-            raise APIUsageError(f'obs/atn space mismatch: all envs must share one Stochastic configuration, got p in {ps}')
-        self.driver_env = StochasticSpec(ps.pop())
-        self.p, self.horizon = self.driver_env.p, self.driver_env.horizon
-        _lib.require_gpu()
-        self.L = _lib.lib()
-        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
-        self.emulated = self.driver_env.emulated
-        self.agents_per_env = [1] * num_envs
-        self.agents_per_batch = self.num_agents = num_envs
-        self.single_observation_space = self.driver_env.single_observation_space
-        self.single_action_space = self.driver_env.single_action_space
-        self.action_space = spaces.MultiDiscrete([2] * num_envs)
-        self.observation_space = spaces.Box(low=0, high=1, shape=(num_envs, 1), dtype=np.float32)
-        self.agent_ids = np.arange(num_envs)
-        self.initialized = False
-        self.flag = RESET
-        self.info_mode = info_mode
-        self.env_offset = int(env_offset)
-        self.obs_dim = 1
-        self.episode_len = self.horizon + 1
-        dev = self.device
-        self.state = torch.zeros(self.L.pfa_stochastic_state_bytes(num_envs), dtype=torch.uint8, device=dev)
-        self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.float32, device=dev)
-        self.observations = self.obs_buf[:, :1]
-        self.rewards = torch.zeros(num_envs, dtype=torch.float32, device=dev)
-        self.terminals_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
-        self.truncations_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
-        self.masks_u8 = torch.ones(num_envs, dtype=torch.uint8, device=dev)
-        self.terminals = self.terminals_u8.view(torch.bool)
-        self.truncations = self.truncations_u8.view(torch.bool)
-        self.masks = self.masks_u8.view(torch.bool)
-        self._actions = torch.zeros(num_envs, dtype=torch.int64, device=dev)
-        self._fin = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
-        self._fin_ret = torch.zeros(num_envs, dtype=torch.float64, device=dev)
-        self._fin_len = torch.zeros(num_envs, dtype=torch.int32, device=dev)
-        self._fin_score = torch.zeros(num_envs, dtype=torch.float64, device=dev)
-        self._stats = torch.zeros(4, dtype=torch.float64, device=dev)
-        self.infos = []
-        self.sends = 0
-
-    def _live(self):
-        return (_lib.ptr(self.obs_buf), _lib.ptr(self.rewards), _lib.ptr(self.terminals_u8), _lib.ptr(self.truncations_u8),
-                _lib.ptr(self.masks_u8))
-
-    def async_reset(self, seed=42):
-        self.flag = RECV
-        make_seeds(seed, self.num_agents)           # validated like Serial does; the env itself ignores seeds
-        _lib.check(self.L.pfa_stochastic_async_reset(_lib.ptr(self.state), self.num_agents, *self._live(), _lib.stream_handle()),
-                   'async_reset')
-        self.sends = 0
-        self.infos = []
-
-    def send(self, actions):
-        import torch
-        send_precheck(self, actions)
-        if not torch.is_tensor(actions):
-            a = np.asarray(actions)
-            if not self.initialized and not self.action_space.contains(a):
-                raise APIUsageError('Actions do not match action space')
-            actions = torch.as_tensor(np.ascontiguousarray(a, dtype=np.int64))
-        elif not self.initialized:
-            if actions.shape != (self.num_agents,) or actions.dtype not in (torch.int64, torch.int32):
-                raise APIUsageError('Actions do not match action space')
-        self.initialized = True
-        self._actions.copy_(actions.reshape(-1), non_blocking=True)
-        _lib.check(self.L.pfa_stochastic_send(_lib.ptr(self.state), self.num_agents, self.p, self.horizon, _lib.ptr(self._actions),
-                                              *self._live(), _lib.stream_handle()), 'send')
-        self.sends += 1
-        self.infos = self._collect_infos() if self.info_mode == 'sync' else []
-
-    def recv(self):
-        recv_precheck(self)
-        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)
-
-    def close(self):
-        self.flag = CLOSE
-
-    def _collect_infos(self):
-        if self.sends % self.episode_len != self.horizon:      # every env finishes on the same sends
-            return []
-        _lib.check(self.L.pfa_stochastic_last_infos(_lib.ptr(self.state), self.num_agents, _lib.ptr(self._fin), _lib.ptr(self._fin_ret),
-                                                    _lib.ptr(self._fin_len), _lib.ptr(self._fin_score), _lib.stream_handle()),
-                   'last_infos')
-        fin = self._fin.cpu().numpy().astype(bool)
-        ret, ln, sc = self._fin_ret.cpu().numpy(), self._fin_len.cpu().numpy(), self._fin_score.cpu().numpy()
-        return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i])) for i in np.nonzero(fin)[0]]
-
-    def episode_stats(self, reset=True):
-        _lib.check(self.L.pfa_stochastic_episode_stats(_lib.ptr(self.state), self.num_agents, _lib.ptr(self._stats), 1 if reset else 0,
-                                                       _lib.stream_handle()), 'episode_stats')
-        return self._stats
-
-    def fused_rollout_mlp(self, fp, experience, noise, key, stream):
-        """clean_pufferl.evaluate's T-step loop as one persistent kernel (csrc/stochastic.hip)."""
-        _lib.check(self.L.pfa_rollout_mlp_stochastic(_lib.ptr(self.state), self.num_agents, self.p, self.horizon, _lib.ptr(fp.flat),
-                                                     C.byref(fp.dims), C.byref(experience.c), _lib.ptr(noise), C.byref(key),
-                                                     self.env_offset, *self._live(), stream), 'rollout_stochastic')
-        self.sends += experience.horizon
-
-
-def make_memory(mem_length=2, mem_delay=2, **kwargs):
-    """Env creator token with the signature of ocean.environment.make_memory (ocean/environment.py:41-44)."""
-    return MemorySpec(mem_length, mem_delay)
-
-
-class MemorySpec:
-    """What ``driver_env`` exposes to policies and clean_pufferl for ocean.Memory (ocean.py:80-88)."""
-
-    def __init__(self, mem_length=2, mem_delay=2):
-        self.mem_length, self.mem_delay = int(mem_length), int(mem_delay)
-        self.horizon = 2 * self.mem_length + self.mem_delay
-        self.single_observation_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float32)
-        self.single_action_space = spaces.Discrete(2)
-        self.observation_space = self.single_observation_space
-        self.action_space = self.single_action_space
-        self.num_agents = 1
-        self.render_mode = 'ansi'
-        self.emulated = namespace(observation_dtype=np.dtype(np.float32),
-                                  emulated_observation_dtype=np.dtype((np.float32, (1,))))
-        self.done = True
-
-    def render(self):
-        return ''
-
-    def close(self):
+def _creator_kwargs(creator, args, kwargs, names, defaults, family):
+    """Resolve keyword values the way the reference creator's signature would (defaults < positional < keyword)."""
+    import inspect
+    name = getattr(creator, '__name__', '')
+    if family not in name.lower():
+        raise APIUsageError(f'this backend only hosts ocean make_{family} envs on device (got creator {name!r})')
+    vals = dict(zip(names, defaults))
+    try:
+        sig = inspect.signature(creator)
+        for n in names:
+            if n in sig.parameters and sig.parameters[n].default is not inspect._empty:
+                vals[n] = sig.parameters[n].default
+    except (TypeError, ValueError):
         pass
+    for i, n in enumerate(names):
+        if len(args) > i:
+            vals[n] = args[i]
+        vals[n] = kwargs.get(n, vals[n])
+    return tuple(vals[n] for n in names)
 
 
-class Memory:
-    """Device-resident vecenv of N ocean Memory envs (csrc/memory.hip) — the env family that needs the recurrent policy.
-    Same live-buffer conventions and ``info_mode`` as ``Squared``; the solutions of future episodes come from the tape the
-    backend keeps ahead of the sends (numpy's process-global legacy stream, which does not depend on actions).  There is no
-    fused rollout kernel for this env: clean_pufferl.evaluate steps it through ``device_send`` (no host sync per step)."""
+class _DeviceVecEnv:
+    """Backend protocol (pufferlib/vector.py) over a device-resident env family with one observation value per env: live
+    buffers as torch device tensors aliased by recv() (like Serial's numpy buffers, vector.py:158-162), RESET->RECV->SEND
+    state machine, ``info_mode`` 'sync' (exact per-episode info dicts, one small D2H on the sends that finish episodes) or
+    'lazy' (recv() returns [], statistics through ``episode_stats``).  Subclasses provide the kernels:
+    ``_k_reset(seed)``, ``_k_send(actions)``, ``_k_stats(reset)``, ``_k_infos()`` and ``_finishing_send(sends)``."""
     reset = reset
     step = step
     obs_stride = 16
+    FAMILY = ''
+    NAMES = ()
+    DEFAULTS = ()
+    SEEDED = False          # whether the env family reads the seeds async_reset is given
 
     @property
     def num_envs(self):
         return self.agents_per_batch
 
     def __init__(self, env_creators, env_args, env_kwargs, num_envs, info_mode='sync', env_offset=0, device=None, **kwargs):
-        import inspect
         import torch
         for k in kwargs:
             if k not in ('num_workers', 'batch_size', 'zero_copy', 'backend'):
                 raise APIUsageError(f'Invalid argument: {k}')
         if len(env_creators) != num_envs:
             raise APIUsageError('env_creators must be a list of length num_envs')
-        specs = set()
-        for c, a, k in zip(env_creators, env_args, env_kwargs):
-            if 'memory' not in getattr(c, '__name__', '').lower():
-                raise APIUsageError('pufferlib_amd.vector.Memory only hosts ocean make_memory envs on device '
-                                    f'(got creator {getattr(c, "__name__", c)!r})')
-            vals = dict(mem_length=2, mem_delay=2)
-            try:
-                sig = inspect.signature(c)
-                for name in vals:
-                    if name in sig.parameters and sig.parameters[name].default is not inspect._empty:
-                        vals[name] = sig.parameters[name].default
-            except (TypeError, ValueError):
-                pass
-            for i, name in enumerate(('mem_length', 'mem_delay')):
-                if len(a) > i:
-                    vals[name] = a[i]
-                vals[name] = k.get(name, vals[name])
-            specs.add((int(vals['mem_length']), int(vals['mem_delay'])))
+        specs = {_creator_kwargs(c, a, k, self.NAMES, self.DEFAULTS, self.FAMILY)
+                 for c, a, k in zip(env_creators, env_args, env_kwargs)}
         if len(specs) != 1:
-            raise APIUsageError(f'obs/atn space mismatch: all envs must share one Memory configuration, got {specs}')
-        L_, D_ = specs.pop()
-        self.driver_env = MemorySpec(L_, D_)
-        self.horizon = self.driver_env.horizon
+            raise APIUsageError(f'obs/atn space mismatch: all envs must share one configuration, got {specs}')
         _lib.require_gpu()
         self.L = _lib.lib()
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self.driver_env = self._spec(*specs.pop())
         self.emulated = self.driver_env.emulated
         self.agents_per_env = [1] * num_envs
         self.agents_per_batch = self.num_agents = num_envs
         self.single_observation_space = self.driver_env.single_observation_space
         self.single_action_space = self.driver_env.single_action_space
-        self.action_space = spaces.MultiDiscrete([2] * num_envs)
-        self.observation_space = spaces.Box(low=-1, high=1, shape=(num_envs, 1), dtype=np.float32)
+        self.action_space = spaces.MultiDiscrete([self.single_action_space.n] * num_envs)
+        self.observation_space = spaces.Box(low=self.single_observation_space.low.min(), high=self.single_observation_space.high.max(),
+                                            shape=(num_envs, 1), dtype=np.float32)
         self.agent_ids = np.arange(num_envs)
         self.initialized = False
         self.flag = RESET
         self.info_mode = info_mode
         self.env_offset = int(env_offset)
         self.obs_dim = 1
-        self.episode_len = self.horizon          # H - 1 steps + the auto-reset row
-        self.tape_rounds = 256
-        self.cfg = _lib.MemoryConfig(num_envs, L_, D_, self.tape_rounds)
-        nbytes = self.L.pfa_memory_state_bytes(C.byref(self.cfg))
-        if nbytes == 0:
-            raise APIUsageError(self.L.pfa_last_error().decode())
         dev = self.device
-        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.float32, device=dev)
         self.observations = self.obs_buf[:, :1]
         self.rewards = torch.zeros(num_envs, dtype=torch.float32, device=dev)
@@ -583,41 +412,27 @@ class Memory:
         self._stats = torch.zeros(4, dtype=torch.float64, device=dev)
         self.infos = []
         self.sends = 0
-        self.rounds_filled = 0
+        self._alloc_state()
 
     def _live(self):
         return (_lib.ptr(self.obs_buf), _lib.ptr(self.rewards), _lib.ptr(self.terminals_u8), _lib.ptr(self.truncations_u8),
                 _lib.ptr(self.masks_u8))
 
-    def _rounds_needed(self, upto_send):
-        """Reset rounds consumed by sends 1..upto_send: every env resets on sends k*horizon."""
-        return upto_send // self.episode_len
-
-    def ensure_tape(self, extra_sends):
-        need = self._rounds_needed(self.sends + extra_sends)
-        if need - self._rounds_needed(self.sends) > self.tape_rounds:
-            raise APIUsageError(f'{extra_sends} sends need more reset rounds than the tape holds ({self.tape_rounds})')
-        if need > self.rounds_filled:
-            _lib.check(self.L.pfa_memory_fill_tape(_lib.ptr(self.state), C.byref(self.cfg), need - self.rounds_filled,
-                                                   _lib.stream_handle()), 'fill_tape')
-            self.rounds_filled = need
+    def _fin_ptrs(self):
+        return _lib.ptr(self._fin), _lib.ptr(self._fin_ret), _lib.ptr(self._fin_len), _lib.ptr(self._fin_score)
 
     def async_reset(self, seed=42):
         self.flag = RECV
         seeds = make_seeds(seed, self.num_agents)
-        if any(s != seeds[0] + i for i, s in enumerate(seeds)):
-            raise APIUsageError('pufferlib_amd.vector.Memory needs consecutive seeds (seed + env index)')
-        _lib.check(self.L.pfa_memory_async_reset(_lib.ptr(self.state), C.byref(self.cfg), int(seeds[0]), *self._live(),
-                                                 _lib.stream_handle()), 'async_reset')
+        if self.SEEDED and any(s != seeds[0] + i for i, s in enumerate(seeds)):
+            raise APIUsageError(f'pufferlib_amd.vector.{type(self).__name__} needs consecutive seeds (seed + env index)')
+        self._k_reset(int(seeds[0]))
         self.sends = 0
-        self.rounds_filled = 0
         self.infos = []
 
     def device_send(self, actions):
         """send() for a device int64 tensor of actions, no protocol bookkeeping and no host sync (rollout loops)."""
-        self.ensure_tape(1)
-        _lib.check(self.L.pfa_memory_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(actions), *self._live(),
-                                          _lib.stream_handle()), 'send')
+        self._k_send(actions)
         self.sends += 1
 
     def send(self, actions):
@@ -644,19 +459,147 @@ class Memory:
         self.flag = CLOSE
 
     def _collect_infos(self):
-        if self.sends % self.episode_len != self.episode_len - 1:      # every env finishes on the same sends
+        if not self._finishing_send(self.sends):     # every env of these families finishes on the same sends
             return []
-        _lib.check(self.L.pfa_memory_last_infos(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._fin), _lib.ptr(self._fin_ret),
-                                                _lib.ptr(self._fin_len), _lib.ptr(self._fin_score), _lib.stream_handle()),
-                   'last_infos')
+        self._k_infos()
         fin = self._fin.cpu().numpy().astype(bool)
         ret, ln, sc = self._fin_ret.cpu().numpy(), self._fin_len.cpu().numpy(), self._fin_score.cpu().numpy()
         return [dict(episode_return=float(ret[i]), episode_length=int(ln[i]), score=float(sc[i])) for i in np.nonzero(fin)[0]]
 
     def episode_stats(self, reset=True):
-        _lib.check(self.L.pfa_memory_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._stats), 1 if reset else 0,
-                                                   _lib.stream_handle()), 'episode_stats')
+        """(count, sum episode_return, sum episode_length, sum score) of the episodes finished since the last reset of the
+        accumulators, as a device f64 tensor — what clean_pufferl.evaluate averages (clean_pufferl.py:127-137)."""
+        self._k_stats(1 if reset else 0)
         return self._stats
+
+
+def make_stochastic(p=0.7, horizon=100, **kwargs):
+    """Env creator token with the signature of ocean.environment.make_stochastic (ocean/environment.py:61-64).  The
+    reference's creator ignores its ``horizon`` argument and always builds Stochastic(horizon=100); so does this one."""
+    return StochasticSpec(p)
+
+
+class StochasticSpec(_SimpleSpec):
+    """ocean.Stochastic (ocean.py:543-549)."""
+
+    def __init__(self, p=0.7):
+        super().__init__(0, 1, 2)
+        self.p = float(p)
+        self.horizon = 100
+
+
+class Stochastic(_DeviceVecEnv):
+    """Device-resident vecenv of N ocean Stochastic envs (csrc/stochastic.hip).  The env draws no random numbers, so there
+    is no reset tape and seeds only matter to the policy's noise rows; it has a fused rollout kernel for the MLP policy."""
+    FAMILY, NAMES, DEFAULTS = 'stochastic', ('p',), (0.7,)
+
+    def _spec(self, p):
+        return StochasticSpec(p)
+
+    def _alloc_state(self):
+        import torch
+        self.p, self.horizon = self.driver_env.p, self.driver_env.horizon
+        self.episode_len = self.horizon + 1
+        self.state = torch.zeros(self.L.pfa_stochastic_state_bytes(self.num_agents), dtype=torch.uint8, device=self.device)
+
+    def _finishing_send(self, sends):
+        return sends % self.episode_len == self.horizon
+
+    def _k_reset(self, seed):
+        _lib.check(self.L.pfa_stochastic_async_reset(_lib.ptr(self.state), self.num_agents, *self._live(), _lib.stream_handle()),
+                   'async_reset')
+
+    def _k_send(self, actions):
+        _lib.check(self.L.pfa_stochastic_send(_lib.ptr(self.state), self.num_agents, self.p, self.horizon, _lib.ptr(actions),
+                                              *self._live(), _lib.stream_handle()), 'send')
+
+    def _k_stats(self, reset):
+        _lib.check(self.L.pfa_stochastic_episode_stats(_lib.ptr(self.state), self.num_agents, _lib.ptr(self._stats), reset,
+                                                       _lib.stream_handle()), 'episode_stats')
+
+    def _k_infos(self):
+        _lib.check(self.L.pfa_stochastic_last_infos(_lib.ptr(self.state), self.num_agents, *self._fin_ptrs(), _lib.stream_handle()),
+                   'last_infos')
+
+    def fused_rollout_mlp(self, fp, experience, noise, key, stream):
+        """clean_pufferl.evaluate's T-step loop as one persistent kernel (csrc/stochastic.hip)."""
+        _lib.check(self.L.pfa_rollout_mlp_stochastic(_lib.ptr(self.state), self.num_agents, self.p, self.horizon, _lib.ptr(fp.flat),
+                                                     C.byref(fp.dims), C.byref(experience.c), _lib.ptr(noise), C.byref(key),
+                                                     self.env_offset, *self._live(), stream), 'rollout_stochastic')
+        self.sends += experience.horizon
+
+
+def make_memory(mem_length=2, mem_delay=2, **kwargs):
+    """Env creator token with the signature of ocean.environment.make_memory (ocean/environment.py:41-44)."""
+    return MemorySpec(mem_length, mem_delay)
+
+
+class MemorySpec(_SimpleSpec):
+    """ocean.Memory (ocean.py:80-88)."""
+
+    def __init__(self, mem_length=2, mem_delay=2):
+        super().__init__(-1, 1, 2)
+        self.mem_length, self.mem_delay = int(mem_length), int(mem_delay)
+        self.horizon = 2 * self.mem_length + self.mem_delay
+
+
+class Memory(_DeviceVecEnv):
+    """Device-resident vecenv of N ocean Memory envs (csrc/memory.hip) — the env family that needs the recurrent policy.
+    The solutions of future episodes come from the tape the backend keeps ahead of the sends (numpy's process-global legacy
+    stream, which does not depend on actions).  There is no fused rollout kernel for this env: clean_pufferl.evaluate steps
+    it through ``device_send`` (no host sync per step)."""
+    FAMILY, NAMES, DEFAULTS = 'memory', ('mem_length', 'mem_delay'), (2, 2)
+    SEEDED = True
+
+    def _spec(self, mem_length, mem_delay):
+        return MemorySpec(mem_length, mem_delay)
+
+    def _alloc_state(self):
+        import torch
+        self.horizon = self.driver_env.horizon
+        self.episode_len = self.horizon          # H - 1 steps + the auto-reset row
+        self.tape_rounds = 256
+        self.cfg = _lib.MemoryConfig(self.num_agents, self.driver_env.mem_length, self.driver_env.mem_delay, self.tape_rounds)
+        nbytes = self.L.pfa_memory_state_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise APIUsageError(self.L.pfa_last_error().decode())
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.rounds_filled = 0
+
+    def _rounds_needed(self, upto_send):
+        """Reset rounds consumed by sends 1..upto_send: every env resets on sends k*horizon."""
+        return upto_send // self.episode_len
+
+    def ensure_tape(self, extra_sends):
+        need = self._rounds_needed(self.sends + extra_sends)
+        if need - self._rounds_needed(self.sends) > self.tape_rounds:
+            raise APIUsageError(f'{extra_sends} sends need more reset rounds than the tape holds ({self.tape_rounds})')
+        if need > self.rounds_filled:
+            _lib.check(self.L.pfa_memory_fill_tape(_lib.ptr(self.state), C.byref(self.cfg), need - self.rounds_filled,
+                                                   _lib.stream_handle()), 'fill_tape')
+            self.rounds_filled = need
+
+    def _finishing_send(self, sends):
+        return sends % self.episode_len == self.episode_len - 1
+
+    def _k_reset(self, seed):
+        _lib.check(self.L.pfa_memory_async_reset(_lib.ptr(self.state), C.byref(self.cfg), seed, *self._live(), _lib.stream_handle()),
+                   'async_reset')
+        self.sends = 0
+        self.rounds_filled = 0
+
+    def _k_send(self, actions):
+        self.ensure_tape(1)
+        _lib.check(self.L.pfa_memory_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(actions), *self._live(),
+                                          _lib.stream_handle()), 'send')
+
+    def _k_stats(self, reset):
+        _lib.check(self.L.pfa_memory_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._stats), reset,
+                                                   _lib.stream_handle()), 'episode_stats')
+
+    def _k_infos(self):
+        _lib.check(self.L.pfa_memory_last_infos(_lib.ptr(self.state), C.byref(self.cfg), *self._fin_ptrs(), _lib.stream_handle()),
+                   'last_infos')
 
     def debug_solutions(self):
         """(solution digits per env as a bit mask, tape underrun flag) — test introspection."""
@@ -666,6 +609,64 @@ class Memory:
         _lib.check(self.L.pfa_memory_debug_solutions(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(bits), _lib.ptr(under),
                                                      _lib.stream_handle()), 'debug_solutions')
         return bits.cpu().numpy(), int(under.item())
+
+
+def make_bandit(num_actions=10, reward_scale=1, reward_noise=1, **kwargs):
+    """Env creator token with the signature of ocean.environment.make_bandit (ocean/environment.py:33-37)."""
+    return BanditSpec(num_actions, reward_scale, reward_noise)
+
+
+class BanditSpec(_SimpleSpec):
+    """ocean.Bandit (ocean.py:22-31)."""
+
+    def __init__(self, num_actions=10, reward_scale=1, reward_noise=1):
+        super().__init__(-1, 1, int(num_actions))
+        self.num_actions, self.reward_scale, self.reward_noise = int(num_actions), reward_scale, reward_noise
+        self.hard_fixed_seed = 42
+
+
+class Bandit(_DeviceVecEnv):
+    """Device-resident vecenv of N ocean Bandit envs (csrc/bandit.hip).  Every reset reseeds numpy's global generator with the
+    hard fixed seed, so the solution and the reward noise env i sees are the same in every episode: they are drawn here,
+    once, with numpy's own legacy RandomState — the generator the reference calls — and the kernels keep the state machine."""
+    FAMILY, NAMES, DEFAULTS = 'bandit', ('num_actions', 'reward_scale', 'reward_noise'), (10, 1, 1)
+
+    def _spec(self, num_actions, reward_scale, reward_noise):
+        return BanditSpec(num_actions, reward_scale, reward_noise)
+
+    def _alloc_state(self):
+        import torch
+        spec = self.driver_env
+        if not 2 <= spec.num_actions <= 15:
+            raise APIUsageError('the policy kernels take 1..15 actions')
+        self.episode_len = 2                      # one step + the auto-reset row
+        rs = np.random.RandomState(spec.hard_fixed_seed)              # ocean.py:36-42: seed(42) then randint for the solution
+        self.solution = int(rs.randint(0, spec.num_actions))
+        self.scale = float(spec.reward_scale)
+        self.noise = None
+        if spec.reward_noise != 0:                                     # ocean.py:55-57: randn() * reward_scale, env order
+            table = np.array([rs.randn() * spec.reward_scale for _ in range(self.num_agents)], np.float64)
+            self.noise = torch.as_tensor(table).to(self.device)
+        self.state = torch.zeros(self.L.pfa_bandit_state_bytes(self.num_agents), dtype=torch.uint8, device=self.device)
+
+    def _finishing_send(self, sends):
+        return sends % 2 == 1
+
+    def _k_reset(self, seed):
+        _lib.check(self.L.pfa_bandit_async_reset(_lib.ptr(self.state), self.num_agents, *self._live(), _lib.stream_handle()),
+                   'async_reset')
+
+    def _k_send(self, actions):
+        _lib.check(self.L.pfa_bandit_send(_lib.ptr(self.state), self.num_agents, self.solution, self.scale, _lib.ptr(self.noise),
+                                          _lib.ptr(actions), *self._live(), _lib.stream_handle()), 'send')
+
+    def _k_stats(self, reset):
+        _lib.check(self.L.pfa_bandit_episode_stats(_lib.ptr(self.state), self.num_agents, _lib.ptr(self._stats), reset,
+                                                   _lib.stream_handle()), 'episode_stats')
+
+    def _k_infos(self):
+        _lib.check(self.L.pfa_bandit_last_infos(_lib.ptr(self.state), self.num_agents, *self._fin_ptrs(), _lib.stream_handle()),
+                   'last_infos')
 
 
 def make(env_creator_or_creators, env_args=None, env_kwargs=None, backend=Squared, num_envs=1, **kwargs):

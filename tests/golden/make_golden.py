@@ -12,6 +12,7 @@ Fixtures written (all small, committed):
   gae.npz            c_gae.compute_gae (c_gae.pyx:11-32) on KAT / random / boundary inputs
   squared_<tag>.npz  pufferlib.vector.Serial over ocean make_squared (vector.py:70-166,
                      ocean.py:406-513, emulation.py:124-234, postprocess.py:8-54): lock-step trajectories
+  bandit.npz         pufferlib.vector.Serial over ocean make_bandit (ocean.py:8-63): numpy legacy randint + gauss
   memory_<tag>.npz   pufferlib.vector.Serial over ocean make_memory (ocean.py:65-123): numpy's global legacy stream
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
@@ -166,6 +167,40 @@ def gen_memory(tag, num_envs, mem_length, mem_delay, seed, steps):
     print(f'memory_{tag}.npz', np.stack(obs).shape, 'infos', len(info_rows))
 
 
+def gen_bandit(num_envs=37, num_actions=10, reward_scale=1, reward_noise=1, seed=5, steps=9):
+    """pufferlib.vector.Serial over ocean make_bandit (ocean.py:8-63): every reset reseeds numpy's global generator with the
+    hard fixed seed 42, draws the solution with randint, and each step adds np.random.randn() * reward_scale."""
+    import pufferlib.vector
+    import pufferlib.environments.ocean as ocean
+    vec = pufferlib.vector.make(ocean.env_creator('bandit'), env_kwargs=dict(num_actions=num_actions, reward_scale=reward_scale,
+                                                                              reward_noise=reward_noise),
+                                num_envs=num_envs, backend=pufferlib.vector.Serial)
+    rng = np.random.RandomState(900)
+    vec.async_reset(seed)
+    obs, rew, term, acts, info_rows = [], [], [], [], []
+
+    def snap(k):
+        o, r, te, tr, infos, ids, masks = vec.recv()
+        assert masks.all() and not tr.any()
+        obs.append(o.copy()); rew.append(r.copy()); term.append(te.copy())
+        for j, i in enumerate(infos):
+            info_rows.append((k, j, i['episode_return'], i['episode_length'], float(i['score'])))
+
+    snap(0)
+    sol = vec.envs[0].env.env.solution_idx
+    for k in range(1, steps + 1):
+        a = rng.randint(0, num_actions, size=num_envs)
+        a[::3] = sol
+        acts.append(a)
+        vec.send(a)
+        snap(k)
+    np.savez_compressed(os.path.join(HERE, 'bandit.npz'), config=np.array([num_envs, num_actions, seed, steps], np.int64),
+                        scale_noise=np.array([reward_scale, reward_noise], np.float64), solution=np.array([sol]),
+                        obs=np.stack(obs), rewards=np.stack(rew), terminals=np.stack(term), actions=np.stack(acts).astype(np.int8),
+                        infos=np.array(info_rows, np.float64).reshape(-1, 5))
+    print('bandit.npz', np.stack(obs).shape, 'infos', len(info_rows), 'solution', sol)
+
+
 def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
     import pufferlib
     import pufferlib.vector
@@ -280,6 +315,7 @@ if __name__ == '__main__':
     gen_squared('d4t3', 16, 4, 3, 3, 60)       # n=32 > 21: set-rejection sampling
     gen_squared('d3t1_big', 700, 3, 1, 4090, 12)  # crosses several MT19937 regenerations per reset round
     gen_stochastic()
+    gen_bandit()
     gen_memory('l2d2', 5, 2, 2, 11, 40)
     gen_memory('l3d1', 130, 3, 1, 4090, 30)    # 130 x 7 words per reset round: crosses MT19937 blocks
     gen_ppo('mlp', use_rnn=False)

@@ -13,6 +13,8 @@ def _train(kind, recurrent, updates, n=1024, horizon=128, **envkw):
     torch.manual_seed(0)
     if kind == 'squared':
         vec = vector.make(vector.make_squared, env_kwargs=envkw, num_envs=n, backend=vector.Squared)
+    elif kind == 'bandit':
+        vec = vector.make(vector.make_bandit, env_kwargs=envkw, num_envs=n, backend=vector.Bandit)
     else:
         vec = vector.make(vector.make_stochastic, env_kwargs=envkw, num_envs=n, backend=vector.Stochastic)
     base = models.Default(vec.driver_env)
@@ -49,3 +51,8 @@ def test_ppo_solves_squared_with_the_recurrent_policy():
 def test_ppo_learns_the_stochastic_policy(p):
     first, last = _train('stochastic', False, 60, p=p)
     assert first < 0.97 and last > 0.99, (first, last)          # score = 1 - (p - action-0 fraction)^2 at the episode end
+
+
+def test_ppo_finds_the_bandit_arm_under_reward_noise():
+    first, last = _train('bandit', False, 40, horizon=32)
+    assert first < 0.3 and last > 0.8, (first, last)            # score = fraction of pulls on the solution arm (chance 0.1)

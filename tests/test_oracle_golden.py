@@ -224,3 +224,41 @@ def test_numpy_legacy_stream_restatement_matches_numpy():
         want = np.random.RandomState(seed).randint(0, 2, size=2000)
         got = np.array([L.po_mt_u32(st) & 1 for _ in range(2000)])
         assert np.array_equal(got, want), seed
+
+
+def test_bandit_oracle_replays_reference_trajectory(golden_dir):
+    """ocean.Bandit under Serial (tests/golden/bandit.npz): reseed-to-42 at every reset, solution from numpy's legacy randint,
+    reward noise from its legacy gauss (cached second value across envs) — rewards (f32) and infos (f64) bit for bit."""
+    from oracle import c_oracle
+    g = np.load(os.path.join(golden_dir, 'bandit.npz'))
+    n, na, seed, steps = (int(x) for x in g['config'])
+    vec = c_oracle.BanditSerial(n, na, *g['scale_noise'])
+    vec.async_reset(seed)
+    assert vec.solution == int(g['solution'][0])
+    infos = []
+    for k in range(steps + 1):
+        o, r, te, tr, info, ids, m = vec.recv()
+        assert np.array_equal(o, g['obs'][k]) and np.array_equal(r, g['rewards'][k]) and np.array_equal(te, g['terminals'][k]), k
+        for j, i in enumerate(info):
+            infos.append((k, j, i['episode_return'], i['episode_length'], i['score']))
+        if k < steps:
+            vec.send(g['actions'][k].astype(np.int64))
+    assert np.array_equal(np.array(infos, np.float64).reshape(-1, 5), g['infos'])
+
+
+def test_numpy_legacy_gauss_and_randint_restatement_matches_numpy():
+    from oracle import c_oracle
+    import ctypes as C
+    L = c_oracle.lib()
+    for seed in (0, 42, 99991):
+        st = (C.c_uint8 * 4096)()
+        L.po_np_seed(st, seed)
+        rs = np.random.RandomState(seed)
+        for n in (10, 2, 7, 1000, 2 ** 31):
+            assert L.po_np_randint(st, n) == rs.randint(0, n), (seed, n)
+        want = [rs.randn() for _ in range(1001)]                     # odd count: leaves a cached value behind
+        got = [L.po_np_randn(st) for _ in range(1001)]
+        assert got == want, seed
+        L.po_np_seed(st, seed + 1)                                    # reseeding must drop the cached value
+        rs.seed(seed + 1)
+        assert L.po_np_randn(st) == rs.randn()
