@@ -227,6 +227,21 @@ int pfa_bandit_last_infos(void *state, int32_t num_envs, uint8_t *finished, doub
                           int32_t *episode_length, double *score, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Multiagent vecenv — replaces pufferlib.vector.Serial over ocean.environment.make_multiagent
+ * (ocean/environment.py:76-79) = PettingZooPufferEnv + MultiagentEpisodeStats + ocean.Multiagent (ocean.py:148-224): two
+ * agent rows per env (row 2e: observation 0, scores with action 0; row 2e+1: observation 1, scores with action 1), every
+ * step terminal, the next send the reset row.  All row arrays hold 2 * num_envs rows (observations 16 floats per row).
+ * episode_stats: out4 = (finished steps of agent 1, its score sum, the same for agent 2) — the per-slot means are the
+ * `1/score`, `2/score` statistics clean_pufferl.evaluate derives from the reference's infos.
+ * ------------------------------------------------------------------------------------------ */
+size_t pfa_multiagent_state_bytes(int32_t num_envs);
+int pfa_multiagent_async_reset(void *state, int32_t num_envs, float *obs, float *rewards, uint8_t *terminals,
+                               uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_multiagent_send(void *state, int32_t num_envs, const int64_t *actions, float *obs, float *rewards,
+                        uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_multiagent_episode_stats(void *state, int32_t num_envs, double *out4, int32_t reset, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * PPO update — the minibatch loop of clean_pufferl.train (clean_pufferl.py:175-258).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {

@@ -353,3 +353,42 @@ class BanditSerial:
 
     def recv(self):
         return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)
+
+
+class MultiagentSerial:
+    """``pufferlib.vector.Serial`` over ``make_multiagent`` envs (ocean/environment.py:76-79), restated in numpy: two agent rows
+    per env in env-major order (emulation.py:325-345), row 2e observes 0 and scores with action 0, row 2e+1 observes 1 and
+    scores with action 1 (ocean.py:187-205); every step is terminal for both (ocean.py:160-163), so the next send is the
+    env's reset row (emulation.py:283-284, vector.py:147-149).  Infos: the env's own per-agent dicts (ocean.py:207-210;
+    MultiagentEpisodeStats leaves them untouched, postprocess.py:159-177)."""
+
+    def __init__(self, num_envs):
+        self.num_envs = num_envs
+        n = 2 * num_envs
+        self.observations = np.zeros((n, 1), np.float32)
+        self.rewards = np.zeros(n, np.float32)
+        self.terminals = np.zeros(n, bool)
+        self.truncations = np.zeros(n, bool)
+        self.masks = np.ones(n, bool)
+        self.agent_ids = np.arange(n)
+        self.done = np.zeros(num_envs, bool)
+        self.infos = []
+
+    def async_reset(self, seed=42):
+        self.observations[:, 0] = np.arange(2 * self.num_envs) % 2
+        self.rewards[:] = 0
+        self.terminals[:] = False
+        self.done[:] = False
+        self.infos = []
+
+    def send(self, actions):
+        a = np.asarray(actions).reshape(self.num_envs, 2)
+        stepped = ~self.done
+        score = (a == np.array([0, 1])) & stepped[:, None]
+        self.rewards[:] = score.reshape(-1)
+        self.terminals[:] = np.repeat(stepped, 2)
+        self.infos = [{1: {'score': int(s[0])}, 2: {'score': int(s[1])}} for s, st in zip(score, stepped) if st]
+        self.done = stepped.copy()
+
+    def recv(self):
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)

@@ -35,7 +35,7 @@ from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
-from .vector import Bandit, Memory, Squared, Stochastic
+from .vector import Bandit, Memory, Multiagent, Squared, Stochastic
 
 
 def seed_everything(seed, torch_deterministic=True):
@@ -247,7 +247,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     n_params = sum(p.numel() for p in policy.parameters())
     msg = f'Model Size: {n_params} parameters'
 
-    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory, Bandit))   # anything else speaks the recv/send protocol on the host
+    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory, Bandit, Multiagent))   # anything else speaks the recv/send protocol on the host
     if not isinstance(policy, (Policy, RecurrentPolicy)):
         from .models import find_lstm
         if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
@@ -343,7 +343,7 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
-    if isinstance(vecenv, (Memory, Bandit)):   # no fused kernel for these envs: protocol-level pieces, still no host sync per step
+    if isinstance(vecenv, (Memory, Bandit, Multiagent)):   # no fused kernel for these envs: protocol-level pieces, still no host sync per step
         with profile.eval_forward:
             _rollout_stepwise(data, noise, T, N)
         return _finish_evaluate(data, N, T)
@@ -429,11 +429,8 @@ def _finish_evaluate(data, N, T):
             dist, _, _ = _dist()
             dist.all_reduce(st)
         st = st.cpu().numpy()                            # the one sync of evaluate()
-        data.stats = {}
-        infos = {}
-        if st[0] > 0:
-            data.stats = dict(episode_return=st[1] / st[0], episode_length=st[2] / st[0], score=st[3] / st[0])
-            infos = {k: [v] for k, v in data.stats.items()}
+        data.stats = vecenv.stats_from_sums(st)
+        infos = {k: [v] for k, v in data.stats.items()}
     return data.stats, infos
 
 

@@ -115,14 +115,15 @@ def init_native(force_single=False):
         return False
     L = _lib.lib()
     ok = 1
-    ident = np.zeros(128, np.uint8)
+    ident = np.zeros(129, np.uint8)                   # 128-byte id + rank 0's success flag, so nobody waits on a dead id
     if rank == 0:
-        if L.pfa_dist_unique_id(ident.ctypes.data_as(C.c_void_p)) != 0:
-            ok = 0
+        ok = int(L.pfa_dist_unique_id(ident.ctypes.data_as(C.c_void_p)) == 0)
+        ident[128] = ok
     if w > 1:
         t = torch.from_numpy(ident).cuda()
         d.broadcast(t, src=0)
         ident = t.cpu().numpy()
+        ok = int(ident[128])
     if ok and L.pfa_dist_init(ident.ctypes.data_as(C.c_void_p), rank, w) != 0:
         ok = 0
     if w > 1:

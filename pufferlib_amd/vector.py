@@ -77,6 +77,14 @@ def env_creator(name='squared'):
     raise ValueError('Invalid environment name')
 
 
+def episode_means(st):
+    """The means clean_pufferl.evaluate reports (clean_pufferl.py:127-137) from the (all-reduced) ``episode_stats`` sums
+    (count, sum episode_return, sum episode_length, sum score)."""
+    if st[0] <= 0:
+        return {}
+    return dict(episode_return=st[1] / st[0], episode_length=st[2] / st[0], score=st[3] / st[0])
+
+
 class SquaredSpec:
     """What ``driver_env`` exposes to policies (models.py:26-37) and to clean_pufferl (:40-43)."""
 
@@ -289,6 +297,8 @@ class Squared:
                                                     1 if reset else 0, _lib.stream_handle()), 'episode_stats')
         return self._stats
 
+    stats_from_sums = staticmethod(episode_means)
+
     # -- test introspection -------------------------------------------------------------------------------
     def debug_targets(self):
         import torch
@@ -360,6 +370,7 @@ class _DeviceVecEnv:
     NAMES = ()
     DEFAULTS = ()
     SEEDED = False          # whether the env family reads the seeds async_reset is given
+    AGENTS_PER_ENV = 1      # agent rows per env, env-major (PettingZoo emulation order, emulation.py:325-345)
 
     @property
     def num_envs(self):
@@ -381,7 +392,9 @@ class _DeviceVecEnv:
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         self.driver_env = self._spec(*specs.pop())
         self.emulated = self.driver_env.emulated
-        self.agents_per_env = [1] * num_envs
+        self.env_count = num_envs
+        self.agents_per_env = [self.AGENTS_PER_ENV] * num_envs
+        num_envs = num_envs * self.AGENTS_PER_ENV                      # agent rows from here on
         self.agents_per_batch = self.num_agents = num_envs
         self.single_observation_space = self.driver_env.single_observation_space
         self.single_action_space = self.driver_env.single_action_space
@@ -423,7 +436,7 @@ class _DeviceVecEnv:
 
     def async_reset(self, seed=42):
         self.flag = RECV
-        seeds = make_seeds(seed, self.num_agents)
+        seeds = make_seeds(seed, self.env_count)
         if self.SEEDED and any(s != seeds[0] + i for i, s in enumerate(seeds)):
             raise APIUsageError(f'pufferlib_amd.vector.{type(self).__name__} needs consecutive seeds (seed + env index)')
         self._k_reset(int(seeds[0]))
@@ -471,6 +484,8 @@ class _DeviceVecEnv:
         accumulators, as a device f64 tensor — what clean_pufferl.evaluate averages (clean_pufferl.py:127-137)."""
         self._k_stats(1 if reset else 0)
         return self._stats
+
+    stats_from_sums = staticmethod(episode_means)
 
 
 def make_stochastic(p=0.7, horizon=100, **kwargs):
@@ -667,6 +682,67 @@ class Bandit(_DeviceVecEnv):
     def _k_infos(self):
         _lib.check(self.L.pfa_bandit_last_infos(_lib.ptr(self.state), self.num_agents, *self._fin_ptrs(), _lib.stream_handle()),
                    'last_infos')
+
+
+def make_multiagent(**kwargs):
+    """Env creator token with the signature of ocean.environment.make_multiagent (ocean/environment.py:76-79)."""
+    return MultiagentSpec()
+
+
+class MultiagentSpec(_SimpleSpec):
+    """ocean.Multiagent behind PettingZooPufferEnv (ocean.py:148-174, emulation.py:236-306)."""
+
+    def __init__(self):
+        super().__init__(0, 1, 2)
+        self.num_agents = 2
+        self.possible_agents = [1, 2]
+
+
+class Multiagent(_DeviceVecEnv):
+    """Device-resident vecenv of N ocean Multiagent envs (csrc/multiagent.hip): two agent rows per env, env-major, so
+    ``num_agents == 2 * len(env_creators)`` like the reference's Serial over PettingZooPufferEnv (vector.py:86-93).  Infos are
+    the env's own ``{1: {'score': r}, 2: {'score': r}}`` per env; ``episode_stats`` holds the per-slot sums behind the
+    ``1/score`` / ``2/score`` means clean_pufferl.evaluate reports."""
+    FAMILY, NAMES, DEFAULTS = 'multiagent', (), ()
+    AGENTS_PER_ENV = 2
+
+    def _spec(self):
+        return MultiagentSpec()
+
+    def _alloc_state(self):
+        import torch
+        self.episode_len = 2
+        self.state = torch.zeros(self.L.pfa_multiagent_state_bytes(self.env_count), dtype=torch.uint8, device=self.device)
+
+    def _finishing_send(self, sends):
+        return sends % 2 == 1
+
+    def _k_reset(self, seed):
+        _lib.check(self.L.pfa_multiagent_async_reset(_lib.ptr(self.state), self.env_count, *self._live(), _lib.stream_handle()),
+                   'async_reset')
+
+    def _k_send(self, actions):
+        _lib.check(self.L.pfa_multiagent_send(_lib.ptr(self.state), self.env_count, _lib.ptr(actions), *self._live(),
+                                              _lib.stream_handle()), 'send')
+
+    def _k_stats(self, reset):
+        _lib.check(self.L.pfa_multiagent_episode_stats(_lib.ptr(self.state), self.env_count, _lib.ptr(self._stats), reset,
+                                                       _lib.stream_handle()), 'episode_stats')
+
+    def _collect_infos(self):
+        if not self._finishing_send(self.sends):
+            return []
+        r = self.rewards.cpu().numpy().astype(np.int64).reshape(-1, 2)      # ocean.py:207-210: score = the int reward
+        return [{1: {'score': int(a)}, 2: {'score': int(b)}} for a, b in r]
+
+    @staticmethod
+    def stats_from_sums(st):
+        out = {}
+        if st[0] > 0:
+            out['1/score'] = st[1] / st[0]
+        if st[2] > 0:
+            out['2/score'] = st[3] / st[2]
+        return out
 
 
 def make(env_creator_or_creators, env_args=None, env_kwargs=None, backend=Squared, num_envs=1, **kwargs):

@@ -14,6 +14,7 @@ Fixtures written (all small, committed):
                      ocean.py:406-513, emulation.py:124-234, postprocess.py:8-54): lock-step trajectories
   bandit.npz         pufferlib.vector.Serial over ocean make_bandit (ocean.py:8-63): numpy legacy randint + gauss
   memory_<tag>.npz   pufferlib.vector.Serial over ocean make_memory (ocean.py:65-123): numpy's global legacy stream
+  multiagent.npz     pufferlib.vector.Serial over ocean make_multiagent (ocean.py:148-224) under PettingZooPufferEnv
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
@@ -201,6 +202,37 @@ def gen_bandit(num_envs=37, num_actions=10, reward_scale=1, reward_noise=1, seed
     print('bandit.npz', np.stack(obs).shape, 'infos', len(info_rows), 'solution', sol)
 
 
+def gen_multiagent(num_envs=19, seed=3, steps=8):
+    """pufferlib.vector.Serial over ocean make_multiagent (ocean.py:148-224): two agent rows per env through
+    PettingZooPufferEnv (emulation.py:236-420); infos are the env's own {agent: {'score': reward}} per env."""
+    import pufferlib.vector
+    import pufferlib.environments.ocean as ocean
+    vec = pufferlib.vector.make(ocean.env_creator('multiagent'), num_envs=num_envs, backend=pufferlib.vector.Serial)
+    assert vec.num_agents == 2 * num_envs
+    rng = np.random.RandomState(901)
+    vec.async_reset(seed)
+    obs, rew, term, acts, info_rows = [], [], [], [], []
+
+    def snap(k):
+        o, r, te, tr, infos, ids, masks = vec.recv()
+        assert masks.all() and not tr.any() and np.array_equal(ids, np.arange(2 * num_envs))
+        obs.append(o.copy()); rew.append(r.copy()); term.append(te.copy())
+        for j, i in enumerate(infos):
+            assert sorted(i) == [1, 2] and all(list(v) == ['score'] for v in i.values())
+            info_rows.append((k, j, i[1]['score'], i[2]['score']))
+
+    snap(0)
+    for k in range(1, steps + 1):
+        a = rng.randint(0, 2, size=2 * num_envs)
+        acts.append(a)
+        vec.send(a)
+        snap(k)
+    np.savez_compressed(os.path.join(HERE, 'multiagent.npz'), config=np.array([num_envs, seed, steps], np.int64),
+                        obs=np.stack(obs), rewards=np.stack(rew), terminals=np.stack(term), actions=np.stack(acts).astype(np.int8),
+                        infos=np.array(info_rows, np.int64).reshape(-1, 4))
+    print('multiagent.npz', np.stack(obs).shape, 'infos', len(info_rows))
+
+
 def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
     import pufferlib
     import pufferlib.vector
@@ -316,6 +348,7 @@ if __name__ == '__main__':
     gen_squared('d3t1_big', 700, 3, 1, 4090, 12)  # crosses several MT19937 regenerations per reset round
     gen_stochastic()
     gen_bandit()
+    gen_multiagent()
     gen_memory('l2d2', 5, 2, 2, 11, 40)
     gen_memory('l3d1', 130, 3, 1, 4090, 30)    # 130 x 7 words per reset round: crosses MT19937 blocks
     gen_ppo('mlp', use_rnn=False)

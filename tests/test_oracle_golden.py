@@ -262,3 +262,22 @@ def test_numpy_legacy_gauss_and_randint_restatement_matches_numpy():
         L.po_np_seed(st, seed + 1)                                    # reseeding must drop the cached value
         rs.seed(seed + 1)
         assert L.po_np_randn(st) == rs.randn()
+
+
+def test_multiagent_oracle_replays_reference_trajectory(golden_dir):
+    """ocean.Multiagent under Serial + PettingZooPufferEnv (tests/golden/multiagent.npz): env-major agent rows, per-slot scoring
+    rule, terminal-every-step / reset-row alternation and the per-env info dicts."""
+    from oracle import c_oracle
+    g = np.load(os.path.join(golden_dir, 'multiagent.npz'))
+    n, seed, steps = (int(x) for x in g['config'])
+    vec = c_oracle.MultiagentSerial(n)
+    vec.async_reset(seed)
+    infos = []
+    for k in range(steps + 1):
+        o, r, te, tr, info, ids, m = vec.recv()
+        assert np.array_equal(o, g['obs'][k]) and np.array_equal(r, g['rewards'][k]) and np.array_equal(te, g['terminals'][k]), k
+        assert m.all() and not tr.any()
+        infos += [(k, j, i[1]['score'], i[2]['score']) for j, i in enumerate(info)]
+        if k < steps:
+            vec.send(g['actions'][k].astype(np.int64))
+    assert np.array_equal(np.array(infos, np.int64).reshape(-1, 4), g['infos'])
