@@ -242,6 +242,32 @@ int pfa_multiagent_send(void *state, int32_t num_envs, const int64_t *actions, f
 int pfa_multiagent_episode_stats(void *state, int32_t num_envs, double *out4, int32_t reset, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Structured-observation unpack — replaces pufferlib.pytorch.nativize_tensor
+ * (pufferlib/pytorch.py:96-145): flat emulated rows [num_rows][row_bytes] (device, 16-byte aligned) -> one dense tensor
+ * per leaf of the observation space, in one launch.  A field is a leaf as pufferlib.pytorch.nativize_dtype
+ * (pytorch.py:48-94) describes it: byte offset inside the row, element count, element dtype.  to_f32 == 0 copies the
+ * elements as they are into `out` ([num_rows][count], dense, 16-byte aligned); to_f32 == 1 converts them to f32
+ * (the `.float()` encoders apply next, models.py:50) and writes rows `out_stride` floats apart, so leaves can land in
+ * column ranges of one [num_rows][total] matrix (torch.cat of the flattened leaves).
+ * ------------------------------------------------------------------------------------------ */
+#define PFA_NAT_MAX_FIELDS 32
+typedef enum {
+    PFA_NAT_U8 = 0, PFA_NAT_I8 = 1, PFA_NAT_U16 = 2, PFA_NAT_I16 = 3, PFA_NAT_U32 = 4, PFA_NAT_I32 = 5,
+    PFA_NAT_U64 = 6, PFA_NAT_I64 = 7, PFA_NAT_F16 = 8, PFA_NAT_F32 = 9, PFA_NAT_F64 = 10
+} pfa_nat_dtype;
+typedef struct {
+    void *out;          /* device */
+    int32_t offset;     /* bytes from the start of a row */
+    int32_t count;      /* elements per row */
+    int32_t dtype;      /* pfa_nat_dtype of the source elements */
+    int32_t to_f32;
+    int32_t out_stride; /* elements between output rows; == count unless to_f32 */
+    int32_t reserved;
+} pfa_nat_field;
+int pfa_nativize_rows(const void *rows, int64_t num_rows, int32_t row_bytes, const pfa_nat_field *fields /* host */,
+                      int32_t num_fields, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * PPO update — the minibatch loop of clean_pufferl.train (clean_pufferl.py:175-258).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {

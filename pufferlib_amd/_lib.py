@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'nativize.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -59,6 +59,14 @@ def build(force=False, verbose=False):
 class SquaredConfig(C.Structure):
     _fields_ = [('num_envs', C.c_int32), ('distance_to_target', C.c_int32), ('num_targets', C.c_int32),
                 ('obs_stride', C.c_int32), ('tape_rounds', C.c_int32)]
+
+
+NAT_MAX_FIELDS = 32
+
+
+class NatField(C.Structure):
+    _fields_ = [('out', C.c_void_p), ('offset', C.c_int32), ('count', C.c_int32), ('dtype', C.c_int32), ('to_f32', C.c_int32),
+                ('out_stride', C.c_int32), ('reserved', C.c_int32)]
 
 
 class MemoryConfig(C.Structure):
@@ -134,6 +142,7 @@ _SIGNATURES = {
     'pfa_multiagent_async_reset': (C.c_int, [P, C.c_int32, P, P, P, P, P, P]),
     'pfa_multiagent_send': (C.c_int, [P, C.c_int32, P, P, P, P, P, P, P]),
     'pfa_multiagent_episode_stats': (C.c_int, [P, C.c_int32, P, C.c_int32, P]),
+    'pfa_nativize_rows': (C.c_int, [P, C.c_int64, C.c_int32, P, C.c_int32, P]),
     'pfa_ppo_workspace_bytes': (C.c_size_t, [C.POINTER(MlpDims), C.c_int64, C.POINTER(PpoHparams)]),
     'pfa_ppo_adv_stats': (C.c_int, [C.POINTER(Experience), C.c_int64, C.POINTER(PpoHparams), P, P, P]),
     'pfa_ppo_mlp_grad': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, C.POINTER(MlpDims),

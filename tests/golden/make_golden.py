@@ -15,6 +15,7 @@ Fixtures written (all small, committed):
   bandit.npz         pufferlib.vector.Serial over ocean make_bandit (ocean.py:8-63): numpy legacy randint + gauss
   memory_<tag>.npz   pufferlib.vector.Serial over ocean make_memory (ocean.py:65-123): numpy's global legacy stream
   multiagent.npz     pufferlib.vector.Serial over ocean make_multiagent (ocean.py:148-224) under PettingZooPufferEnv
+  nativize.npz       pufferlib.pytorch.nativize_dtype / nativize_tensor (pytorch.py:48-145) on emulated Dict/Tuple spaces
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
@@ -233,6 +234,80 @@ def gen_multiagent(num_envs=19, seed=3, steps=8):
     print('multiagent.npz', np.stack(obs).shape, 'infos', len(info_rows))
 
 
+def nativize_cases():
+    """name -> observation space (tests/shims gymnasium).  Shared with the tests through the fixture only."""
+    import gymnasium.spaces as S
+    box = lambda shape, dt: S.Box(low=0, high=1, shape=shape, dtype=dt)   # noqa: E731
+    return {
+        'spaces_env': S.Dict({'image': box((5, 5), np.float32), 'flat': box((5,), np.int8)}),               # ocean.Spaces
+        'all_f32': S.Dict({'a': box((3,), np.float32), 'b': box((2, 2), np.float32)}),                      # non-byte sample rows
+        'mixed': S.Dict({'u8': box((3,), np.uint8), 'f64': box((2,), np.float64), 'i16': box((5,), np.int16),
+                         'f32': box((4, 3), np.float32), 'i64': box((1,), np.int64), 'f16': box((7,), np.float16)}),
+        'nested': S.Dict({'x': box((3,), np.uint8), 'inner': S.Dict({'p': box((2,), np.int32), 'q': box((3,), np.uint8)}),
+                          'y': S.Tuple([box((2,), np.uint16), box((1,), np.float32)])}),
+        'tuple': S.Tuple([box((4,), np.int8), box((2, 3), np.int32), S.Discrete(5)]),
+        'wide': S.Dict({'map': box((40, 40), np.uint8), 'vec': box((700,), np.float32), 'id': box((3,), np.int32)}),
+    }
+
+
+def dtype_spec(dt):
+    """Nested literal of an aligned structured dtype: [(name, spec), ...] for structs, (base, shape) for leaves."""
+    if dt.fields is not None:
+        return [(name, dtype_spec(sub)) for name, (sub, _) in dt.fields.items()]
+    base, shape = dt.subdtype if dt.subdtype is not None else (dt, ())
+    return (str(base), tuple(shape))
+
+
+def dtype_from_spec(spec):
+    """Inverse of dtype_spec, built the way the reference builds it (emulation.py:68-80: align=True at every level)."""
+    if isinstance(spec, list):
+        return np.dtype([(name, dtype_from_spec(sub)) for name, sub in spec], align=True)
+    return np.dtype((spec[0], spec[1]), align=True)
+
+
+def gen_nativize(rows_per_case=21):
+    """pufferlib.pytorch.nativize_dtype + nativize_tensor (pytorch.py:48-145) on the dtypes the reference's own emulation builds
+    (emulation.emulate_observation_space, emulation.py:96-110) for several observation spaces; random row bytes."""
+    import pufferlib
+    import pufferlib.emulation
+    import pufferlib.pytorch
+    out = {}
+    rng = np.random.RandomState(77)
+    for name, space in nativize_cases().items():
+        emulated_space, structured = pufferlib.emulation.emulate_observation_space(space)
+        emulated = pufferlib.namespace(observation_dtype=emulated_space.dtype, emulated_observation_dtype=structured)
+        native = pufferlib.pytorch.nativize_dtype(emulated)
+        sample = np.dtype(emulated_space.dtype)
+        D = int(emulated_space.shape[0])
+        if sample.kind == 'f':
+            rows = rng.randn(rows_per_case, D).astype(sample)
+        else:
+            rows = rng.randint(0, 256, size=(rows_per_case, D * sample.itemsize)).astype(np.uint8).view(sample)
+            if sample.itemsize == 1:     # keep f16/f32/f64 leaves free of NaN payloads (NaN != NaN in comparisons)
+                rows = rows.copy()
+        leaves = pufferlib.pytorch.nativize_tensor(torch.from_numpy(rows), native)
+        table = []
+
+        def walk(nd, lv, path):
+            if isinstance(nd, tuple):
+                dt, shape, off, delta = nd
+                table.append(('/'.join(path), str(dt).replace('torch.', ''), list(shape), int(off), int(delta)))
+                out[f'{name}:leaf:' + '/'.join(path)] = lv.contiguous().view(torch.uint8).numpy().copy()   # bytes: NaN-safe
+            else:
+                for k in nd:
+                    walk(nd[k], lv[k], path + (str(k),))
+        walk(native, leaves, ())
+        out[f'{name}:rows'] = rows.view(np.uint8).reshape(rows_per_case, -1)
+        out[f'{name}:sample'] = np.array(str(sample))
+        spec = dtype_spec(structured)
+        assert dtype_from_spec(spec) == structured and dtype_from_spec(spec).itemsize == structured.itemsize
+        out[f'{name}:descr'] = np.array(repr(spec))
+        out[f'{name}:table'] = np.array(repr(table))
+        print('nativize', name, 'row bytes', rows.view(np.uint8).reshape(rows_per_case, -1).shape[1], 'leaves', len(table))
+    out['cases'] = np.array(list(nativize_cases()))
+    np.savez_compressed(os.path.join(HERE, 'nativize.npz'), **out)
+
+
 def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
     import pufferlib
     import pufferlib.vector
@@ -348,6 +423,7 @@ if __name__ == '__main__':
     gen_squared('d3t1_big', 700, 3, 1, 4090, 12)  # crosses several MT19937 regenerations per reset round
     gen_stochastic()
     gen_bandit()
+    gen_nativize()
     gen_multiagent()
     gen_memory('l2d2', 5, 2, 2, 11, 40)
     gen_memory('l3d1', 130, 3, 1, 4090, 30)    # 130 x 7 words per reset round: crosses MT19937 blocks
