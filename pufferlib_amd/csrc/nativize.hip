@@ -184,8 +184,30 @@ __global__ void __launch_bounds__(kNatThreads) nativize_direct_kernel(NatArgs a,
         const uint8_t *src = a.rows + (size_t)(r0 + r) * D + f.offset;
         if (f.to_f32) {
             float *out = reinterpret_cast<float *>(f.out) + (size_t)(r0 + r) * f.out_stride;
-            for (int k = threadIdx.x; k < f.count; k += kNatThreads)
-                out[k] = nat_to_f32(gather_bytes(src + (size_t)k * f.isz, f.isz), f.code);
+            const bool natural = (((uintptr_t)src) & (uintptr_t)(f.isz - 1)) == 0;
+            // four elements per lane (one 4..16-byte load, one 16-byte store) where the run allows it
+            const int chunk = 4 * f.isz;
+            const bool vec = f.isz <= 4 && (((uintptr_t)src) & (uintptr_t)(chunk - 1)) == 0 && (((uintptr_t)out) & 15) == 0;
+            const int nv = vec ? f.count >> 2 : 0;
+            for (int q = threadIdx.x; q < nv; q += kNatThreads) {
+                const uint8_t *p = src + (size_t)q * chunk;
+                float4 v;
+                if (f.isz == 1) {
+                    const uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+                    v = make_float4(nat_to_f32(w & 0xff, f.code), nat_to_f32((w >> 8) & 0xff, f.code), nat_to_f32((w >> 16) & 0xff, f.code),
+                                    nat_to_f32(w >> 24, f.code));
+                } else if (f.isz == 2) {
+                    const uint2 w = *reinterpret_cast<const uint2 *>(p);
+                    v = make_float4(nat_to_f32(w.x & 0xffff, f.code), nat_to_f32(w.x >> 16, f.code), nat_to_f32(w.y & 0xffff, f.code),
+                                    nat_to_f32(w.y >> 16, f.code));
+                } else {
+                    const uint4 w = *reinterpret_cast<const uint4 *>(p);
+                    v = make_float4(nat_to_f32(w.x, f.code), nat_to_f32(w.y, f.code), nat_to_f32(w.z, f.code), nat_to_f32(w.w, f.code));
+                }
+                reinterpret_cast<float4 *>(out)[q] = v;
+            }
+            for (int k = (nv << 2) + threadIdx.x; k < f.count; k += kNatThreads)
+                out[k] = nat_to_f32(load_bits(src + (size_t)k * f.isz, f.isz, natural), f.code);
         } else {
             const size_t fb = (size_t)f.count * f.isz;
             uint8_t *out = reinterpret_cast<uint8_t *>(f.out) + (size_t)(r0 + r) * fb;
