@@ -25,9 +25,12 @@
 
 namespace pfa {
 
-constexpr int kGradThreads = 512;
-constexpr int kGradWaves = kGradThreads / 64;
-constexpr int kGradPairs = kGradWaves / 2;  // (producer, consumer) wavefront pairs per workgroup
+// (producer, consumer) wavefront pairs per workgroup.  Rows of up to 64 floats: 4 pairs = 8 waves, two per SIMD, two workgroups
+// per CU.  Rows of 96 / 128 floats: the W1 fragment table (57 / 74 KB) and the consumer's dW1 accumulators (192 / 256 registers)
+// leave room for 2 pairs = 4 waves, one per SIMD with the whole register file, one workgroup per CU.
+constexpr int grad_pairs(int dp) { return dp <= 64 ? 4 : 2; }
+constexpr int grad_threads(int dp) { return grad_pairs(dp) * 2 * 64; }
+constexpr int grad_waves_per_simd(int dp) { return dp <= 64 ? 2 : 1; }
 constexpr int kNumStats = 8;                // 6 used: pg, v, entropy, old_kl, kl, clipfrac
 
 // LDS map of kernel A (floats).  A workgroup is 4 PAIRS of wavefronts; wave p (producer) and wave p+4 (consumer) share a
@@ -50,7 +53,7 @@ struct GradLds {
     static constexpr int kPairFloats = kDT + 16 * DS;
     static constexpr int kW1Floats = kMT * 64 * W1S;
     static constexpr int kTabFloats = kMT * 64 * 4;
-    static constexpr int kFloats = kGradPairs * kPairFloats + kW1Floats + 3 * kTabFloats;
+    static constexpr int kFloats = grad_pairs(DP) * kPairFloats + kW1Floats + 3 * kTabFloats;
 };
 
 // "Native" layout of one workgroup partial: gradients in MFMA C-fragment order (conflict-free LDS reduction and
@@ -207,13 +210,14 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
 // VALU-heavy loss).  alpha_j: the consumer is done reading hidden/dout(j-1), so they may be overwritten; beta_j: published.
 // dh's C fragment (rows 4g+r, column u = c) IS the B fragment dW1 = X^T dh needs, so the consumer never stages dh.
 template <int DP, int ABL = 0, int KKU = DP / 4>
-__global__ void __launch_bounds__(kGradThreads, 2)
+__global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, pfa_ppo_hparams hp,
                         const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
     using L = GradLds<DP>;
     using NL = NativeLayout<DP>;
     constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KT = DP / 16, KS = DP / 4, V = DP / 4, W1S = L::W1S;
     constexpr int NLD = (16 * V + 63) / 64;  // float4 loads per lane per tile
+    constexpr int kGradPairs = grad_pairs(DP), kGradThreads = grad_threads(DP);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
     const int pair = wv & (kGradPairs - 1);
@@ -229,13 +233,9 @@ __global__ void __launch_bounds__(kGradThreads, 2)
     {
         constexpr int N1 = kMT * 64 * KS / kGradThreads, N2 = kMT * 64 * 4 / kGradThreads;
         static_assert(kMT * 64 * KS % kGradThreads == 0 && kMT * 64 * 4 % kGradThreads == 0, "table sizes");
-        float t1[N1], tb[N2], tw[N2], tv[N2];
-#pragma unroll
-        for (int j = 0; j < N1; ++j) {
-            const int i = threadIdx.x + j * kGradThreads;
-            const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64), cc = ln & 15, gg = ln >> 4;
-            t1[j] = params[off.w1 + (16 * m + cc) * DP + 4 * kk + gg];
-        }
+        constexpr int CH = N1 > 16 ? 16 : N1;  // W1 table in chunks of <= 16 loads per thread (wide rows: keeps the prologue small)
+        static_assert(N1 % CH == 0, "table chunking");
+        float tb[N2], tw[N2], tv[N2];
 #pragma unroll
         for (int j = 0; j < N2; ++j) {
             const int i = threadIdx.x + j * kGradThreads;
@@ -244,11 +244,21 @@ __global__ void __launch_bounds__(kGradThreads, 2)
             tw[j] = w2v_at(params, off, a, cc, 16 * m + 4 * gg + r);    // A[i=o=cc][k-slot gg] for u = 16m+4gg+r
             tv[j] = w2v_at(params, off, a, 4 * gg + r, 16 * m + cc);    // B[k-slot gg][j=u=16m+cc] for o = 4gg+r
         }
+#pragma unroll 1
+        for (int j0 = 0; j0 < N1; j0 += CH) {
+            float t1[CH];
 #pragma unroll
-        for (int j = 0; j < N1; ++j) {
-            const int i = threadIdx.x + j * kGradThreads;
-            const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64);
-            w1t[(m * 64 + ln) * W1S + kk] = t1[j];
+            for (int j = 0; j < CH; ++j) {
+                const int i = threadIdx.x + (j0 + j) * kGradThreads;
+                const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64), cc = ln & 15, gg = ln >> 4;
+                t1[j] = params[off.w1 + (16 * m + cc) * DP + 4 * kk + gg];
+            }
+#pragma unroll
+            for (int j = 0; j < CH; ++j) {
+                const int i = threadIdx.x + (j0 + j) * kGradThreads;
+                const int kk = i % KS, ln = (i / KS) & 63, m = i / (KS * 64);
+                w1t[(m * 64 + ln) * W1S + kk] = t1[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < N2; ++j) {
@@ -759,9 +769,9 @@ static double *norm_partials_of(void *workspace, int dp) {  // after the gradien
     return (double *)((char *)workspace + align_up((size_t)256 * native_count(dp) * sizeof(float), 256));
 }
 
-static int grad_grid(int64_t mb_rows) {
+static int grad_grid(int64_t mb_rows, int dp) {
     const int64_t tiles = mb_rows / 16;
-    const int64_t wgs = (tiles + kGradPairs - 1) / kGradPairs;
+    const int64_t wgs = (tiles + grad_pairs(dp) - 1) / grad_pairs(dp);
     return (int)(wgs < 256 ? (wgs < 1 ? 1 : wgs) : 256);
 }
 
@@ -801,7 +811,9 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
                                 int64_t global_mb_rows, float *grads, void *workspace, pfa_stream_t stream) {
     if (int rc = check_update_args(exp, batch_rows, dims, hp)) return rc;
     PFA_REQUIRE(dims && dims->hidden == kHidden, "ppo.grad: hidden must be %d", kHidden);
-    PFA_REQUIRE(dims->obs_stride == 16 || dims->obs_stride == 32 || dims->obs_stride == 64, "ppo.grad: obs_stride must be 16/32/64");
+    PFA_REQUIRE(dims->obs_stride == 16 || dims->obs_stride == 32 || dims->obs_stride == 64 || dims->obs_stride == 96 ||
+                    dims->obs_stride == 128,
+                "ppo.grad: obs_stride must be 16/32/64/96/128");
     PFA_REQUIRE(dims->num_actions >= 1 && dims->num_actions <= 15, "ppo.grad: num_actions must be in 1..15");
     PFA_REQUIRE(mb >= 0 && mb < hp->num_minibatches, "ppo.grad: minibatch index out of range");
     PFA_REQUIRE(exp->obs && exp->actions && exp->logprobs && exp->values && exp->advantages && exp->returns && params && grads &&
@@ -811,7 +823,7 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     const int64_t mbs = batch_rows / hp->num_minibatches;
     PFA_REQUIRE(mbs % 16 == 0, "ppo.grad: minibatch_size must be a multiple of 16 (got %lld)", (long long)mbs);
     PFA_REQUIRE(global_mb_rows >= mbs, "ppo.grad: global_mb_rows < local minibatch rows");
-    const int grid = grad_grid(mbs);
+    const int grid = grad_grid(mbs, dims->obs_stride);
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
 #define PFA_LAUNCH_GRAD_K(DPV, KKUV)                                                                                       \
@@ -825,7 +837,7 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
             attr_set = true;                                                                                               \
         }                                                                                                                  \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV>), dim3(grid), dim3(kGradThreads), lds_bytes,                  \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes,              \
                            (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions, *hp, adv_stats,       \
                            (double)global_mb_rows, partials);                                                              \
     }
@@ -835,6 +847,8 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
         switch (dims->obs_stride) {
             case 16: PFA_LAUNCH_GRAD(16) break;
             case 32: PFA_LAUNCH_GRAD(32) break;
+            case 96: PFA_LAUNCH_GRAD(96) break;
+            case 128: PFA_LAUNCH_GRAD(128) break;
             default:
                 if ((dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)   // 7x7 grid: 3 of 16 k-steps are pure padding
                 else PFA_LAUNCH_GRAD(64)
@@ -851,6 +865,10 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
                                     (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
         case 32: hipLaunchKernelGGL(ppo_reduce_kernel<32>, dim3((NativeLayout<32>::kCount + 63) / 64), dim3(256), 0,
                                     (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+        case 96: hipLaunchKernelGGL(ppo_reduce_kernel<96>, dim3((NativeLayout<96>::kCount + 63) / 64), dim3(256), 0,
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+        case 128: hipLaunchKernelGGL(ppo_reduce_kernel<128>, dim3((NativeLayout<128>::kCount + 63) / 64), dim3(256), 0,
+                                     (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
         default: hipLaunchKernelGGL(ppo_reduce_kernel<64>, dim3((NativeLayout<64>::kCount + 63) / 64), dim3(256), 0,
                                     (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
     }
@@ -917,7 +935,7 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
                               const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats, float *grads,
                               void *workspace, int32_t abl, pfa_stream_t stream) {
     const int64_t mbs = batch_rows / hp->num_minibatches;
-    const int grid = grad_grid(mbs);
+    const int grid = grad_grid(mbs, 64);
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
     constexpr size_t lds_bytes = (size_t)GradLds<64>::kFloats * sizeof(float);
@@ -925,7 +943,7 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
     case A:                                                                                                            \
         PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A>,                                    \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A>), dim3(grid), dim3(kGradThreads), lds_bytes, (hipStream_t)stream, \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A>), dim3(grid), dim3(grad_threads(64)), lds_bytes, (hipStream_t)stream, \
                            *exp, map, (long long)mbs, params, dims->num_actions, *hp, adv_stats, (double)mbs, partials); \
         break;
     switch (abl) {

@@ -247,9 +247,10 @@ def test_native_data_parallel_path_single_rank_equals_plain():
         np.testing.assert_allclose(l1[k], l0[k], rtol=1e-5, atol=1e-7)
 
 
-@pytest.mark.parametrize('d,nt,n,horizon,nmb,bptt', [(1, 4, 40, 16, 2, 8), (2, 2, 96, 32, 4, 16), (3, 2, 24, 48, 1, 4)])
+@pytest.mark.parametrize('d,nt,n,horizon,nmb,bptt', [(1, 4, 40, 16, 2, 8), (2, 2, 96, 32, 4, 16), (3, 2, 24, 48, 1, 4), (4, 3, 72, 32, 2, 16),
+                                                     (5, 2, 200, 32, 4, 8)])
 def test_other_grid_sizes_rollout_and_update_vs_oracle(d, nt, n, horizon, nmb, bptt):
-    """obs_stride 16 / 32 / 64 (d = 1, 2, 3), several targets, env counts that are not multiples of 16, one
+    """obs_stride 16 / 32 / 64 / 96 / 128 (d = 1..5; the two wide strides run the 2-pair form of the gradient kernel), several targets, env counts that are not multiples of 16, one
     minibatch, short bptt: replay the device rollout's actions on the C oracle (bit-exact env side) and compare the
     update with the torch-fp32 restatement."""
     from pufferlib_amd import clean_pufferl
