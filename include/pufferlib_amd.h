@@ -103,7 +103,8 @@ int pfa_squared_debug_stream_pos(void *state, const pfa_squared_config *cfg, uin
 
 /* ------------------------------------------------------------------------------------------
  * MLP policy — pufferlib.models.Default (models.py:24-62) wrapped by frameworks.cleanrl.Policy
- * (cleanrl.py:50-66) with sample_logits (cleanrl.py:25-47), one Discrete head.
+ * (cleanrl.py:50-66) with sample_logits (cleanrl.py:25-47): one Discrete head, or the MultiDiscrete branch (models.py:29-35,
+ * 55-58: one decoder Linear per head; cleanrl.py:31-44: one multinomial per head, log-probabilities and entropies summed).
  * Flat fp32 parameter vector, in this order (obs_stride columns per encoder row, pad columns 0):
  *   encoder.weight [H][obs_stride], encoder.bias [H], decoder.weight [A][H], decoder.bias [A],
  *   value_head.weight [1][H], value_head.bias [1].
@@ -112,7 +113,11 @@ typedef struct {
     int32_t obs_dim;     /* true feature count (informational) */
     int32_t obs_stride;  /* floats per obs row, multiple of 16, <= 128 */
     int32_t hidden;      /* 128 */
-    int32_t num_actions; /* A <= 15 */
+    int32_t num_actions; /* A <= 15: decoder rows = logits of all heads */
+    uint32_t heads;      /* 0: one Discrete(A) head.  MultiDiscrete: head h has (heads >> 4h) & 15 logits, heads back to back in
+                          * decoder row order, sizes summing to A; actions are then stored packed the same way, head h's choice
+                          * in bits 4h..4h+3.  Only the standalone forward (pfa_mlp_forward_sample) and the MLP update
+                          * (pfa_ppo_mlp_grad) take several heads; the fused rollouts and the recurrent path refuse them. */
 } pfa_mlp_dims;
 
 int64_t pfa_mlp_param_count(const pfa_mlp_dims *dims);

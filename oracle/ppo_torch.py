@@ -32,9 +32,19 @@ class Policy:
     LSTM_NAMES = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
 
     def __init__(self, weights, recurrent=False):
-        """``weights``: dict name -> array using the short names above."""
+        """``weights``: dict name -> array using the short names above.  A MultiDiscrete policy (models.py:29-35: one
+        decoder Linear per head) is recognised by its ``decoder.<h>.weight`` keys; parameters keep the reference's
+        named_parameters order."""
         self.recurrent = recurrent
-        self.names = list(self.MLP_NAMES) + (list(self.LSTM_NAMES) if recurrent else [])
+        self.heads = None
+        if 'decoder.0.weight' in weights:
+            nh = len([k for k in weights if k.startswith('decoder.') and k.endswith('.weight')])
+            self.heads = [int(np.asarray(weights[f'decoder.{h}.weight']).shape[0]) for h in range(nh)]
+            dec = [f'decoder.{h}.{w}' for h in range(nh) for w in ('weight', 'bias')]
+            self.names = ['encoder.weight', 'encoder.bias'] + dec + ['value_head.weight', 'value_head.bias']
+        else:
+            self.names = list(self.MLP_NAMES)
+        self.names += list(self.LSTM_NAMES) if recurrent else []
         self.params = [torch.tensor(np.asarray(weights[n]), dtype=torch.float32, requires_grad=True)
                        for n in self.names]
 
@@ -45,9 +55,10 @@ class Policy:
         keys = [k[len(prefix):] for k in sd if k.startswith(prefix)]
         recurrent = any('recurrent.' in k for k in keys)
         w = {}
-        for n in cls.MLP_NAMES:
-            k = ('policy.policy.' if recurrent else 'policy.') + n
-            w[n] = sd[prefix + k]
+        base = 'policy.policy.' if recurrent else 'policy.'
+        for k in keys:
+            if k.startswith(base) and 'recurrent.' not in k:
+                w[k[len(base):]] = sd[prefix + k]
         if recurrent:
             for n in cls.LSTM_NAMES:
                 w[n] = sd[prefix + 'policy.recurrent.' + n]
@@ -67,6 +78,9 @@ class Policy:
     # models.py:53-62
     def decode(self, hidden):
         value = torch.nn.functional.linear(hidden, self.p('value_head.weight'), self.p('value_head.bias'))
+        if self.heads is not None:      # models.py:55-58: a list of per-head logits
+            return [torch.nn.functional.linear(hidden, self.p(f'decoder.{h}.weight'), self.p(f'decoder.{h}.bias'))
+                    for h in range(len(self.heads))], value
         logits = torch.nn.functional.linear(hidden, self.p('decoder.weight'), self.p('decoder.bias'))
         return logits, value
 
@@ -111,8 +125,20 @@ class Policy:
 
 
 def sample_logits(logits, action=None, noise=None):
-    """cleanrl.py:25-47 for a single Discrete head.  ``noise`` replaces torch.multinomial's
-    internal exponential draw: action = argmax(softmax(logits) / noise)."""
+    """cleanrl.py:25-47.  ``noise`` replaces torch.multinomial's internal exponential draw:
+    action = argmax(softmax(logits) / noise).  A list of logits is the MultiDiscrete branch: one draw per head (noise
+    columns concatenated in head order), actions [batch, heads], log-probabilities and entropies summed over heads."""
+    if isinstance(logits, (list, tuple)):
+        batch = logits[0].shape[0]
+        cols = np.cumsum([0] + [l.shape[1] for l in logits])
+        acts, logprob, entropy = [], 0.0, 0.0
+        for h, l in enumerate(logits):
+            a_h = None if action is None else action.reshape(batch, -1)[:, h]
+            n_h = None if noise is None else noise[:, cols[h]:cols[h + 1]]
+            a_h, lp, en = sample_logits(l, a_h, n_h)
+            acts.append(a_h)
+            logprob, entropy = logprob + lp, entropy + en
+        return torch.stack(acts, dim=1), logprob, entropy
     normalized = logits - logits.logsumexp(dim=-1, keepdim=True)
     if action is None:
         probs = torch.softmax(logits, dim=-1)
@@ -149,7 +175,7 @@ class Trainer:
         self.epoch = 0
         D = int(np.prod(vec.observations.shape[1:]))
         self.obs = torch.zeros(batch_size, D)
-        self.actions = np.zeros(batch_size, np.int64)
+        self.actions = np.zeros((batch_size,) + ((len(policy.heads),) if policy.heads is not None else ()), np.int64)
         self.logprobs = np.zeros(batch_size, np.float32)
         self.rewards = np.zeros(batch_size, np.float32)
         self.dones = np.zeros(batch_size, np.float32)
@@ -223,7 +249,7 @@ class Trainer:
                     _, newlogprob, entropy = sample_logits(logits, action=atn.reshape(-1))
                 else:
                     logits, newvalue, _ = self.policy.forward(obs.reshape(mbs, -1))
-                    _, newlogprob, entropy = sample_logits(logits, action=atn.reshape(-1))
+                    _, newlogprob, entropy = sample_logits(logits, action=atn.reshape(mbs, -1) if self.policy.heads else atn.reshape(-1))
                 logratio = newlogprob - b_logp[mb].reshape(-1)
                 ratio = logratio.exp()
                 with torch.no_grad():

@@ -74,7 +74,8 @@ class MemoryConfig(C.Structure):
 
 
 class MlpDims(C.Structure):
-    _fields_ = [('obs_dim', C.c_int32), ('obs_stride', C.c_int32), ('hidden', C.c_int32), ('num_actions', C.c_int32)]
+    _fields_ = [('obs_dim', C.c_int32), ('obs_stride', C.c_int32), ('hidden', C.c_int32), ('num_actions', C.c_int32),
+                ('heads', C.c_uint32)]       # MultiDiscrete head sizes, 4 bits each (0 = one Discrete head)
 
 
 class NoiseKey(C.Structure):

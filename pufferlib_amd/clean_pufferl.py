@@ -67,7 +67,7 @@ class HipAdam:
         self.exp_avg_sq = flat_params.flat_like()
         self.step_count = 0
         self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False,
-                                  params=list(range(6)))]
+                                  params=list(range(len(flat_params.split(flat_params.flat)))))]
 
     def zero_grad(self):
         pass
@@ -274,6 +274,8 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         vecenv.env_offset = env_offset
     vecenv.async_reset(config.seed + env_offset)          # clean_pufferl.py:39; env i of rank r gets seed + r*N + i
     fp = policy.adopt(obs_stride, device)
+    if fp.multidiscrete and not host_mode:
+        raise NotImplementedError('MultiDiscrete action heads run on the host-vecenv path; the device-resident envs take one Discrete head')
     native_dp = False
     if world > 1:
         dist.broadcast(fp.flat, src=0)

@@ -12,6 +12,15 @@ import torch
 from . import _lib
 from .models import FlatParams
 
+KERNEL_STRIDES = (16, 32, 64, 96, 128)     # observation row strides (floats) the policy kernels are built for
+
+
+def obs_stride_for(obs_dim):
+    for s in KERNEL_STRIDES:
+        if obs_dim <= s:
+            return s
+    raise NotImplementedError(f'flat observation of {obs_dim} floats: the MLP/LSTM kernels take rows of up to 128 floats')
+
 
 class Policy(torch.nn.Module):
     def __init__(self, policy, seed=0):
@@ -49,9 +58,8 @@ class Policy(torch.nn.Module):
         rows = x.shape[0]
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]
-        stride = max(16, (D + 15) // 16 * 16)
-        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) % 16 == 0 and x2.stride(0) <= 128 \
-                and x2.data_ptr() % 16 == 0:
+        stride = obs_stride_for(D)
+        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in KERNEL_STRIDES and x2.data_ptr() % 16 == 0:
             stride = x2.stride(0)            # e.g. the vecenv's live buffer, already padded
             src = x2
         else:
@@ -71,7 +79,7 @@ class Policy(torch.nn.Module):
         _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(src), rows, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(noise),
                                             C.byref(key), 0, _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(entropy),
                                             _lib.ptr(value), _lib.stream_handle()), 'mlp_forward_sample')
-        return actions, logprob, entropy, value.unsqueeze(1)
+        return fp.unpack_actions(actions), logprob, entropy, value.unsqueeze(1)
 
 
 class RecurrentPolicy(torch.nn.Module):
@@ -118,9 +126,8 @@ class RecurrentPolicy(torch.nn.Module):
         rows = x.shape[0]
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]
-        stride = max(16, (D + 15) // 16 * 16)
-        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) % 16 == 0 and x2.stride(0) <= 128 \
-                and x2.data_ptr() % 16 == 0:
+        stride = obs_stride_for(D)
+        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in KERNEL_STRIDES and x2.data_ptr() % 16 == 0:
             stride = x2.stride(0)
             src = torch.as_strided(x2, (rows, stride), (stride, 1))
         else:

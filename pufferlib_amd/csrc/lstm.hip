@@ -476,7 +476,7 @@ extern "C" int pfa_lstm_heads_sample(const float *h, int64_t rows, const float *
                                      const float *noise, const pfa_noise_key *key, int64_t row_offset, int64_t *actions,
                                      float *logprob, float *entropy, float *value, pfa_stream_t stream) {
     PFA_REQUIRE(h && params && dims && actions && logprob && value && rows >= 0, "lstm_heads_sample: bad arguments");
-    PFA_REQUIRE(dims->hidden == kLstmH && dims->num_actions >= 1 && dims->num_actions <= 15, "lstm_heads_sample: bad dims");
+    PFA_REQUIRE(dims->hidden == kLstmH && dims->num_actions >= 1 && dims->num_actions <= 15 && dims->heads == 0, "lstm_heads_sample: bad dims");
     PFA_REQUIRE(noise || key, "lstm_heads_sample: need a noise tensor or a Philox key");
     if (rows == 0) return 0;
     const long long tiles = (rows + 15) / 16;

@@ -22,6 +22,7 @@
 
 #include "common.hpp"
 #include "mlp_tile.hpp"
+#include "sampler.hpp"
 
 namespace pfa {
 
@@ -107,8 +108,68 @@ struct LossOut {
 };
 
 // PPO loss for the rows of one tile (clean_pufferl.py:202-238) and d(loss)/d(out^T fragment).
-__device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScalars &rs, int a, int g, const pfa_ppo_hparams &hp,
-                                                 float adv_mean, float adv_den, float inv_rows) {
+// MH: MultiDiscrete (cleanrl.py:31-44) — `heads` packs the head sizes, rs.action the per-head choices (pfa_mlp_dims.heads); the
+// log-softmax, the chosen log-probability and the entropy are taken per head and summed.  The single-head instantiation is the
+// code the headline workload runs, unchanged.
+template <bool MH>
+__device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScalars &rs, int a, uint32_t heads, int g,
+                                                 const pfa_ppo_hparams &hp, float adv_mean, float adv_den, float inv_rows) {
+    float nl[4], p[4], hent[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
+    bool chosen[4];
+    if constexpr (MH) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            nl[r] = p[r] = hent[r] = 0.0f;
+            chosen[r] = false;
+            if (4 * g + r == a) new_value = out[r];
+        }
+        int start = 0;
+        for (int h = 0; h < 8; ++h) {
+            const int sz = (int)((heads >> (4 * h)) & 15u);
+            if (sz == 0) break;  // uniform
+            bool mem[4];
+            float lmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = 4 * g + r;
+                mem[r] = o >= start && o < start + sz;
+                if (mem[r]) lmax = fmaxf(lmax, out[r]);
+            }
+            lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
+            lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
+            float ev[4], se = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                ev[r] = mem[r] ? expf(out[r] - lmax) : 0.0f;
+                se += ev[r];
+            }
+            se += __shfl_xor(se, 16, 64);
+            se += __shfl_xor(se, 32, 64);
+            const float lse = lmax + logf(se), inv_se = 1.0f / se;
+            const int act = start + (int)(((uint32_t)rs.action >> (4 * h)) & 15u);
+            float he = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (mem[r]) {
+                    nl[r] = out[r] - lse;
+                    p[r] = ev[r] * inv_se;
+                    he -= nl[r] * p[r];
+                    chosen[r] = 4 * g + r == act;
+                    if (chosen[r]) new_logprob += nl[r];
+                }
+            he += __shfl_xor(he, 16, 64);
+            he += __shfl_xor(he, 32, 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (mem[r]) hent[r] = he;
+            ent += he;
+            start += sz;
+        }
+        new_logprob += __shfl_xor(new_logprob, 16, 64);
+        new_logprob += __shfl_xor(new_logprob, 32, 64);
+        new_value += __shfl_xor(new_value, 16, 64);
+        new_value += __shfl_xor(new_value, 32, 64);
+    } else {
     // log-softmax over the A logits of row c, spread over lane groups: reduce with xor 16 / 32
     float lmax = -INFINITY;
 #pragma unroll
@@ -126,14 +187,14 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
     se += __shfl_xor(se, 32, 64);
     const float lse = lmax + logf(se);
     const float inv_se = 1.0f / se;
-    float nl[4], p[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 4 * g + r;
         nl[r] = out[r] - lse;
         p[r] = ev[r] * inv_se;  // softmax; the exponentials are shared with the log-sum-exp
         if (o < a) ent -= nl[r] * p[r];
-        if (o == rs.action) new_logprob = nl[r];
+        chosen[r] = o == rs.action;
+        if (chosen[r]) new_logprob = nl[r];
         if (o == a) new_value = out[r];
     }
     ent += __shfl_xor(ent, 16, 64);
@@ -142,6 +203,9 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
     new_logprob += __shfl_xor(new_logprob, 32, 64);
     new_value += __shfl_xor(new_value, 16, 64);
     new_value += __shfl_xor(new_value, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hent[r] = ent;
+    }
 
     const float logratio = new_logprob - rs.old_logprob;
     const float ratio = expf(logratio);
@@ -185,7 +249,7 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
         float d = 0.0f;
         if (o < a) {
             // d new_logprob/d logit_o = [o==action] - p_o ; d entropy/d logit_o = -p_o (nl_o + H)
-            d = g_lp * ((o == rs.action ? 1.0f : 0.0f) - p[r]) + hp.ent_coef * scale * p[r] * (nl[r] + ent);
+            d = g_lp * ((chosen[r] ? 1.0f : 0.0f) - p[r]) + hp.ent_coef * scale * p[r] * (nl[r] + hent[r]);
         } else if (o == a) {
             d = dv;
         }
@@ -209,10 +273,10 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
 // i.e. the consumer's whole share of tile j (160 MFMAs) runs under the producer's forward + loss of tile j+1 (192 MFMAs + the
 // VALU-heavy loss).  alpha_j: the consumer is done reading hidden/dout(j-1), so they may be overwritten; beta_j: published.
 // dh's C fragment (rows 4g+r, column u = c) IS the B fragment dW1 = X^T dh needs, so the consumer never stages dh.
-template <int DP, int ABL = 0, int KKU = DP / 4>
+template <int DP, int ABL = 0, int KKU = DP / 4, bool MH = false>
 __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
-    ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, pfa_ppo_hparams hp,
-                        const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
+    ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, uint32_t heads,
+                        pfa_ppo_hparams hp, const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
     using L = GradLds<DP>;
     using NL = NativeLayout<DP>;
     constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KT = DP / 16, KS = DP / 4, V = DP / 4, W1S = L::W1S;
@@ -385,7 +449,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 lo.dout = out * rs.weight;
                 lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs.adv;
             } else {
-                lo = ppo_loss_tile(out, rs, a, g, hp, adv_mean, adv_den, inv_rows);
+                lo = ppo_loss_tile<MH>(out, rs, a, heads, g, hp, adv_mean, adv_den, inv_rows);
             }
             const f32x4 dout = lo.dout;
 #pragma unroll
@@ -815,6 +879,8 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
                     dims->obs_stride == 128,
                 "ppo.grad: obs_stride must be 16/32/64/96/128");
     PFA_REQUIRE(dims->num_actions >= 1 && dims->num_actions <= 15, "ppo.grad: num_actions must be in 1..15");
+    PFA_REQUIRE(dims->heads == 0 || heads_count(dims->heads, dims->num_actions) >= 1, "ppo.grad: head sizes 0x%x do not sum to num_actions %d",
+                dims->heads, dims->num_actions);
     PFA_REQUIRE(mb >= 0 && mb < hp->num_minibatches, "ppo.grad: minibatch index out of range");
     PFA_REQUIRE(exp->obs && exp->actions && exp->logprobs && exp->values && exp->advantages && exp->returns && params && grads &&
                     workspace,
@@ -826,22 +892,25 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     const int grid = grad_grid(mbs, dims->obs_stride);
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
-#define PFA_LAUNCH_GRAD_K(DPV, KKUV)                                                                                       \
+#define PFA_LAUNCH_GRAD_KM(DPV, KKUV, MHV)                                                                                  \
     {                                                                                                                      \
         constexpr size_t lds_bytes = (size_t)GradLds<DPV>::kFloats * sizeof(float);                                        \
         static_assert((size_t)2 * NativeLayout<DPV>::kCount * sizeof(float) <= lds_bytes,                                   \
                       "the two reduction buffers must fit in the tile/table area");                                       \
         static bool attr_set = false;                                                                                      \
         if (!attr_set) {                                                                                                   \
-            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV, 0, KKUV>,                             \
+            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV>,                        \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
             attr_set = true;                                                                                               \
         }                                                                                                                  \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes,              \
-                           (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions, *hp, adv_stats,       \
-                           (double)global_mb_rows, partials);                                                              \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes,         \
+                           (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions, dims->heads, *hp,     \
+                           adv_stats, (double)global_mb_rows, partials);                                                   \
     }
-#define PFA_LAUNCH_GRAD(DPV) PFA_LAUNCH_GRAD_K(DPV, DPV / 4)
+#define PFA_LAUNCH_GRAD_K(DPV, KKUV) PFA_LAUNCH_GRAD_KM(DPV, KKUV, false)
+#define PFA_LAUNCH_GRAD(DPV)                                        \
+    if (dims->heads) PFA_LAUNCH_GRAD_KM(DPV, DPV / 4, true)         \
+    else PFA_LAUNCH_GRAD_KM(DPV, DPV / 4, false)
     {
         ScopedKernelTimer timer("ppo_mlp_grad", (hipStream_t)stream);
         switch (dims->obs_stride) {
@@ -850,11 +919,12 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
             case 96: PFA_LAUNCH_GRAD(96) break;
             case 128: PFA_LAUNCH_GRAD(128) break;
             default:
-                if ((dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)   // 7x7 grid: 3 of 16 k-steps are pure padding
+                if (!dims->heads && (dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)   // 7x7 grid: 3 of 16 k-steps are pure padding
                 else PFA_LAUNCH_GRAD(64)
                 break;
         }
     }
+#undef PFA_LAUNCH_GRAD_KM
 #undef PFA_LAUNCH_GRAD
 #undef PFA_LAUNCH_GRAD_K
     PFA_LAUNCH_CHECK();
@@ -944,7 +1014,7 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
         PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A>,                                    \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
         hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A>), dim3(grid), dim3(grad_threads(64)), lds_bytes, (hipStream_t)stream, \
-                           *exp, map, (long long)mbs, params, dims->num_actions, *hp, adv_stats, (double)mbs, partials); \
+                           *exp, map, (long long)mbs, params, dims->num_actions, 0u, *hp, adv_stats, (double)mbs, partials); \
         break;
     switch (abl) {
         PFA_PROBE_CASE(0) PFA_PROBE_CASE(1) PFA_PROBE_CASE(2) PFA_PROBE_CASE(4) PFA_PROBE_CASE(6) PFA_PROBE_CASE(7)

@@ -22,8 +22,8 @@ namespace pfa {
 // ---------------------------------------------------------------------------------------------
 template <int DP>
 __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const float *obs, long long rows, const float *params,
-                                                                         int a, const float *noise, uint64_t seed,
-                                                                         uint64_t step, long long row_offset,
+                                                                         int a, uint32_t heads, const float *noise,
+                                                                         uint64_t seed, uint64_t step, long long row_offset,
                                                                          long long *actions, float *logprob, float *entropy,
                                                                          float *value) {
     __shared__ float xs[XTile<DP>::kFloats];
@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
         const long long row = tile * 16 + le;
         const bool ok = row < rows;
         const float q = ok ? noise_lane(noise ? noise + row * a : nullptr, seed, step, (uint64_t)(row_offset + row), lo, a) : 1.0f;
-        const LaneSample sm = sample_lanes(part, le, lo, a, q);
+        const LaneSample sm = heads ? sample_lanes_heads(part, le, lo, a, heads, q) : sample_lanes(part, le, lo, a, q);
         if (ok && lo == 0) {
             actions[row] = sm.action;
             logprob[row] = sm.logprob;
@@ -153,6 +153,8 @@ static int check_dims(const pfa_mlp_dims *d) {
                 "mlp: obs_stride must be one of 16/32/64/96/128 (got %d)", d->obs_stride);
     PFA_REQUIRE(d->obs_dim >= 1 && d->obs_dim <= d->obs_stride, "mlp: obs_dim %d out of range", d->obs_dim);
     PFA_REQUIRE(d->num_actions >= 1 && d->num_actions <= 15, "mlp: num_actions must be in 1..15 (got %d)", d->num_actions);
+    PFA_REQUIRE(d->heads == 0 || heads_count(d->heads, d->num_actions) >= 1, "mlp: head sizes 0x%x do not sum to num_actions %d",
+                d->heads, d->num_actions);
     return 0;
 }
 
@@ -187,7 +189,7 @@ extern "C" int pfa_mlp_forward_sample(const float *obs, int64_t rows, const floa
     const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
     PFA_DISPATCH_DP(dims->obs_stride,
                     hipLaunchKernelGGL(mlp_forward_sample_kernel<DP>, dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, obs,
-                                       (long long)rows, params, dims->num_actions, noise, seed, step, (long long)row_offset,
+                                       (long long)rows, params, dims->num_actions, dims->heads, noise, seed, step, (long long)row_offset,
                                        (long long *)actions, logprob, entropy, value));
     PFA_LAUNCH_CHECK();
     return 0;
@@ -199,6 +201,7 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
                                        uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream) {
     if (int rc = check_dims(dims)) return rc;
     PFA_REQUIRE(state && cfg && params && exp && obs && rewards && terminals && truncations && masks, "rollout: null buffer");
+    PFA_REQUIRE(dims->heads == 0, "rollout: the fused rollout samples one Discrete head");
     PFA_REQUIRE(cfg->obs_stride == dims->obs_stride, "rollout: env obs_stride %d != policy obs_stride %d", cfg->obs_stride,
                 dims->obs_stride);
     PFA_REQUIRE(exp->horizon_T >= 1, "rollout: horizon must be >= 1");

@@ -103,5 +103,9 @@ __device__ __forceinline__ LaneSample sample_lanes(const float (*part)[kOut * 16
     const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
     return sample_row16(mine, lo, a, q);
 }
+__device__ __forceinline__ LaneSample sample_lanes_heads(const float (*part)[kOut * 16], int le, int lo, int a, uint32_t heads, float q) {
+    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+    return sample_row16_heads(mine, lo, a, heads, q);
+}
 
 }  // namespace pfa

@@ -33,6 +33,40 @@ __device__ __forceinline__ LaneSample sample_row16(float mine, int lo, int a, fl
     return r;
 }
 
+// MultiDiscrete (cleanrl.py:31-44): `heads` packs the head sizes (pfa_mlp_dims.heads); one draw per head over its own
+// logit columns, the choices packed like the sizes, log-probabilities and entropies summed over heads.
+__host__ __device__ inline int heads_count(uint32_t heads, int a) {  // number of heads, or -1 if the sizes do not sum to a
+    int n = 0, total = 0;
+    for (; n < 8 && ((heads >> (4 * n)) & 15u) != 0; ++n) total += (int)((heads >> (4 * n)) & 15u);
+    return (n < 8 ? (heads >> (4 * n)) == 0 : true) && total == a ? n : -1;
+}
+
+__device__ __forceinline__ LaneSample sample_row16_heads(float mine, int lo, int a, uint32_t heads, float q) {
+    LaneSample r;
+    r.action = 0;
+    r.logprob = r.entropy = 0.0f;
+    int start = 0;
+    for (int h = 0; h < 8; ++h) {
+        const int sz = (int)((heads >> (4 * h)) & 15u);
+        if (sz == 0) break;  // uniform
+        const bool member = lo >= start && lo < start + sz;
+        const float mx = row16_max(member ? mine : -INFINITY);
+        const float ex_ = member ? expf(mine - mx) : 0.0f;
+        const float se = row16_sum(ex_);
+        const float lse = mx + logf(se);
+        float best = member ? (ex_ / se) / q : -INFINITY;
+        int besti = lo;
+        row16_argmax(best, besti);
+        const float nl = mine - lse;
+        r.action |= (besti - start) << (4 * h);
+        r.logprob += row16_sum(lo == besti ? nl : 0.0f);
+        r.entropy += row16_sum(member ? -nl * expf(nl) : 0.0f);
+        start += sz;
+    }
+    r.value = row16_sum(lo == a ? mine : 0.0f);
+    return r;
+}
+
 // Exp(1) noise of (row, step, column lo): explicit tensor if given, else the Philox stream (philox.hpp).
 __device__ __forceinline__ float noise_lane(const float *noise_row_ptr, uint64_t seed, uint64_t step, uint64_t row, int lo,
                                             int a) {

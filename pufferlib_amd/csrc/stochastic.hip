@@ -229,6 +229,7 @@ extern "C" int pfa_rollout_mlp_stochastic(void *state, int32_t num_envs, double 
                                           uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream) {
     PFA_REQUIRE(state && num_envs >= 1 && horizon >= 1 && params && dims && exp && obs && rewards && terminals && truncations && masks,
                 "rollout_stochastic: bad arguments");
+    PFA_REQUIRE(dims->heads == 0, "rollout_stochastic: the fused rollout samples one Discrete head");
     PFA_REQUIRE(dims->hidden == kHidden && dims->obs_stride == kStoDP && dims->obs_dim == 1,
                 "rollout_stochastic: the policy must take 1 observation value in rows of 16 floats");
     PFA_REQUIRE(dims->num_actions >= 2 && dims->num_actions <= 15, "rollout_stochastic: num_actions out of range");

@@ -19,15 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib, utils
-
-_STRIDES = (16, 32, 64, 96, 128)
-
-
-def obs_stride_for(obs_dim):
-    for s in _STRIDES:
-        if obs_dim <= s:
-            return s
-    raise NotImplementedError(f'flat observation of {obs_dim} floats: the MLP/LSTM kernels take rows of up to 128 floats')
+from .cleanrl import obs_stride_for  # noqa: F401  (re-exported: create() and the tests size host rows with it)
 
 
 class HostBridge:
@@ -80,11 +72,14 @@ class HostBridge:
             dev[:n].copy_(host[:n], non_blocking=True)
         return n, order
 
-    def download_actions(self, actions_dev, n, order):
-        """Device actions (env_id order) -> host numpy in the row order recv() used.  Synchronises."""
+    def download_actions(self, actions_dev, n, order, nvec=None):
+        """Device actions (env_id order) -> host numpy in the row order recv() used; ``nvec`` unpacks the per-head choices of
+        a MultiDiscrete policy into [n, heads] (what vecenv.send expects, vector.py:139-141).  Synchronises."""
         self.act_pin[:n].copy_(actions_dev[:n], non_blocking=True)
         torch.cuda.current_stream().synchronize()
         a = self.act_pin.numpy()[:n]
+        if nvec is not None:
+            a = (a[:, None] >> (4 * np.arange(len(nvec)))) & 15
         if order is None:
             return a.copy()
         out = np.empty_like(a)
@@ -144,7 +139,7 @@ def evaluate(data):
                                         _lib.ptr(bridge.rew), _lib.ptr(bridge.done), _lib.ptr(actions), _lib.ptr(logprob),
                                         _lib.ptr(value), _lib.ptr(bridge.ids), _lib.ptr(bridge.mask), _lib.ptr(bridge.counters),
                                         _lib.ptr(bridge.stored_dropped), stream), 'store_rows')
-            actions_np = bridge.download_actions(actions, n, order)
+            actions_np = bridge.download_actions(actions, n, order, fp.nvec if fp.multidiscrete else None)
             sent_rows += nmask
             recvs += 1
             for i in info:                                           # clean_pufferl.py:110-113

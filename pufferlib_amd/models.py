@@ -20,18 +20,24 @@ def layer_init(layer, std=np.sqrt(2), bias_const=0.0):
 
 
 class Default(nn.Module):
-    """Linear(obs -> 128) + ReLU, Linear(128 -> n_actions) (orthogonal, std 0.01), Linear(128 -> 1)."""
+    """Linear(obs -> 128) + ReLU, Linear(128 -> n_actions) (orthogonal, std 0.01), Linear(128 -> 1).  A MultiDiscrete action
+    space gets one decoder Linear per head in an nn.ModuleList (models.py:29-35), state_dict keys ``decoder.<h>.weight``."""
 
     def __init__(self, env, hidden_size=HIDDEN):
         super().__init__()
         if hidden_size != HIDDEN:
             raise ValueError(f'pufferlib_amd.models.Default supports hidden_size={HIDDEN} only')
         self.obs_dim = int(np.prod(env.single_observation_space.shape))
-        self.num_actions = int(env.single_action_space.n)
         self.encoder = nn.Linear(self.obs_dim, hidden_size)
-        self.decoder = layer_init(nn.Linear(hidden_size, self.num_actions), std=0.01)
+        self.is_multidiscrete = hasattr(env.single_action_space, 'nvec')
+        if self.is_multidiscrete:
+            nvec = [int(n) for n in env.single_action_space.nvec]
+            self.num_actions = sum(nvec)
+            self.decoder = nn.ModuleList([layer_init(nn.Linear(hidden_size, n), std=0.01) for n in nvec])
+        else:
+            self.num_actions = int(env.single_action_space.n)
+            self.decoder = layer_init(nn.Linear(hidden_size, self.num_actions), std=0.01)
         self.value_head = nn.Linear(hidden_size, 1)
-        self.is_multidiscrete = False
 
     def forward(self, observations):
         raise RuntimeError('pufferlib_amd.models.Default is a parameter container: call it through '
@@ -75,12 +81,21 @@ def find_lstm(module):
 MLP_KEYS = ['encoder.weight', 'encoder.bias', 'decoder.weight', 'decoder.bias', 'value_head.weight', 'value_head.bias']
 
 
+def decoder_heads(mlp):
+    """[logits per head] of a Default-shaped module: one entry for a Discrete decoder, one per Linear of a MultiDiscrete
+    ModuleList (models.py:29-35)."""
+    if isinstance(mlp.decoder, nn.Linear):
+        return [int(mlp.decoder.weight.shape[0])]
+    return [int(d.weight.shape[0]) for d in mlp.decoder]
+
+
 def find_mlp(module):
     """Locate the Default-shaped submodule inside a policy wrapper (ours or the reference's
     frameworks.cleanrl.Policy -> .policy).  Returns the module owning encoder/decoder/value_head."""
     for m in module.modules():
         if all(hasattr(m, n) for n in ('encoder', 'decoder', 'value_head')) and isinstance(getattr(m, 'encoder'), nn.Linear):
-            if isinstance(m.decoder, nn.Linear):
+            if isinstance(m.decoder, nn.Linear) or (isinstance(m.decoder, nn.ModuleList) and len(m.decoder) >= 1
+                                                    and all(isinstance(d, nn.Linear) for d in m.decoder)):
                 return m
     raise ValueError('policy has no encoder/decoder/value_head Linear layers (models.Default shape)')
 
@@ -92,12 +107,18 @@ class FlatParams:
         mlp = find_mlp(policy_module)
         self.mlp = mlp
         H, D = mlp.encoder.weight.shape
-        A = mlp.decoder.weight.shape[0]
+        self.nvec = decoder_heads(mlp)
+        self.multidiscrete = not isinstance(mlp.decoder, nn.Linear)
+        A = sum(self.nvec)
         if H != HIDDEN:
             raise ValueError(f'hidden size must be {HIDDEN}')
-        if not (mlp.value_head.weight.shape == (1, H) and mlp.decoder.weight.shape[1] == H):
+        decs = list(mlp.decoder) if self.multidiscrete else [mlp.decoder]
+        if not (mlp.value_head.weight.shape == (1, H) and all(d.weight.shape[1] == H for d in decs)):
             raise ValueError('unexpected head shapes')
-        self.dims = _lib.MlpDims(int(D), int(obs_stride), int(H), int(A))
+        if A > 15 or (self.multidiscrete and (len(self.nvec) > 8 or max(self.nvec) > 15)):
+            raise NotImplementedError(f'action heads {self.nvec}: the policy kernels take up to 15 logits in up to 8 heads')
+        heads = sum(n << (4 * h) for h, n in enumerate(self.nvec)) if self.multidiscrete else 0
+        self.dims = _lib.MlpDims(int(D), int(obs_stride), int(H), int(A), heads)
         self.obs_dim, self.obs_stride, self.num_actions = int(D), int(obs_stride), int(A)
         DP = self.obs_stride
         self.mlp_count = H * DP + H + A * H + A + H + 1
@@ -105,22 +126,15 @@ class FlatParams:
         if self.lstm is not None:
             if (self.lstm.input_size, self.lstm.hidden_size, self.lstm.num_layers) != (H, H, 1) or self.lstm.bidirectional:
                 raise ValueError(f'the recurrent policy must use nn.LSTM({H}, {H}, 1)')
+            if self.multidiscrete:
+                raise NotImplementedError('MultiDiscrete action heads are built for the MLP policy only')
         self.count = self.mlp_count + (8 * H * H + 8 * H if self.lstm is not None else 0)
         self.flat = torch.zeros(self.count, dtype=torch.float32, device=device)
-        o = 0
-        self.views = {}
-        self.views['encoder.weight'] = self.flat[o:o + H * DP].view(H, DP)[:, :D]; o += H * DP
-        self.views['encoder.bias'] = self.flat[o:o + H]; o += H
-        self.views['decoder.weight'] = self.flat[o:o + A * H].view(A, H); o += A * H
-        self.views['decoder.bias'] = self.flat[o:o + A]; o += A
-        self.views['value_head.weight'] = self.flat[o:o + H].view(1, H); o += H
-        self.views['value_head.bias'] = self.flat[o:o + 1]; o += 1
-        assert o == self.mlp_count
+        self.views = self.split_mlp(self.flat)
         self.lstm_views = self._lstm_views(self.flat)
         with torch.no_grad():
             for name, view in self.views.items():
-                mod, attr = name.split('.')
-                p = getattr(getattr(mlp, mod), attr)
+                p = mlp.get_parameter(name)
                 view.copy_(p.detach().to(device=device, dtype=torch.float32))
                 p.data = view          # the module now aliases the flat buffer
             for name, view in self.lstm_views.items():
@@ -147,20 +161,42 @@ class FlatParams:
         flat = self.flat if flat is None else flat
         return flat[:HIDDEN * self.obs_stride].view(HIDDEN, self.obs_stride)
 
+    def unpack_actions(self, packed):
+        """Kernel action words -> what the reference hands to envs: [rows] for a Discrete head, [rows, heads] for MultiDiscrete
+        (head h's choice sits in bits 4h..4h+3 of the word, include/pufferlib_amd.h: pfa_mlp_dims.heads)."""
+        if not self.multidiscrete:
+            return packed
+        shifts = torch.arange(0, 4 * len(self.nvec), 4, device=packed.device, dtype=packed.dtype)
+        return (packed.unsqueeze(-1) >> shifts) & 15
+
     def flat_like(self):
         return torch.zeros_like(self.flat)
 
+    def split_mlp(self, flat):
+        """Views of a flat vector with the MLP parameters' names and shapes, in the reference's named_parameters order.  The
+        decoder block is [A][H] weights then [A] biases; a MultiDiscrete head owns a run of rows / entries of it."""
+        H, D, DP, A = HIDDEN, self.obs_dim, self.obs_stride, self.num_actions
+        out = {}
+        out['encoder.weight'] = flat[:H * DP].view(H, DP)[:, :D]
+        out['encoder.bias'] = flat[H * DP:H * DP + H]
+        o = H * DP + H
+        w, b = flat[o:o + A * H].view(A, H), flat[o + A * H:o + A * H + A]
+        if self.multidiscrete:
+            r = 0
+            for h, n in enumerate(self.nvec):
+                out[f'decoder.{h}.weight'], out[f'decoder.{h}.bias'] = w[r:r + n], b[r:r + n]
+                r += n
+        else:
+            out['decoder.weight'], out['decoder.bias'] = w, b
+        o += A * H + A
+        out['value_head.weight'] = flat[o:o + H].view(1, H)
+        out['value_head.bias'] = flat[o + H:o + H + 1]
+        assert o + H + 1 == self.mlp_count
+        return out
+
     def split(self, flat):
         """Views of another flat vector (gradients, Adam moments) with the parameters' shapes."""
-        H, D, DP, A = HIDDEN, self.obs_dim, self.obs_stride, self.num_actions
-        o = 0
-        out = {}
-        out['encoder.weight'] = flat[o:o + H * DP].view(H, DP)[:, :D]; o += H * DP
-        out['encoder.bias'] = flat[o:o + H]; o += H
-        out['decoder.weight'] = flat[o:o + A * H].view(A, H); o += A * H
-        out['decoder.bias'] = flat[o:o + A]; o += A
-        out['value_head.weight'] = flat[o:o + H].view(1, H); o += H
-        out['value_head.bias'] = flat[o:o + 1]
+        out = self.split_mlp(flat)
         for k, v in self._lstm_views(flat).items():
             out['recurrent.' + k] = v
         return out

@@ -19,6 +19,8 @@ Fixtures written (all small, committed):
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
+  ppo_spaces.npz     same as ppo_mlp on ocean make_spaces: Dict observation emulated to 108-byte rows, Dict action emulated to
+                     MultiDiscrete([2, 2]) -> models.Default's per-head decoders and sample_logits' list branch (cleanrl.py:25-47)
 """
 import os
 import sys
@@ -308,7 +310,7 @@ def gen_nativize(rows_per_case=21):
     np.savez_compressed(os.path.join(HERE, 'nativize.npz'), **out)
 
 
-def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
+def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2, env='squared'):
     import pufferlib
     import pufferlib.vector
     import pufferlib.models
@@ -329,13 +331,13 @@ def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
 
     batch = num_envs * horizon
     config = pufferlib.namespace(
-        env='squared', seed=1, torch_deterministic=True, cpu_offload=False, device='cpu',
+        env=env, seed=1, torch_deterministic=True, cpu_offload=False, device='cpu',
         total_timesteps=batch * 8, learning_rate=2.5e-4, anneal_lr=True, gamma=0.99, gae_lambda=0.95,
         update_epochs=2, norm_adv=True, clip_coef=0.1, clip_vloss=True, vf_coef=0.5, vf_clip_coef=0.1,
         max_grad_norm=0.5, ent_coef=0.01, target_kl=None, batch_size=batch, minibatch_size=batch // 4,
         bptt_horizon=8, compile=False, compile_mode='reduce-overhead', checkpoint_interval=10 ** 9,
         data_dir='/tmp/golden_experiments', exp_id='golden')
-    vec = pufferlib.vector.make(ocean.env_creator('squared'), num_envs=num_envs, backend=pufferlib.vector.Serial)
+    vec = pufferlib.vector.make(ocean.env_creator(env), num_envs=num_envs, backend=pufferlib.vector.Serial)
 
     torch.manual_seed(1)
     policy = pufferlib.models.Default(vec.driver_env, hidden_size=128)
@@ -372,8 +374,9 @@ def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2):
             noise.clear()
             clean_pufferl.evaluate(data)
             out[f'it{it}.noise'] = np.stack(noise)                       # (T, N, A)
-            out[f'it{it}.obs'] = exp.obs.numpy().reshape(batch, -1).astype(np.int8)  # storage (step-major) order
-            out[f'it{it}.actions'] = exp.actions_np.copy().astype(np.int8)
+            # storage (step-major) order; Squared cells are -1/0/1, Spaces rows are the emulated bytes
+            out[f'it{it}.obs'] = exp.obs.numpy().reshape(batch, -1).astype(np.int8 if env == 'squared' else np.uint8)
+            out[f'it{it}.actions'] = exp.actions_np.copy().astype(np.int8)      # [batch] or [batch, heads] (MultiDiscrete)
             out[f'it{it}.logprobs'] = exp.logprobs_np.copy()
             out[f'it{it}.rewards'] = exp.rewards_np.copy()
             out[f'it{it}.dones'] = exp.dones_np.copy()
@@ -429,3 +432,4 @@ if __name__ == '__main__':
     gen_memory('l3d1', 130, 3, 1, 4090, 30)    # 130 x 7 words per reset round: crosses MT19937 blocks
     gen_ppo('mlp', use_rnn=False)
     gen_ppo('lstm', use_rnn=True)
+    gen_ppo('spaces', use_rnn=False, env='spaces')

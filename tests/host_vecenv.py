@@ -81,3 +81,123 @@ class HostSquaredPool:
 
     def close(self):
         pass
+
+
+class SpacesReplay:
+    """``pufferlib.vector.Serial`` over ``make_spaces`` envs (ocean.py:356-404 behind GymnasiumPufferEnv + EpisodeStats) with the
+    OBSERVATIONS played back from a recording of the unmodified reference (tests/golden/ppo_spaces.npz): the env draws them from
+    numpy's global generator without looking at the actions, so only the reward rule is computed here.  Rows are the emulated
+    108-byte structs {flat: int8[5] @0, image: f32[5,5] @8}; actions are MultiDiscrete([2, 2]) = (flat, image) (Dict keys in
+    sorted order, emulation.py:111-121).  Every step is terminal, the next send is the reset row."""
+
+    def __init__(self, obs_rounds):
+        from pufferlib_amd import spaces
+        self.obs_rounds = np.asarray(obs_rounds, np.uint8)            # [recvs][N][108]
+        n = self.obs_rounds.shape[1]
+        self.single_observation_space = spaces.Box(low=0, high=255, shape=(108,), dtype=np.uint8)
+        self.single_action_space = spaces.MultiDiscrete([2, 2])
+        self.driver_env = self
+        self.num_envs = self.num_agents = self.agents_per_batch = n
+        self.agent_ids = np.arange(n)
+        self.observations = np.zeros((n, 108), np.uint8)            # what ppo_torch.Trainer sizes its buffers from
+        self.emulated = True
+        self.k = 0
+        self.rewards = np.zeros(n, np.float32)
+        self.terminals = np.zeros(n, bool)
+        self.infos = []
+
+    def async_reset(self, seed=42):
+        self.k = 0
+        self.rewards[:] = 0
+        self.terminals[:] = False
+        self.infos = []
+
+    def recv(self):
+        n = self.num_agents
+        return (self.obs_rounds[self.k].copy(), self.rewards.copy(), self.terminals.copy(), np.zeros(n, bool), self.infos,
+                self.agent_ids, np.ones(n, bool))
+
+    def send(self, actions):
+        a = np.asarray(actions).reshape(self.num_agents, 2)
+        rows = self.obs_rounds[self.k]
+        self.k += 1
+        if self.terminals.any():                                     # vector.py:147-149: reset row, action ignored
+            self.rewards[:] = 0
+            self.terminals[:] = False
+            self.infos = []
+            return
+        self.infos = []
+        for e in range(self.num_agents):
+            flat = rows[e, 0:5].view(np.int8)
+            image = rows[e, 8:108].view(np.float32).reshape(5, 5)
+            reward = 0                                               # ocean.py:392-399
+            if (np.sum(image) > 0) == a[e, 1]:
+                reward += 0.5
+            if (np.sum(flat) > 0) == a[e, 0]:
+                reward += 0.5
+            self.rewards[e] = reward
+            self.infos.append(dict(score=reward, episode_return=reward, episode_length=1))
+        self.terminals[:] = True
+
+    def close(self):
+        pass
+
+
+class HostMultiHead:
+    """A small deterministic host vecenv with a MultiDiscrete action space (test stand-in for the reference's emulated Dict /
+    Tuple action envs): observations are seeded noise, head h is rewarded for matching ``floor(|obs[h]| * 7) % nvec[h]``, an
+    env terminates every ``period`` steps and the following send is its reset row (vector.py:147-149)."""
+
+    def __init__(self, num_envs, nvec, obs_dim=20, period=5, seed=0):
+        from pufferlib_amd import spaces
+        self.nvec = [int(x) for x in nvec]
+        self.single_observation_space = spaces.Box(low=-10, high=10, shape=(obs_dim,), dtype=np.float32)
+        self.single_action_space = spaces.MultiDiscrete(self.nvec)
+        self.driver_env = self
+        self.num_envs = self.num_agents = self.agents_per_batch = num_envs
+        self.agent_ids = np.arange(num_envs)
+        self.emulated = True
+        self.period, self.seed = period, seed
+        self.observations = np.zeros((num_envs, obs_dim), np.float32)
+        self.async_reset()
+
+    def _draw(self):
+        self.observations[:] = self.rng.randn(*self.observations.shape).astype(np.float32)
+
+    def async_reset(self, seed=42):
+        n = self.num_agents
+        self.rng = np.random.RandomState(self.seed)
+        self.tick = np.arange(n) % self.period                       # staggered episode ends
+        self.done = np.zeros(n, bool)
+        self.rewards = np.zeros(n, np.float32)
+        self.terminals = np.zeros(n, bool)
+        self.ep_return = np.zeros(n, np.float64)
+        self.infos = []
+        self._draw()
+
+    def recv(self):
+        n = self.num_agents
+        return (self.observations.copy(), self.rewards.copy(), self.terminals.copy(), np.zeros(n, bool), self.infos, self.agent_ids,
+                np.ones(n, bool))
+
+    def send(self, actions):
+        a = np.asarray(actions).reshape(self.num_agents, len(self.nvec))
+        target = np.floor(np.abs(self.observations[:, :len(self.nvec)]) * 7).astype(np.int64) % np.array(self.nvec)
+        self.infos = []
+        old_done = self.done.copy()
+        hit = (a == target).mean(1)
+        self._draw()
+        for e in range(self.num_agents):
+            if old_done[e]:
+                self.rewards[e], self.terminals[e], self.done[e], self.tick[e], self.ep_return[e] = 0, False, False, 0, 0
+                continue
+            self.rewards[e] = hit[e]
+            self.ep_return[e] += float(np.float32(hit[e]))
+            self.tick[e] += 1
+            self.terminals[e] = self.done[e] = self.tick[e] >= self.period
+            if self.done[e]:
+                self.infos.append(dict(episode_return=self.ep_return[e], episode_length=int(self.tick[e]),
+                                       score=self.ep_return[e] / self.tick[e]))
+
+    def close(self):
+        pass

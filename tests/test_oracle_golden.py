@@ -281,3 +281,43 @@ def test_multiagent_oracle_replays_reference_trajectory(golden_dir):
         if k < steps:
             vec.send(g['actions'][k].astype(np.int64))
     assert np.array_equal(np.array(infos, np.int64).reshape(-1, 4), g['infos'])
+
+
+def spaces_noise(g, it, n, horizon):
+    """The recording holds one [N, 2] slab per torch.multinomial call, two calls (heads) per step: -> [T, N, 4]."""
+    q = g[f'it{it}.noise']
+    return q.reshape(horizon, 2, n, 2).transpose(0, 2, 1, 3).reshape(horizon, n, 4)
+
+
+def test_multidiscrete_ppo_replay_matches_reference(golden_dir):
+    """models.Default's per-head decoders + sample_logits' list branch + [batch, heads] actions through create/evaluate/train
+    (tests/golden/ppo_spaces.npz: the unmodified reference on ocean Spaces, Dict obs -> 108-byte rows, Dict action ->
+    MultiDiscrete([2, 2])).  Observations are played back (host_vecenv.SpacesReplay), everything else is recomputed."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from host_vecenv import SpacesReplay
+    torch.set_num_threads(1)
+    g = _load(golden_dir, 'ppo_spaces.npz')
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    lr, gamma, lam, clip, vf_coef, vf_clip, mgn, ent = (float(x) for x in g['hparams'])
+    pol = ppo_torch.Policy.from_reference_state_dict({k[3:]: g[k] for k in g.files if k.startswith('w0.')})
+    assert pol.heads == [2, 2]
+    rounds = np.concatenate([g[f'it{it}.obs'].reshape(horizon, n, 108) for it in range(iters)])
+    rounds = np.concatenate([rounds, rounds[-1:]])                    # the recv after the last send is never looked at
+    tr = ppo_torch.Trainer(pol, SpacesReplay(rounds), batch_size=n * horizon, minibatch_size=mbs, bptt_horizon=bptt,
+                           update_epochs=epochs, learning_rate=lr, gamma=gamma, gae_lambda=lam, clip_coef=clip, vf_coef=vf_coef,
+                           vf_clip_coef=vf_clip, max_grad_norm=mgn, ent_coef=ent, total_timesteps=total, seed=1)
+    for it in range(iters):
+        stats = tr.evaluate(spaces_noise(g, it, n, horizon))
+        assert np.array_equal(tr.actions, g[f'it{it}.actions'].astype(np.int64)), 'actions differ'
+        assert np.array_equal(tr.rewards, g[f'it{it}.rewards']) and np.array_equal(tr.dones, g[f'it{it}.dones'])
+        np.testing.assert_allclose(tr.logprobs, g[f'it{it}.logprobs'], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(tr.values, g[f'it{it}.values'], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']], g[f'it{it}.stats'], rtol=1e-12)
+        L = tr.train()
+        got = [L['policy_loss'], L['value_loss'], L['entropy'], L['old_approx_kl'], L['approx_kl'], L['clipfrac'], L['explained_variance']]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=2e-5, atol=1e-7)
+        m, v = tr.adam_moments()
+        for name, arr in pol.state_arrays().items():
+            np.testing.assert_allclose(arr, g[f'it{it}.w.policy.' + name], rtol=1e-5, atol=1e-6, err_msg=name)
+            np.testing.assert_allclose(m[name], g[f'it{it}.m.policy.' + name], rtol=1e-4, atol=1e-7, err_msg=name)
