@@ -145,8 +145,8 @@ class SpacesReplay:
 
 class HostMultiHead:
     """A small deterministic host vecenv with a MultiDiscrete action space (test stand-in for the reference's emulated Dict /
-    Tuple action envs): observations are seeded noise, head h is rewarded for matching ``floor(|obs[h]| * 7) % nvec[h]``, an
-    env terminates every ``period`` steps and the following send is its reset row (vector.py:147-149)."""
+    Tuple action envs): observations are seeded N(0, 1) noise, head h is rewarded for naming the equal-probability bin obs[h]
+    falls in (nvec[h] bins), an env terminates every ``period`` steps and the following send is its reset row (vector.py:147-149)."""
 
     def __init__(self, num_envs, nvec, obs_dim=20, period=5, seed=0):
         from pufferlib_amd import spaces
@@ -158,6 +158,8 @@ class HostMultiHead:
         self.agent_ids = np.arange(num_envs)
         self.emulated = True
         self.period, self.seed = period, seed
+        from statistics import NormalDist
+        self.edges = [np.array([NormalDist().inv_cdf(i / k) for i in range(1, k)]) for k in self.nvec]
         self.observations = np.zeros((num_envs, obs_dim), np.float32)
         self.async_reset()
 
@@ -182,7 +184,7 @@ class HostMultiHead:
 
     def send(self, actions):
         a = np.asarray(actions).reshape(self.num_agents, len(self.nvec))
-        target = np.floor(np.abs(self.observations[:, :len(self.nvec)]) * 7).astype(np.int64) % np.array(self.nvec)
+        target = np.stack([np.digitize(self.observations[:, h], self.edges[h]) for h in range(len(self.nvec))], 1)
         self.infos = []
         old_done = self.done.copy()
         hit = (a == target).mean(1)
