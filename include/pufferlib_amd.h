@@ -116,8 +116,9 @@ typedef struct {
     int32_t num_actions; /* A <= 15: decoder rows = logits of all heads */
     uint32_t heads;      /* 0: one Discrete(A) head.  MultiDiscrete: head h has (heads >> 4h) & 15 logits, heads back to back in
                           * decoder row order, sizes summing to A; actions are then stored packed the same way, head h's choice
-                          * in bits 4h..4h+3.  Only the standalone forward (pfa_mlp_forward_sample) and the MLP update
-                          * (pfa_ppo_mlp_grad) take several heads; the fused rollouts and the recurrent path refuse them. */
+                          * in bits 4h..4h+3.  The standalone policy steps (pfa_mlp_forward_sample, pfa_lstm_policy_step)
+                          * and the updates (pfa_ppo_mlp_grad, pfa_lstm_heads_loss) take several heads; the fused device
+                          * rollouts refuse them. */
 } pfa_mlp_dims;
 
 int64_t pfa_mlp_param_count(const pfa_mlp_dims *dims);

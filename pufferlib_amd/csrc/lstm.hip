@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(256) gather_obs_tm_kernel(const float *obs, Ti
 // gradients w.r.t. the 16 padded head outputs and w.r.t. h.  16 lanes per row.  stats_partial: [gridDim.x][8].
 __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, long long rows, TimeMajorMap map,
                                                              pfa_experience ex, const float *params, int dp, int a,
-                                                             pfa_ppo_hparams hp, const double *adv_stats, double global_rows,
+                                                             uint32_t heads, pfa_ppo_hparams hp, const double *adv_stats,
+                                                             double global_rows,
                                                              float *dout /* [rows][16] */, float *dh /* [rows][128] */,
                                                              float *stats_partial) {
     __shared__ float w2v[kOut * (kLstmH + 1)];
@@ -286,15 +287,22 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
         const float old_logprob = ex.logprobs[fr], old_value = ex.values[fr], adv_raw = ex.advantages[fr], ret = ex.returns[fr];
         const float mine = head_dot(hs[le], w2v, b2v, lo);
         // log-softmax over the row's logits
-        const bool is_logit = lo < a;
-        const float mx = row16_max(is_logit ? mine : -INFINITY);
-        const float ev = is_logit ? expf(mine - mx) : 0.0f;
-        const float se = row16_sum(ev);
-        const float lse = mx + logf(se);
-        const float nl = mine - lse;
-        const float p = ev / se;
-        const float ent = row16_sum(is_logit ? -nl * p : 0.0f);
-        const float new_logprob = row16_sum(lo == action ? nl : 0.0f);
+        bool is_logit = lo < a, chosen;
+        float nl, p, ent, hent, new_logprob;
+        if (heads == 0) {
+            const float mx = row16_max(is_logit ? mine : -INFINITY);
+            const float ev = is_logit ? expf(mine - mx) : 0.0f;
+            const float se = row16_sum(ev);
+            const float lse = mx + logf(se);
+            nl = mine - lse;
+            p = ev / se;
+            ent = hent = row16_sum(is_logit ? -nl * p : 0.0f);
+            chosen = lo == action;
+            new_logprob = row16_sum(chosen ? nl : 0.0f);
+        } else {  // MultiDiscrete: per-head softmax, sums over heads (sampler.hpp)
+            const Row16Eval ev = eval_row16_heads(mine, lo, a, heads, action);
+            nl = ev.nl, p = ev.p, hent = ev.head_entropy, ent = ev.entropy, chosen = ev.chosen, new_logprob = ev.logprob;
+        }
         const float new_value = row16_sum(lo == a ? mine : 0.0f);
         const float logratio = new_logprob - old_logprob;
         const float ratio = expf(logratio);
@@ -325,7 +333,7 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
         }
         dv *= hp.vf_coef * scale;
         float d = 0.0f;
-        if (is_logit) d = g_lp * ((lo == action ? 1.0f : 0.0f) - p) + hp.ent_coef * scale * p * (nl + ent);
+        if (is_logit) d = g_lp * ((chosen ? 1.0f : 0.0f) - p) + hp.ent_coef * scale * p * (nl + hent);
         else if (lo == a) d = dv;
         if (ok) {
             dout[row * kOut + lo] = d;
@@ -531,6 +539,8 @@ extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, in
                                    int64_t global_mb_rows, float *dout, float *dh, float *loss_sums8, float *head_bias_grad16,
                                    void *workspace, pfa_stream_t stream) {
     PFA_REQUIRE(h && exp && params && dims && hp && dout && dh && loss_sums8 && workspace, "lstm_heads_loss: null buffer");
+    PFA_REQUIRE(dims->heads == 0 || heads_count(dims->heads, dims->num_actions) >= 1, "lstm_heads_loss: head sizes 0x%x do not sum to %d",
+                dims->heads, dims->num_actions);
     PFA_REQUIRE(!hp->norm_adv || adv_stats, "lstm_heads_loss: norm_adv needs adv_stats");
     const long long mbs = batch_rows / hp->num_minibatches;
     TimeMajorMap map{mb, hp->num_minibatches, hp->bptt_horizon, mbs / hp->bptt_horizon};
@@ -538,7 +548,7 @@ extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, in
     const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
     float *partial = (float *)workspace;
     hipLaunchKernelGGL(lstm_heads_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, mbs, map, *exp, params,
-                       dims->obs_stride, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, dout, dh, partial);
+                       dims->obs_stride, dims->num_actions, dims->heads, *hp, adv_stats, (double)global_mb_rows, dout, dh, partial);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, (int)grid, loss_sums8, head_bias_grad16);
     PFA_LAUNCH_CHECK();

@@ -72,15 +72,19 @@ __device__ __forceinline__ LaneSample lstm_sample(const float (*part)[kOut * 16]
     const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
     return sample_row16(mine, lo, a, q);
 }
+__device__ __forceinline__ LaneSample lstm_sample_heads(const float (*part)[kOut * 16], int le, int lo, int a, uint32_t heads, float q) {
+    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+    return sample_row16_heads(mine, lo, a, heads, q);
+}
 
 // ---------------------------------------------------------------------------------------------
 // policy(obs, (h, c)) in rollout mode over `rows` rows; h, c [rows][128] are updated in place.
 // ---------------------------------------------------------------------------------------------
 template <int DP>
 __global__ void __launch_bounds__(kLstmThreads) lstm_policy_step_kernel(const float *obs, long long rows, const float *params,
-                                                                       int a, const float4 *wpack, float *h, float *cell,
-                                                                       const float *noise, uint64_t seed, uint64_t step,
-                                                                       long long row_offset, long long *actions,
+                                                                       int a, uint32_t heads, const float4 *wpack, float *h,
+                                                                       float *cell, const float *noise, uint64_t seed,
+                                                                       uint64_t step, long long row_offset, long long *actions,
                                                                        float *logprob, float *entropy, float *value) {
     __shared__ LstmLds<DP> L;
     LstmFrags<DP> w;
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_policy_step_kernel(const fl
         const long long row = tile * 16 + le;
         const bool ok = row < rows;
         const float q = ok ? noise_lane(noise ? noise + row * a : nullptr, seed, step, (uint64_t)(row_offset + row), lo, a) : 1.0f;
-        const LaneSample sm = lstm_sample(L.part, le, lo, a, q);
+        const LaneSample sm = heads ? lstm_sample_heads(L.part, le, lo, a, heads, q) : lstm_sample(L.part, le, lo, a, q);
         if (ok && lo == 0) {
             actions[row] = sm.action;
             logprob[row] = sm.logprob;
@@ -207,7 +211,8 @@ static int check_lstm_dims(const pfa_mlp_dims *d) {
     PFA_REQUIRE(d->obs_stride == 16 || d->obs_stride == 32 || d->obs_stride == 64 || d->obs_stride == 96 || d->obs_stride == 128,
                 "lstm: obs_stride must be one of 16/32/64/96/128 (got %d)", d->obs_stride);
     PFA_REQUIRE(d->num_actions >= 1 && d->num_actions <= 15, "lstm: num_actions must be in 1..15 (got %d)", d->num_actions);
-    PFA_REQUIRE(d->heads == 0, "lstm: the recurrent path samples one Discrete head");
+    PFA_REQUIRE(d->heads == 0 || heads_count(d->heads, d->num_actions) >= 1, "lstm: head sizes 0x%x do not sum to num_actions %d",
+                d->heads, d->num_actions);
     return 0;
 }
 
@@ -256,8 +261,8 @@ extern "C" int pfa_lstm_policy_step(const float *obs, int64_t rows, const float 
     ScopedKernelTimer timer("lstm_policy_step", (hipStream_t)stream);
     PFA_LSTM_DISPATCH_DP(dims->obs_stride,
                          hipLaunchKernelGGL(lstm_policy_step_kernel<DP>, dim3(grid), dim3(kLstmThreads), 0, (hipStream_t)stream, obs,
-                                            (long long)rows, params, dims->num_actions, (const float4 *)wpack, h, c, noise, seed,
-                                            step, (long long)row_offset, (long long *)actions, logprob, entropy, value));
+                                            (long long)rows, params, dims->num_actions, dims->heads, (const float4 *)wpack, h, c,
+                                            noise, seed, step, (long long)row_offset, (long long *)actions, logprob, entropy, value));
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -270,6 +275,7 @@ extern "C" int pfa_rollout_lstm_squared(void *state, const pfa_squared_config *c
     if (int rc = check_lstm_dims(dims)) return rc;
     PFA_REQUIRE(state && cfg && params && wpack && h && c && exp && obs && rewards && terminals && truncations && masks,
                 "rollout_lstm: null buffer");
+    PFA_REQUIRE(dims->heads == 0, "rollout_lstm: the fused rollout samples one Discrete head");
     PFA_REQUIRE(cfg->obs_stride == dims->obs_stride, "rollout_lstm: env obs_stride %d != policy obs_stride %d", cfg->obs_stride,
                 dims->obs_stride);
     PFA_REQUIRE(exp->horizon_T >= 1, "rollout_lstm: horizon must be >= 1");

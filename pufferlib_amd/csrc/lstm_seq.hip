@@ -341,7 +341,6 @@ static int check_seq_dims(const pfa_mlp_dims *d) {
     PFA_REQUIRE(d->obs_stride == 16 || d->obs_stride == 32 || d->obs_stride == 64 || d->obs_stride == 96 || d->obs_stride == 128,
                 "lstm_seq: obs_stride must be one of 16/32/64/96/128 (got %d)", d->obs_stride);
     PFA_REQUIRE(d->num_actions >= 1 && d->num_actions <= 15, "lstm_seq: num_actions must be in 1..15 (got %d)", d->num_actions);
-    PFA_REQUIRE(d->heads == 0, "lstm_seq: the recurrent path takes one Discrete head");
     return 0;
 }
 

@@ -67,6 +67,43 @@ __device__ __forceinline__ LaneSample sample_row16_heads(float mine, int lo, int
     return r;
 }
 
+// Training-mode sample_logits (cleanrl.py:38-44, given actions) on the same 16 lanes: this lane's normalised logit and
+// softmax probability, the entropy of the head it belongs to, whether it is its head's chosen column, and the row's summed
+// log-probability / entropy.  heads == 0 is one Discrete(a) head.
+struct Row16Eval {
+    float nl, p, head_entropy, logprob, entropy;
+    bool is_logit, chosen;
+};
+__device__ __forceinline__ Row16Eval eval_row16_heads(float mine, int lo, int a, uint32_t heads, int packed_action) {
+    Row16Eval r;
+    r.nl = r.p = r.head_entropy = r.logprob = r.entropy = 0.0f;
+    r.is_logit = lo < a;
+    r.chosen = false;
+    if (heads == 0) heads = (uint32_t)a;  // a <= 15: one nibble
+    int start = 0;
+    for (int h = 0; h < 8; ++h) {
+        const int sz = (int)((heads >> (4 * h)) & 15u);
+        if (sz == 0) break;  // uniform
+        const bool member = lo >= start && lo < start + sz;
+        const float mx = row16_max(member ? mine : -INFINITY);
+        const float ev = member ? expf(mine - mx) : 0.0f;
+        const float se = row16_sum(ev);
+        const float nl = mine - (mx + logf(se)), p = ev / se;
+        const float he = row16_sum(member ? -nl * p : 0.0f);
+        const int act = start + ((packed_action >> (4 * h)) & 15);
+        r.logprob += row16_sum(lo == act ? nl : 0.0f);
+        r.entropy += he;
+        if (member) {
+            r.nl = nl;
+            r.p = p;
+            r.head_entropy = he;
+            r.chosen = lo == act;
+        }
+        start += sz;
+    }
+    return r;
+}
+
 // Exp(1) noise of (row, step, column lo): explicit tensor if given, else the Philox stream (philox.hpp).
 __device__ __forceinline__ float noise_lane(const float *noise_row_ptr, uint64_t seed, uint64_t step, uint64_t row, int lo,
                                             int a) {

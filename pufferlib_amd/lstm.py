@@ -45,7 +45,7 @@ def policy_step(fp, obs, h, c, noise, key, row_offset, wpack=None):
     _lib.check(L.pfa_lstm_policy_step(_lib.ptr(obs), rows, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(wpack), _lib.ptr(h),
                                       _lib.ptr(c), _lib.ptr(noise), C.byref(key), row_offset, _lib.ptr(actions),
                                       _lib.ptr(logprob), _lib.ptr(entropy), _lib.ptr(value), stream), 'lstm_policy_step')
-    return actions, logprob, entropy, value.unsqueeze(1)
+    return fp.unpack_actions(actions), logprob, entropy, value.unsqueeze(1)
 
 
 class Engine:

@@ -126,8 +126,6 @@ class FlatParams:
         if self.lstm is not None:
             if (self.lstm.input_size, self.lstm.hidden_size, self.lstm.num_layers) != (H, H, 1) or self.lstm.bidirectional:
                 raise ValueError(f'the recurrent policy must use nn.LSTM({H}, {H}, 1)')
-            if self.multidiscrete:
-                raise NotImplementedError('MultiDiscrete action heads are built for the MLP policy only')
         self.count = self.mlp_count + (8 * H * H + 8 * H if self.lstm is not None else 0)
         self.flat = torch.zeros(self.count, dtype=torch.float32, device=device)
         self.views = self.split_mlp(self.flat)

@@ -128,14 +128,54 @@ def test_three_heads_rollout_and_update_vs_oracle_trainer():
             np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, rtol=1e-5, atol=1e-5, err_msg=k)
 
 
-def test_unsupported_combinations_fail_loudly():
+def test_three_heads_with_the_recurrent_policy_vs_oracle_trainer():
+    """LSTMWrapper over the multi-head Default (models.py:84-111 -> decode_actions list branch): recurrent policy step with
+    per-head sampling on the host path, then the BPTT update whose heads/loss kernel takes the per-head softmax."""
     from host_vecenv import HostMultiHead
+    from oracle import ppo_torch
     from pufferlib_amd import clean_pufferl, cleanrl, models
     from test_gpu_ppo import _config
+    nvec, n, horizon, nmb, bptt = [3, 4, 2], 32, 32, 2, 8
     hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
-    vec = HostMultiHead(16, [3, 2])
-    rec = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
-    with pytest.raises(NotImplementedError):
-        clean_pufferl.create(_config(16, 16, 128, 8, 1, 10 ** 5, hp), vec, rec)
+    B = n * horizon
+    vec = HostMultiHead(n, nvec)
+    torch.manual_seed(6)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    sd0 = {k: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    data = clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, hp, seed=3), vec, pol)
+    opol = ppo_torch.Policy.from_reference_state_dict(sd0)
+    assert opol.recurrent and opol.heads == nvec
+    tr = ppo_torch.Trainer(opol, HostMultiHead(n, nvec), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt, update_epochs=2,
+                           learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3], vf_coef=hp[4], vf_clip_coef=hp[5],
+                           max_grad_norm=hp[6], ent_coef=hp[7], total_timesteps=B * 10, seed=3)
+    for it in range(2):
+        noise = torch.empty(horizon, n, sum(nvec)).exponential_(1)
+        data.noise = noise.clone()
+        clean_pufferl.evaluate(data)
+        tr.evaluate(noise.numpy())
+        e = data.experience
+        sm = lambda x: x.view(n, horizon, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
+        assert np.array_equal(sm(data.flat_params.unpack_actions(e.actions.long())), tr.actions), it
+        assert np.array_equal(sm(e.rewards), tr.rewards)
+        np.testing.assert_allclose(sm(e.logprobs), tr.logprobs, rtol=1e-4, atol=1e-5)
+        Lo = tr.train()
+        clean_pufferl.train(data)
+        L = data.losses
+        np.testing.assert_allclose([L.policy_loss, L.value_loss, L.entropy, L.approx_kl], [Lo[k] for k in ('policy_loss', 'value_loss', 'entropy', 'approx_kl')],
+                                   rtol=1e-3, atol=1e-5)
+        sd = pol.state_dict()
+        for k, arr in opol.state_arrays().items():
+            key = ('policy.recurrent.' + k) if k.endswith('_l0') else ('policy.policy.' + k)
+            np.testing.assert_allclose(sd[key].cpu().numpy(), arr, rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_unsupported_combinations_fail_loudly():
+    from host_vecenv import HostMultiHead
+    from pufferlib_amd import clean_pufferl
+    from test_gpu_ppo import _config
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
     with pytest.raises(NotImplementedError):
         clean_pufferl.create(_config(16, 16, 128, 8, 1, 10 ** 5, hp), HostMultiHead(16, [9, 9]), _policy(HostMultiHead(16, [9, 9])))
