@@ -68,3 +68,49 @@ def test_gae_fold_later_composes_affine_maps_in_order():
     assert float(pdist.gae_fold_later(maps, 0)[0]) == 7.0
     assert float(pdist.gae_fold_later(maps, 1)[0]) == 4.0
     assert float(pdist.gae_fold_later(maps, 2)[0]) == 0.0
+
+
+@pytest.mark.parametrize('recurrent', [False, True])
+def test_multidiscrete_policy_layout_head_packing_and_action_words(recurrent):
+    """models.Default on a MultiDiscrete space: one decoder Linear per head with the reference's state_dict keys
+    (models.py:29-35), all of them rows of ONE [A][H] block of the flat vector (what the kernels multiply), head sizes packed
+    four bits each in pfa_mlp_dims.heads, and the kernel's action words unpacked to [rows, heads]."""
+    from pufferlib_amd import _lib, cleanrl, models, namespace, spaces
+    from pufferlib_amd.models import FlatParams
+    nvec = [3, 4, 2, 5]
+    env = namespace(single_observation_space=spaces.Box(low=-1, high=1, shape=(20,), dtype=np.float32),
+                    single_action_space=spaces.MultiDiscrete(nvec))
+    base = models.Default(env)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(env, base)) if recurrent else cleanrl.Policy(base)
+    prefix = 'policy.policy.' if recurrent else 'policy.'
+    keys = [k[len(prefix):] for k in pol.state_dict() if k.startswith(prefix)]
+    assert keys == ['encoder.weight', 'encoder.bias'] + [f'decoder.{h}.{w}' for h in range(4) for w in ('weight', 'bias')] + \
+        ['value_head.weight', 'value_head.bias']
+    before = {k: v.detach().clone() for k, v in pol.state_dict().items()}
+    fp = FlatParams(pol.policy, 32, 'cpu')
+    assert fp.multidiscrete and fp.nvec == nvec and fp.num_actions == 14
+    assert fp.dims.heads == 3 | (4 << 4) | (2 << 8) | (5 << 12) and fp.dims.num_actions == 14
+    L = _lib.lib()
+    assert fp.count == (L.pfa_lstm_param_count if recurrent else L.pfa_mlp_param_count)(C.byref(fp.dims))
+    for k, v in pol.state_dict().items():
+        assert torch.equal(v, before[k]) and v.untyped_storage().data_ptr() == fp.flat.untyped_storage().data_ptr(), k
+    # the heads are consecutive rows of one [14][128] block followed by one [14] bias vector
+    o = 128 * 32 + 128
+    block = fp.flat[o:o + 14 * 128].view(14, 128)
+    assert torch.equal(block, torch.cat([before[f'{prefix}decoder.{h}.weight'] for h in range(4)]))
+    assert torch.equal(fp.flat[o + 14 * 128:o + 14 * 128 + 14], torch.cat([before[f'{prefix}decoder.{h}.bias'] for h in range(4)]))
+    words = torch.tensor([0, 2 | (3 << 4) | (1 << 8) | (4 << 12), 1 | (0 << 4) | (0 << 8) | (2 << 12)])
+    assert fp.unpack_actions(words).tolist() == [[0, 0, 0, 0], [2, 3, 1, 4], [1, 0, 0, 2]]
+    # a Discrete policy hands the words through unchanged
+    single = FlatParams(_policy(False).policy, 64, 'cpu')
+    assert not single.multidiscrete and single.dims.heads == 0 and single.unpack_actions(words) is words
+
+
+def test_too_many_logits_or_heads_are_refused():
+    from pufferlib_amd import cleanrl, models, namespace, spaces
+    from pufferlib_amd.models import FlatParams
+    box = spaces.Box(low=-1, high=1, shape=(4,), dtype=np.float32)
+    for nvec in ([8, 8], [2] * 9):
+        env = namespace(single_observation_space=box, single_action_space=spaces.MultiDiscrete(nvec))
+        with pytest.raises(NotImplementedError):
+            FlatParams(cleanrl.Policy(models.Default(env)).policy, 16, 'cpu')
