@@ -197,6 +197,19 @@ class Profile:
         return True
 
 
+def gpu_busy_percent(device_index=None):
+    """What the reference reads with torch.cuda.utilization() (clean_pufferl.py:501), from the amdgpu driver's own counter:
+    /sys/bus/pci/devices/<domain:bus:device.0>/gpu_busy_percent of the current HIP device (no amdsmi module needed).
+    0 when the counter cannot be read (no GPU, container without sysfs)."""
+    try:
+        props = torch.cuda.get_device_properties(torch.cuda.current_device() if device_index is None else device_index)
+        path = f'/sys/bus/pci/devices/{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0/gpu_busy_percent'
+        with open(path) as f:
+            return int(f.read().strip())
+    except Exception:
+        return 0
+
+
 class Utilization(Thread):
     """clean_pufferl.Utilization (clean_pufferl.py:484-507) — sampling thread for the dashboard; optional."""
 
@@ -218,7 +231,7 @@ class Utilization(Thread):
                 self.gpu_mem.append(free / total)
             except Exception:
                 self.gpu_mem.append(0)
-            self.gpu_util.append(0)
+            self.gpu_util.append(gpu_busy_percent())
             time.sleep(self.delay)
 
     def stop(self):

@@ -365,3 +365,20 @@ def test_checkpoint_round_trip_resumes_bit_identically(tmp_path):
     assert torch.equal(a.flat_params.flat, b.flat_params.flat)
     for k in a.losses:
         assert a.losses[k] == b.losses[k], k
+
+
+def test_gpu_utilisation_counter_for_the_dashboard():
+    """clean_pufferl.Utilization's gpu_util row (clean_pufferl.py:501: torch.cuda.utilization()) read from amdgpu's sysfs counter of
+    the current device; 0 is also what it reports where the container hides the counter."""
+    from pufferlib_amd import clean_pufferl
+    x = torch.randn(4096, 4096, device='cuda')
+    for _ in range(20):
+        x = x @ x * 1e-4
+    v = clean_pufferl.gpu_busy_percent()
+    torch.cuda.synchronize()
+    assert isinstance(v, int) and 0 <= v <= 100
+    u = clean_pufferl.Utilization(delay=0.01)
+    import time
+    time.sleep(0.1)
+    u.stop()
+    assert len(u.gpu_util) >= 1 and len(u.gpu_mem) == len(u.gpu_util) and 0 < u.gpu_mem[-1] <= 1
