@@ -111,7 +111,7 @@ int pfa_squared_debug_stream_pos(void *state, const pfa_squared_config *cfg, uin
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int32_t obs_dim;     /* true feature count (informational) */
-    int32_t obs_stride;  /* floats per obs row, multiple of 16, <= 128 */
+    int32_t obs_stride;  /* floats per obs row: 16, 32, 64, 96 or 128; the recurrent entry points (pfa_lstm_*) also take 160 */
     int32_t hidden;      /* 128 */
     int32_t num_actions; /* A <= 15: decoder rows = logits of all heads */
     uint32_t heads;      /* 0: one Discrete(A) head.  MultiDiscrete: head h has (heads >> 4h) & 15 logits, heads back to back in

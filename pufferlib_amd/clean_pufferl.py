@@ -278,7 +278,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         from . import hostpath
         _lib.require_gpu()
         device = torch.device('cuda', torch.cuda.current_device())
-        obs_stride = hostpath.obs_stride_for(int(np.prod(vecenv.single_observation_space.shape)))
+        obs_stride = hostpath.obs_stride_for(int(np.prod(vecenv.single_observation_space.shape)), recurrent)
         host_bridge = hostpath.HostBridge(vecenv, obs_stride, device)
     else:
         device = vecenv.device

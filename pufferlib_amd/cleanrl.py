@@ -12,14 +12,16 @@ import torch
 from . import _lib
 from .models import FlatParams
 
-KERNEL_STRIDES = (16, 32, 64, 96, 128)     # observation row strides (floats) the policy kernels are built for
+KERNEL_STRIDES = (16, 32, 64, 96, 128)     # observation row strides (floats) every policy kernel is built for
+RECURRENT_STRIDES = KERNEL_STRIDES + (160,)  # the recurrent path also takes MiniGrid-shaped 160-byte rows (SURVEY config C3)
 
 
-def obs_stride_for(obs_dim):
-    for s in KERNEL_STRIDES:
+def obs_stride_for(obs_dim, recurrent=False):
+    for s in (RECURRENT_STRIDES if recurrent else KERNEL_STRIDES):
         if obs_dim <= s:
             return s
-    raise NotImplementedError(f'flat observation of {obs_dim} floats: the MLP/LSTM kernels take rows of up to 128 floats')
+    raise NotImplementedError(f'flat observation of {obs_dim} floats: the MLP kernels take rows of up to 128 floats, the '
+                              'recurrent path up to 160')
 
 
 class Policy(torch.nn.Module):
@@ -126,8 +128,8 @@ class RecurrentPolicy(torch.nn.Module):
         rows = x.shape[0]
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]
-        stride = obs_stride_for(D)
-        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in KERNEL_STRIDES and x2.data_ptr() % 16 == 0:
+        stride = obs_stride_for(D, recurrent=True)
+        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in RECURRENT_STRIDES and x2.data_ptr() % 16 == 0:
             stride = x2.stride(0)
             src = torch.as_strided(x2, (rows, stride), (stride, 1))
         else:

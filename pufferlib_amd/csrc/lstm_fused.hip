@@ -208,8 +208,9 @@ __global__ void __launch_bounds__(kLstmThreads) rollout_lstm_squared_kernel(Squa
 static int check_lstm_dims(const pfa_mlp_dims *d) {
     PFA_REQUIRE(d != nullptr, "lstm: null dims");
     PFA_REQUIRE(d->hidden == kHidden, "lstm: hidden must be %d (got %d)", kHidden, d->hidden);
-    PFA_REQUIRE(d->obs_stride == 16 || d->obs_stride == 32 || d->obs_stride == 64 || d->obs_stride == 96 || d->obs_stride == 128,
-                "lstm: obs_stride must be one of 16/32/64/96/128 (got %d)", d->obs_stride);
+    PFA_REQUIRE(d->obs_stride == 16 || d->obs_stride == 32 || d->obs_stride == 64 || d->obs_stride == 96 || d->obs_stride == 128 ||
+                    d->obs_stride == 160,
+                "lstm: obs_stride must be one of 16/32/64/96/128/160 (got %d)", d->obs_stride);
     PFA_REQUIRE(d->num_actions >= 1 && d->num_actions <= 15, "lstm: num_actions must be in 1..15 (got %d)", d->num_actions);
     PFA_REQUIRE(d->heads == 0 || heads_count(d->heads, d->num_actions) >= 1, "lstm: head sizes 0x%x do not sum to num_actions %d",
                 d->heads, d->num_actions);
@@ -222,6 +223,7 @@ static int check_lstm_dims(const pfa_mlp_dims *d) {
         case 32: { constexpr int DP = 32; CALL; } break;   \
         case 64: { constexpr int DP = 64; CALL; } break;   \
         case 96: { constexpr int DP = 96; CALL; } break;   \
+        case 160: { constexpr int DP = 160; CALL; } break; \
         default: { constexpr int DP = 128; CALL; } break;  \
     }
 

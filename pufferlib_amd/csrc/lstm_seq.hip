@@ -338,8 +338,9 @@ __global__ void __launch_bounds__(256) lstm_bias_final_kernel(const float *__res
 static int check_seq_dims(const pfa_mlp_dims *d) {
     PFA_REQUIRE(d != nullptr, "lstm_seq: null dims");
     PFA_REQUIRE(d->hidden == kHidden, "lstm_seq: hidden must be %d (got %d)", kHidden, d->hidden);
-    PFA_REQUIRE(d->obs_stride == 16 || d->obs_stride == 32 || d->obs_stride == 64 || d->obs_stride == 96 || d->obs_stride == 128,
-                "lstm_seq: obs_stride must be one of 16/32/64/96/128 (got %d)", d->obs_stride);
+    PFA_REQUIRE(d->obs_stride == 16 || d->obs_stride == 32 || d->obs_stride == 64 || d->obs_stride == 96 || d->obs_stride == 128 ||
+                    d->obs_stride == 160,
+                "lstm_seq: obs_stride must be one of 16/32/64/96/128/160 (got %d)", d->obs_stride);
     PFA_REQUIRE(d->num_actions >= 1 && d->num_actions <= 15, "lstm_seq: num_actions must be in 1..15 (got %d)", d->num_actions);
     return 0;
 }
@@ -350,6 +351,7 @@ static int check_seq_dims(const pfa_mlp_dims *d) {
         case 32: { constexpr int DP = 32; CALL; } break;   \
         case 64: { constexpr int DP = 64; CALL; } break;   \
         case 96: { constexpr int DP = 96; CALL; } break;   \
+        case 160: { constexpr int DP = 160; CALL; } break; \
         default: { constexpr int DP = 128; CALL; } break;  \
     }
 

@@ -203,3 +203,58 @@ class HostMultiHead:
 
     def close(self):
         pass
+
+
+class HostByteRows:
+    """Host vecenv with MiniGrid-shaped observations (SURVEY config C3: the aligned struct {direction: int64, image:
+    uint8[7,7,3]} = 155 -> 160 bytes per row, which models.Default reads as 160 floats, models.py:50) and Discrete(7) actions.
+    Bytes are seeded noise in [0, 10]; the rewarded action is byte 8 modulo 7; episodes of ``period`` steps with the reset row
+    after the terminal (vector.py:147-149)."""
+
+    def __init__(self, num_envs, row_bytes=160, num_actions=7, period=9, seed=0):
+        from pufferlib_amd import spaces
+        self.single_observation_space = spaces.Box(low=0, high=255, shape=(row_bytes,), dtype=np.uint8)
+        self.single_action_space = spaces.Discrete(num_actions)
+        self.driver_env = self
+        self.num_envs = self.num_agents = self.agents_per_batch = num_envs
+        self.agent_ids = np.arange(num_envs)
+        self.emulated = True
+        self.num_actions, self.period, self.seed = num_actions, period, seed
+        self.observations = np.zeros((num_envs, row_bytes), np.uint8)
+        self.async_reset()
+
+    def async_reset(self, seed=42):
+        n = self.num_agents
+        self.rng = np.random.RandomState(self.seed)
+        self.tick = np.arange(n) % self.period
+        self.done = np.zeros(n, bool)
+        self.rewards = np.zeros(n, np.float32)
+        self.terminals = np.zeros(n, bool)
+        self.ep_return = np.zeros(n, np.float64)
+        self.infos = []
+        self.observations[:] = self.rng.randint(0, 11, self.observations.shape)
+
+    def recv(self):
+        n = self.num_agents
+        return (self.observations.copy(), self.rewards.copy(), self.terminals.copy(), np.zeros(n, bool), self.infos, self.agent_ids,
+                np.ones(n, bool))
+
+    def send(self, actions):
+        a = np.asarray(actions).reshape(self.num_agents)
+        hit = (a == self.observations[:, 8] % self.num_actions).astype(np.float32)
+        self.observations[:] = self.rng.randint(0, 11, self.observations.shape)
+        self.infos = []
+        for e in range(self.num_agents):
+            if self.done[e]:
+                self.rewards[e], self.terminals[e], self.done[e], self.tick[e], self.ep_return[e] = 0, False, False, 0, 0
+                continue
+            self.rewards[e] = hit[e]
+            self.ep_return[e] += float(hit[e])
+            self.tick[e] += 1
+            self.terminals[e] = self.done[e] = self.tick[e] >= self.period
+            if self.done[e]:
+                self.infos.append(dict(episode_return=self.ep_return[e], episode_length=int(self.tick[e]),
+                                       score=self.ep_return[e] / self.tick[e]))
+
+    def close(self):
+        pass

@@ -359,3 +359,56 @@ def test_recurrent_policy_trains_on_other_grid_sizes(d, nt):
     for k, w in want.items():
         full = ('policy.recurrent.' if k.endswith('_l0') else 'policy.policy.') + k
         np.testing.assert_allclose(sd[full].cpu().numpy(), w, rtol=1e-4, atol=2e-6, err_msg=k)
+
+
+def test_minigrid_shaped_160_byte_rows_vs_oracle_trainer():
+    """BASELINE configs[2] / SURVEY config C3 shape: LSTM policy on 160-byte observation rows (read as 160 floats), 7 actions,
+    through the host path: rollout (recurrent policy step, state carried per agent) and two BPTT updates against the
+    torch-fp32 oracle trainer."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from host_vecenv import HostByteRows
+    from oracle import ppo_torch
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from test_gpu_ppo import _config
+    n, horizon, nmb, bptt = 48, 32, 2, 16
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
+    B = n * horizon
+    vec = HostByteRows(n)
+    torch.manual_seed(8)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+    with torch.no_grad():
+        pol.policy.policy.encoder.weight.mul_(0.3)            # byte-valued inputs: keep the hidden layer in a sane range
+    sd0 = {k: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    data = clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, hp, seed=3), vec, pol)
+    assert data.flat_params.obs_stride == 160 and data.flat_params.obs_dim == 160
+    opol = ppo_torch.Policy.from_reference_state_dict(sd0)
+    tr = ppo_torch.Trainer(opol, HostByteRows(n), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt, update_epochs=2,
+                           learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3], vf_coef=hp[4], vf_clip_coef=hp[5],
+                           max_grad_norm=hp[6], ent_coef=hp[7], total_timesteps=B * 10, seed=3)
+    sm = lambda x: x.view(n, horizon, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
+    for it in range(2):
+        noise = torch.empty(horizon, n, 7).exponential_(1)
+        data.noise = noise.clone()
+        clean_pufferl.evaluate(data)
+        tr.evaluate(noise.numpy())
+        e = data.experience
+        assert np.array_equal(sm(e.obs), tr.obs.numpy()), it
+        assert np.array_equal(sm(e.actions.long()), tr.actions), it
+        assert np.array_equal(sm(e.rewards), tr.rewards)
+        np.testing.assert_allclose(sm(e.logprobs), tr.logprobs, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(sm(e.values), tr.values, rtol=1e-4, atol=1e-4)
+        Lo = tr.train()
+        clean_pufferl.train(data)
+        L = data.losses
+        np.testing.assert_allclose([L.policy_loss, L.value_loss, L.entropy, L.approx_kl], [Lo[k] for k in ('policy_loss', 'value_loss', 'entropy', 'approx_kl')],
+                                   rtol=1e-3, atol=1e-5)
+        sd = pol.state_dict()
+        for k, arr in opol.state_arrays().items():
+            key = ('policy.recurrent.' + k) if k.endswith('_l0') else ('policy.policy.' + k)
+            np.testing.assert_allclose(sd[key].cpu().numpy(), arr, rtol=1e-4, atol=2e-5, err_msg=k)
+    # the MLP kernels stop at 128 floats per row: loud, not a fallback
+    with pytest.raises(NotImplementedError):
+        clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, hp, seed=3), HostByteRows(n),
+                             cleanrl.Policy(models.Default(vec.driver_env)))
