@@ -36,6 +36,20 @@ def lib():
         L.po_np_randint.argtypes = [C.c_void_p, C.c_uint32]
         L.po_np_randn.restype = C.c_double
         L.po_np_randn.argtypes = [C.c_void_p]
+        L.po_np_randint_i8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.po_np_sum_f32.restype = C.c_float
+        L.po_np_sum_f32.argtypes = [C.c_void_p, C.c_int]
+        L.po_spaces_create.restype = C.c_void_p
+        L.po_spaces_create.argtypes = [C.c_int]
+        L.po_spaces_free.argtypes = [C.c_void_p]
+        L.po_spaces_seed_global.argtypes = [C.c_void_p, C.c_uint32]
+        L.po_spaces_async_reset.argtypes = [C.c_void_p]
+        L.po_spaces_send.argtypes = [C.c_void_p, C.c_void_p]
+        for name, rt in (('observations', C.c_uint8), ('rewards', C.c_float), ('terminals', C.c_uint8), ('info_score', C.c_double)):
+            f = getattr(L, 'po_spaces_' + name)
+            f.restype = C.POINTER(rt)
+            f.argtypes = [C.c_void_p]
+        L.po_spaces_num_infos.argtypes = [C.c_void_p]
         L.po_bandit_create.restype = C.c_void_p
         L.po_bandit_create.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
         L.po_bandit_free.argtypes = [C.c_void_p]
@@ -389,6 +403,49 @@ class MultiagentSerial:
         self.terminals[:] = np.repeat(stepped, 2)
         self.infos = [{1: {'score': int(s[0])}, 2: {'score': int(s[1])}} for s, st in zip(score, stepped) if st]
         self.done = stepped.copy()
+
+    def recv(self):
+        return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)
+
+
+class SpacesSerial:
+    """``pufferlib.vector.Serial`` over ``make_spaces`` envs (ocean/environment.py:66-69) restated in C: Dict observation emulated
+    to 108-byte rows, Dict action emulated to MultiDiscrete([2, 2]); every reset draws ``randn(5, 5)`` and
+    ``randint(-1, 2, (5,), dtype=int8)`` from numpy's process-global legacy generator, which the env never seeds (ocean.py:380) —
+    ``global_seed`` is the ``np.random.seed`` the trainer issued before (clean_pufferl.py:596-600)."""
+
+    def __init__(self, num_envs, global_seed=1):
+        self.L = lib()
+        self.num_envs = num_envs
+        self.h = self.L.po_spaces_create(num_envs)
+        self.L.po_spaces_seed_global(self.h, int(global_seed))
+        n = num_envs
+        as_arr = np.ctypeslib.as_array
+        self.observations = as_arr(self.L.po_spaces_observations(self.h), (n, 108))
+        self.rewards = as_arr(self.L.po_spaces_rewards(self.h), (n,))
+        self.terminals = as_arr(self.L.po_spaces_terminals(self.h), (n,)).view(bool)
+        self.truncations = np.zeros(n, bool)
+        self.masks = np.ones(n, bool)
+        self.agent_ids = np.arange(n)
+        self.infos = []
+
+    def __del__(self):
+        try:
+            self.L.po_spaces_free(self.h)
+        except Exception:
+            pass
+
+    def async_reset(self, seed=42):
+        self.L.po_spaces_async_reset(self.h)      # the seed never reaches the env's generator
+        self.infos = []
+
+    def send(self, actions):
+        a = np.ascontiguousarray(np.asarray(actions), dtype=np.int64)
+        assert a.shape == (self.num_envs, 2)
+        self.L.po_spaces_send(self.h, a.ctypes.data)
+        k = self.L.po_spaces_num_infos(self.h)
+        sc = np.ctypeslib.as_array(self.L.po_spaces_info_score(self.h), (max(k, 1),))[:k]
+        self.infos = [dict(score=float(s), episode_return=float(s), episode_length=1) for s in sc]
 
     def recv(self):
         return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids, self.masks)

@@ -354,6 +354,120 @@ double po_np_randn(po_np_state *s) { /* legacy_gauss */
     return f * x2;
 }
 
+void po_np_randint_i8(po_np_state *s, int low, int high, int count, int8_t *out) {
+    const uint8_t rng = (uint8_t)(high - 1 - low), off = (uint8_t)low; /* closed range, offset wraps like the C cast */
+    uint32_t buf = 0;
+    int bcnt = 0;
+    uint8_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4;
+    for (int i = 0; i < count; i++) {
+        if (rng == 0) {
+            out[i] = (int8_t)off;
+            continue;
+        }
+        uint8_t val;
+        do { /* buffered_bounded_masked_uint8 */
+            if (!bcnt) {
+                buf = po_mt_u32(&s->mt);
+                bcnt = 3;
+            } else {
+                buf >>= 8;
+                bcnt -= 1;
+            }
+            val = (uint8_t)buf & mask;
+        } while (val > rng);
+        out[i] = (int8_t)(uint8_t)(off + val);
+    }
+}
+
+float po_np_sum_f32(const float *a, int n) { /* numpy/core/src/umath/loops_utils.h.src: pairwise sum, blocks below 128 elements */
+    if (n < 8) {
+        float res = 0.0f;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    float r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+/* ---- Serial(make_spaces) — ocean.py:356-404 ---- */
+#define PO_SPACES_ROW 108
+struct po_spaces_vec {
+    int n, n_infos;
+    po_np_state rng; /* np.random's global state */
+    int *done, *image_sign, *flat_sign;
+    uint8_t *obs, *terminals;
+    float *rewards;
+    double *info_score;
+};
+po_spaces_vec *po_spaces_create(int num_envs) {
+    po_spaces_vec *v = (po_spaces_vec *)calloc(1, sizeof(*v));
+    v->n = num_envs;
+    v->done = (int *)calloc((size_t)num_envs, sizeof(int));
+    v->image_sign = (int *)calloc((size_t)num_envs, sizeof(int));
+    v->flat_sign = (int *)calloc((size_t)num_envs, sizeof(int));
+    v->obs = (uint8_t *)calloc((size_t)num_envs, PO_SPACES_ROW);
+    v->terminals = (uint8_t *)calloc((size_t)num_envs, 1);
+    v->rewards = (float *)calloc((size_t)num_envs, sizeof(float));
+    v->info_score = (double *)calloc((size_t)num_envs, sizeof(double));
+    po_np_seed(&v->rng, 0);
+    return v;
+}
+void po_spaces_free(po_spaces_vec *v) {
+    if (!v) return;
+    free(v->done); free(v->image_sign); free(v->flat_sign); free(v->obs); free(v->terminals); free(v->rewards); free(v->info_score);
+    free(v);
+}
+void po_spaces_seed_global(po_spaces_vec *v, uint32_t seed) { po_np_seed(&v->rng, seed); }
+static void spaces_reset(po_spaces_vec *v, int e) { /* ocean.py:380-389; row layout emulation.py:68-80 (align=True) */
+    float image[25];
+    int8_t flat[5];
+    for (int i = 0; i < 25; i++) image[i] = (float)po_np_randn(&v->rng); /* randn(5, 5).astype(float32) */
+    po_np_randint_i8(&v->rng, -1, 2, 5, flat);
+    v->image_sign[e] = po_np_sum_f32(image, 25) > 0.0f;
+    int fs = 0;
+    for (int i = 0; i < 5; i++) fs += flat[i];
+    v->flat_sign[e] = fs > 0;
+    uint8_t *row = v->obs + (size_t)e * PO_SPACES_ROW;
+    memset(row, 0, PO_SPACES_ROW);
+    memcpy(row, flat, 5);
+    memcpy(row + 8, image, sizeof(image));
+    v->done[e] = 0;
+    v->rewards[e] = 0.0f;
+    v->terminals[e] = 0;
+}
+void po_spaces_async_reset(po_spaces_vec *v) {
+    v->n_infos = 0;
+    for (int e = 0; e < v->n; e++) spaces_reset(v, e);
+}
+void po_spaces_send(po_spaces_vec *v, const int64_t *actions) { /* vector.py:137-156 over ocean.py:391-404 */
+    v->n_infos = 0;
+    for (int e = 0; e < v->n; e++) {
+        if (v->done[e]) {
+            spaces_reset(v, e);
+            continue;
+        }
+        double reward = 0.0;
+        if (v->image_sign[e] == (int)actions[2 * e + 1]) reward += 0.5; /* Dict keys sorted: action 0 = flat, 1 = image */
+        if (v->flat_sign[e] == (int)actions[2 * e]) reward += 0.5;
+        v->rewards[e] = (float)reward;
+        v->terminals[e] = 1;
+        v->done[e] = 1;
+        v->info_score[v->n_infos++] = reward;
+    }
+}
+const uint8_t *po_spaces_observations(const po_spaces_vec *v) { return v->obs; }
+const float *po_spaces_rewards(const po_spaces_vec *v) { return v->rewards; }
+const uint8_t *po_spaces_terminals(const po_spaces_vec *v) { return v->terminals; }
+int po_spaces_num_infos(const po_spaces_vec *v) { return v->n_infos; }
+const double *po_spaces_info_score(const po_spaces_vec *v) { return v->info_score; }
+
 /* ---- Serial(make_bandit) — ocean.py:8-63 ---- */
 struct po_bandit_vec {
     int n, num_actions, n_infos, solution;

@@ -84,6 +84,29 @@ double po_np_randn(po_np_state *s);                        /* np.random.randn() 
  * ocean.Bandit (ocean.py:8-63): every reset reseeds numpy's global generator with hard_fixed_seed = 42 and draws
  * solution_idx = randint(0, num_actions); a step returns ((action == solution) + randn() * reward_scale) * reward_scale
  * (noise only if reward_noise != 0) and always terminates. */
+/* numpy legacy generator, small-integer path: RandomState.randint(low, high, size, dtype=np.int8) — masked rejection on BYTES
+ * of buffered 32-bit words, a fresh buffer per call (_bounded_integers: random_bounded_uint8_fill / buffered_uint8). */
+void po_np_randint_i8(po_np_state *s, int low, int high, int count, int8_t *out);
+/* np.sum of a contiguous float32 array (numpy's pairwise summation: 8 running sums, then the tail) */
+float po_np_sum_f32(const float *a, int n);
+
+/* ---- Serial over ocean.environment.make_spaces (ocean/environment.py:66-69; ocean.py:356-404) ----
+ * Observation rows are the emulated 108-byte structs {flat: int8[5] @0, image: f32[5][5] @8} (emulation.py:68-110), actions
+ * MultiDiscrete([2, 2]) = (flat, image) (emulation.py:111-121).  reset() draws from numpy's process-global generator WITHOUT
+ * seeding it (the seed argument is ignored, ocean.py:380), so the stream is whatever np.random.seed last set:
+ * po_spaces_seed_global restates that call (clean_pufferl.seed_everything, clean_pufferl.py:596-600). */
+typedef struct po_spaces_vec po_spaces_vec;
+po_spaces_vec *po_spaces_create(int num_envs);
+void po_spaces_free(po_spaces_vec *v);
+void po_spaces_seed_global(po_spaces_vec *v, uint32_t seed);
+void po_spaces_async_reset(po_spaces_vec *v);
+void po_spaces_send(po_spaces_vec *v, const int64_t *actions /* [N][2] */);
+const uint8_t *po_spaces_observations(const po_spaces_vec *v); /* [N][108] */
+const float *po_spaces_rewards(const po_spaces_vec *v);
+const uint8_t *po_spaces_terminals(const po_spaces_vec *v);
+int po_spaces_num_infos(const po_spaces_vec *v);
+const double *po_spaces_info_score(const po_spaces_vec *v);
+
 typedef struct po_bandit_vec po_bandit_vec;
 po_bandit_vec *po_bandit_create(int num_envs, int num_actions, double reward_scale, double reward_noise);
 void po_bandit_free(po_bandit_vec *v);

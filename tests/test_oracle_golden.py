@@ -321,3 +321,51 @@ def test_multidiscrete_ppo_replay_matches_reference(golden_dir):
         for name, arr in pol.state_arrays().items():
             np.testing.assert_allclose(arr, g[f'it{it}.w.policy.' + name], rtol=1e-5, atol=1e-6, err_msg=name)
             np.testing.assert_allclose(m[name], g[f'it{it}.m.policy.' + name], rtol=1e-4, atol=1e-7, err_msg=name)
+
+
+def test_numpy_int8_randint_and_f32_sum_restatements_match_numpy():
+    """RandomState.randint(low, high, size, dtype=int8) (bytes of buffered words, fresh buffer per call) interleaved with randn, and
+    np.sum over contiguous float32 arrays (pairwise blocks) — the two pieces of numpy arithmetic ocean.Spaces leans on."""
+    import ctypes as C
+    from oracle import c_oracle
+    L = c_oracle.lib()
+    for seed in (0, 1, 12345):
+        st = (C.c_uint8 * 4096)()
+        L.po_np_seed(st, seed)
+        rs = np.random.RandomState(seed)
+        for low, high, cnt in ((-1, 2, 5), (0, 2, 7), (-3, 4, 33), (0, 1, 4), (-128, 128, 9), (5, 6, 3), (-1, 2, 1)):
+            got = np.zeros(cnt, np.int8)
+            L.po_np_randint_i8(st, low, high, cnt, got.ctypes.data)
+            assert np.array_equal(got, rs.randint(low, high, (cnt,), dtype=np.int8)), (seed, low, high)
+            assert L.po_np_randn(st) == rs.randn()
+    rng = np.random.default_rng(0)
+    for n in (1, 7, 8, 9, 24, 25, 31, 64, 127):
+        for _ in range(50):
+            a = rng.standard_normal(n).astype(np.float32)
+            assert L.po_np_sum_f32(a.ctypes.data, n) == np.sum(a.reshape(-1)), n
+    for _ in range(200):
+        a = rng.standard_normal((5, 5)).astype(np.float32)
+        assert L.po_np_sum_f32(a.ctypes.data, 25) == np.sum(a)
+
+
+def test_spaces_oracle_replays_reference_observation_stream_and_rewards(golden_dir):
+    """ocean.Spaces under Serial as the reference's create/evaluate drove it (tests/golden/ppo_spaces.npz: np.random.seed(1) by
+    seed_everything, envs never reseed): the emulated 108-byte rows of 2 x 32 steps x 16 envs, rewards and terminals under the
+    recorded actions, bit for bit."""
+    from oracle import c_oracle
+    g = _load(golden_dir, 'ppo_spaces.npz')
+    n, horizon, _, _, _, _, iters = (int(x) for x in g['config'])
+    vec = c_oracle.SpacesSerial(n, global_seed=1)
+    vec.async_reset(1)
+    for it in range(iters):
+        obs = g[f'it{it}.obs'].reshape(horizon, n, 108)
+        acts = g[f'it{it}.actions'].reshape(horizon, n, 2).astype(np.int64)
+        rew, done = g[f'it{it}.rewards'].reshape(horizon, n), g[f'it{it}.dones'].reshape(horizon, n)
+        scores = []                                   # infos of THIS evaluate's T recv() calls (clean_pufferl.py:110-113)
+        for t in range(horizon):
+            o, r, d, _, info, _, _ = vec.recv()
+            assert np.array_equal(o, obs[t]), (it, t)
+            assert np.array_equal(r, rew[t]) and np.array_equal(d.astype(np.float32), done[t]), (it, t)
+            scores += [i['score'] for i in info]
+            vec.send(acts[t])
+        assert abs(np.mean(scores) - g[f'it{it}.stats'][2]) < 1e-12, it
