@@ -369,3 +369,20 @@ def test_spaces_oracle_replays_reference_observation_stream_and_rewards(golden_d
             scores += [i['score'] for i in info]
             vec.send(acts[t])
         assert abs(np.mean(scores) - g[f'it{it}.stats'][2]) < 1e-12, it
+
+
+def test_parallel_form_of_the_spaces_stream_equals_the_sequential_one():
+    """oracle/spaces_stream.py (acceptance marks -> per-position reset lengths -> pointer doubling -> independent row fills) against
+    the sequential C restatement over 3 rounds of 40 envs: the algorithm the device tape kernel for ocean.Spaces will implement."""
+    from oracle import c_oracle, spaces_stream
+    n, rounds = 40, 3
+    for seed in (1, 7):
+        vec = c_oracle.SpacesSerial(n, global_seed=seed)
+        vec.async_reset()
+        want = [vec.observations.copy()]
+        for _ in range(rounds - 1):
+            vec.send(np.zeros((n, 2), np.int64))          # terminal step
+            vec.send(np.zeros((n, 2), np.int64))          # reset row: fresh observations
+            want.append(vec.observations.copy())
+        got = spaces_stream.parallel_rows(seed, n * rounds, window=n * rounds * 90)
+        assert np.array_equal(got, np.concatenate(want)), seed
