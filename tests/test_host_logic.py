@@ -46,6 +46,10 @@ def test_obs_stride_selection():
     assert [hostpath.obs_stride_for(d) for d in (1, 16, 17, 49, 64, 65, 96, 97, 128)] == [16, 16, 32, 64, 64, 96, 96, 128, 128]
     with pytest.raises(NotImplementedError):
         hostpath.obs_stride_for(129)
+    # the recurrent path also takes MiniGrid-shaped 160-byte rows (BASELINE configs[2])
+    assert [hostpath.obs_stride_for(d, True) for d in (49, 128, 129, 155, 160)] == [64, 128, 160, 160, 160]
+    with pytest.raises(NotImplementedError):
+        hostpath.obs_stride_for(161, True)
 
 
 def test_experience_shape_checks_raise_before_touching_the_gpu():
