@@ -654,6 +654,11 @@ def try_load_checkpoint(data):
     print(f'Loaded checkpoint {resume["model_name"]}')
 
 
+def count_params(policy):
+    """clean_pufferl.py:548-549: trainable parameter count (the dashboard's "Params" row)."""
+    return sum(p.numel() for p in policy.parameters() if p.requires_grad)
+
+
 def print_dashboard(env_name, utilization, global_step, epoch, profile, losses, stats, msg, clear=False):
     """Plain-text stand-in for the rich dashboard (clean_pufferl.py:644-738): same numbers, one block."""
     lines = [f'[pufferlib_amd] env={env_name} steps={global_step} epoch={epoch} SPS={profile.SPS:,.0f} '

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from .models import layer_init  # noqa: F401  (pufferlib.pytorch.layer_init, pytorch.py:193-197)
 
 numpy_to_torch_dtype_dict = {
     np.dtype('float64'): torch.float64, np.dtype('float32'): torch.float32, np.dtype('float16'): torch.float16,

@@ -118,3 +118,25 @@ def test_too_many_logits_or_heads_are_refused():
         env = namespace(single_observation_space=box, single_action_space=spaces.MultiDiscrete(nvec))
         with pytest.raises(NotImplementedError):
             FlatParams(cleanrl.Policy(models.Default(env)).policy, 16, 'cpu')
+
+
+def test_public_surface_has_the_names_reference_code_imports():
+    """The drop-in boundary by name: what demo.py, policies and user code reach for in the reference modules this
+    package mirrors."""
+    import pufferlib_amd
+    from pufferlib_amd import clean_pufferl, cleanrl, models, pytorch, vector
+    for name in ('create', 'evaluate', 'train', 'close', 'Profile', 'make_losses', 'Experience', 'Utilization', 'save_checkpoint',
+                 'try_load_checkpoint', 'count_params', 'seed_everything', 'print_dashboard'):
+        assert hasattr(clean_pufferl, name), name                      # clean_pufferl.py:30-644
+    for name in ('make', 'reset', 'step', 'make_seeds', 'RESET', 'SEND', 'RECV'):
+        assert hasattr(vector, name), name                              # pufferlib/vector.py
+    for name in ('Policy', 'RecurrentPolicy'):
+        assert hasattr(cleanrl, name), name                             # pufferlib/frameworks/cleanrl.py:50-93
+    for name in ('Default', 'LSTMWrapper'):
+        assert hasattr(models, name), name                              # pufferlib/models.py
+    for name in ('nativize_dtype', 'nativize_tensor', 'nativize_observation', 'flattened_tensor_size', 'layer_init',
+                 'numpy_to_torch_dtype_dict'):
+        assert hasattr(pytorch, name), name                             # pufferlib/pytorch.py
+    assert hasattr(pufferlib_amd, 'namespace')
+    pol = cleanrl.Policy(models.Default(vector.make_squared()))
+    assert clean_pufferl.count_params(pol) == 128 * 49 + 128 + 8 * 128 + 8 + 128 + 1
