@@ -89,7 +89,8 @@ int pfa_squared_send(void *state, const pfa_squared_config *cfg, const int64_t *
                      pfa_stream_t stream);
 /* Episode statistics of episodes finished since the last call with reset != 0
  * (what clean_pufferl.evaluate averages from infos, clean_pufferl.py:119-121,144-152):
- * out[0]=count, out[1]=sum episode_return, out[2]=sum episode_length, out[3]=sum score (f64, device). */
+ * out[0]=count, out[1]=sum episode_return, out[2]=sum episode_length, out[3]=sum score (f64, device); out[4] = the tape
+ * underrun flag (non-zero if a reset ever needed a target round pfa_squared_fill_tape had not drawn yet) — `out4` holds 5 doubles. */
 int pfa_squared_episode_stats(void *state, const pfa_squared_config *cfg, double *out4, int32_t reset,
                               pfa_stream_t stream);
 /* Per-env view for infos of the LAST send: finished[N] u8, episode_return[N] f64, episode_length[N] i32,
@@ -208,6 +209,7 @@ int pfa_memory_async_reset(void *state, const pfa_memory_config *cfg, int64_t se
 int pfa_memory_fill_tape(void *state, const pfa_memory_config *cfg, int32_t rounds, pfa_stream_t stream);
 int pfa_memory_send(void *state, const pfa_memory_config *cfg, const int64_t *actions, float *obs, float *rewards,
                     uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+/* out4[0..3] as Squared's; out4[4] = tape underrun flag (5 doubles) */
 int pfa_memory_episode_stats(void *state, const pfa_memory_config *cfg, double *out4, int32_t reset, pfa_stream_t stream);
 int pfa_memory_last_infos(void *state, const pfa_memory_config *cfg, uint8_t *finished, double *episode_return,
                           int32_t *episode_length, double *score, pfa_stream_t stream);
@@ -325,25 +327,9 @@ int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *para
  * Default heads, gate order i,f,g,o.  Flat parameter vector = the MLP vector above followed by
  *   recurrent.weight_ih_l0 [512][128], weight_hh_l0 [512][128], bias_ih_l0 [512], bias_hh_l0 [512].
  * Every product runs on the fused MFMA kernels declared further down (pfa_lstm_pack / pfa_rollout_lstm_squared /
- * pfa_lstm_policy_step / pfa_lstm_seq_forward / pfa_lstm_seq_backward / pfa_gemm_tn_f32); the entry points up to
- * pfa_lstm_heads_sample are the step-wise pieces (csrc/lstm.hip).  All row-indexed buffers are dense [rows][...] fp32.
+ * pfa_lstm_policy_step / pfa_lstm_seq_forward / pfa_lstm_seq_backward / pfa_gemm_tn_f32).  All row-indexed buffers are
+ * dense [rows][...] fp32.
  * ------------------------------------------------------------------------------------------ */
-int pfa_relu(float *x, int64_t n, pfa_stream_t stream);                       /* torch.relu of encode_observations */
-int pfa_relu_grad(float *dx, const float *x, int64_t n, pfa_stream_t stream); /* dx *= (x > 0), x = relu output */
-/* One nn.LSTM cell step given the gate pre-activations [rows][512] (overwritten with the activations i,f,g,o). */
-int pfa_lstm_cell_fwd(float *gates, const float *c_prev, float *c_out, float *h_out, int64_t rows, pfa_stream_t stream);
-/* Its backward: d loss / d h_t = dh + dh2 (heads path + recurrent path, dh2 nullable); dgates = d loss / d
- * pre-activations; dc holds d loss / d c_t on entry and d loss / d c_{t-1} on exit. */
-int pfa_lstm_cell_bwd(const float *gates_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
-                      float *dc, float *dgates, int64_t rows, pfa_stream_t stream);
-/* Deterministic column sums (bias gradients); workspace >= pfa_colsum_workspace_bytes(cols). */
-size_t pfa_colsum_workspace_bytes(int32_t cols);
-int pfa_colsum(const float *a, int64_t rows, int32_t cols, int64_t ld, float *out, int32_t accumulate, void *workspace,
-               pfa_stream_t stream);
-/* decode_actions on h [rows][128] + sample_logits (rollout mode), same sampler and noise stream as the MLP path. */
-int pfa_lstm_heads_sample(const float *h, int64_t rows, const float *params, const pfa_mlp_dims *dims,
-                          const float *noise, const pfa_noise_key *key, int64_t row_offset, int64_t *actions,
-                          float *logprob, float *entropy, float *value, pfa_stream_t stream);
 /* --- fused recurrent policy (csrc/lstm_fused.hip) ---
  * Flat parameter vector of the recurrent policy = the MLP block above followed by nn.LSTM's weight_ih_l0 [512][128],
  * weight_hh_l0 [512][128], bias_ih_l0 [512], bias_hh_l0 [512].  pfa_lstm_pack re-tiles [W_ih | W_hh] into the MFMA

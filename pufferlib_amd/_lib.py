@@ -151,13 +151,6 @@ _SIGNATURES = {
     'pfa_ppo_mlp_train': (C.c_int, [C.POINTER(Experience), C.c_int64, P, C.POINTER(MlpDims), C.POINTER(PpoHparams), P, P, P, P,
                                     C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P,
                                     C.c_int32, P]),
-    'pfa_relu': (C.c_int, [P, C.c_int64, P]),
-    'pfa_relu_grad': (C.c_int, [P, P, C.c_int64, P]),
-    'pfa_lstm_cell_fwd': (C.c_int, [P, P, P, P, C.c_int64, P]),
-    'pfa_lstm_cell_bwd': (C.c_int, [P, P, P, P, P, P, P, C.c_int64, P]),
-    'pfa_colsum_workspace_bytes': (C.c_size_t, [C.c_int32]),
-    'pfa_colsum': (C.c_int, [P, C.c_int64, C.c_int32, C.c_int64, P, C.c_int32, P, P]),
-    'pfa_lstm_heads_sample': (C.c_int, [P, C.c_int64, P, C.POINTER(MlpDims), P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
     'pfa_store_step': (C.c_int, [C.POINTER(Experience), C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P]),
     'pfa_store_rows': (C.c_int, [C.POINTER(Experience), C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P, P, P, P, P]),
     'pfa_gather_obs_time_major': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, C.POINTER(PpoHparams), C.c_int32, P, P]),

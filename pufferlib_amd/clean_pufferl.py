@@ -328,7 +328,6 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         log_sums=torch.zeros(10, dtype=torch.float64, device=device),
         noise=None,            # optional explicit Exp(1) tensor [T][N][A] for the next evaluate() (parity tests)
         tape_stream=torch.cuda.Stream(device=device),   # reset-target tape is drawn one rollout ahead, off the critical path
-        tape_event=None,
     )
     return data
 
@@ -368,9 +367,7 @@ def evaluate(data):
         return _finish_evaluate(data, N, T)
     with profile.env:
         main = torch.cuda.current_stream()
-        if data.tape_event is not None:
-            main.wait_event(data.tape_event)     # rounds for this rollout were drawn under the previous rollout
-        vecenv.ensure_tape(T)                    # no-op when the prefetch covered it
+        vecenv.ensure_tape(T)                    # waits for the prefetch (vecenv.tape_event); draws nothing when it covered T
         start_point = torch.cuda.Event()
         start_point.record(main)                 # everything before this rollout (incl. the rollout before it) is done
     with profile.eval_forward:           # one persistent kernel for all T steps, either policy
@@ -391,8 +388,9 @@ def evaluate(data):
             with torch.cuda.stream(data.tape_stream):
                 data.tape_stream.wait_event(start_point)
                 vecenv.ensure_tape(T)
-                data.tape_event = torch.cuda.Event()
-                data.tape_event.record(data.tape_stream)
+                ev = torch.cuda.Event()
+                ev.record(data.tape_stream)
+                vecenv.tape_event = ev           # the vecenv owns it: send()/async_reset() outside evaluate() wait on it too
     return _finish_evaluate(data, N, T)
 
 
@@ -444,6 +442,9 @@ def _finish_evaluate(data, N, T):
             dist, _, _ = _dist()
             dist.all_reduce(st)
         st = st.cpu().numpy()                            # the one sync of evaluate()
+        if st.shape[0] > 4 and st[4] != 0:
+            raise RuntimeError('reset-target tape underrun: an env reset before its tape round was drawn (host bookkeeping of '
+                               'ensure_tape / the side-stream prefetch is wrong); the rollout replayed stale targets')
         data.stats = vecenv.stats_from_sums(st)
         infos = {k: [v] for k, v in data.stats.items()}
     return data.stats, infos
@@ -573,10 +574,17 @@ def train(data):
         # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
         _lib.check(L.pfa_train_log_sums(C.byref(experience.c), B, experience.num_envs, _lib.ptr(data.loss_acc),
                                         _lib.ptr(data.log_sums), _lib.ptr(data.workspace), stream), 'train_log_sums')
+        if data.native_dp:                                      # explained variance over the GLOBAL batch, like the (global) losses
+            _lib.check(L.pfa_dist_all_reduce_f64(C.c_void_p(data.log_sums.data_ptr() + 6 * 8), 4, stream), 'ev all-reduce')
+        elif world > 1:
+            ev_sums = data.log_sums[6:10].clone()
+            dist.all_reduce(ev_sums)
+            data.log_sums[6:10] = ev_sums
         acc = data.log_sums.cpu().numpy()                       # the one sync of train()
         s_y, s_yy, s_a, s_aa = acc[6:10]
-        var_y = s_yy / B - (s_y / B) ** 2
-        var_res = s_aa / B - (s_a / B) ** 2                      # y_true - y_pred = advantages
+        Bg = B * world
+        var_y = s_yy / Bg - (s_y / Bg) ** 2
+        var_res = s_aa / Bg - (s_a / Bg) ** 2                    # y_true - y_pred = advantages
         ev = float('nan') if var_y == 0 else 1 - var_res / var_y
         (losses.policy_loss, losses.value_loss, losses.entropy, losses.old_approx_kl, losses.approx_kl,
          losses.clipfrac) = (float(x) for x in acc[:6])
@@ -621,14 +629,16 @@ def save_checkpoint(data):
     os.makedirs(path, exist_ok=True)
     model_name = f'model_{data.epoch:06d}.pt'
     model_path = os.path.join(path, model_name)
-    if os.path.exists(model_path):
-        return model_path
-    torch.save(data.uncompiled_policy, model_path)      # whole module, loadable by the reference's eval path
+    if getattr(data, '_last_saved_epoch', None) == data.epoch and os.path.exists(model_path):
+        return model_path                                # close() right after the final periodic save of THIS process
+    torch.save(data.uncompiled_policy, model_path)      # whole module, loadable by the reference's eval path; always overwrites
     state = dict(optimizer_state_dict=data.optimizer.state_dict(), global_step=data.global_step,
-                 agent_step=data.global_step, update=data.epoch, model_name=model_name, exp_id=config.exp_id)
+                 agent_step=data.global_step, update=data.epoch, model_name=model_name, exp_id=config.exp_id,
+                 noise_step=int(data.policy.noise_step))   # Philox action-noise stream position (no reference counterpart)
     state_path = os.path.join(path, 'trainer_state.pt')
     torch.save(state, state_path + '.tmp')
     os.rename(state_path + '.tmp', state_path)
+    data._last_saved_epoch = data.epoch
     return model_path
 
 
@@ -651,6 +661,7 @@ def try_load_checkpoint(data):
     data.optimizer.load_state_dict(resume['optimizer_state_dict'])
     data.global_step = resume['global_step']
     data.epoch = resume['update']
+    data.policy.noise_step = int(resume.get('noise_step', data.policy.noise_step))
     print(f'Loaded checkpoint {resume["model_name"]}')
 
 

@@ -61,7 +61,8 @@ class Policy(torch.nn.Module):
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]
         stride = obs_stride_for(D)
-        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in KERNEL_STRIDES and x2.data_ptr() % 16 == 0:
+        if (x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in KERNEL_STRIDES
+                and x2.data_ptr() % 16 == 0):   # any other dtype takes the .float() copy below, like models.Default (models.py:50)
             stride = x2.stride(0)            # e.g. the vecenv's live buffer, already padded
             src = x2
         else:
@@ -129,7 +130,8 @@ class RecurrentPolicy(torch.nn.Module):
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]
         stride = obs_stride_for(D, recurrent=True)
-        if x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in RECURRENT_STRIDES and x2.data_ptr() % 16 == 0:
+        if (x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in RECURRENT_STRIDES
+                and x2.data_ptr() % 16 == 0):
             stride = x2.stride(0)
             src = torch.as_strided(x2, (rows, stride), (stride, 1))
         else:

@@ -25,7 +25,9 @@ __device__ __forceinline__ void episode_account(EpisodeFin &f, double ret, int l
 
 // out4 = {episodes finished, sum of returns, sum of lengths, sum of scores} since the last reset of the accumulators;
 // single workgroup, fixed-order f64 sums (deterministic).
-static __global__ void __launch_bounds__(256) episode_stats_kernel(EpisodeFin *fin, int n, double *out4, int reset) {
+// `underrun` (optional): the env family's tape-underrun flag, reported as out[4] so that the trainer's one readback sees it.
+static __global__ void __launch_bounds__(256) episode_stats_kernel(EpisodeFin *fin, int n, double *out4, int reset,
+                                                                   const int *underrun = nullptr) {
     __shared__ double sh[4][256];
     double a[4] = {0.0, 0.0, 0.0, 0.0};
     for (int e = threadIdx.x; e < n; e += 256) {
@@ -47,6 +49,7 @@ static __global__ void __launch_bounds__(256) episode_stats_kernel(EpisodeFin *f
         for (int i = 0; i < 256; ++i) s += sh[threadIdx.x][i];
         out4[threadIdx.x] = s;
     }
+    if (threadIdx.x == 4 && underrun) out4[4] = (double)*underrun;
 }
 
 static __global__ void __launch_bounds__(256) episode_infos_kernel(const EpisodeFin *fin, int n, uint8_t *finished, double *ret, int *len,

@@ -22,87 +22,6 @@ namespace pfa {
 constexpr int kLstmH = 128;
 constexpr int kHeadStatCols = 24;  // per-workgroup partials of lstm_heads_loss: 8 loss sums + 16 column sums of dout
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__global__ void __launch_bounds__(256) relu_kernel(float *x, long long n) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) x[i] = fmaxf(x[i], 0.0f);
-}
-
-// dx *= (x > 0)   (x = relu output)
-__global__ void __launch_bounds__(256) relu_grad_kernel(float *dx, const float *x, long long n) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dx[i] = x[i] > 0.0f ? dx[i] : 0.0f;
-}
-
-// gates: [rows][4H] pre-activations in, activations (i,f,g,o) out.  c_prev may alias c_out only if rows do not overlap.
-__global__ void __launch_bounds__(256) lstm_cell_fwd_kernel(float *gates, const float *c_prev, float *c_out, float *h_out,
-                                                           long long rows) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= rows * kLstmH) return;
-    const long long row = idx / kLstmH;
-    const int j = (int)(idx - row * kLstmH);
-    float *gr = gates + row * 4 * kLstmH;
-    const float i = sigmoidf_(gr[j]);
-    const float f = sigmoidf_(gr[kLstmH + j]);
-    const float g = tanhf(gr[2 * kLstmH + j]);
-    const float o = sigmoidf_(gr[3 * kLstmH + j]);
-    const float c = f * c_prev[idx] + i * g;
-    gr[j] = i;
-    gr[kLstmH + j] = f;
-    gr[2 * kLstmH + j] = g;
-    gr[3 * kLstmH + j] = o;
-    c_out[idx] = c;
-    h_out[idx] = o * tanhf(c);
-}
-
-// Backward of one cell step.  gates_act = (i,f,g,o) saved by the forward; dh = d loss / d h_t (heads + recurrent);
-// dc (in/out) = d loss / d c_t from step t+1 on entry, d loss / d c_{t-1} on exit.  dgates = d loss / d pre-activations.
-__global__ void __launch_bounds__(256) lstm_cell_bwd_kernel(const float *gates_act, const float *c_prev, const float *c,
-                                                           const float *dh, const float *dh2, float *dc, float *dgates,
-                                                           long long rows) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= rows * kLstmH) return;
-    const long long row = idx / kLstmH;
-    const int j = (int)(idx - row * kLstmH);
-    const float *ga = gates_act + row * 4 * kLstmH;
-    float *dg = dgates + row * 4 * kLstmH;
-    const float i = ga[j], f = ga[kLstmH + j], g = ga[2 * kLstmH + j], o = ga[3 * kLstmH + j];
-    const float tc = tanhf(c[idx]);
-    const float dhv = dh[idx] + (dh2 ? dh2[idx] : 0.0f);  // heads path + recurrent path
-    const float d_o = dhv * tc;
-    const float d_c = dhv * o * (1.0f - tc * tc) + dc[idx];
-    dg[j] = d_c * g * i * (1.0f - i);
-    dg[kLstmH + j] = d_c * c_prev[idx] * f * (1.0f - f);
-    dg[2 * kLstmH + j] = d_c * i * (1.0f - g * g);
-    dg[3 * kLstmH + j] = d_o * o * (1.0f - o);
-    dc[idx] = d_c * f;
-}
-
-// Deterministic column sums of a [rows][cols] matrix (leading dimension ld): stage 1 per (64-column block, row chunk).
-constexpr int kColChunks = 128;
-__global__ void __launch_bounds__(256) colsum_partial_kernel(const float *a, long long rows, int cols, long long ld,
-                                                            float *partial /* [kColChunks][cols] */) {
-    __shared__ float sh[4][64];
-    const int cl = threadIdx.x & 63, rs = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cl;
-    const long long per = (rows + kColChunks - 1) / kColChunks;
-    const long long lo = (long long)blockIdx.y * per, hi = lo + per < rows ? lo + per : rows;
-    float s = 0.0f;
-    if (col < cols)
-        for (long long r = lo + rs; r < hi; r += 4) s += a[r * ld + col];
-    sh[rs][cl] = s;
-    __syncthreads();
-    if (rs == 0 && col < cols) partial[(size_t)blockIdx.y * cols + col] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
-}
-__global__ void __launch_bounds__(256) colsum_final_kernel(const float *partial, int cols, float *out, int accumulate) {
-    const int col = blockIdx.x * 256 + threadIdx.x;
-    if (col >= cols) return;
-    float s = 0.0f;
-    for (int i = 0; i < kColChunks; ++i) s += partial[(size_t)i * cols + col];
-    out[col] = accumulate ? out[col] + s : s;
-}
-
 // Heads weights of models.Default inside the flat parameter vector, staged in LDS as W2v[16][128(+1)].
 __device__ __forceinline__ void stage_heads(const float *params, int dp, int a, float *w2v /* [16][129] */, float *b2v) {
     const MlpOffsets off = mlp_offsets(dp, a);
@@ -119,38 +38,6 @@ __device__ __forceinline__ float head_dot(const float *hrow, const float *w2v, c
 #pragma unroll 8
     for (int u = 0; u < kLstmH; ++u) acc = fmaf(hrow[u], w[u], acc);  // k-ordered fma chain, like nn.Linear's fp32 dot
     return acc;
-}
-
-// policy(obs, state) tail in rollout mode: decode_actions on h + sample_logits.  16 lanes per row, lane lo = output lo.
-__global__ void __launch_bounds__(256) lstm_heads_sample_kernel(const float *h, long long rows, const float *params, int dp,
-                                                               int a, const float *noise, uint64_t seed, uint64_t step,
-                                                               long long row_offset, long long *actions, float *logprob,
-                                                               float *entropy, float *value) {
-    __shared__ float w2v[kOut * (kLstmH + 1)];
-    __shared__ float b2v[kOut];
-    __shared__ float hs[16][kLstmH];
-    stage_heads(params, dp, a, w2v, b2v);
-    const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
-    const long long tiles = (rows + 15) / 16;
-    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 16 * kLstmH; i += 256) {
-            const long long r = tile * 16 + i / kLstmH;
-            hs[i / kLstmH][i % kLstmH] = r < rows ? h[r * kLstmH + i % kLstmH] : 0.0f;
-        }
-        __syncthreads();
-        const long long row = tile * 16 + le;
-        const bool ok = row < rows;
-        const float mine = head_dot(hs[le], w2v, b2v, lo);
-        const float q = ok ? noise_lane(noise ? noise + row * a : nullptr, seed, step, (uint64_t)(row_offset + row), lo, a) : 1.0f;
-        const LaneSample sm = sample_row16(mine, lo, a, q);
-        if (ok && lo == 0) {
-            actions[row] = sm.action;
-            logprob[row] = sm.logprob;
-            if (entropy) entropy[row] = sm.entropy;
-            value[row] = sm.value;
-        }
-    }
 }
 
 // Experience.store of one rollout step (clean_pufferl.py:436-450) into the env-major buffers: row (e, t) at e*T + t.
@@ -428,72 +315,6 @@ static unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace pfa
 
 using namespace pfa;
-
-extern "C" int pfa_relu(float *x, int64_t n, pfa_stream_t stream) {
-    PFA_REQUIRE(x && n >= 0, "relu: bad arguments");
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(relu_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x, (long long)n);
-    PFA_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int pfa_relu_grad(float *dx, const float *x, int64_t n, pfa_stream_t stream) {
-    PFA_REQUIRE(dx && x && n >= 0, "relu_grad: bad arguments");
-    if (n == 0) return 0;
-    hipLaunchKernelGGL(relu_grad_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, dx, x, (long long)n);
-    PFA_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int pfa_lstm_cell_fwd(float *gates, const float *c_prev, float *c_out, float *h_out, int64_t rows,
-                                 pfa_stream_t stream) {
-    PFA_REQUIRE(gates && c_prev && c_out && h_out && rows >= 0, "lstm_cell_fwd: bad arguments");
-    if (rows == 0) return 0;
-    hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(blocks_for(rows * kLstmH)), dim3(256), 0, (hipStream_t)stream, gates, c_prev,
-                       c_out, h_out, (long long)rows);
-    PFA_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int pfa_lstm_cell_bwd(const float *gates_act, const float *c_prev, const float *c, const float *dh, const float *dh2,
-                                 float *dc, float *dgates, int64_t rows, pfa_stream_t stream) {
-    PFA_REQUIRE(gates_act && c_prev && c && dh && dc && dgates && rows >= 0, "lstm_cell_bwd: bad arguments");
-    if (rows == 0) return 0;
-    hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(blocks_for(rows * kLstmH)), dim3(256), 0, (hipStream_t)stream, gates_act, c_prev,
-                       c, dh, dh2, dc, dgates, (long long)rows);
-    PFA_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" size_t pfa_colsum_workspace_bytes(int32_t cols) { return (size_t)kColChunks * (size_t)cols * sizeof(float); }
-
-extern "C" int pfa_colsum(const float *a, int64_t rows, int32_t cols, int64_t ld, float *out, int32_t accumulate, void *workspace,
-                          pfa_stream_t stream) {
-    PFA_REQUIRE(a && out && workspace && rows >= 0 && cols >= 1 && ld >= cols, "colsum: bad arguments");
-    float *partial = (float *)workspace;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, kColChunks), dim3(256), 0, (hipStream_t)stream, a,
-                       (long long)rows, (int)cols, (long long)ld, partial);
-    PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, partial, (int)cols, out,
-                       (int)accumulate);
-    PFA_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int pfa_lstm_heads_sample(const float *h, int64_t rows, const float *params, const pfa_mlp_dims *dims,
-                                     const float *noise, const pfa_noise_key *key, int64_t row_offset, int64_t *actions,
-                                     float *logprob, float *entropy, float *value, pfa_stream_t stream) {
-    PFA_REQUIRE(h && params && dims && actions && logprob && value && rows >= 0, "lstm_heads_sample: bad arguments");
-    PFA_REQUIRE(dims->hidden == kLstmH && dims->num_actions >= 1 && dims->num_actions <= 15 && dims->heads == 0, "lstm_heads_sample: bad dims");
-    PFA_REQUIRE(noise || key, "lstm_heads_sample: need a noise tensor or a Philox key");
-    if (rows == 0) return 0;
-    const long long tiles = (rows + 15) / 16;
-    hipLaunchKernelGGL(lstm_heads_sample_kernel, dim3((unsigned)(tiles < 2048 ? tiles : 2048)), dim3(256), 0, (hipStream_t)stream, h,
-                       (long long)rows, params, dims->obs_stride, dims->num_actions, noise, key ? key->seed : 0,
-                       key ? key->step : 0, (long long)row_offset, (long long *)actions, logprob, entropy, value);
-    PFA_LAUNCH_CHECK();
-    return 0;
-}
 
 extern "C" int pfa_store_step(const pfa_experience *exp, int32_t t, int32_t num_envs, int32_t obs_stride, const float *obs,
                               const float *rewards, const uint8_t *terminals, const int64_t *actions, const float *logprob,

@@ -320,7 +320,7 @@ extern "C" int pfa_memory_episode_stats(void *state, const pfa_memory_config *cf
     if (int rc = check_memory_config(cfg)) return rc;
     PFA_REQUIRE(state && out4, "memory.episode_stats: null buffer");
     hipLaunchKernelGGL(episode_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, memory_view(state, *cfg).fin, (int)cfg->num_envs,
-                       out4, (int)reset);
+                       out4, (int)reset, (const int *)&memory_view(state, *cfg).hdr->underrun);
     PFA_LAUNCH_CHECK();
     return 0;
 }

@@ -297,6 +297,7 @@ __global__ void __launch_bounds__(256) squared_stats_kernel(SquaredView v, doubl
         __syncthreads();
     }
     if (threadIdx.x < 4) out4[threadIdx.x] = sh[threadIdx.x][0];
+    if (threadIdx.x == 4) out4[4] = (double)v.hdr->underrun;   // a reset found no tape round: host bookkeeping error, never silent
 }
 
 __global__ void squared_infos_kernel(SquaredView v, uint8_t *fin, double *ret, int32_t *len, double *score) {

@@ -1,17 +1,45 @@
-"""Error types of the boundary, same names and bases as pufferlib/exceptions.py:5-22."""
+"""Error types of the boundary, same names and bases as pufferlib/exceptions.py:5-22.
+
+Whenever the reference's ``pufferlib.exceptions`` module is loaded in the process, an error raised here is an instance of
+BOTH this module's class and the reference's (a combined subclass, created on first use): a caller of
+``pufferlib.vector.make(..., backend=pufferlib_amd.vector.Squared)`` that catches ``pufferlib.exceptions.APIUsageError``
+also catches what this backend raises — whichever package was imported first."""
+import sys
+
+_combined = {}
+
+
+def _resolve(cls, name):
+    ref_mod = sys.modules.get('pufferlib.exceptions')
+    ref = getattr(ref_mod, name, None) if ref_mod is not None else None
+    if not isinstance(ref, type) or ref is cls or issubclass(cls, ref):
+        return cls
+    key = (cls, ref)
+    if key not in _combined:
+        try:
+            _combined[key] = type(name, (cls, ref), {'__module__': cls.__module__})
+        except TypeError:            # incompatible layouts: keep our own class
+            _combined[key] = cls
+    return _combined[key]
 
 
 class APIUsageError(RuntimeError):
     """Raised when the vecenv / trainer API is used incorrectly."""
 
+    def __new__(cls, *args, **kwargs):
+        return RuntimeError.__new__(_resolve(cls, 'APIUsageError') if cls is APIUsageError else cls, *args)
+
     def __init__(self, message='API usage error.'):
         self.message = message
-        super().__init__(self.message)
+        RuntimeError.__init__(self, self.message)
 
 
 class InvalidAgentError(ValueError):
+    def __new__(cls, *args, **kwargs):
+        return ValueError.__new__(_resolve(cls, 'InvalidAgentError') if cls is InvalidAgentError else cls, *args)
+
     def __init__(self, agent_id, agents):
-        super().__init__(f'Invalid agent/team ({agent_id}) specified. Valid values:\n{agents}')
+        ValueError.__init__(self, f'Invalid agent/team ({agent_id}) specified. Valid values:\n{agents}')
 
 
 class ExtensionError(RuntimeError):

@@ -47,6 +47,7 @@ class HostBridge:
         self.ids64 = torch.zeros(n, dtype=torch.int64, device=device)
         self.counters = torch.zeros(self.total_agents, dtype=torch.int32, device=device)
         self.stored_dropped = torch.zeros(2, dtype=torch.int32, device=device)
+        self.stored_pin = torch.zeros(2, dtype=torch.int32, **pin)
 
     def upload(self, o, r, d, env_id, mask):
         """Stage one recv() (numpy arrays, any row order) and start its H2D copies.  Returns (rows, order) with
@@ -76,6 +77,7 @@ class HostBridge:
         """Device actions (env_id order) -> host numpy in the row order recv() used; ``nvec`` unpacks the per-head choices of
         a MultiDiscrete policy into [n, heads] (what vecenv.send expects, vector.py:139-141).  Synchronises."""
         self.act_pin[:n].copy_(actions_dev[:n], non_blocking=True)
+        self.stored_pin.copy_(self.stored_dropped, non_blocking=True)   # rides on the same sync: rows stored so far
         torch.cuda.current_stream().synchronize()
         a = self.act_pin.numpy()[:n]
         if nvec is not None:
@@ -97,10 +99,14 @@ def evaluate(data):
     infos = defaultdict(list)
     bridge.counters.zero_()
     bridge.stored_dropped.zero_()
-    sent_rows = 0
     recvs = 0
+    stored = 0
     eng = data.lstm_engine
-    while sent_rows < experience.batch_size:                       # `while not experience.full` (clean_pufferl.py:84)
+    # `while not experience.full` (clean_pufferl.py:84).  "Full" = every agent has its batch_size / num_agents rows: a genuinely
+    # async pool (fast workers return more often, vector.py:382-390) keeps being stepped until the slow agents have caught up;
+    # surplus rows of an agent that is already complete are acted on but not stored (counted in stored_dropped[1]).
+    max_recvs = 64 * max(1, experience.batch_size // max(1, bridge.max_rows)) + 64
+    while stored < experience.batch_size:
         with profile.env:
             o, r, d, t, info, env_id, mask = vecenv.recv()
         with profile.eval_misc:
@@ -140,8 +146,11 @@ def evaluate(data):
                                         _lib.ptr(value), _lib.ptr(bridge.ids), _lib.ptr(bridge.mask), _lib.ptr(bridge.counters),
                                         _lib.ptr(bridge.stored_dropped), stream), 'store_rows')
             actions_np = bridge.download_actions(actions, n, order, fp.nvec if fp.multidiscrete else None)
-            sent_rows += nmask
+            stored = int(bridge.stored_pin[0])
             recvs += 1
+            if recvs > max_recvs:
+                raise RuntimeError(f'host rollout: {stored} of {experience.batch_size} rows after {recvs} recv() calls — some agents '
+                                   'never report (env-major experience needs batch_size / num_agents rows from every agent)')
             for i in info:                                           # clean_pufferl.py:110-113
                 for k, v in utils.unroll_nested_dict(i):
                     infos[k].append(v)
@@ -149,10 +158,7 @@ def evaluate(data):
             vecenv.send(actions_np)
 
     with profile.eval_misc:
-        stored, dropped = (int(x) for x in bridge.stored_dropped.cpu().numpy())
-        if stored != experience.batch_size or dropped:
-            raise RuntimeError(f'host rollout stored {stored} of {experience.batch_size} rows and dropped {dropped}: every agent '
-                               'must contribute batch_size / num_agents rows per rollout (env-major experience layout)')
+        data.host_rows_dropped = int(bridge.stored_pin[1])          # surplus rows of already-complete agents (async pools)
         data.noise = None
         experience.ptr = experience.batch_size
         experience.step = experience.horizon

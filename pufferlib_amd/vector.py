@@ -212,10 +212,18 @@ class Squared:
         self._fin_ret = torch.zeros(num_envs, dtype=torch.float64, device=dev)
         self._fin_len = torch.zeros(num_envs, dtype=torch.int32, device=dev)
         self._fin_score = torch.zeros(num_envs, dtype=torch.float64, device=dev)
-        self._stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self._stats = torch.zeros(5, dtype=torch.float64, device=dev)   # 4 sums + tape underrun flag (0 for envs without a tape)
         self.infos = []
         self.sends = 0            # sends since async_reset
         self.rounds_filled = 0    # reset rounds drawn into the tape (mirrors the device counter)
+        self.tape_event = None    # recorded by whoever filled tape rounds on ANOTHER stream (the trainer's prefetch)
+
+    def _wait_tape(self):
+        """Order the current stream behind a tape fill enqueued on a side stream: `rounds_filled` (host mirror) already counts
+        those rounds, so every consumer of the tape — send(), a fused rollout, async_reset() — must wait for the fill itself."""
+        if self.tape_event is not None:
+            import torch
+            torch.cuda.current_stream().wait_event(self.tape_event)
 
     # -- tape bookkeeping (host mirror; the stream position itself lives on device) --------------------
     def _rounds_needed(self, upto_send):
@@ -223,6 +231,7 @@ class Squared:
         return upto_send // self.episode_len
 
     def ensure_tape(self, extra_sends):
+        self._wait_tape()
         need = self._rounds_needed(self.sends + extra_sends)
         consumed = self._rounds_needed(self.sends)
         if need - consumed > self.tape_rounds:
@@ -242,6 +251,8 @@ class Squared:
         seeds = make_seeds(seed, self.num_agents)
         if any(s != seeds[0] + i for i, s in enumerate(seeds)):
             raise APIUsageError('pufferlib_amd.vector.Squared needs consecutive seeds (seed + env index)')
+        self._wait_tape()
+        self.tape_event = None
         _lib.check(self.L.pfa_squared_async_reset(_lib.ptr(self.state), C.byref(self.cfg), int(seeds[0]), *self._live(),
                                                   _lib.stream_handle()), 'async_reset')
         self.sends = 0
@@ -422,7 +433,7 @@ class _DeviceVecEnv:
         self._fin_ret = torch.zeros(num_envs, dtype=torch.float64, device=dev)
         self._fin_len = torch.zeros(num_envs, dtype=torch.int32, device=dev)
         self._fin_score = torch.zeros(num_envs, dtype=torch.float64, device=dev)
-        self._stats = torch.zeros(4, dtype=torch.float64, device=dev)
+        self._stats = torch.zeros(5, dtype=torch.float64, device=dev)   # 4 sums + tape underrun flag (0 for envs without a tape)
         self.infos = []
         self.sends = 0
         self._alloc_state()

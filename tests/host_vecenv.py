@@ -48,10 +48,11 @@ class HostSquaredPool:
     recv() hands out ONE group's rows (agents_per_batch = num_envs / workers < num_agents), send() steps that group only,
     groups take turns.  Each group is its own C-oracle SquaredSerial, i.e. has its own `random` stream like a worker process."""
 
-    def __init__(self, num_envs, workers=2, distance_to_target=3, num_targets=1):
+    def __init__(self, num_envs, workers=2, distance_to_target=3, num_targets=1, schedule=None):
         from oracle import c_oracle
         from pufferlib_amd import vector
         assert num_envs % workers == 0
+        self.schedule = list(schedule) if schedule is not None else list(range(workers))   # which group answers recv() k (cyclic)
         self.per = num_envs // workers
         self.groups = [c_oracle.SquaredSerial(self.per, distance_to_target, num_targets) for _ in range(workers)]
         self.driver_env = vector.SquaredSpec(distance_to_target, num_targets)
@@ -70,14 +71,14 @@ class HostSquaredPool:
         self.turn = 0
 
     def recv(self):
-        w = self.turn
+        w = self.schedule[self.turn % len(self.schedule)]
         o, r, d, t, infos, ids, mask = self.groups[w].recv()
         infos = [{k: v for k, v in i.items() if not k.startswith('_')} for i in infos]
         return o.copy(), r.copy(), d.copy(), t.copy(), infos, ids + w * self.per, mask.copy()
 
     def send(self, actions):
-        self.groups[self.turn].send(np.asarray(actions, np.int64))
-        self.turn = (self.turn + 1) % len(self.groups)
+        self.groups[self.schedule[self.turn % len(self.schedule)]].send(np.asarray(actions, np.int64))
+        self.turn += 1
 
     def close(self):
         pass

@@ -164,3 +164,35 @@ def test_envpool_batches_smaller_than_the_env_count(recurrent):
     if recurrent:
         h = data.lstm_engine.lstm_h[0]
         assert torch.isfinite(h).all() and float(h.abs().sum()) > 0
+
+
+def test_uneven_async_pool_fast_workers_return_more_often():
+    """A genuinely async pool (vector.py:382-390: first-ready workers): group 0 answers twice per cycle, group 1 once.  The
+    rollout keeps stepping until the slow group has its T rows; the fast group's surplus rows are acted on, not stored, and
+    nothing raises.  Stored rows of every group replay on a fresh oracle group (the first T steps of each)."""
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from host_vecenv import HostSquaredPool
+    from oracle import c_oracle
+    from test_gpu_ppo import _config
+    n, workers, horizon = 32, 2, 8
+    per = n // workers
+    vec = HostSquaredPool(n, workers, schedule=[0, 0, 1])
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 4, 1, n * horizon * 8, HP, seed=4), vec, pol)
+    clean_pufferl.evaluate(data)
+    e = data.experience
+    assert data.host_rows_dropped > 0 and e.ptr == e.batch_size
+    assert vec.turn == 3 * horizon                                     # the slow group needed T of its turns
+    obs = e.obs.view(n, horizon, -1)[:, :, :49].cpu().numpy()
+    acts, rew = (x.view(n, horizon).cpu().numpy() for x in (e.actions, e.rewards))
+    for w in range(workers):
+        ref = c_oracle.SquaredSerial(per, 3, 1)
+        ref.async_reset(4 + w * per)
+        rows = slice(w * per, (w + 1) * per)
+        for t in range(horizon):
+            o, r, d, _, _, _, _ = ref.recv()
+            assert np.array_equal(o.reshape(per, -1), obs[rows, t]), (w, t)
+            assert np.array_equal(r, rew[rows, t]), (w, t)
+            ref.send(acts[rows, t].astype(np.int64))
+    clean_pufferl.train(data)
+    assert torch.isfinite(data.flat_params.flat).all()

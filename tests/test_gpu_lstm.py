@@ -37,51 +37,6 @@ def _step_major(x, n, t):
     return x.view(n, t, *x.shape[1:]).transpose(0, 1).reshape(n * t, *x.shape[1:]).cpu().numpy()
 
 
-def test_cell_kernels_match_torch_autograd():
-    from pufferlib_amd import _lib
-    L = _lib.lib()
-    torch.manual_seed(0)
-    R, H = 37, 128
-    pre = torch.randn(R, 4 * H, device='cuda', requires_grad=True)
-    c0 = torch.randn(R, H, device='cuda', requires_grad=True)
-    i, f, g, o = pre.chunk(4, dim=1)
-    c1 = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(g)
-    h1 = torch.sigmoid(o) * torch.tanh(c1)
-    dh, dc1 = torch.randn(R, H, device='cuda'), torch.randn(R, H, device='cuda')
-    (h1 * dh).sum().backward(retain_graph=True, inputs=[pre, c0])
-    gpre_h, gc0_h = pre.grad.clone(), c0.grad.clone()
-    pre.grad = None
-    c0.grad = None
-    ((h1 * dh).sum() + (c1 * dc1).sum()).backward(inputs=[pre, c0])
-
-    gates = pre.detach().clone()
-    c_out, h_out = torch.empty(R, H, device='cuda'), torch.empty(R, H, device='cuda')
-    _lib.check(L.pfa_lstm_cell_fwd(_lib.ptr(gates), _lib.ptr(c0.detach()), _lib.ptr(c_out), _lib.ptr(h_out), R, None), 'fwd')
-    np.testing.assert_allclose(c_out.cpu().numpy(), c1.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(h_out.cpu().numpy(), h1.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
-    dcv = dc1.clone()
-    dgates = torch.empty(R, 4 * H, device='cuda')
-    _lib.check(L.pfa_lstm_cell_bwd(_lib.ptr(gates), _lib.ptr(c0.detach()), _lib.ptr(c_out), _lib.ptr(dh), None, _lib.ptr(dcv),
-                                   _lib.ptr(dgates), R, None), 'bwd')
-    np.testing.assert_allclose(dgates.cpu().numpy(), pre.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(dcv.cpu().numpy(), c0.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
-
-
-def test_colsum_and_relu_grad():
-    from pufferlib_amd import _lib
-    L = _lib.lib()
-    a = torch.randn(1000, 512, device='cuda')
-    out = torch.empty(512, device='cuda')
-    ws = torch.empty(L.pfa_colsum_workspace_bytes(512), dtype=torch.uint8, device='cuda')
-    _lib.check(L.pfa_colsum(_lib.ptr(a), 1000, 512, 512, _lib.ptr(out), 0, _lib.ptr(ws), None), 'colsum')
-    np.testing.assert_allclose(out.cpu().numpy(), a.double().sum(0).float().cpu().numpy(), rtol=1e-5, atol=1e-4)
-    x = torch.relu(torch.randn(4096, device='cuda'))
-    dx = torch.randn(4096, device='cuda')
-    want = torch.where(x > 0, dx, torch.zeros_like(dx))
-    _lib.check(L.pfa_relu_grad(_lib.ptr(dx), _lib.ptr(x), 4096, None), 'relu_grad')
-    assert torch.equal(dx, want)
-
-
 def test_create_evaluate_train_replays_golden_lstm(golden_dir):
     from pufferlib_amd import clean_pufferl
     g = np.load(os.path.join(golden_dir, 'ppo_lstm.npz'))

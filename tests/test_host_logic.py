@@ -140,3 +140,48 @@ def test_public_surface_has_the_names_reference_code_imports():
     assert hasattr(pufferlib_amd, 'namespace')
     pol = cleanrl.Policy(models.Default(vector.make_squared()))
     assert clean_pufferl.count_params(pol) == 128 * 49 + 128 + 8 * 128 + 8 + 128 + 1
+
+
+def test_errors_are_also_the_reference_classes_once_pufferlib_exceptions_is_loaded():
+    """pufferlib/exceptions.py:5-22: a caller that catches the reference's APIUsageError must catch ours, whichever package
+    was imported first.  Uses the reference's own file when the tree is present (build container), a stand-in otherwise."""
+    import importlib.util
+    import os
+    import sys
+    import types
+    from pufferlib_amd import exceptions as ours
+    assert type(ours.APIUsageError('x')) is ours.APIUsageError                   # nothing loaded: plain class
+    ref_file = '/root/reference/pufferlib/exceptions.py'
+    saved = sys.modules.get('pufferlib.exceptions')
+    try:
+        if os.path.exists(ref_file):
+            spec = importlib.util.spec_from_file_location('pufferlib.exceptions', ref_file)
+            mod = importlib.util.module_from_spec(spec)
+            sys.dont_write_bytecode, old = True, sys.dont_write_bytecode
+            try:
+                spec.loader.exec_module(mod)
+            finally:
+                sys.dont_write_bytecode = old
+        else:
+            mod = types.ModuleType('pufferlib.exceptions')
+
+            class APIUsageError(RuntimeError):
+                def __init__(self, message='API usage error.'):
+                    self.message = message
+                    super().__init__(self.message)
+
+            class InvalidAgentError(ValueError):
+                def __init__(self, agent_id, agents):
+                    super().__init__(f'Invalid agent/team ({agent_id}) specified. Valid values:\n{agents}')
+            mod.APIUsageError, mod.InvalidAgentError = APIUsageError, InvalidAgentError
+        sys.modules['pufferlib.exceptions'] = mod
+        with pytest.raises(mod.APIUsageError, match='Call reset before stepping') as ei:
+            raise ours.APIUsageError('Call reset before stepping')
+        assert isinstance(ei.value, ours.APIUsageError) and ei.value.message == 'Call reset before stepping'
+        with pytest.raises(mod.InvalidAgentError):
+            raise ours.InvalidAgentError(7, [1, 2])
+    finally:
+        if saved is None:
+            sys.modules.pop('pufferlib.exceptions', None)
+        else:
+            sys.modules['pufferlib.exceptions'] = saved
