@@ -206,6 +206,36 @@ def philox4x32_10(ctr, key):
     return out
 
 
+def philox4x32_10_bulk(c0, c1, c2, c3, k0, k1):
+    """The same 10 rounds on uint32 arrays (numpy, vectorised): returns the four output word arrays.  Checked word for word
+    against po_philox4x32_10 in tests/test_oracle_golden.py."""
+    c0, c1, c2, c3 = (np.asarray(x, np.uint64) & 0xFFFFFFFF for x in np.broadcast_arrays(c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0 & 0xFFFFFFFF), np.uint64(k1 & 0xFFFFFFFF)
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+        n1 = p1 & MASK
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+        n3 = p0 & MASK
+        c0, c1, c2, c3 = n0, n1, n2, n3
+        k0 = (k0 + np.uint64(0x9E3779B9)) & MASK
+        k1 = (k1 + np.uint64(0xBB67AE85)) & MASK
+    return tuple(x.astype(np.uint32) for x in (c0, c1, c2, c3))
+
+
+def philox_exp_noise(seed, step, rows, cols, row_offset=0):
+    """Exp(1) action noise [rows][cols] of rollout step `step` as pufferlib_amd/csrc/philox.hpp defines the stream:
+    key = (seed lo, seed hi), counter = (global row, column / 4, step lo, step hi), u = ((w >> 8) + 0.5) * 2^-24, q = -log(u)."""
+    nj = (cols + 3) // 4
+    r = (np.arange(rows, dtype=np.uint64) + np.uint64(row_offset))[:, None]
+    j = np.arange(nj, dtype=np.uint64)[None, :]
+    w = philox4x32_10_bulk(r, j, np.uint64(step & 0xFFFFFFFF), np.uint64(step >> 32), seed & 0xFFFFFFFF, seed >> 32)
+    words = np.stack(w, axis=-1).reshape(rows, nj * 4)[:, :cols]
+    u = ((words >> 8).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+    return -np.log(u)
+
+
 class StochasticSerial:
     """``pufferlib.vector.Serial`` over ``make_stochastic`` envs (ocean/environment.py:61-64: horizon 100), restated in C.
     Same protocol and buffer aliasing as SquaredSerial."""

@@ -435,7 +435,7 @@ def _finish_evaluate(data, N, T):
         experience.ptr = experience.batch_size
         experience.step = T
         data.global_step += N * T * data.world_size      # sum(mask) per recv (clean_pufferl.py:90), all ranks
-        st = vecenv.episode_stats(reset=True)
+        st = vecenv.stats_with_flag(reset=True)         # 4 sums + the tape underrun flag
         if data.native_dp:
             _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(st), st.numel(), _lib.stream_handle()), 'stats all-reduce')
         elif data.world_size > 1:

@@ -306,9 +306,13 @@ class Squared:
         reset of the accumulators — what clean_pufferl.evaluate reports (clean_pufferl.py:144-152)."""
         _lib.check(self.L.pfa_squared_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._stats),
                                                     1 if reset else 0, _lib.stream_handle()), 'episode_stats')
-        return self._stats
+        return self._stats[:4]      # [4] = tape underrun flag: read by the trainer from the same buffer (stats_with_flag)
 
     stats_from_sums = staticmethod(episode_means)
+
+    def stats_with_flag(self, reset=True):
+        self.episode_stats(reset)
+        return self._stats
 
     # -- test introspection -------------------------------------------------------------------------------
     def debug_targets(self):
@@ -494,9 +498,13 @@ class _DeviceVecEnv:
         """(count, sum episode_return, sum episode_length, sum score) of the episodes finished since the last reset of the
         accumulators, as a device f64 tensor — what clean_pufferl.evaluate averages (clean_pufferl.py:127-137)."""
         self._k_stats(1 if reset else 0)
-        return self._stats
+        return self._stats[:4]      # [4] = tape underrun flag: read by the trainer from the same buffer (stats_with_flag)
 
     stats_from_sums = staticmethod(episode_means)
+
+    def stats_with_flag(self, reset=True):
+        self.episode_stats(reset)
+        return self._stats
 
 
 def make_stochastic(p=0.7, horizon=100, **kwargs):

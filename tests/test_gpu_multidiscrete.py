@@ -74,15 +74,15 @@ def test_spaces_golden_replay_through_create_evaluate_train(golden_dir):
         assert np.array_equal(step_major(e.obs)[:, :108], g[f'it{it}.obs'].astype(np.float32))
         assert np.array_equal(step_major(e.rewards), g[f'it{it}.rewards']) and np.array_equal(step_major(e.dones), g[f'it{it}.dones'])
         np.testing.assert_allclose(step_major(e.logprobs), g[f'it{it}.logprobs'], rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(step_major(e.values), g[f'it{it}.values'], rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(step_major(e.values), g[f'it{it}.values'], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']], g[f'it{it}.stats'], rtol=1e-12)
         clean_pufferl.train(data)
         L = data.losses
         np.testing.assert_allclose([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
-                                   g[f'it{it}.losses'][:6], rtol=2e-4, atol=1e-5)
+                                   g[f'it{it}.losses'][:6], rtol=1e-5, atol=1e-5)
         sd = pol.state_dict()
         for k in sd:
-            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'it{it}.w.' + k], rtol=1e-4, atol=1e-5, err_msg=k)
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'it{it}.w.' + k], rtol=1e-5, atol=1e-5, err_msg=k)
 
 
 def test_three_heads_rollout_and_update_vs_oracle_trainer():
@@ -122,7 +122,7 @@ def test_three_heads_rollout_and_update_vs_oracle_trainer():
         L = data.losses
         np.testing.assert_allclose([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
                                    [Lo[k] for k in ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac')],
-                                   rtol=1e-4, atol=1e-5)
+                                   rtol=1e-5, atol=1e-5)
         sd = pol.state_dict()
         for k, arr in opol.state_arrays().items():
             np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, rtol=1e-5, atol=1e-5, err_msg=k)
@@ -160,16 +160,16 @@ def test_three_heads_with_the_recurrent_policy_vs_oracle_trainer():
         sm = lambda x: x.view(n, horizon, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
         assert np.array_equal(sm(data.flat_params.unpack_actions(e.actions.long())), tr.actions), it
         assert np.array_equal(sm(e.rewards), tr.rewards)
-        np.testing.assert_allclose(sm(e.logprobs), tr.logprobs, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(sm(e.logprobs), tr.logprobs, rtol=1e-5, atol=1e-5)
         Lo = tr.train()
         clean_pufferl.train(data)
         L = data.losses
         np.testing.assert_allclose([L.policy_loss, L.value_loss, L.entropy, L.approx_kl], [Lo[k] for k in ('policy_loss', 'value_loss', 'entropy', 'approx_kl')],
-                                   rtol=1e-3, atol=1e-5)
+                                   rtol=1e-5, atol=1e-5)
         sd = pol.state_dict()
         for k, arr in opol.state_arrays().items():
             key = ('policy.recurrent.' + k) if k.endswith('_l0') else ('policy.policy.' + k)
-            np.testing.assert_allclose(sd[key].cpu().numpy(), arr, rtol=1e-4, atol=2e-5, err_msg=k)
+            np.testing.assert_allclose(sd[key].cpu().numpy(), arr, rtol=1e-5, atol=1e-5, err_msg=k)
 
 
 def test_unsupported_combinations_fail_loudly():

@@ -1,0 +1,191 @@
+"""Parity to the letter on the BASELINE configurations (VERDICT r01 "next round" item 1).
+
+* the full-size update — 4096 envs x 128 steps, 4 minibatches of 131 072 rows — through create -> evaluate -> train, i.e. the
+  code path bench.py times (obs_dim 49 specialisation, 8 tiles per wavefront pair, the native epoch x minibatch loop), MLP
+  and LSTM, against the torch-fp32 oracle trainer (oracle/ppo_torch.py, pinned against the unmodified reference);
+* every branch of clean_pufferl.py:202-238 / :256-264: norm_adv, clip_vloss, anneal_lr, target_kl early break;
+* all 128 steps of the in-kernel Philox action noise at 4096 envs.
+
+Tolerance is north_star's: returns / advantages / losses / weights within 1e-5 fp32, written allclose(rtol=1e-5, atol=1e-5);
+integer quantities bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-5, atol=1e-5)
+LOSS_KEYS = ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac')
+HP = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+
+
+def _step_major(x, n, t):
+    return x.view(n, t, *x.shape[1:]).transpose(0, 1).reshape(n * t, *x.shape[1:]).cpu().numpy()
+
+
+def _build(n, recurrent, seed_w, d=3, nt=1, perturb=0.05):
+    from pufferlib_amd import cleanrl, models, vector
+    vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=d, num_targets=nt), num_envs=n,
+                      backend=vector.Squared)
+    torch.manual_seed(seed_w)
+    base = models.Default(vec.driver_env)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base)) if recurrent else cleanrl.Policy(base)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(perturb * torch.randn_like(p))      # off the near-uniform init: ratios, clipping and the value clip engage
+    return vec, pol
+
+
+def _oracle_trainer(pol, data, n, horizon, nmb, bptt, epochs, hp, total, d=3, nt=1, **flags):
+    """The torch-fp32 restatement of clean_pufferl.train, handed the device rollout's experience in storage order."""
+    from oracle import c_oracle, ppo_torch
+    exp = data.experience
+    B = n * horizon
+    D = (2 * d + 1) ** 2
+    tr = ppo_torch.Trainer(pol, c_oracle.SquaredSerial(n, d, nt), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt,
+                           update_epochs=epochs, learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3],
+                           vf_coef=hp[4], vf_clip_coef=hp[5], max_grad_norm=hp[6], ent_coef=hp[7], total_timesteps=total,
+                           seed=1, **flags)
+    tr.obs = torch.as_tensor(_step_major(exp.obs, n, horizon)[:, :D].copy())
+    tr.actions = _step_major(exp.actions, n, horizon).astype(np.int64)
+    tr.logprobs = _step_major(exp.logprobs, n, horizon).copy()
+    tr.rewards = _step_major(exp.rewards, n, horizon).copy()
+    tr.dones = _step_major(exp.dones, n, horizon).copy()
+    tr.values = _step_major(exp.values, n, horizon).copy()
+    tr.global_step = data.global_step
+    return tr
+
+
+def _oracle_policy(pol, recurrent):
+    from oracle import ppo_torch
+    sd = {k: v.detach().cpu().clone() for k, v in pol.state_dict().items()}
+    if recurrent:
+        return ppo_torch.Policy.from_reference_state_dict(sd)
+    return ppo_torch.Policy({k[len('policy.'):]: v.numpy().copy() for k, v in sd.items()})
+
+
+def _compare(pol, opol, data, Lo, recurrent, tr, what):
+    L = data.losses
+    got = [getattr(L, k) for k in LOSS_KEYS]
+    want = [Lo[k] for k in LOSS_KEYS]
+    err = np.abs(np.array(got) - np.array(want))
+    np.testing.assert_allclose(got, want, err_msg=f'{what}: losses {LOSS_KEYS}', **TOL)
+    sd = pol.state_dict()
+    worst = 0.0
+    for k, arr in opol.state_arrays().items():
+        full = (('policy.recurrent.' if k.endswith('_l0') else 'policy.policy.') + k) if recurrent else 'policy.' + k
+        mine = sd[full].cpu().numpy()
+        worst = max(worst, float(np.abs(mine - arr).max()))
+        np.testing.assert_allclose(mine, arr, err_msg=f'{what}: {k}', **TOL)
+    # advantages / returns of every minibatch (flatten_batch, clean_pufferl.py:466-482)
+    exp = data.experience
+    for m in range(exp.num_minibatches):
+        idx = exp.minibatch_rows_index(m)
+        np.testing.assert_allclose(exp.advantages[idx].cpu().numpy(), tr.b_advantages[m].numpy(), **TOL)
+        np.testing.assert_allclose(exp.returns[idx].cpu().numpy(), tr.b_returns[m].numpy(), **TOL)
+    return float(err.max()), worst
+
+
+@pytest.mark.parametrize('recurrent,epochs', [(False, 4), (True, 1)])
+def test_full_size_update_through_create_evaluate_train(recurrent, epochs, capsys):
+    """BASELINE configs[1] (and configs[2]'s policy): 4096 envs x 128 steps, 4 minibatches of 131 072 rows, bptt 16.
+    MLP: all 4 epochs = the 16 optimizer steps one bench step runs.  LSTM: one epoch (4 steps, state carried across the
+    minibatches) — the oracle's BPTT over 524 288 rows on the host is what bounds the test time."""
+    from pufferlib_amd import clean_pufferl
+    from test_gpu_ppo import _config
+    n, horizon, nmb, bptt = 4096, 128, 4, 16
+    B = n * horizon
+    vec, pol = _build(n, recurrent, seed_w=11)
+    cfg = _config(n, horizon, B // nmb, bptt, epochs, B * 10, HP)
+    data = clean_pufferl.create(cfg, vec, pol)
+    opol = _oracle_policy(pol, recurrent)
+    clean_pufferl.evaluate(data)
+    tr = _oracle_trainer(opol, data, n, horizon, nmb, bptt, epochs, HP, B * 10)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    Lo = tr.train()
+    clean_pufferl.train(data)
+    if not recurrent:       # the configuration under test is the specialised one bench.py runs
+        assert data.flat_params.obs_dim == 49 and data.flat_params.obs_stride == 64 and data.experience.minibatch_size == 131072
+    loss_err, w_err = _compare(pol, opol, data, Lo, recurrent, tr, 'full size')
+    np.testing.assert_allclose(data.losses.explained_variance, Lo['explained_variance'], rtol=1e-4, atol=1e-5)
+    with capsys.disabled():
+        print(f'\n[parity full-size {"lstm" if recurrent else "mlp"}] max |loss err| {loss_err:.2e}, max |weight err| {w_err:.2e}')
+
+
+FLAGS = [dict(norm_adv=False), dict(clip_vloss=False), dict(norm_adv=False, clip_vloss=False), dict(anneal_lr=False),
+         dict(target_kl=1e-7), dict(target_kl=10.0)]
+
+
+@pytest.mark.parametrize('recurrent', [False, True])
+@pytest.mark.parametrize('flags', FLAGS, ids=lambda f: ','.join(f'{k}={v}' for k, v in f.items()))
+def test_update_branches_vs_oracle_trainer(recurrent, flags):
+    """clean_pufferl.py:211-213 (norm_adv), :222-235 (clip_vloss), :256-258 (target_kl break after an epoch), :261-264
+    (anneal_lr) — each switched away from the default, two train() calls so the lr schedule matters."""
+    from pufferlib_amd import clean_pufferl
+    from test_gpu_ppo import _config
+    n, horizon, nmb, bptt, epochs = 128, 32, 2, 8, 3
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
+    B = n * horizon
+    vec, pol = _build(n, recurrent, seed_w=5)
+    cfg = _config(n, horizon, B // nmb, bptt, epochs, B * 6, hp, **flags)
+    data = clean_pufferl.create(cfg, vec, pol)
+    opol = _oracle_policy(pol, recurrent)
+    tr = None
+    for it in range(2):
+        clean_pufferl.evaluate(data)
+        tr_new = _oracle_trainer(opol, data, n, horizon, nmb, bptt, epochs, hp, B * 6, **flags)
+        if tr is not None:               # one optimizer / lr schedule across the two updates
+            tr_new.opt = tr.opt
+            for g in tr_new.opt.param_groups:
+                g['params'] = opol.params
+            tr_new.epoch = tr.epoch
+        tr = tr_new
+        lr_used = tr.opt.param_groups[0]['lr']
+        assert abs(data.optimizer.param_groups[0]['lr'] - lr_used) < 1e-12
+        Lo = tr.train()
+        clean_pufferl.train(data)
+        _compare(pol, opol, data, Lo, recurrent, tr, f'{flags} update {it}')
+        assert abs(data.optimizer.param_groups[0]['lr'] - tr.opt.param_groups[0]['lr']) < 1e-12
+    if flags.get('anneal_lr') is False:
+        assert data.optimizer.param_groups[0]['lr'] == hp[0]
+    if flags.get('target_kl') == 1e-7:   # the break really happened: one epoch's worth of optimizer steps per update
+        assert data.optimizer.step_count == 2 * nmb, data.optimizer.step_count
+    if flags.get('target_kl') == 10.0:
+        assert data.optimizer.step_count == 2 * nmb * epochs
+
+
+def test_philox_actions_all_128_steps_at_4096_envs():
+    """Every step of the full-size rollout: the device's Philox -> Exp(1) -> argmax(p/q) against the oracle fed the same
+    stream (oracle/c_oracle.philox_exp_noise, numpy, checked word for word against the C restatement).  The oracle follows the
+    device's actions so one near-tie cannot cascade; integer env trajectories must then be identical at every step."""
+    from pufferlib_amd import clean_pufferl
+    from oracle import c_oracle, ppo_torch
+    from test_gpu_ppo import _config
+    n, horizon = 4096, 128
+    vec, pol = _build(n, False, seed_w=2, perturb=0.0)
+    cfg = _config(n, horizon, n * horizon // 4, 16, 1, n * horizon * 4, HP, seed=1)
+    data = clean_pufferl.create(cfg, vec, pol)
+    opol = _oracle_policy(pol, False)
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    acts = _step_major(exp.actions, n, horizon)
+    obs = _step_major(exp.obs, n, horizon)[:, :49]
+    lps = _step_major(exp.logprobs, n, horizon)
+    vals = _step_major(exp.values, n, horizon)
+    ovec = c_oracle.SquaredSerial(n, 3, 1)
+    ovec.async_reset(1)
+    mism = 0
+    for t in range(horizon):
+        o = ovec.recv()[0]
+        rows = slice(t * n, (t + 1) * n)
+        assert np.array_equal(o.reshape(n, -1), obs[rows]), t
+        noise = c_oracle.philox_exp_noise(1, t, n, 8)
+        with torch.no_grad():
+            logits, value, _ = opol.forward(torch.as_tensor(o.reshape(n, -1).copy()))
+            a, _, _ = ppo_torch.sample_logits(logits, noise=torch.as_tensor(noise))
+            _, lp_dev, _ = ppo_torch.sample_logits(logits, action=torch.as_tensor(acts[rows].astype(np.int64)))
+        mism += int((a.numpy() != acts[rows]).sum())
+        np.testing.assert_allclose(lps[rows], lp_dev.numpy(), **TOL)      # log-prob of the action the device took
+        np.testing.assert_allclose(vals[rows], value.flatten().numpy(), **TOL)
+        ovec.send(acts[rows].astype(np.int64))
+    assert mism <= 16, f'{mism} action mismatches in {horizon * n} samples (only near-ties in p/q may differ)'

@@ -86,7 +86,7 @@ def test_create_evaluate_train_replays_golden(golden_dir):
             np.testing.assert_allclose(exp.returns[idx].cpu().numpy(), g[f'it{it}.returns'][m], **TOL)
         L = data.losses
         got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance]
-        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=1e-5, atol=1e-5)
         sd = pol.state_dict()
         m_, v_ = data.flat_params.split(data.optimizer.exp_avg), data.flat_params.split(data.optimizer.exp_avg_sq)
         for k in sd:
@@ -138,7 +138,7 @@ def test_update_vs_torch_oracle(n, horizon, nmb, bptt):
     np.testing.assert_allclose(
         [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
         [Lo['policy_loss'], Lo['value_loss'], Lo['entropy'], Lo['old_approx_kl'], Lo['approx_kl'], Lo['clipfrac']],
-        rtol=1e-4, atol=1e-5)
+        rtol=1e-5, atol=1e-5)
     sd = pol.state_dict()
     for k, arr in opol.state_arrays().items():
         np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=k, **TOL)
@@ -299,7 +299,7 @@ def test_other_grid_sizes_rollout_and_update_vs_oracle(d, nt, n, horizon, nmb, b
     np.testing.assert_allclose(
         [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
         [Lo['policy_loss'], Lo['value_loss'], Lo['entropy'], Lo['old_approx_kl'], Lo['approx_kl'], Lo['clipfrac']],
-        rtol=1e-4, atol=1e-5)
+        rtol=1e-5, atol=1e-5)
     sd = pol.state_dict()
     for k, arr in opol.state_arrays().items():
         np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=k, **TOL)

@@ -130,7 +130,7 @@ def test_fused_rollout_equals_stepwise_protocol_and_oracle_update():
     clean_pufferl.train(data)
     L = data.losses
     np.testing.assert_allclose([L.policy_loss, L.value_loss, L.entropy, L.approx_kl], [Lo[k] for k in ('policy_loss', 'value_loss', 'entropy', 'approx_kl')],
-                               rtol=1e-4, atol=1e-5)
+                               rtol=1e-5, atol=1e-5)
     sd = pol.state_dict()
     for k, arr in opol.state_arrays().items():
         np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, rtol=1e-5, atol=1e-5, err_msg=k)
