@@ -33,7 +33,8 @@ EPOCHS = 4
 BPTT = 16
 D, NT = 3, 1             # obs 7x7 = 49 floats, padded to a 64-float row (256 B)
 # SURVEY.md §8d algorithmic figures (MLP, obs row 64 f32, 8 actions, hidden 128)
-FLOP_PER_ROW_UPDATE = 39680          # fwd 18 688 + bwd 20 992 per row per epoch
+FLOP_PER_ROW_UPDATE = 39680          # fwd 18 688 + bwd 20 992 per row per epoch (the 64-float padded row)
+FLOP_PER_ROW_USEFUL = 2 * (49 * 128 + 128 * 9) + 2 * 49 * 128 + 2 * 2 * 128 * 9   # the same on the 49 real columns: 32 000
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 
 
@@ -47,18 +48,21 @@ def make_config(total_timesteps):
                      checkpoint_interval=0, data_dir='/tmp/pfa_bench', exp_id='bench')
 
 
-def cpu_baseline(budget_s=20.0):
-    """The oracle port timed on a bounded sample: same per-env workload (squared d=3, T=128, 4 minibatches,
-    4 epochs, MLP 128) at 256 envs; >= 1 timed evaluate+train iteration after a warm-up one."""
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def _oracle_trainer(n, seed=1):
     import numpy as np
     import torch
     from oracle import c_oracle, ppo_torch
-    n = 256
     B = n * HORIZON
-    # threads actually used: the reference's torch CPU path scales poorly past a socket's worth of cores on
-    # these tiny GEMMs (256 threads measured 800x slower than 16 on the GPU box), so cap and report the cap
-    cores = min(os.cpu_count() or 1, 16)
-    torch.set_num_threads(cores)
     vec = c_oracle.SquaredSerial(n, D, NT)
     torch.manual_seed(1)
     w = {'encoder.weight': torch.randn(128, 49) * 0.1, 'encoder.bias': torch.zeros(128),
@@ -67,25 +71,91 @@ def cpu_baseline(budget_s=20.0):
     pol = ppo_torch.Policy({k: v.numpy() for k, v in w.items()})
     tr = ppo_torch.Trainer(pol, vec, batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT, update_epochs=EPOCHS,
                            learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, vf_coef=0.5,
-                           vf_clip_coef=0.1, max_grad_norm=0.5, ent_coef=0.01, total_timesteps=B * 1000, seed=1)
-    rng = np.random.default_rng(0)
+                           vf_clip_coef=0.1, max_grad_norm=0.5, ent_coef=0.01, total_timesteps=B * 1000, seed=seed)
+    return tr, np.random.default_rng(0)
+
+
+def cpu_baseline(budget_s=24.0):
+    """The CPU oracle port (oracle/: C restatement of Serial(Squared) on 1 core + the torch-fp32 restatement of the policy and
+    of clean_pufferl.train) timed on the SAME configuration the GPU number is quoted on — 4096 envs x 128 steps, 4 minibatches
+    x 4 epochs — for 1 warm-up + as many evaluate+train iterations as fit the budget (at least 1).  The unmodified reference
+    itself cannot travel to the GPU box; its own measurement (survey container) rides along as `reference_measured`."""
+    import torch
+    cores_avail = os.cpu_count() or 1
+    # threads actually used: the reference's torch CPU path scales poorly past a socket's worth of cores on these tiny GEMMs
+    # (256 threads measured 800x slower than 16 on the GPU box), so cap and report the cap
+    cores = min(cores_avail, 16)
+    torch.set_num_threads(cores)
+    n = NUM_ENVS
+    B = n * HORIZON
+    tr, rng = _oracle_trainer(n)
 
     def one():
-        tr.evaluate(rng.exponential(size=(HORIZON, n, 8)).astype(np.float32))
+        tr.evaluate(rng.exponential(size=(HORIZON, n, 8)).astype('float32'))
         tr.train()
 
+    t0 = time.perf_counter()
     one()  # warm-up
+    warm = time.perf_counter() - t0
     t0 = time.perf_counter()
     iters = 0
     while True:
         one()
         iters += 1
-        if time.perf_counter() - t0 > budget_s / 2 or iters >= 200:
+        if time.perf_counter() - t0 + warm > budget_s or iters >= 50:
             break
     dt = time.perf_counter() - t0
-    return dict(value=iters * B / dt, unit='env_steps/s', cores=cores, kind='port',
-                sample=f'{iters} evaluate+train iterations of {n} envs x {HORIZON} steps (same env, policy, '
-                       f'{NMB} minibatches x {EPOCHS} epochs) after 1 warm-up; C env on 1 core, torch-fp32 on {cores} threads')
+    return dict(value=iters * B / dt, unit='env_steps/s', cores=cores, cores_available=cores_avail, cpu_model=_cpu_model(), kind='port',
+                sample=f'{iters} evaluate+train iteration(s) of {n} envs x {HORIZON} steps (batch {B}, {NMB} minibatches x {EPOCHS} '
+                       f'epochs: the bench configuration itself) after 1 warm-up; C env on 1 core, torch-fp32 on {cores} threads',
+                reference_measured=dict(value=47.8e3, unit='env_steps/s', config='the unmodified reference (clean_pufferl + '
+                                        'pufferlib.vector.Serial + c_gae), squared 4096 envs x 128, MLP, 1 iteration',
+                                        box='8-core Xeon @ 2.1 GHz, survey container (no GPU)', source='BASELINE.md section 2'))
+
+
+def self_check(data, pol):
+    """One more (untimed) evaluate + train, the train replayed by the torch-fp32 oracle trainer on the device rollout's
+    experience at the FULL bench size (one epoch = 4 optimizer steps over all 524 288 rows, to bound the host time): losses and
+    post-update weights must agree within north_star's 1e-5.  The oracle is the checker here, never the thing timed."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle, ppo_torch
+    from pufferlib_amd import clean_pufferl
+    n, T = NUM_ENVS, HORIZON
+    B = n * T
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    w0 = {k[len('policy.'):]: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    opol = ppo_torch.Policy(w0)
+    epochs_saved = data.config.update_epochs
+    data.config.update_epochs = 1
+    tr = ppo_torch.Trainer(opol, c_oracle.SquaredSerial(n, D, NT), batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT,
+                           update_epochs=1, learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, vf_coef=0.5,
+                           vf_clip_coef=0.1, max_grad_norm=0.5, ent_coef=0.01, total_timesteps=data.config.total_timesteps, seed=1)
+    sm = lambda x: x.view(n, T, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
+    tr.obs = torch.as_tensor(sm(exp.obs)[:, :49].copy())
+    tr.actions = sm(exp.actions).astype(np.int64)
+    tr.logprobs, tr.rewards, tr.dones, tr.values = (sm(x).copy() for x in (exp.logprobs, exp.rewards, exp.dones, exp.values))
+    tr.global_step = data.global_step
+    tr.opt.param_groups[0]['lr'] = data.optimizer.param_groups[0]['lr']
+    # the oracle starts from fresh Adam moments; give it the device's (the trainer has been running)
+    m, v = data.flat_params.split(data.optimizer.exp_avg), data.flat_params.split(data.optimizer.exp_avg_sq)
+    for i, name in enumerate(opol.names):
+        p = opol.params[i]
+        tr.opt.state[p] = dict(step=torch.tensor(float(data.optimizer.step_count)), exp_avg=m[name].detach().cpu().clone(),
+                               exp_avg_sq=v[name].detach().cpu().clone())
+    Lo = tr.train()
+    clean_pufferl.train(data)
+    data.config.update_epochs = epochs_saved
+    keys = ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac')
+    loss_err = max(abs(float(getattr(data.losses, k)) - float(Lo[k])) for k in keys)
+    sd = pol.state_dict()
+    w_err = max(float(np.abs(sd['policy.' + k].cpu().numpy() - arr).max()) for k, arr in opol.state_arrays().items())
+    adv_err = float(np.abs(exp.advantages.cpu().numpy() - c_oracle.compute_gae(
+        exp.dones.cpu().numpy(), exp.values.cpu().numpy(), exp.rewards.cpu().numpy(), 0.99, 0.95)).max())
+    assert loss_err <= 1e-5 and w_err <= 1e-5 and adv_err <= 1e-5, (loss_err, w_err, adv_err)
+    return dict(rows=B, optimizer_steps=NMB, max_abs_loss_err=loss_err, max_abs_weight_err=w_err, max_abs_advantage_err=adv_err,
+                tolerance=1e-5, checker='oracle/ppo_torch.py + oracle/puffer_oracle.c')
 
 
 def main():
@@ -185,6 +255,9 @@ def main():
             n, ms = kernel_ms(name)
             breakdown[name] = dict(launches_per_step=n // KB, ms_per_step=round(ms / KB, 4))
 
+    import torch as _t
+    assert bool(_t.isfinite(data.flat_params.flat).all()), 'non-finite weights after the timed loop'
+    assert all(_t.isfinite(_t.tensor(float(v))) for k, v in data.losses.items() if k != 'explained_variance'), dict(data.losses)
     if rank == 0:
         value = world * per_gpu * K / dt
         launches, total_ms = grad_launches, grad_total_ms
@@ -210,12 +283,17 @@ def main():
                                    + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+                         'frac_useful': (achieved * FLOP_PER_ROW_USEFUL / FLOP_PER_ROW_UPDATE / PEAK_FP32_MFMA_TFLOPS
+                                         if args.policy == 'mlp' else None),   # on the 49 real columns (32 000 FLOP/row)
+                         'traffic': traffic,
                          'avg_launch_ms': avg_ms, 'launches': launches,
                          'flop_per_launch': flop_row * rows_per_launch},
             'kernel_ms_per_step': breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:
+            if args.policy == 'mlp':
+                out['self_check'] = self_check(data, pol)
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

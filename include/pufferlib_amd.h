@@ -293,33 +293,35 @@ int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_p
                       double *stats, void *workspace, pfa_stream_t stream);
 /* Forward + loss + backward for minibatch `mb`: writes the flat gradient (same layout as params, already
  * divided by `global_mb_rows`, so an all-reduce SUM over ranks yields the global-minibatch mean gradient)
- * followed by 8 floats of loss sums over this rank's rows:
- *   grads[P+0..5] = sum pg_loss, sum v_loss, sum entropy, sum -logratio, sum (ratio-1-logratio), sum clipped. */
+ * followed by 16 floats: the loss sums over this rank's rows, accumulated in f64 and stored as (hi, lo) float pairs
+ * (sum_i = (double)grads[P+2i] + (double)grads[P+2i+1]; an f32 all-reduce of the bucket keeps ~48 bits of each sum):
+ *   i = 0..5: sum pg_loss, sum v_loss, sum entropy, sum -logratio, sum (ratio-1-logratio), sum clipped.
+ */
 int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
                      const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
                      int64_t global_mb_rows, float *grads, void *workspace, pfa_stream_t stream);
 /* clip_grad_norm_(max_grad_norm) + Adam(eps) step (:240-244; torch.optim.Adam single-tensor semantics, bias
  * correction with `step` = 1-based optimizer step count).  grad_scale multiplies grads first.
- * If loss_sums/losses are given: losses[i] += loss_sums[i] * loss_scale for i < 6, i.e. the running
+ * If loss_sums (the 16-float tail above) / losses (f64[8]) are given: losses[i] += sum_i * loss_scale for i < 6, i.e. the running
  * {policy_loss, value_loss, entropy, old_approx_kl, approx_kl, clipfrac} of clean_pufferl.py:249-254 with
  * loss_scale = 1 / (global_mb_rows * num_minibatches).  norm_partials (nullable): n f64 pieces of sum(g^2) left in
  * the workspace by pfa_ppo_mlp_grad (valid only when grads were not modified since, i.e. single rank); when
  * null the norm is recomputed from `grads` (after an all-reduce). */
 int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t count,
                        float lr, float beta1, float beta2, float eps, int64_t step, float max_grad_norm,
-                       float grad_scale, const float *loss_sums, float *losses, float loss_scale,
+                       float grad_scale, const float *loss_sums, double *losses, double loss_scale,
                        const double *norm_partials, int32_t n_norm_partials, pfa_stream_t stream);
 
 /* The whole minibatch loop of one clean_pufferl.train call on ONE rank (clean_pufferl.py:175-258 without the
  * target_kl early exit): update_epochs x num_minibatches x { pfa_ppo_mlp_grad, pfa_adam_clip_step } enqueued from
  * native code (no per-step host work).  opt_step = optimizer steps taken before this call; losses as above.
- * data_parallel != 0: every optimizer step all-reduces the flat bucket [gradient | 8 loss sums] over the RCCL
+ * data_parallel != 0: every optimizer step all-reduces the flat bucket [gradient | 16 loss-sum floats] over the RCCL
  * communicator of pfa_dist_init on `stream` (gradients are pre-divided by the GLOBAL minibatch rows = local rows x
  * world size; adv_stats must already hold the all-reduced sums) and takes the clip norm after the reduce. */
 int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                       const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                       float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
-                      float max_grad_norm, int32_t update_epochs, float *losses, void *workspace,
+                      float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
                       int32_t data_parallel, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -385,7 +387,7 @@ int pfa_store_rows(const pfa_experience *exp, int32_t rows, int32_t num_slots, i
 int pfa_gather_obs_time_major(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const pfa_ppo_hparams *hp,
                               int32_t obs_stride, float *out, pfa_stream_t stream);
 /* decode_actions + PPO loss on the time-major hidden states h [mbs][128] of minibatch mb: dout [mbs][16] (d loss / d the
- * padded head outputs), dh [mbs][128] (d loss / d h through the heads), loss_sums8 as in pfa_ppo_mlp_grad,
+ * padded head outputs), dh [mbs][128] (d loss / d h through the heads), loss_sums8 = the 16-float (hi, lo) tail of pfa_ppo_mlp_grad,
  * head_bias_grad16 (nullable) = column sums of dout = d loss / d (decoder.bias | value_head.bias | padding). */
 size_t pfa_lstm_heads_loss_workspace_bytes(void);
 int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
@@ -421,7 +423,7 @@ int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
 /* What train() logs (clean_pufferl.py:249-254,266-270) in one device buffer of 10 f64: out[0..5] = `losses` (the six
  * running means above), out[6..9] = sum y_true, sum y_true^2, sum adv, sum adv^2 with y_pred = values in storage
  * (step-major) order and y_true = advantages (env-major) + y_pred — the reference's explained-variance inputs. */
-int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, const float *losses,
+int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, const double *losses,
                        double *out10, void *workspace, pfa_stream_t stream);
 
 #ifdef __cplusplus

@@ -17,7 +17,7 @@ Experience is stored env-major on device, which is the order the reference gets 
 
 Data parallel (no reference counterpart): one process per GPU; rank r owns envs
 [r*N, (r+1)*N) (seeds seed + global index), parameters are broadcast from rank 0 at create(), and every
-optimizer step all-reduces one flat bucket (gradient + 8 loss sums) over RCCL; the advantage-normalisation sums
+optimizer step all-reduces one flat bucket (gradient + 8 loss sums as float pairs) over RCCL; the advantage-normalisation sums
 are all-reduced once per update so every rank normalises with the global-minibatch mean/std.
 """
 import ctypes as C
@@ -322,9 +322,9 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         flat_params=fp, rank=rank, world_size=world, native_dp=native_dp, lstm_engine=lstm_engine,
         env_offset=env_offset, host_bridge=host_bridge,
         workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
-        grads=torch.zeros(fp.count + 8, dtype=torch.float32, device=device),
+        grads=torch.zeros(fp.count + 16, dtype=torch.float32, device=device),   # gradient + 8 loss sums as (hi, lo) float pairs
         adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
-        loss_acc=torch.zeros(8, dtype=torch.float32, device=device),
+        loss_acc=torch.zeros(8, dtype=torch.float64, device=device),
         log_sums=torch.zeros(10, dtype=torch.float64, device=device),
         noise=None,            # optional explicit Exp(1) tensor [T][N][A] for the next evaluate() (parity tests)
         tape_stream=torch.cuda.Stream(device=device),   # reset-target tape is drawn one rollout ahead, off the critical path
@@ -527,7 +527,7 @@ def train(data):
                         dist.all_reduce(data.grads)
                     eng.clip_adam(data.grads, opt, config.max_grad_norm, data.loss_acc, loss_scale)
             if config.target_kl is not None:
-                if float(data.grads[fp.count + 4].item()) / global_mb_rows > config.target_kl:
+                if float(data.grads[fp.count + 8:fp.count + 10].double().sum().item()) / global_mb_rows > config.target_kl:
                     break
     native_loop = data.lstm_engine is None and (world == 1 or data.native_dp) and config.target_kl is None
     if native_loop:
@@ -561,7 +561,7 @@ def train(data):
         epochs_run += 1
         if config.target_kl is not None:
             # approx_kl of the LAST minibatch of this epoch (clean_pufferl.py:256-258) — needs a sync
-            last_kl = float(data.grads[fp.count + 4].item()) / global_mb_rows
+            last_kl = float(data.grads[fp.count + 8:fp.count + 10].double().sum().item()) / global_mb_rows
             if last_kl > config.target_kl:
                 break
 

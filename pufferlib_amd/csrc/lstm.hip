@@ -264,19 +264,25 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
     }
 }
 // 1024 threads: 32 strided chains per column (8 loss statistics + 16 head-output column sums), then a fixed-order tree.
-__global__ void __launch_bounds__(1024) stats_final_kernel(const float *partial, int nblocks, float *out8, float *out16) {
-    __shared__ float sh[32][32];
+// The 8 loss statistics are summed in f64 and leave as (hi, lo) float pairs (the tail of the gradient bucket, ppo_tile.hpp).
+__global__ void __launch_bounds__(1024) stats_final_kernel(const float *partial, int nblocks, float *loss_pairs16, float *out16) {
+    __shared__ double sh[32][32];
     const int i = threadIdx.x & 31, chain = threadIdx.x >> 5;
-    float s = 0.0f;
+    double s = 0.0;
     if (i < kHeadStatCols)
-        for (int b = chain; b < nblocks; b += 32) s += partial[(size_t)b * kHeadStatCols + i];
+        for (int b = chain; b < nblocks; b += 32) s += (double)partial[(size_t)b * kHeadStatCols + i];
     sh[chain][i] = s;
     __syncthreads();
     if (threadIdx.x < kHeadStatCols) {
-        float t = 0.0f;
+        double t = 0.0;
         for (int q = 0; q < 32; ++q) t += sh[q][threadIdx.x];
-        if (threadIdx.x < 8) out8[threadIdx.x] = t;
-        else if (out16) out16[threadIdx.x - 8] = t;
+        if (threadIdx.x < 8) {
+            const float hi = (float)t;
+            loss_pairs16[2 * threadIdx.x] = hi;
+            loss_pairs16[2 * threadIdx.x + 1] = (float)(t - (double)hi);
+        } else if (out16) {
+            out16[threadIdx.x - 8] = (float)t;
+        }
     }
 }
 

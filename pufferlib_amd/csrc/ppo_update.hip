@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "mlp_tile.hpp"
 #include "sampler.hpp"
+#include "ppo_tile.hpp"
 
 namespace pfa {
 
@@ -32,7 +33,6 @@ namespace pfa {
 constexpr int grad_pairs(int dp) { return dp <= 64 ? 4 : 2; }
 constexpr int grad_threads(int dp) { return grad_pairs(dp) * 2 * 64; }
 constexpr int grad_waves_per_simd(int dp) { return dp <= 64 ? 2 : 1; }
-constexpr int kNumStats = 8;                // 6 used: pg, v, entropy, old_kl, kl, clipfrac
 
 // LDS map of kernel A (floats).  A workgroup is 4 PAIRS of wavefronts; wave p (producer) and wave p+4 (consumer) share a
 // SIMD, so one wave's LDS waits / VALU stretches (the loss math) are covered by the other's MFMAs (two waves per SIMD fit
@@ -70,199 +70,18 @@ struct NativeLayout {
     static constexpr int kCount = kStats + kNumStats;
 };
 
-struct RowMap {  // minibatch row q -> flat env-major experience row (clean_pufferl.py:455-457)
-    int mb, nmb, horizon;
-    __device__ __forceinline__ long long flat(long long q) const {
-        const long long k = q / horizon, h = q - k * horizon;
-        return ((long long)mb + k * nmb) * horizon + h;
-    }
-    // 32-bit flat row of minibatch row q (batches stay far below 2^31 rows).
-    __device__ __forceinline__ unsigned row32(unsigned q) const {
-        const unsigned k = q / (unsigned)horizon, h = q - k * (unsigned)horizon;
-        return ((unsigned)mb + k * (unsigned)nmb) * (unsigned)horizon + h;
-    }
-    // Flat row of row r (0..15) of 16-row tile `tile` (wave-uniform).  When bptt_horizon is a multiple of 16 a tile
-    // never straddles a segment: `first` = row32(16*tile), computed ONCE per tile on the scalar unit, then + r.
-    __device__ __forceinline__ unsigned tile_first(unsigned tile) const {
-        return row32(__builtin_amdgcn_readfirstlane(tile) * 16u);
-    }
-    __device__ __forceinline__ unsigned tile_row(unsigned tile, unsigned first, int r, bool aligned) const {
-        return aligned ? first + (unsigned)r : row32(tile * 16u + (unsigned)r);
-    }
-};
-
-__device__ __forceinline__ void wave_lds_fence() {
-    // LDS is in-order per wave; this only stops the compiler from moving LDS accesses across the hand-off
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
-struct RowScalars {
-    int action;
-    float old_logprob, old_value, adv, ret, weight;  // weight 0 for rows of a padding tile
-};
-
-struct LossOut {
-    f32x4 dout;
-    float pg, v_loss, ent, neg_logratio, kl, clipped;
-};
-
-// PPO loss for the rows of one tile (clean_pufferl.py:202-238) and d(loss)/d(out^T fragment).
-// MH: MultiDiscrete (cleanrl.py:31-44) — `heads` packs the head sizes, rs.action the per-head choices (pfa_mlp_dims.heads); the
-// log-softmax, the chosen log-probability and the entropy are taken per head and summed.  The single-head instantiation is the
-// code the headline workload runs, unchanged.
-template <bool MH>
-__device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScalars &rs, int a, uint32_t heads, int g,
-                                                 const pfa_ppo_hparams &hp, float adv_mean, float adv_den, float inv_rows) {
-    float nl[4], p[4], hent[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
-    bool chosen[4];
-    if constexpr (MH) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            nl[r] = p[r] = hent[r] = 0.0f;
-            chosen[r] = false;
-            if (4 * g + r == a) new_value = out[r];
-        }
-        int start = 0;
-        for (int h = 0; h < 8; ++h) {
-            const int sz = (int)((heads >> (4 * h)) & 15u);
-            if (sz == 0) break;  // uniform
-            bool mem[4];
-            float lmax = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int o = 4 * g + r;
-                mem[r] = o >= start && o < start + sz;
-                if (mem[r]) lmax = fmaxf(lmax, out[r]);
-            }
-            lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
-            lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
-            float ev[4], se = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ev[r] = mem[r] ? expf(out[r] - lmax) : 0.0f;
-                se += ev[r];
-            }
-            se += __shfl_xor(se, 16, 64);
-            se += __shfl_xor(se, 32, 64);
-            const float lse = lmax + logf(se), inv_se = 1.0f / se;
-            const int act = start + (int)(((uint32_t)rs.action >> (4 * h)) & 15u);
-            float he = 0.0f;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (mem[r]) {
-                    nl[r] = out[r] - lse;
-                    p[r] = ev[r] * inv_se;
-                    he -= nl[r] * p[r];
-                    chosen[r] = 4 * g + r == act;
-                    if (chosen[r]) new_logprob += nl[r];
-                }
-            he += __shfl_xor(he, 16, 64);
-            he += __shfl_xor(he, 32, 64);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (mem[r]) hent[r] = he;
-            ent += he;
-            start += sz;
-        }
-        new_logprob += __shfl_xor(new_logprob, 16, 64);
-        new_logprob += __shfl_xor(new_logprob, 32, 64);
-        new_value += __shfl_xor(new_value, 16, 64);
-        new_value += __shfl_xor(new_value, 32, 64);
-    } else {
-    // log-softmax over the A logits of row c, spread over lane groups: reduce with xor 16 / 32
-    float lmax = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (4 * g + r < a) lmax = fmaxf(lmax, out[r]);
-    lmax = fmaxf(lmax, __shfl_xor(lmax, 16, 64));
-    lmax = fmaxf(lmax, __shfl_xor(lmax, 32, 64));
-    float ev[4], se = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        ev[r] = 4 * g + r < a ? expf(out[r] - lmax) : 0.0f;
-        se += ev[r];
-    }
-    se += __shfl_xor(se, 16, 64);
-    se += __shfl_xor(se, 32, 64);
-    const float lse = lmax + logf(se);
-    const float inv_se = 1.0f / se;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
-        nl[r] = out[r] - lse;
-        p[r] = ev[r] * inv_se;  // softmax; the exponentials are shared with the log-sum-exp
-        if (o < a) ent -= nl[r] * p[r];
-        chosen[r] = o == rs.action;
-        if (chosen[r]) new_logprob = nl[r];
-        if (o == a) new_value = out[r];
-    }
-    ent += __shfl_xor(ent, 16, 64);
-    ent += __shfl_xor(ent, 32, 64);
-    new_logprob += __shfl_xor(new_logprob, 16, 64);
-    new_logprob += __shfl_xor(new_logprob, 32, 64);
-    new_value += __shfl_xor(new_value, 16, 64);
-    new_value += __shfl_xor(new_value, 32, 64);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) hent[r] = ent;
-    }
-
-    const float logratio = new_logprob - rs.old_logprob;
-    const float ratio = expf(logratio);
-    const float adv = hp.norm_adv ? (rs.adv - adv_mean) / adv_den : rs.adv;
-    const float lo = 1.0f - hp.clip_coef, hi = 1.0f + hp.clip_coef;
-    const float pg1 = -adv * ratio;
-    const float pg2 = -adv * fminf(fmaxf(ratio, lo), hi);
-    const bool inside = ratio >= lo && ratio <= hi;
-    // d pg / d ratio under torch.max's tie rule (grad/2 to each side) and clamp's pass-through inside [lo, hi]
-    float dpg_dratio;
-    if (pg1 > pg2) dpg_dratio = -adv;
-    else if (pg1 < pg2) dpg_dratio = inside ? -adv : 0.0f;
-    else dpg_dratio = inside ? -adv : -0.5f * adv;
-    const float scale = inv_rows * rs.weight;
-    const float g_lp = dpg_dratio * ratio * scale;  // d loss / d new_logprob
-
-    float v_loss, dv;
-    if (hp.clip_vloss) {
-        const float du = new_value - rs.ret;
-        const float vl_u = du * du;
-        const float delta = new_value - rs.old_value;
-        const float v_clipped = rs.old_value + fminf(fmaxf(delta, -hp.vf_clip_coef), hp.vf_clip_coef);
-        const float dc = v_clipped - rs.ret;
-        const float vl_c = dc * dc;
-        const bool vin = delta >= -hp.vf_clip_coef && delta <= hp.vf_clip_coef;
-        v_loss = 0.5f * fmaxf(vl_u, vl_c);
-        const float gu = 2.0f * du, gc = vin ? 2.0f * dc : 0.0f;
-        const float sel = vl_u > vl_c ? gu : (vl_u < vl_c ? gc : 0.5f * (gu + gc));
-        dv = 0.5f * sel;
-    } else {
-        const float du = new_value - rs.ret;
-        v_loss = 0.5f * du * du;
-        dv = du;
-    }
-    dv *= hp.vf_coef * scale;
-
-    LossOut lo_;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
-        float d = 0.0f;
-        if (o < a) {
-            // d new_logprob/d logit_o = [o==action] - p_o ; d entropy/d logit_o = -p_o (nl_o + H)
-            d = g_lp * ((chosen[r] ? 1.0f : 0.0f) - p[r]) + hp.ent_coef * scale * p[r] * (nl[r] + hent[r]);
-        } else if (o == a) {
-            d = dv;
-        }
-        lo_.dout[r] = d;
-    }
-    lo_.pg = fmaxf(pg1, pg2) * rs.weight;
-    lo_.v_loss = v_loss * rs.weight;
-    lo_.ent = ent * rs.weight;
-    lo_.neg_logratio = -logratio * rs.weight;
-    lo_.kl = ((ratio - 1.0f) - logratio) * rs.weight;
-    lo_.clipped = (fabsf(ratio - 1.0f) > hp.clip_coef ? 1.0f : 0.0f) * rs.weight;
-    return lo_;
-}
+#ifdef PFA_PROBES
+// tools/probe_grad.py --trace: s_memtime stamps of workgroup 0 (lane 0 of every wave), [wave][tile][8]
+__device__ unsigned long long *g_trace = nullptr;
+__device__ int g_trace_tiles = 0;
+#define PFA_STAMP(j, k)                                                                                         \
+    do {                                                                                                        \
+        if (g_trace && blockIdx.x == 0 && lane == 0 && (j) < g_trace_tiles)                                     \
+            g_trace[((size_t)wv * g_trace_tiles + (j)) * 8 + (k)] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define PFA_STAMP(j, k) do { } while (0)
+#endif
 
 // ABL: ablation mask for tools/probe_grad.py (-DPFA_PROBES builds only; the product always runs ABL = 0):
 //   1 skip the loss math   2 skip the consumer's dW1 MFMAs   4 skip the forward MFMAs
@@ -273,7 +92,10 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
 // i.e. the consumer's whole share of tile j (160 MFMAs) runs under the producer's forward + loss of tile j+1 (192 MFMAs + the
 // VALU-heavy loss).  alpha_j: the consumer is done reading hidden/dout(j-1), so they may be overwritten; beta_j: published.
 // dh's C fragment (rows 4g+r, column u = c) IS the B fragment dW1 = X^T dh needs, so the consumer never stages dh.
-template <int DP, int ABL = 0, int KKU = DP / 4, bool MH = false>
+// KTM / COL: dW1 = X^T dh is contracted on MFMA for the first KTM 16-column tiles of X only; COL adds ONE trailing column
+// (k = 16 KTM) as 32 VALU fmas per tile.  Columns beyond that are observation padding whose gradient is 0 by construction.
+// The 7x7 grid (49 = 3 x 16 + 1 columns) runs <KTM = 3, COL = true>: 32 MFMAs (1024 matrix-pipe cycles) less per tile.
+template <int DP, int ABL = 0, int KKU = DP / 4, bool MH = false, int KTM = DP / 16, bool COL = false>
 __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, uint32_t heads,
                         pfa_ppo_hparams hp, const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
@@ -392,6 +214,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
         float *hsP = pl + L::kHT, *dsP = pl + L::kDT;
         for (int j = 0; j < J; ++j) {
             float *xs = pl + L::kXT + (j & 1) * 16 * XS;
+            PFA_STAMP(j, 0);
             // ---- stage X(j), forward, heads, loss (registers + this tile's X slot only) ------------------------------
 #pragma unroll
             for (int q = 0; q < NLD; ++q) {
@@ -406,6 +229,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             const RowScalars rs = rspre;
             prefetch(pair_global + (long long)(j + 1) * pair_count);  // lands during this tile's ~10k cycles
             wave_lds_fence();
+            PFA_STAMP(j, 1);
 
             f32x4 h[kMT];
 #pragma unroll
@@ -444,12 +268,14 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 }
                 out = (o[0] + o[1]) + (o[2] + o[3]);  // out^T[o = 4g + r][row = c]
             }
+            if (out[0] == 12345.678f) PFA_STAMP(j, 7);   // (never true) pins the stamp behind the heads' result
+            PFA_STAMP(j, 2);
             LossOut lo;
             if constexpr (ABL & 1) {
                 lo.dout = out * rs.weight;
                 lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs.adv;
             } else {
-                lo = ppo_loss_tile<MH>(out, rs, a, heads, g, hp, adv_mean, adv_den, inv_rows);
+                lo = ppo_loss_tile<MH, !MH>(out, rs, a, heads, g, hp, adv_mean, adv_den, inv_rows);   // one head: permlane-swap reductions
             }
             const f32x4 dout = lo.dout;
 #pragma unroll
@@ -462,12 +288,16 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 stats[4] += lo.kl;
                 stats[5] += lo.clipped;
             }
+            if (stats[0] == 12345.678f) PFA_STAMP(j, 7);
+            PFA_STAMP(j, 3);
             __syncthreads();  // alpha_j: the consumer has finished with hidden/dout of tile j-1
+            PFA_STAMP(j, 4);
             // ---- publish hidden(j) [row][u] and dout(j) [row][o] ------------------------------------------------------
 #pragma unroll
             for (int m = 0; m < kMT; ++m) *reinterpret_cast<f32x4 *>(hsP + c * HS + 16 * m + 4 * g) = h[m];
             *reinterpret_cast<f32x4 *>(dsP + c * DS + 4 * g) = dout;  // dout[row = c][o = 4g..4g+3]
             __syncthreads();  // beta_j
+            PFA_STAMP(j, 5);
             // ---- dW2v^T[u][o] += hidden^T . dout, both operands back from LDS in A/B fragment order -----------------------
             if (!(ABL & 2)) {
                 float dfrag[4];  // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c)
@@ -529,11 +359,14 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
         }
     } else {
         // ------------------------------------------------------------------------------------------ consumer
-        f32x4 acc_dw1[KT][kMT];
+        f32x4 acc_dw1[KTM][kMT];
+        float acc_col[kMT];   // COL: dW1[u = 16m + c][k = 16 KTM], per-lane partial over the lane's rows 4g + r
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
+        for (int m = 0; m < kMT; ++m) {
 #pragma unroll
-            for (int m = 0; m < kMT; ++m) acc_dw1[kt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < KTM; ++kt) acc_dw1[kt][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc_col[m] = 0.0f;
+        }
         __syncthreads();  // fragment tables ready (same barrier as the producers')
 
         float db1[kMT];
@@ -548,11 +381,13 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             if ((ABL & 2) || tile >= tiles) return;
             const float *xs = pl + L::kXT + (jj & 1) * 16 * XS;
             const f32x4 dout = *reinterpret_cast<const f32x4 *>(dsP + c * DS + 4 * g);
-            float xa[KT][4];
+            float xa[KTM][4], xc[4];
 #pragma unroll
-            for (int kt = 0; kt < KT; ++kt)
+            for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
+                for (int kt = 0; kt < KTM; ++kt) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
+                xc[r] = COL ? xs[(4 * g + r) * XS + 16 * KTM] : 0.0f;
+            }
 #pragma unroll
             for (int m0 = 0; m0 < kMT; m0 += 4) {  // four hidden tiles = four independent accumulator chains
                 f32x4 dh[4], wb[4];
@@ -574,19 +409,25 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                     for (int r = 0; r < 4; ++r) {
                         dh[q][r] = hrow[q][r] > 0.0f ? dh[q][r] : 0.0f;  // relu'
                         db1[m0 + q] += dh[q][r];
+                        if (COL) acc_col[m0 + q] = fmaf(xc[r], dh[q][r], acc_col[m0 + q]);
                     }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int kt = 0; kt < KT; ++kt) acc_dw1[kt][m0 + q] = mfma16(xa[kt][r], dh[q][r], acc_dw1[kt][m0 + q]);
+                        for (int kt = 0; kt < KTM; ++kt) acc_dw1[kt][m0 + q] = mfma16(xa[kt][r], dh[q][r], acc_dw1[kt][m0 + q]);
             }
         };
         for (int j = 0; j < J; ++j) {
+            PFA_STAMP(j, 0);
             if (j > 0) backward_tile(j - 1);
+            if (acc_dw1[0][0][0] == 12345.678f) PFA_STAMP(j, 7);
+            PFA_STAMP(j, 1);
             __syncthreads();  // alpha_j
+            PFA_STAMP(j, 2);
             __syncthreads();  // beta_j
+            PFA_STAMP(j, 3);
         }
         backward_tile(J - 1);
         __syncthreads();  // alpha_J / beta_J: same barrier count as the producers
@@ -597,6 +438,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
         for (int m = 0; m < kMT; ++m) {
             db1[m] += __shfl_xor(db1[m], 16, 64);
             db1[m] += __shfl_xor(db1[m], 32, 64);
+            if (COL) acc_col[m] = gsum<true>(acc_col[m]);   // over the lane groups: all 16 rows of the tile
         }
         float *red = lds + (pair & 1) * NL::kCount;
         for (int turn = 0; turn < kGradPairs / 2; ++turn) {
@@ -609,7 +451,12 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int idx = NL::kDw1 + ((kt * kMT + m) * 4 + r) * 64 + lane;
-                            red[idx] = (first ? 0.0f : red[idx]) + acc_dw1[kt][m][r];
+                            // k-tiles beyond KTM: the trailing column sits in the slot of (kt = KTM, r = 0, g = 0) -> W1[16m + c][16 KTM],
+                            // every other slot there is the (zero) gradient of observation padding
+                            float val = 0.0f;
+                            if (kt < KTM) val = acc_dw1[kt < KTM ? kt : 0][m][r];
+                            else if (COL && kt == KTM && r == 0 && g == 0) val = acc_col[m];
+                            red[idx] = (first ? 0.0f : red[idx]) + val;
                         }
                 if (g == 0) {
 #pragma unroll
@@ -634,9 +481,11 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, 
                                                         double *norm_partials) {
     using NL = NativeLayout<DP>;
     __shared__ float sh[4][64];
+    __shared__ double shd[4][64];   // the loss-sum slots are carried in f64
     const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + ql;
     float acc = 0.0f;
+    double dacc = 0.0;
     if (q < NL::kCount) {
         for (int i0 = sl; i0 < nparts; i0 += 64) {
             float v[16];
@@ -646,10 +495,14 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, 
                 v[u] = i < nparts ? partials[(size_t)i * NL::kCount + q] : 0.0f;
             }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) acc += v[u];
+            for (int u = 0; u < 16; ++u) {
+                acc += v[u];
+                if (q >= NL::kStats) dacc += (double)v[u];
+            }
         }
     }
     sh[sl][ql] = acc;
+    shd[sl][ql] = dacc;
     __syncthreads();
     if (sl != 0) return;
     const MlpOffsets off = mlp_offsets(DP, a);
@@ -672,7 +525,11 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, 
             if (o < a) p = off.b2 + o;
             else if (o == a) p = off.bv;
         } else {
-            p = off.count + (q - NL::kStats);
+            // loss sums: summed over the partials in f64 and left as (hi, lo) float pairs behind the gradient
+            const double t = (shd[0][ql] + shd[1][ql]) + (shd[2][ql] + shd[3][ql]);
+            const float hi = (float)t;
+            grads[off.count + 2 * (q - NL::kStats)] = hi;
+            grads[off.count + 2 * (q - NL::kStats) + 1] = (float)(t - (double)hi);
         }
         if (p >= 0) grads[p] = s;
     }
@@ -752,9 +609,9 @@ __global__ void __launch_bounds__(256) ev_partial_kernel(const float *adv, const
     if (threadIdx.x < 4) partial[blockIdx.x * 4 + threadIdx.x] = sh[threadIdx.x][0];
 }
 // out[0..5] = the six running loss means (f32 -> f64), out[6..9] = the four sums: one D2H copy serves train()'s log line.
-__global__ void ev_final_kernel(const double *partial, const float *losses, double *out10) {
+__global__ void ev_final_kernel(const double *partial, const double *losses, double *out10) {
     const int q = threadIdx.x;
-    if (q < 6) out10[q] = losses ? (double)losses[q] : 0.0;
+    if (q < 6) out10[q] = losses ? losses[q] : 0.0;
     if (q >= 6 && q < 10) {
         double s = 0.0;
         for (int b = 0; b < kEvBlocks; ++b) s += partial[b * 4 + (q - 6)];
@@ -770,7 +627,7 @@ __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, 
                                                                 float *exp_avg_sq, long long count, float neg_step_size,
                                                                 float bc2_sqrt, float beta1, float beta2, float eps,
                                                                 float max_grad_norm, float grad_scale, const float *loss_sums,
-                                                                float *losses, float loss_scale, const double *norm_partials,
+                                                                double *losses, double loss_scale, const double *norm_partials,
                                                                 int n_norm_partials) {
     __shared__ double sh[kAdamThreads / 64];
     double ss = 0.0;
@@ -814,7 +671,8 @@ __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, 
         exp_avg[i] = m;
         exp_avg_sq[i] = v;
     }
-    if (blockIdx.x == 0 && loss_sums && losses && threadIdx.x < 6) losses[threadIdx.x] += loss_sums[threadIdx.x] * loss_scale;
+    if (blockIdx.x == 0 && loss_sums && losses && threadIdx.x < 6)   // (hi, lo) pairs of the f64 sums
+        losses[threadIdx.x] += ((double)loss_sums[2 * threadIdx.x] + (double)loss_sums[2 * threadIdx.x + 1]) * loss_scale;
 }
 
 static int check_update_args(const pfa_experience *ex, int64_t batch_rows, const pfa_mlp_dims *dims,
@@ -829,8 +687,11 @@ static int check_update_args(const pfa_experience *ex, int64_t batch_rows, const
 }
 
 static size_t native_count(int dp) { return (size_t)(dp / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats; }
-static double *norm_partials_of(void *workspace, int dp) {  // after the gradient partials
-    return (double *)((char *)workspace + align_up((size_t)256 * native_count(dp) * sizeof(float), 256));
+static size_t partials_bytes(const pfa_mlp_dims *dims) {
+    return align_up((size_t)256 * native_count(dims->obs_stride) * sizeof(float), 256);
+}
+static double *norm_partials_of(void *workspace, const pfa_mlp_dims *dims) {  // after the gradient partials
+    return (double *)((char *)workspace + partials_bytes(dims));
 }
 
 static int grad_grid(int64_t mb_rows, int dp) {
@@ -846,11 +707,10 @@ using namespace pfa;
 extern "C" size_t pfa_ppo_workspace_bytes(const pfa_mlp_dims *dims, int64_t batch_rows, const pfa_ppo_hparams *hp) {
     if (!dims || !hp || hp->num_minibatches < 1) return 0;
     (void)batch_rows;
-    const size_t native = (size_t)(dims->obs_stride / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats;
-    const size_t partials = align_up((size_t)256 * native * sizeof(float), 256);
+    const size_t native = native_count(dims->obs_stride);
     const size_t advp = align_up((size_t)hp->num_minibatches * kAdvChunks * 2 * sizeof(double), 256);
     const size_t normp = align_up(((native + 63) / 64) * sizeof(double), 256);
-    return partials + (advp > normp ? advp : normp);
+    return partials_bytes(dims) + (advp > normp ? advp : normp);
 }
 
 extern "C" int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_ppo_hparams *hp, double *stats,
@@ -889,24 +749,25 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     const int64_t mbs = batch_rows / hp->num_minibatches;
     PFA_REQUIRE(mbs % 16 == 0, "ppo.grad: minibatch_size must be a multiple of 16 (got %lld)", (long long)mbs);
     PFA_REQUIRE(global_mb_rows >= mbs, "ppo.grad: global_mb_rows < local minibatch rows");
-    const int grid = grad_grid(mbs, dims->obs_stride);
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
-#define PFA_LAUNCH_GRAD_KM(DPV, KKUV, MHV)                                                                                  \
+    const int grid = grad_grid(mbs, dims->obs_stride);
+#define PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, KTMV, COLV)                                                                    \
     {                                                                                                                      \
         constexpr size_t lds_bytes = (size_t)GradLds<DPV>::kFloats * sizeof(float);                                        \
         static_assert((size_t)2 * NativeLayout<DPV>::kCount * sizeof(float) <= lds_bytes,                                   \
                       "the two reduction buffers must fit in the tile/table area");                                       \
         static bool attr_set = false;                                                                                      \
         if (!attr_set) {                                                                                                   \
-            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV>,                        \
+            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV>,            \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
             attr_set = true;                                                                                               \
         }                                                                                                                  \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes,         \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes, \
                            (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions, dims->heads, *hp,     \
                            adv_stats, (double)global_mb_rows, partials);                                                   \
     }
+#define PFA_LAUNCH_GRAD_KM(DPV, KKUV, MHV) PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, DPV / 16, false)
 #define PFA_LAUNCH_GRAD_K(DPV, KKUV) PFA_LAUNCH_GRAD_KM(DPV, KKUV, false)
 #define PFA_LAUNCH_GRAD(DPV)                                        \
     if (dims->heads) PFA_LAUNCH_GRAD_KM(DPV, DPV / 4, true)         \
@@ -919,17 +780,19 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
             case 96: PFA_LAUNCH_GRAD(96) break;
             case 128: PFA_LAUNCH_GRAD(128) break;
             default:
-                if (!dims->heads && (dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)   // 7x7 grid: 3 of 16 k-steps are pure padding
+                if (!dims->heads && dims->obs_dim == 49) PFA_LAUNCH_GRAD_FULL(64, 13, false, 3, true)   // 7x7 grid: 13 of 16 forward k-steps, dW1 = 3 k-tiles + column 48
+                else if (!dims->heads && (dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)
                 else PFA_LAUNCH_GRAD(64)
                 break;
         }
     }
 #undef PFA_LAUNCH_GRAD_KM
+#undef PFA_LAUNCH_GRAD_FULL
 #undef PFA_LAUNCH_GRAD
 #undef PFA_LAUNCH_GRAD_K
     PFA_LAUNCH_CHECK();
     ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
-    double *normp = norm_partials_of(workspace, dims->obs_stride);
+    double *normp = norm_partials_of(workspace, dims);
     switch (dims->obs_stride) {
         case 16: hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3((NativeLayout<16>::kCount + 63) / 64), dim3(256), 0,
                                     (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
@@ -948,7 +811,7 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
 
 extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, float lr,
                                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, float grad_scale,
-                                  const float *loss_sums, float *losses, float loss_scale, const double *norm_partials,
+                                  const float *loss_sums, double *losses, double loss_scale, const double *norm_partials,
                                   int32_t n_norm_partials, pfa_stream_t stream) {
     PFA_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam: null buffer");
     PFA_REQUIRE(count >= 1 && step >= 1, "adam: count and step must be >= 1");
@@ -968,7 +831,7 @@ extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_
 extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                                  const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                                  float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
-                                 float max_grad_norm, int32_t update_epochs, float *losses, void *workspace,
+                                 float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
                                  int32_t data_parallel, pfa_stream_t stream) {
     if (int rc = check_update_args(exp, batch_rows, dims, hp)) return rc;
     PFA_REQUIRE(update_epochs >= 0 && opt_step >= 0, "ppo.train: bad epoch / step count");
@@ -977,21 +840,21 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
     const int64_t mbs = batch_rows / hp->num_minibatches;
     const int64_t global_mbs = mbs * world;
     const int64_t count = mlp_offsets(dims->obs_stride, dims->num_actions).count;
-    const float loss_scale = (float)(1.0 / ((double)global_mbs * hp->num_minibatches));
+    const double loss_scale = 1.0 / ((double)global_mbs * hp->num_minibatches);
     for (int e = 0; e < update_epochs; ++e)
         for (int mb = 0; mb < hp->num_minibatches; ++mb) {
             if (int rc = pfa_ppo_mlp_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, global_mbs, grads, workspace, stream))
                 return rc;
             ++opt_step;
             if (data_parallel) {
-                // one flat bucket per optimizer step: gradient (already / global rows) + 8 loss sums, on this stream
-                if (int rc = dist_all_reduce(grads, (size_t)count + kNumStats, false, (hipStream_t)stream)) return rc;
+                // one flat bucket per optimizer step: gradient (already / global rows) + the loss-sum pairs, on this stream
+                if (int rc = dist_all_reduce(grads, (size_t)count + kTailFloats, false, (hipStream_t)stream)) return rc;
                 if (int rc = pfa_adam_clip_step(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, opt_step,
                                                 max_grad_norm, 1.0f, grads + count, losses, loss_scale, nullptr, 0, stream))
                     return rc;
             } else if (int rc = pfa_adam_clip_step(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, opt_step,
                                                    max_grad_norm, 1.0f, grads + count, losses, loss_scale,
-                                                   norm_partials_of(workspace, dims->obs_stride),
+                                                   norm_partials_of(workspace, dims),
                                                    (int)((native_count(dims->obs_stride) + 63) / 64), stream)) {
                 return rc;
             }
@@ -1001,6 +864,11 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
 
 #ifdef PFA_PROBES
 // Probe-only entry (tools/probe_grad.py): same launch as pfa_ppo_mlp_grad for obs_stride 64 with an ablation mask.
+extern "C" int pfa_probe_set_trace(unsigned long long *buf, int tiles) {
+    PFA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)));
+    PFA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_tiles), &tiles, sizeof(tiles)));
+    return 0;
+}
 extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
                               const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats, float *grads,
                               void *workspace, int32_t abl, pfa_stream_t stream) {
@@ -1011,9 +879,9 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
     constexpr size_t lds_bytes = (size_t)GradLds<64>::kFloats * sizeof(float);
 #define PFA_PROBE_CASE(A)                                                                                              \
     case A:                                                                                                            \
-        PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A>,                                    \
+        PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A, 13>,                                \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A>), dim3(grid), dim3(grad_threads(64)), lds_bytes, (hipStream_t)stream, \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A, 13>), dim3(grid), dim3(grad_threads(64)), lds_bytes, (hipStream_t)stream, \
                            *exp, map, (long long)mbs, params, dims->num_actions, 0u, *hp, adv_stats, (double)mbs, partials); \
         break;
     switch (abl) {
@@ -1027,7 +895,7 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
 }
 #endif
 
-extern "C" int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, const float *losses,
+extern "C" int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, const double *losses,
                                   double *out10, void *workspace, pfa_stream_t stream) {
     PFA_REQUIRE(exp && exp->advantages && exp->values && out10 && workspace, "train_log_sums: null buffer");
     PFA_REQUIRE(num_envs >= 1 && batch_rows % num_envs == 0, "train_log_sums: batch must be whole rollout steps");

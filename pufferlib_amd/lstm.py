@@ -145,7 +145,7 @@ class Engine:
         self.state = True
         h_all = self.Hs[1:].view(M, H)
         # ---- heads + loss ----------------------------------------------------------------------------------------
-        loss_sums = grads[fp.count:fp.count + 8]
+        loss_sums = grads[fp.count:fp.count + 16]         # 8 f64 sums as (hi, lo) float pairs
         _lib.check(L.pfa_lstm_heads_loss(_lib.ptr(h_all), C.byref(exp.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hp),
                                          _lib.ptr(adv_stats), global_mb_rows, _lib.ptr(self.dout), _lib.ptr(self.dh_heads),
                                          _lib.ptr(loss_sums), _lib.ptr(self.bsum16), _lib.ptr(self.ws), stream), 'lstm_heads_loss')

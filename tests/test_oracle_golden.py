@@ -386,3 +386,18 @@ def test_parallel_form_of_the_spaces_stream_equals_the_sequential_one():
             want.append(vec.observations.copy())
         got = spaces_stream.parallel_rows(seed, n * rounds, window=n * rounds * 90)
         assert np.array_equal(got, np.concatenate(want)), seed
+
+
+def test_vectorised_philox_equals_the_c_restatement():
+    """oracle/c_oracle.philox_exp_noise (numpy) feeds the full-size GPU parity test: pin it word for word against
+    po_philox4x32_10 (the restatement of pufferlib_amd/csrc/philox.hpp's stream), including 64-bit seeds / steps and row offsets."""
+    from oracle import c_oracle
+    for seed, step, off, rows, cols in [(1, 0, 0, 33, 8), (1, 127, 4096, 5, 8), ((9 << 32) | 7, (3 << 32) + 11, 100, 4, 15), (42, 5, 0, 3, 3)]:
+        got = c_oracle.philox_exp_noise(seed, step, rows, cols, row_offset=off)
+        assert got.shape == (rows, cols) and got.dtype == np.float32
+        for e in range(rows):
+            for j in range((cols + 3) // 4):
+                w = c_oracle.philox4x32_10([e + off, j, step & 0xFFFFFFFF, step >> 32], [seed & 0xFFFFFFFF, seed >> 32])
+                u = ((w >> 8).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
+                n = min(4, cols - 4 * j)
+                assert np.array_equal(got[e, 4 * j:4 * j + n], (-np.log(u))[:n]), (seed, step, e, j)
