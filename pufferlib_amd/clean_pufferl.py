@@ -665,6 +665,61 @@ def try_load_checkpoint(data):
     print(f'Loaded checkpoint {resume["model_name"]}')
 
 
+def rollout(env_creator, env_kwargs, agent_creator, agent_kwargs, model_path=None, device='cuda', steps=None, frame_sleep=None):
+    """clean_pufferl.rollout (clean_pufferl.py:551-594), the eval / viewer loop of ``demo.py --mode eval``: one env behind the
+    vecenv API, render, policy forward, step, print the reward.  The env is device-resident when this package hosts its
+    creator (pufferlib_amd.demo.device_backend_for), else the reference's own Serial.  `steps` (None = forever, like the
+    reference) and `frame_sleep` are additions so that the loop can be driven by tests."""
+    from . import demo as _demo
+    from . import vector as _vector
+    cls = _demo.device_backend_for(env_creator)
+
+    def make_env(kw):
+        if cls is not None:
+            return _vector.make(env_creator, env_kwargs=kw, backend=cls)
+        import pufferlib.vector as ref_vector          # a host env: the reference package must be there anyway
+        return ref_vector.make(env_creator, env_kwargs=kw)
+    try:
+        env = make_env({'render_mode': 'rgb_array', **env_kwargs})
+    except Exception:
+        env = make_env(env_kwargs)
+    if model_path is None:
+        agent = agent_creator(env, **agent_kwargs).to(device)
+    else:
+        agent = torch.load(model_path, map_location=device, weights_only=False)
+    ob, info = env.reset()
+    driver = env.driver_env
+    if steps is None:
+        os.system('clear')
+    state = None
+    n = 0
+    rewards = []
+    while steps is None or n < steps:
+        render = driver.render()
+        if driver.render_mode == 'ansi':
+            print('\033[0;0H' + render + '\n')
+            time.sleep(0.6 if frame_sleep is None else frame_sleep)
+        elif driver.render_mode == 'rgb_array':
+            import cv2
+            render = cv2.cvtColor(render, cv2.COLOR_RGB2BGR)
+            cv2.imshow('frame', render)
+            cv2.waitKey(1)
+            time.sleep(1 / 24 if frame_sleep is None else frame_sleep)
+        with torch.no_grad():
+            ob = torch.as_tensor(ob).to(device)
+            if hasattr(agent, 'lstm'):
+                action, _, _, _, state = agent(ob, state)
+            else:
+                action, _, _, _ = agent(ob)
+            action = action.cpu().numpy().reshape(env.action_space.shape)
+        ob, reward = env.step(action)[:2]
+        reward = float(torch.as_tensor(reward).float().mean())
+        rewards.append(reward)
+        print(f'Reward: {reward:.4f}')
+        n += 1
+    return rewards
+
+
 def count_params(policy):
     """clean_pufferl.py:548-549: trainable parameter count (the dashboard's "Params" row)."""
     return sum(p.numel() for p in policy.parameters() if p.requires_grad)

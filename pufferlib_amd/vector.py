@@ -102,9 +102,21 @@ class SquaredSpec:
         self.emulated = namespace(observation_dtype=np.dtype(np.float32),
                                   emulated_observation_dtype=np.dtype((np.float32, (g, g))))
         self.done = True
+        self._live_obs = None        # the vecenv's live observation buffer (set by the backend): render() draws env 0
 
     def render(self):
-        return ''
+        """ocean.Squared.render (ocean.py:514-527) of env 0: targets blue, the agent red, empty cells grey."""
+        if self._live_obs is None:
+            return ''
+        g = self.grid_size
+        grid = self._live_obs[0, :g * g].detach().cpu().numpy().reshape(g, g)
+        chars = []
+        for row in grid:
+            for val in row:
+                color = 94 if val == 1 else (91 if val == -1 else 90)
+                chars.append(f'\033[{color}m██\033[0m')
+            chars.append('\n')
+        return ''.join(chars)
 
     def close(self):
         pass
@@ -200,6 +212,7 @@ class Squared:
         self.state = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
         self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.float32, device=dev)
         self.observations = self.obs_buf[:, :self.obs_dim].unflatten(1, (g, g))   # view, shape (N, g, g)
+        self.driver_env._live_obs = self.obs_buf
         self.rewards = torch.zeros(num_envs, dtype=torch.float32, device=dev)
         self.terminals_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
         self.truncations_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
