@@ -250,6 +250,32 @@ int pfa_multiagent_send(void *state, int32_t num_envs, const int64_t *actions, f
 int pfa_multiagent_episode_stats(void *state, int32_t num_envs, double *out4, int32_t reset, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Device-resident ocean `Spaces` vecenv — replaces pufferlib.vector.Serial over make_spaces
+ * (ocean/environment.py:66-69) = GymnasiumPufferEnv + EpisodeStats + ocean.Spaces (ocean.py:356-404): Dict observation
+ * emulated into 108-byte rows {flat int8[5] @0, image f32[5][5] @8}, handed to the policy as rows of 128 floats holding the
+ * BYTE values (what models.Default computes with observations.float(), models.py:50); Dict action = MultiDiscrete([2, 2]),
+ * here one packed word per env (head 0 = flat in bits 0..3, head 1 = image in bits 4..7, the pfa_mlp_dims.heads convention).
+ * Every step is terminal, the next send the reset row.  Observations come from numpy's process-global legacy generator
+ * (randn(5,5) then randint(-1, 2, 5, int8) per reset, in env order): pfa_spaces_async_reset(seed) = np.random.seed(seed)
+ * (what clean_pufferl.seed_everything does, clean_pufferl.py:596-600) + the N initial resets; later resets read the tape that
+ * pfa_spaces_fill_tape draws ahead (`rounds` x N resets; csrc/spaces.hip resolves the data-dependent stream positions in parallel).
+ * episode_stats: out[0..3] = {episodes, sum return, sum length, sum score}, out[4] = tape underrun flag (5 doubles).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t num_envs;
+    int32_t tape_rounds; /* ring capacity in reset rounds (>= 2) */
+} pfa_spaces_config;
+size_t pfa_spaces_state_bytes(const pfa_spaces_config *cfg);
+int pfa_spaces_async_reset(void *state, const pfa_spaces_config *cfg, int64_t seed, float *obs, float *rewards,
+                           uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_spaces_fill_tape(void *state, const pfa_spaces_config *cfg, int32_t rounds, pfa_stream_t stream);
+int pfa_spaces_send(void *state, const pfa_spaces_config *cfg, const int64_t *actions, float *obs, float *rewards,
+                    uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_spaces_episode_stats(void *state, const pfa_spaces_config *cfg, double *out5, int32_t reset, pfa_stream_t stream);
+int pfa_spaces_last_infos(void *state, const pfa_spaces_config *cfg, uint8_t *finished, double *episode_return,
+                          int32_t *episode_length, double *score, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Structured-observation unpack — replaces pufferlib.pytorch.nativize_tensor
  * (pufferlib/pytorch.py:96-145): flat emulated rows [num_rows][row_bytes] (device, 16-byte aligned) -> one dense tensor
  * per leaf of the observation space, in one launch.  A field is a leaf as pufferlib.pytorch.nativize_dtype
@@ -355,6 +381,13 @@ int pfa_rollout_lstm_squared(void *state, const pfa_squared_config *cfg, const f
                              const pfa_experience *exp, const float *noise, const pfa_noise_key *key,
                              int64_t env_offset, float *obs, float *rewards, uint8_t *terminals,
                              uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+/* The same persistent rollout over the ocean Memory vecenv (pfa_memory_*): clean_pufferl.evaluate (clean_pufferl.py:76-154) for
+ * RecurrentPolicy(LSTMWrapper(Default)) on make_memory envs as ONE launch; the solution tape must hold the reset rounds of
+ * these horizon_T sends (pfa_memory_fill_tape). */
+int pfa_rollout_lstm_memory(void *state, const pfa_memory_config *cfg, const float *params, const pfa_mlp_dims *dims,
+                            const void *wpack, float *h, float *c, const pfa_experience *exp, const float *noise,
+                            const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards, uint8_t *terminals,
+                            uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 /* --- the recurrent policy in training mode (csrc/lstm_seq.hip): forward over the `steps` (= bptt_horizon) time steps
  * of a minibatch of `rows` independent segments and back-propagation through time (clean_pufferl.py:186-193, :244).
  * Time-major buffers: obs_tm [steps][rows][obs_stride], xe / dh_heads / dxe [steps][rows][128], gates_act / dgates

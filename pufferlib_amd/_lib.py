@@ -16,8 +16,8 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'nativize.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp',
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'nativize.hip']
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
@@ -71,6 +71,10 @@ class NatField(C.Structure):
 
 class MemoryConfig(C.Structure):
     _fields_ = [('num_envs', C.c_int32), ('mem_length', C.c_int32), ('mem_delay', C.c_int32), ('tape_rounds', C.c_int32)]
+
+
+class SpacesConfig(C.Structure):
+    _fields_ = [('num_envs', C.c_int32), ('tape_rounds', C.c_int32)]
 
 
 class MlpDims(C.Structure):
@@ -142,6 +146,12 @@ _SIGNATURES = {
     'pfa_multiagent_state_bytes': (C.c_size_t, [C.c_int32]),
     'pfa_multiagent_async_reset': (C.c_int, [P, C.c_int32, P, P, P, P, P, P]),
     'pfa_multiagent_send': (C.c_int, [P, C.c_int32, P, P, P, P, P, P, P]),
+    'pfa_spaces_state_bytes': (C.c_size_t, [C.POINTER(SpacesConfig)]),
+    'pfa_spaces_async_reset': (C.c_int, [P, C.POINTER(SpacesConfig), C.c_int64, P, P, P, P, P, P]),
+    'pfa_spaces_fill_tape': (C.c_int, [P, C.POINTER(SpacesConfig), C.c_int32, P]),
+    'pfa_spaces_send': (C.c_int, [P, C.POINTER(SpacesConfig), P, P, P, P, P, P, P]),
+    'pfa_spaces_episode_stats': (C.c_int, [P, C.POINTER(SpacesConfig), P, C.c_int32, P]),
+    'pfa_spaces_last_infos': (C.c_int, [P, C.POINTER(SpacesConfig), P, P, P, P, P]),
     'pfa_multiagent_episode_stats': (C.c_int, [P, C.c_int32, P, C.c_int32, P]),
     'pfa_nativize_rows': (C.c_int, [P, C.c_int64, C.c_int32, P, C.c_int32, P]),
     'pfa_ppo_workspace_bytes': (C.c_size_t, [C.POINTER(MlpDims), C.c_int64, C.POINTER(PpoHparams)]),
@@ -163,6 +173,8 @@ _SIGNATURES = {
     'pfa_lstm_policy_step': (C.c_int, [P, C.c_int64, P, C.POINTER(MlpDims), P, P, P, P, C.POINTER(NoiseKey), C.c_int64,
                                        P, P, P, P, P]),
     'pfa_rollout_lstm_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), P, P, P, C.POINTER(Experience),
+                                           P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
+    'pfa_rollout_lstm_memory': (C.c_int, [P, C.POINTER(MemoryConfig), P, C.POINTER(MlpDims), P, P, P, C.POINTER(Experience),
                                            P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
     'pfa_lstm_pack_bwd': (C.c_int, [P, C.POINTER(MlpDims), P, P]),
     'pfa_lstm_seq_forward': (C.c_int, [P, C.c_int64, C.c_int32, P, C.POINTER(MlpDims), P, P, P, P, P, P]),

@@ -35,7 +35,7 @@ from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
-from .vector import Bandit, Memory, Multiagent, Squared, Stochastic
+from .vector import Bandit, Memory, Multiagent, Spaces, Squared, Stochastic
 
 
 def seed_everything(seed, torch_deterministic=True):
@@ -260,7 +260,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     n_params = sum(p.numel() for p in policy.parameters())
     msg = f'Model Size: {n_params} parameters'
 
-    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory, Bandit, Multiagent))   # anything else speaks the recv/send protocol on the host
+    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory, Bandit, Multiagent, Spaces))   # anything else speaks the recv/send protocol on the host
     if not isinstance(policy, (Policy, RecurrentPolicy)):
         from .models import find_lstm
         if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
@@ -287,8 +287,8 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         vecenv.env_offset = env_offset
     vecenv.async_reset(config.seed + env_offset)          # clean_pufferl.py:39; env i of rank r gets seed + r*N + i
     fp = policy.adopt(obs_stride, device)
-    if fp.multidiscrete and not host_mode:
-        raise NotImplementedError('MultiDiscrete action heads run on the host-vecenv path; the device-resident envs take one Discrete head')
+    if fp.multidiscrete and not (host_mode or isinstance(vecenv, Spaces)):
+        raise NotImplementedError('MultiDiscrete action heads run on the host-vecenv path and on vector.Spaces; the other device-resident envs take one Discrete head')
     native_dp = False
     if world > 1:
         dist.broadcast(fp.flat, src=0)
@@ -357,7 +357,14 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
-    if isinstance(vecenv, (Memory, Bandit, Multiagent)):   # no fused kernel for these envs: protocol-level pieces, still no host sync per step
+    if isinstance(vecenv, Memory) and data.lstm_engine is not None:   # the env that needs the recurrent policy: one persistent kernel
+        with profile.env:
+            vecenv.ensure_tape(T)
+        with profile.eval_forward:
+            data.lstm_engine.rollout(T, noise, policy.noise_seed, policy.noise_step, vecenv.env_offset)
+            vecenv.sends += T
+        return _finish_evaluate(data, N, T)
+    if isinstance(vecenv, (Memory, Bandit, Multiagent, Spaces)):   # no fused kernel for these envs: protocol-level pieces, still no host sync per step
         with profile.eval_forward:
             _rollout_stepwise(data, noise, T, N)
         return _finish_evaluate(data, N, T)
@@ -408,6 +415,8 @@ def _rollout_stepwise(data, noise, T, N):
     actions = torch.empty(N, dtype=torch.int64, device=dev)
     logprob = torch.empty(N, device=dev)
     value = torch.empty(N, device=dev)
+    if hasattr(vecenv, 'ensure_tape'):
+        vecenv.ensure_tape(T)        # the whole rollout's reset rounds in one go instead of one launch per resetting send
     for t in range(T):
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step + t)
         nz = None if noise is None else noise[t]

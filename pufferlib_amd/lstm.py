@@ -86,18 +86,19 @@ class Engine:
 
     # -------------------------------------------------------------------------------------------- rollout
     def rollout(self, T, noise, key_seed, step0, env_offset):
-        """clean_pufferl.evaluate's loop for a Squared vecenv: one persistent kernel (csrc/lstm_fused.hip).  The caller has
+        """clean_pufferl.evaluate's loop for a Squared or Memory vecenv: one persistent kernel (csrc/lstm_fused.hip).  The caller has
         made sure the reset-target tape holds the rounds of these T sends and accounts for them afterwards."""
         L = _lib.lib()
         vec, exp, fp = self.vec, self.exp, self.fp
         assert T == exp.horizon
         pack_gates(fp, self.wpack)
         key = _lib.NoiseKey(key_seed, step0)
-        _lib.check(L.pfa_rollout_lstm_squared(_lib.ptr(vec.state), C.byref(vec.cfg), _lib.ptr(fp.flat), C.byref(fp.dims),
-                                              _lib.ptr(self.wpack), _lib.ptr(self.lstm_h), _lib.ptr(self.lstm_c), C.byref(exp.c),
-                                              _lib.ptr(noise), C.byref(key), env_offset, _lib.ptr(vec.obs_buf),
-                                              _lib.ptr(vec.rewards), _lib.ptr(vec.terminals_u8), _lib.ptr(vec.truncations_u8),
-                                              _lib.ptr(vec.masks_u8), _lib.stream_handle()), 'rollout_lstm_squared')
+        fn = L.pfa_rollout_lstm_memory if type(vec).__name__ == 'Memory' else L.pfa_rollout_lstm_squared   # same signature
+        _lib.check(fn(_lib.ptr(vec.state), C.byref(vec.cfg), _lib.ptr(fp.flat), C.byref(fp.dims),
+                      _lib.ptr(self.wpack), _lib.ptr(self.lstm_h), _lib.ptr(self.lstm_c), C.byref(exp.c),
+                      _lib.ptr(noise), C.byref(key), env_offset, _lib.ptr(vec.obs_buf),
+                      _lib.ptr(vec.rewards), _lib.ptr(vec.terminals_u8), _lib.ptr(vec.truncations_u8),
+                      _lib.ptr(vec.masks_u8), _lib.stream_handle()), 'rollout_lstm')
 
     def rollout_stepwise(self, T, noise, key_seed, step0, env_offset):
         """The same rollout through the protocol-level pieces (policy_step / store / send), one launch sequence per step —

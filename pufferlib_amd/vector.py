@@ -426,9 +426,12 @@ class _DeviceVecEnv:
         self.agents_per_batch = self.num_agents = num_envs
         self.single_observation_space = self.driver_env.single_observation_space
         self.single_action_space = self.driver_env.single_action_space
-        self.action_space = spaces.MultiDiscrete([self.single_action_space.n] * num_envs)
+        if hasattr(self.single_action_space, 'n'):
+            self.action_space = spaces.MultiDiscrete([self.single_action_space.n] * num_envs)
+        else:                                                              # MultiDiscrete per agent: joint_space tiles it (vector.py:55-68)
+            self.action_space = spaces.MultiDiscrete(np.tile(np.asarray(self.single_action_space.nvec)[None], (num_envs, 1)))
         self.observation_space = spaces.Box(low=self.single_observation_space.low.min(), high=self.single_observation_space.high.max(),
-                                            shape=(num_envs, 1), dtype=np.float32)
+                                            shape=(num_envs,) + tuple(self.single_observation_space.shape), dtype=self.single_observation_space.dtype)
         self.agent_ids = np.arange(num_envs)
         self.initialized = False
         self.flag = RESET
@@ -656,6 +659,118 @@ class Memory(_DeviceVecEnv):
         _lib.check(self.L.pfa_memory_debug_solutions(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(bits), _lib.ptr(under),
                                                      _lib.stream_handle()), 'debug_solutions')
         return bits.cpu().numpy(), int(under.item())
+
+
+def make_spaces(**kwargs):
+    """Env creator token with the signature of ocean.environment.make_spaces (ocean/environment.py:66-69)."""
+    return SpacesSpec()
+
+
+class SpacesSpec:
+    """What ``driver_env`` exposes for ocean.Spaces behind GymnasiumPufferEnv: the EMULATED spaces (emulation.py:96-121) — the
+    Dict observation {flat: int8[5], image: f32[5,5]} as 108 bytes (flat @0, image @8, numpy align=True), the Dict action
+    {flat, image} as MultiDiscrete([2, 2]) in sorted-key order."""
+    ROW_BYTES = 108
+
+    def __init__(self):
+        self.single_observation_space = spaces.Box(low=0, high=255, shape=(self.ROW_BYTES,), dtype=np.uint8)
+        self.single_action_space = spaces.MultiDiscrete([2, 2])
+        self.observation_space = self.single_observation_space
+        self.action_space = self.single_action_space
+        self.num_agents = 1
+        self.render_mode = 'ansi'
+        self.emulated = namespace(
+            observation_dtype=np.dtype(np.uint8),
+            emulated_observation_dtype=np.dtype([('flat', np.int8, (5,)), ('image', np.float32, (5, 5))], align=True))
+        self.done = True
+
+    def render(self):
+        return ''
+
+    def close(self):
+        pass
+
+
+class Spaces(_DeviceVecEnv):
+    """Device-resident vecenv of N ocean Spaces envs (csrc/spaces.hip): structured observation (108-byte emulated rows, kept
+    on device as rows of 128 floats holding the byte values — what models.Default's ``observations.float()`` computes) and a
+    MultiDiscrete([2, 2]) action.  Observations come from numpy's process-global legacy generator, whose data-dependent
+    stream positions the tape kernel resolves ahead of the sends; ``async_reset(seed)`` = ``np.random.seed(seed)`` (what
+    clean_pufferl.seed_everything does before it) followed by the initial resets.  clean_pufferl.evaluate steps it through
+    ``device_send`` with packed action words (head h in bits 4h..4h+3), no host sync per step."""
+    FAMILY, NAMES, DEFAULTS = 'spaces', (), ()
+    SEEDED = False
+    obs_stride = 128
+
+    def _spec(self):
+        return SpacesSpec()
+
+    def _alloc_state(self):
+        import torch
+        self.obs_dim = SpacesSpec.ROW_BYTES
+        self.observations = self.obs_buf[:, :self.obs_dim]       # float byte values; recv() hands out the uint8 rows
+        self.episode_len = 2                                      # one (terminal) step + the auto-reset row
+        self.tape_rounds = 256
+        self.cfg = _lib.SpacesConfig(self.num_agents, self.tape_rounds)
+        nbytes = self.L.pfa_spaces_state_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise APIUsageError(self.L.pfa_last_error().decode())
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        self.rounds_filled = 1
+
+    def _rounds_needed(self, upto_send):
+        """Tape rounds consumed by async_reset (round 0) and sends 1..upto_send (every second send is a reset row)."""
+        return 1 + upto_send // 2
+
+    def ensure_tape(self, extra_sends):
+        need = self._rounds_needed(self.sends + extra_sends)
+        if need - self._rounds_needed(self.sends) >= self.tape_rounds:
+            raise APIUsageError(f'{extra_sends} sends need more reset rounds than the tape holds ({self.tape_rounds})')
+        while need > self.rounds_filled:
+            n = min(need - self.rounds_filled, self.tape_rounds // 2)
+            _lib.check(self.L.pfa_spaces_fill_tape(_lib.ptr(self.state), C.byref(self.cfg), n, _lib.stream_handle()), 'fill_tape')
+            self.rounds_filled += n
+
+    def _finishing_send(self, sends):
+        return sends % 2 == 1
+
+    def _k_reset(self, seed):
+        _lib.check(self.L.pfa_spaces_async_reset(_lib.ptr(self.state), C.byref(self.cfg), seed, *self._live(), _lib.stream_handle()),
+                   'async_reset')
+        self.sends = 0
+        self.rounds_filled = 1
+
+    def _k_send(self, actions):
+        self.ensure_tape(1)
+        _lib.check(self.L.pfa_spaces_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(actions), *self._live(),
+                                          _lib.stream_handle()), 'send')
+
+    def _k_stats(self, reset):
+        _lib.check(self.L.pfa_spaces_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._stats), reset,
+                                                   _lib.stream_handle()), 'episode_stats')
+
+    def _k_infos(self):
+        _lib.check(self.L.pfa_spaces_last_infos(_lib.ptr(self.state), C.byref(self.cfg), *self._fin_ptrs(), _lib.stream_handle()),
+                   'last_infos')
+
+    def send(self, actions):
+        """Actions [N, 2] = (flat, image) per env, as the reference's emulation hands them on (emulation.py:111-121)."""
+        import torch
+        send_precheck(self, actions)
+        a = actions if torch.is_tensor(actions) else torch.as_tensor(np.ascontiguousarray(np.asarray(actions), dtype=np.int64))
+        if tuple(a.shape) != (self.num_agents, 2) or (not self.initialized and (int(a.min()) < 0 or int(a.max()) > 1)):
+            raise APIUsageError('Actions do not match action space')
+        self.initialized = True
+        a = a.to(device=self.device, dtype=torch.int64)
+        self._actions.copy_(a[:, 0] | (a[:, 1] << 4))
+        self.device_send(self._actions)
+        self.infos = self._collect_infos() if self.info_mode == 'sync' else []
+
+    def recv(self):
+        import torch
+        recv_precheck(self)
+        return (self.observations.to(torch.uint8), self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids,
+                self.masks)
 
 
 def make_bandit(num_actions=10, reward_scale=1, reward_noise=1, **kwargs):

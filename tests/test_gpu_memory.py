@@ -94,3 +94,37 @@ def test_only_the_recurrent_policy_learns_memory():
     print('memory scores: lstm', [round(x, 3) for x in lstm[::10]], 'mlp', [round(x, 3) for x in mlp[::10]])
     assert lstm[0] < 0.4 and lstm[-1] > 0.9, lstm[-5:]
     assert mlp[-1] < 0.6, mlp[-5:]          # two hidden digits: a memory-less policy cannot beat chance by much
+
+
+@pytest.mark.parametrize('n,L,D,T', [(50, 2, 2, 37), (4096, 3, 1, 16)])
+def test_fused_recurrent_rollout_equals_the_stepwise_protocol_pieces(n, L, D, T):
+    """evaluate() for Memory + the LSTM policy is ONE persistent kernel (pfa_rollout_lstm_memory); it must equal the
+    protocol-level loop (policy step, Experience.store, device_send: three launches per step) bit for bit — experience rows,
+    live buffers, recurrent state, episode statistics — over two rollouts (state and env phase carry over), ragged tile."""
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from test_gpu_ppo import _config
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    runs = []
+    for fused in (True, False):
+        torch.manual_seed(4)
+        vec = _make(n, L, D)
+        pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+        bptt = T if T < 16 else 16
+        data = clean_pufferl.create(_config(n, T, n * T, 1, 1, n * T * 8, hp, seed=11), vec, pol)
+        out = []
+        for it in range(2):
+            if fused:
+                stats, _ = clean_pufferl.evaluate(data)
+            else:
+                clean_pufferl._rollout_stepwise(data, None, T, n)
+                stats, _ = clean_pufferl._finish_evaluate(data, n, T)
+            e = data.experience
+            out.append([x.clone() for x in (e.obs, e.actions, e.logprobs, e.values, e.rewards, e.dones, vec.obs_buf, vec.rewards,
+                                            vec.terminals_u8, data.lstm_engine.lstm_h, data.lstm_engine.lstm_c)] + [stats])
+        runs.append(out)
+        assert vec.debug_solutions()[1] == 0
+    for it in range(2):
+        for k, (a, b) in enumerate(zip(runs[0][it][:-1], runs[1][it][:-1])):
+            assert torch.equal(a, b), (it, k)
+        assert runs[0][it][-1] == runs[1][it][-1]
+    assert runs[0][1][-1]['episode_length'] == 2 * L + D - 1
