@@ -166,6 +166,10 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--policy', choices=['mlp', 'lstm'], default='mlp',
                     help="'lstm' = LSTMWrapper(128) on the same envs (BASELINE configs[2]'s policy; not the headline metric)")
+    ap.add_argument('--workload', choices=['squared', 'c3'], default='squared',
+                    help="'c3' = BASELINE configs[2] / SURVEY config C3: MiniGrid-shaped 160-byte rows, 7 actions, 100-step episodes from the "
+                         "device-side synthetic generator (the simulator is third-party: env parity unpinned), LSTM(128) policy, bptt 16; "
+                         "not the headline metric")
     ap.add_argument('--no-breakdown', action='store_true', help='skip the extra (untimed) per-kernel breakdown pass')
     args = ap.parse_args()
 
@@ -195,8 +199,13 @@ def main():
     L = _lib.lib()
     K, W = args.steps, args.warmup
     per_gpu = NUM_ENVS * HORIZON
-    vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=D, num_targets=NT), num_envs=NUM_ENVS,
-                      backend=vector.Squared, obs_stride=64)
+    if args.workload == 'c3':
+        args.policy = 'lstm'
+        vec = vector.make(vector.make_synthetic, env_kwargs=dict(obs_values=160, num_actions=7, episode_length=100, obs_high=10),
+                          num_envs=NUM_ENVS, backend=vector.Synthetic)
+    else:
+        vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=D, num_targets=NT), num_envs=NUM_ENVS,
+                          backend=vector.Squared, obs_stride=64)
     if args.policy == 'lstm':
         pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
     else:
@@ -250,7 +259,8 @@ def main():
     if rank == 0 and not args.no_breakdown:
         L.pfa_timing_enable(0)
         names = (('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
-                 else ('rollout_lstm_squared', 'squared_tape', 'gae', 'lstm_seq_fwd', 'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
+                 else (('rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'), 'squared_tape', 'gae', 'lstm_seq_fwd',
+                       'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
         for name in names:
             n, ms = kernel_ms(name)
             breakdown[name] = dict(launches_per_step=n // KB, ms_per_step=round(ms / KB, 4))
@@ -274,13 +284,17 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            'metric': 'env steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs',
+            'metric': 'env steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs' + (' [configs[2] workload]' if args.workload == 'c3' else ''),
             'value': value, 'unit': 'env_steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'squared d={D} nt={NT}, {NUM_ENVS} envs/GPU x {HORIZON} steps, obs 49->64 f32 rows, '
-                                   f'{"MLP 128" if args.policy == "mlp" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[1]'
-                                   + (', sharded as configs[4]' if world > 1 else '') + ')',
+            'config': {'workload': (f'synthetic MiniGrid-shaped rows (160 bytes as 160 f32, 7 actions, 100-step episodes), {NUM_ENVS} envs/GPU x '
+                                    f'{HORIZON} steps, MLP 128 + LSTM 128, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[2]; '
+                                    'env parity unpinned: third-party simulator' + (', sharded' if world > 1 else '') + ')')
+                       if args.workload == 'c3' else
+                       f'squared d={D} nt={NT}, {NUM_ENVS} envs/GPU x {HORIZON} steps, obs 49->64 f32 rows, '
+                       f'{"MLP 128" if args.policy == "mlp" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[1]'
+                       + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,

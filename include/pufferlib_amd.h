@@ -276,6 +276,33 @@ int pfa_spaces_last_infos(void *state, const pfa_spaces_config *cfg, uint8_t *fi
                           int32_t *episode_length, double *score, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Synthetic byte-row vecenv — the device-side generator of BASELINE configs[2]'s workload SHAPE:
+ * MiniGrid-shaped rows (minigrid/environment.py:14-48: 160 emulated bytes, 7 actions, episodes cut at 100 steps) whose
+ * arithmetic lives in the third-party `minigrid` package, not in the reference tree — env parity is unpinned by construction,
+ * so a counter-based generator (csrc/synth_env.hpp) supplies observations and a learnable reward; what is held to parity on
+ * this workload is the policy / GAE / PPO side.  Protocol and buffers as the other device envs; observations are rows of
+ * `obs_stride` floats holding `obs_values` byte values in 0..obs_high.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t num_envs;
+    int32_t obs_values;     /* values per row (<= 160) */
+    int32_t obs_stride;     /* floats per row, multiple of 16 */
+    int32_t num_actions;    /* 2..15 */
+    int32_t episode_length; /* steps per episode; the send after the terminal row is the reset row */
+    int32_t obs_high;       /* values are uniform in 0..obs_high */
+    uint64_t seed;
+    int64_t env_offset;     /* global index of local env 0 (sharding) */
+} pfa_synth_config;
+size_t pfa_synth_state_bytes(const pfa_synth_config *cfg);
+int pfa_synth_async_reset(void *state, const pfa_synth_config *cfg, float *obs, float *rewards, uint8_t *terminals,
+                          uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_synth_send(void *state, const pfa_synth_config *cfg, const int64_t *actions, float *obs, float *rewards,
+                   uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_synth_episode_stats(void *state, const pfa_synth_config *cfg, double *out4, int32_t reset, pfa_stream_t stream);
+int pfa_synth_last_infos(void *state, const pfa_synth_config *cfg, uint8_t *finished, double *episode_return,
+                         int32_t *episode_length, double *score, pfa_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Structured-observation unpack — replaces pufferlib.pytorch.nativize_tensor
  * (pufferlib/pytorch.py:96-145): flat emulated rows [num_rows][row_bytes] (device, 16-byte aligned) -> one dense tensor
  * per leaf of the observation space, in one launch.  A field is a leaf as pufferlib.pytorch.nativize_dtype
@@ -388,6 +415,11 @@ int pfa_rollout_lstm_memory(void *state, const pfa_memory_config *cfg, const flo
                             const void *wpack, float *h, float *c, const pfa_experience *exp, const float *noise,
                             const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards, uint8_t *terminals,
                             uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+/* ... and over the synthetic byte-row vecenv (pfa_synth_*): BASELINE configs[2]'s rollout as one launch. */
+int pfa_rollout_lstm_synth(void *state, const pfa_synth_config *cfg, const float *params, const pfa_mlp_dims *dims,
+                           const void *wpack, float *h, float *c, const pfa_experience *exp, const float *noise,
+                           const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards, uint8_t *terminals,
+                           uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 /* --- the recurrent policy in training mode (csrc/lstm_seq.hip): forward over the `steps` (= bptt_horizon) time steps
  * of a minibatch of `rows` independent segments and back-propagation through time (clean_pufferl.py:186-193, :244).
  * Time-major buffers: obs_tm [steps][rows][obs_stride], xe / dh_heads / dxe [steps][rows][128], gates_act / dgates

@@ -16,8 +16,8 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'nativize.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp',
+SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip']
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
@@ -75,6 +75,11 @@ class MemoryConfig(C.Structure):
 
 class SpacesConfig(C.Structure):
     _fields_ = [('num_envs', C.c_int32), ('tape_rounds', C.c_int32)]
+
+
+class SynthConfig(C.Structure):
+    _fields_ = [('num_envs', C.c_int32), ('obs_values', C.c_int32), ('obs_stride', C.c_int32), ('num_actions', C.c_int32),
+                ('episode_length', C.c_int32), ('obs_high', C.c_int32), ('seed', C.c_uint64), ('env_offset', C.c_int64)]
 
 
 class MlpDims(C.Structure):
@@ -152,6 +157,11 @@ _SIGNATURES = {
     'pfa_spaces_send': (C.c_int, [P, C.POINTER(SpacesConfig), P, P, P, P, P, P, P]),
     'pfa_spaces_episode_stats': (C.c_int, [P, C.POINTER(SpacesConfig), P, C.c_int32, P]),
     'pfa_spaces_last_infos': (C.c_int, [P, C.POINTER(SpacesConfig), P, P, P, P, P]),
+    'pfa_synth_state_bytes': (C.c_size_t, [C.POINTER(SynthConfig)]),
+    'pfa_synth_async_reset': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P, P]),
+    'pfa_synth_send': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P, P, P]),
+    'pfa_synth_episode_stats': (C.c_int, [P, C.POINTER(SynthConfig), P, C.c_int32, P]),
+    'pfa_synth_last_infos': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P]),
     'pfa_multiagent_episode_stats': (C.c_int, [P, C.c_int32, P, C.c_int32, P]),
     'pfa_nativize_rows': (C.c_int, [P, C.c_int64, C.c_int32, P, C.c_int32, P]),
     'pfa_ppo_workspace_bytes': (C.c_size_t, [C.POINTER(MlpDims), C.c_int64, C.POINTER(PpoHparams)]),
@@ -175,6 +185,8 @@ _SIGNATURES = {
     'pfa_rollout_lstm_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), P, P, P, C.POINTER(Experience),
                                            P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
     'pfa_rollout_lstm_memory': (C.c_int, [P, C.POINTER(MemoryConfig), P, C.POINTER(MlpDims), P, P, P, C.POINTER(Experience),
+                                           P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
+    'pfa_rollout_lstm_synth': (C.c_int, [P, C.POINTER(SynthConfig), P, C.POINTER(MlpDims), P, P, P, C.POINTER(Experience),
                                            P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
     'pfa_lstm_pack_bwd': (C.c_int, [P, C.POINTER(MlpDims), P, P]),
     'pfa_lstm_seq_forward': (C.c_int, [P, C.c_int64, C.c_int32, P, C.POINTER(MlpDims), P, P, P, P, P, P]),

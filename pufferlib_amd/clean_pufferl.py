@@ -35,7 +35,7 @@ from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
-from .vector import Bandit, Memory, Multiagent, Spaces, Squared, Stochastic
+from .vector import Bandit, Memory, Multiagent, Spaces, Squared, Stochastic, Synthetic
 
 
 def seed_everything(seed, torch_deterministic=True):
@@ -260,7 +260,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     n_params = sum(p.numel() for p in policy.parameters())
     msg = f'Model Size: {n_params} parameters'
 
-    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory, Bandit, Multiagent, Spaces))   # anything else speaks the recv/send protocol on the host
+    host_mode = not isinstance(vecenv, (Squared, Stochastic, Memory, Bandit, Multiagent, Spaces, Synthetic))   # anything else speaks the recv/send protocol on the host
     if not isinstance(policy, (Policy, RecurrentPolicy)):
         from .models import find_lstm
         if find_lstm(policy) is not None:             # e.g. the reference's RecurrentPolicy(LSTMWrapper(Default))
@@ -357,14 +357,15 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
-    if isinstance(vecenv, Memory) and data.lstm_engine is not None:   # the env that needs the recurrent policy: one persistent kernel
+    if isinstance(vecenv, (Memory, Synthetic)) and data.lstm_engine is not None:   # recurrent policy: one persistent kernel
         with profile.env:
-            vecenv.ensure_tape(T)
+            if hasattr(vecenv, 'ensure_tape'):
+                vecenv.ensure_tape(T)
         with profile.eval_forward:
             data.lstm_engine.rollout(T, noise, policy.noise_seed, policy.noise_step, vecenv.env_offset)
             vecenv.sends += T
         return _finish_evaluate(data, N, T)
-    if isinstance(vecenv, (Memory, Bandit, Multiagent, Spaces)):   # no fused kernel for these envs: protocol-level pieces, still no host sync per step
+    if isinstance(vecenv, (Memory, Bandit, Multiagent, Spaces, Synthetic)):   # no fused kernel for these (env, policy) pairs: protocol-level pieces, still no host sync per step
         with profile.eval_forward:
             _rollout_stepwise(data, noise, T, N)
         return _finish_evaluate(data, N, T)

@@ -17,6 +17,7 @@
 #include "sampler.hpp"
 #include "squared_env.hpp"
 #include "memory_env.hpp"
+#include "synth_env.hpp"
 
 namespace pfa {
 
@@ -295,6 +296,100 @@ __global__ void __launch_bounds__(kLstmThreads) rollout_lstm_memory_kernel(Memor
     store_hstate(h, first, v.n, L.xh[T & 1]);
 }
 
+// ... and over the synthetic byte-row env of BASELINE configs[2] (synth_env.hpp; rows of DP = obs_stride floats).  The 16 lanes
+// of an env's sampling group regenerate its observation row after the step, 16 values per lane (one Philox call each).
+template <int DP>
+__global__ void __launch_bounds__(kLstmThreads) rollout_lstm_synth_kernel(SynthView v, const float *params, int a, const float4 *wpack,
+                                                                         float *h, float *cell, pfa_experience ex, const float *noise,
+                                                                         uint64_t seed, uint64_t step0, long long env_offset,
+                                                                         float *live_obs, float *live_rew, uint8_t *live_term,
+                                                                         uint8_t *live_trunc, uint8_t *live_mask) {
+    constexpr int XS = XTile<DP>::XS;
+    __shared__ LstmLds<DP> L;
+    __shared__ int s_tick[16], s_episode[16];
+    const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
+    const int e = blockIdx.x * 16 + le;
+    const bool env_ok = e < v.n;
+    const bool owner = lo == 0 && env_ok;
+    const int T = ex.horizon_T;
+    const int c = lane_id() & 15;
+    const long long first = (long long)blockIdx.x * 16;
+
+    LstmFrags<DP> w;
+    w.load(params, a);
+    stage_gate_bias(params, DP, a, L.gbias);
+    const float4 *wp = wpack + (size_t)__builtin_amdgcn_readfirstlane(wave_id()) * 16 * 8 * 64;
+
+    lstm_stage_obs<DP>(live_obs, first, v.n, L.xs);
+    load_hstate(h, first, v.n, L.xh[0]);
+    f32x4 cst[2];
+    load_cstate(cell, first + c, first + c < v.n, cst);
+    SynthEnv s = {};
+    float reward = 0.0f;
+    bool terminal = false;
+    int last_fin = 0;
+    if (owner) {
+        s = v.env[e];
+        reward = live_rew[e];
+        terminal = live_term[e] != 0;
+    }
+    __syncthreads();
+
+    for (int t = 0; t < T; ++t) {
+        const int cur = t & 1;
+        lstm_tile_step<DP>(w, wp, L, cur, cst,
+                           [&] { lstm_unstage_obs<DP>(L.xs, ex.obs + (size_t)t * DP, first, v.n, (size_t)T * DP); });
+        const float q = env_ok ? noise_lane(noise ? noise + ((size_t)t * v.n + e) * a : nullptr, seed, step0 + t,
+                                            (uint64_t)(env_offset + e), lo, a)
+                               : 1.0f;
+        const LaneSample sm = lstm_sample(L.part, le, lo, a, q);
+        if (owner) {
+            const size_t row = (size_t)e * T + t;
+            ex.rewards[row] = reward;
+            ex.dones[row] = terminal ? 1.0f : 0.0f;
+            ex.actions[row] = sm.action;
+            ex.logprobs[row] = sm.logprob;
+            ex.values[row] = sm.value;
+            last_fin = 0;
+            if (s.done) {
+                synth_begin_episode(s, reward, terminal);
+            } else {
+                double fr, fs;
+                int fl;
+                if (synth_step(v, s, sm.action, (int)L.xs[le * XS], reward, terminal, fr, fl, fs)) {
+                    episode_account(v.fin[e], fr, fl, fs);
+                    last_fin = 1;
+                }
+            }
+            s_tick[le] = s.tick;
+            s_episode[le] = s.episode;
+        }
+        __syncthreads();
+        if (env_ok && lo * 16 < v.values) {   // the next observation row of this env, 16 values per lane
+            float vals[16];
+            synth_chunk(v, e, s_episode[le], s_tick[le], lo, vals);
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (lo * 16 + k < v.values) L.xs[le * XS + lo * 16 + k] = vals[k];
+        }
+        __syncthreads();
+    }
+
+    if (owner) {
+        v.env[e] = s;
+        v.fin[e].last_fin = last_fin;
+        live_rew[e] = reward;
+        live_term[e] = terminal ? 1 : 0;
+        live_trunc[e] = 0;
+        live_mask[e] = 1;
+    }
+    lstm_unstage_obs<DP>(L.xs, live_obs, first, v.n, (size_t)DP);
+    store_cstate(cell, first + c, first + c < v.n, cst);
+    store_hstate(h, first, v.n, L.xh[T & 1]);
+}
+
+int check_synth_config(const pfa_synth_config *c);   // synthetic.hip
+
 static int check_lstm_dims(const pfa_mlp_dims *d) {
     PFA_REQUIRE(d != nullptr, "lstm: null dims");
     PFA_REQUIRE(d->hidden == kHidden, "lstm: hidden must be %d (got %d)", kHidden, d->hidden);
@@ -406,6 +501,32 @@ extern "C" int pfa_rollout_lstm_memory(void *state, const pfa_memory_config *cfg
     hipLaunchKernelGGL(rollout_lstm_memory_kernel, dim3((unsigned)((cfg->num_envs + 15) / 16)), dim3(kLstmThreads), 0, (hipStream_t)stream,
                        memory_view(state, *cfg), params, dims->num_actions, (const float4 *)wpack, h, c, *exp, noise, seed, step,
                        (long long)env_offset, obs, rewards, terminals, truncations, masks);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_rollout_lstm_synth(void *state, const pfa_synth_config *cfg, const float *params, const pfa_mlp_dims *dims,
+                                      const void *wpack, float *h, float *c, const pfa_experience *exp, const float *noise,
+                                      const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards, uint8_t *terminals,
+                                      uint8_t *truncations, uint8_t *masks, pfa_stream_t stream) {
+    if (int rc = check_lstm_dims(dims)) return rc;
+    if (int rc = check_synth_config(cfg)) return rc;
+    PFA_REQUIRE(state && params && wpack && h && c && exp && obs && rewards && terminals && truncations && masks,
+                "rollout_lstm_synth: null buffer");
+    PFA_REQUIRE(dims->heads == 0 && dims->num_actions == cfg->num_actions, "rollout_lstm_synth: the policy must have one Discrete(%d) head",
+                cfg->num_actions);
+    PFA_REQUIRE(dims->obs_stride == cfg->obs_stride, "rollout_lstm_synth: env obs_stride %d != policy obs_stride %d", cfg->obs_stride,
+                dims->obs_stride);
+    PFA_REQUIRE(exp->horizon_T >= 1 && exp->obs && exp->actions && exp->logprobs && exp->values && exp->rewards && exp->dones,
+                "rollout_lstm_synth: bad experience buffers");
+    PFA_REQUIRE(noise || key, "rollout_lstm_synth: need an explicit noise tensor or a Philox key");
+    const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
+    const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
+    ScopedKernelTimer timer("rollout_lstm_synth", (hipStream_t)stream);
+    PFA_LSTM_DISPATCH_DP(dims->obs_stride,
+                         hipLaunchKernelGGL(rollout_lstm_synth_kernel<DP>, dim3(grid), dim3(kLstmThreads), 0, (hipStream_t)stream,
+                                            synth_view(state, *cfg), params, dims->num_actions, (const float4 *)wpack, h, c, *exp, noise,
+                                            seed, step, (long long)env_offset, obs, rewards, terminals, truncations, masks));
     PFA_LAUNCH_CHECK();
     return 0;
 }

@@ -55,7 +55,7 @@ def device_backend_for(creator):
     from . import vector
     name = _creator_name(creator)
     for key, cls in (('squared', 'Squared'), ('stochastic', 'Stochastic'), ('memory', 'Memory'), ('bandit', 'Bandit'),
-                     ('multiagent', 'Multiagent'), ('spaces', 'Spaces')):
+                     ('multiagent', 'Multiagent'), ('spaces', 'Spaces'), ('synthetic', 'Synthetic')):
         if key in name and hasattr(vector, cls):
             return getattr(vector, cls)
     return None

@@ -93,7 +93,7 @@ class Engine:
         assert T == exp.horizon
         pack_gates(fp, self.wpack)
         key = _lib.NoiseKey(key_seed, step0)
-        fn = L.pfa_rollout_lstm_memory if type(vec).__name__ == 'Memory' else L.pfa_rollout_lstm_squared   # same signature
+        fn = {'Memory': L.pfa_rollout_lstm_memory, 'Synthetic': L.pfa_rollout_lstm_synth}.get(type(vec).__name__, L.pfa_rollout_lstm_squared)   # same signature
         _lib.check(fn(_lib.ptr(vec.state), C.byref(vec.cfg), _lib.ptr(fp.flat), C.byref(fp.dims),
                       _lib.ptr(self.wpack), _lib.ptr(self.lstm_h), _lib.ptr(self.lstm_c), C.byref(exp.c),
                       _lib.ptr(noise), C.byref(key), env_offset, _lib.ptr(vec.obs_buf),

@@ -773,6 +773,71 @@ class Spaces(_DeviceVecEnv):
                 self.masks)
 
 
+def make_synthetic(obs_values=160, num_actions=7, episode_length=100, obs_high=10, **kwargs):
+    """Env creator token of the synthetic byte-row env (BASELINE configs[2]'s workload shape; defaults = MiniGrid's emulated row:
+    160 bytes, 7 actions, episodes cut at 100 steps, minigrid/environment.py:14-48)."""
+    return SyntheticSpec(obs_values, num_actions, episode_length, obs_high)
+
+
+class SyntheticSpec(_SimpleSpec):
+    def __init__(self, obs_values=160, num_actions=7, episode_length=100, obs_high=10):
+        super().__init__(0, int(obs_high), int(num_actions))
+        self.obs_values, self.num_actions = int(obs_values), int(num_actions)
+        self.episode_length, self.obs_high = int(episode_length), int(obs_high)
+        self.single_observation_space = spaces.Box(low=0, high=int(obs_high), shape=(self.obs_values,), dtype=np.uint8)
+        self.observation_space = self.single_observation_space
+        self.emulated = namespace(observation_dtype=np.dtype(np.uint8),
+                                  emulated_observation_dtype=np.dtype((np.uint8, (self.obs_values,))))
+
+
+class Synthetic(_DeviceVecEnv):
+    """Device-resident synthetic byte-row vecenv (csrc/synth_env.hpp): observations from a counter-based generator keyed by
+    (seed, global env, episode, tick), reward 1 when the action equals byte 0 of the shown row modulo the action count.  It is
+    the workload of BASELINE configs[2] (MiniGrid-shaped rows + LSTM policy) — the third-party simulator itself is not part
+    of the reference tree, so there is nothing to be bit-exact with on the env side."""
+    FAMILY, NAMES, DEFAULTS = 'synthetic', ('obs_values', 'num_actions', 'episode_length', 'obs_high'), (160, 7, 100, 10)
+    SEEDED = True
+
+    def _spec(self, obs_values, num_actions, episode_length, obs_high):
+        from .cleanrl import obs_stride_for
+        self.obs_stride = obs_stride_for(int(obs_values), recurrent=True)     # 16 .. 160 floats per row
+        return SyntheticSpec(obs_values, num_actions, episode_length, obs_high)
+
+    def _alloc_state(self):
+        import torch
+        sp = self.driver_env
+        self.obs_dim = sp.obs_values
+        self.observations = self.obs_buf[:, :self.obs_dim]
+        self.episode_len = sp.episode_length + 1
+        self.cfg = _lib.SynthConfig(self.num_agents, sp.obs_values, self.obs_stride, sp.num_actions, sp.episode_length, sp.obs_high, 0,
+                                    self.env_offset)
+        nbytes = self.L.pfa_synth_state_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise APIUsageError(self.L.pfa_last_error().decode())
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+
+    def _finishing_send(self, sends):
+        return sends % self.episode_len == self.episode_len - 1
+
+    def _k_reset(self, seed):
+        self.cfg.seed = int(seed)
+        self.cfg.env_offset = int(self.env_offset)
+        _lib.check(self.L.pfa_synth_async_reset(_lib.ptr(self.state), C.byref(self.cfg), *self._live(), _lib.stream_handle()),
+                   'async_reset')
+
+    def _k_send(self, actions):
+        _lib.check(self.L.pfa_synth_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(actions), *self._live(),
+                                         _lib.stream_handle()), 'send')
+
+    def _k_stats(self, reset):
+        _lib.check(self.L.pfa_synth_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(self._stats), reset,
+                                                  _lib.stream_handle()), 'episode_stats')
+
+    def _k_infos(self):
+        _lib.check(self.L.pfa_synth_last_infos(_lib.ptr(self.state), C.byref(self.cfg), *self._fin_ptrs(), _lib.stream_handle()),
+                   'last_infos')
+
+
 def make_bandit(num_actions=10, reward_scale=1, reward_noise=1, **kwargs):
     """Env creator token with the signature of ocean.environment.make_bandit (ocean/environment.py:33-37)."""
     return BanditSpec(num_actions, reward_scale, reward_noise)
