@@ -482,8 +482,21 @@ int pfa_sumsq_partials(const float *grads, int64_t count, double *partials, int3
 int pfa_dist_unique_id(uint8_t *id128_host);
 int pfa_dist_init(const uint8_t *id128_host, int32_t rank, int32_t world);
 int pfa_dist_finalize(void);
-int pfa_dist_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
+int pfa_dist_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);   /* one-shot peer path when it is open and the bucket fits, else RCCL */
 int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
+
+/* One-shot all-reduce over peer-mapped device memory (csrc/p2p.hip) for the small buckets of the data-parallel update: every
+ * rank writes its bucket into a slot of every peer's buffer over the xGMI mesh, raises a flag, waits for the peers' flags and
+ * sums the slots in rank order (one hop instead of a ring's 2 (R-1); identical bits on every rank).  pfa_p2p_alloc creates
+ * this rank's fine-grained buffer (slots of cap_bytes) and returns its 64-byte IPC handle; the caller gathers all handles
+ * (any transport) and passes them, rank order, to pfa_p2p_open.  Once open, pfa_dist_all_reduce_* and the native train loop
+ * use it for every bucket that fits.  World size <= 8 (one node).  pfa_p2p_status: 0 ok, 1 a peer never arrived. */
+int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64_host);
+int pfa_p2p_open(const uint8_t *handles_host, int32_t rank, int32_t world);
+int pfa_p2p_close(void);
+int pfa_p2p_status(void);
+int pfa_p2p_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
+int pfa_p2p_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
 
 /* What train() logs (clean_pufferl.py:249-254,266-270) in one device buffer of 10 f64: out[0..5] = `losses` (the six
  * running means above), out[6..9] = sum y_true, sum y_true^2, sum adv, sum adv^2 with y_pred = values in storage

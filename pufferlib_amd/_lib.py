@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -201,6 +201,12 @@ _SIGNATURES = {
     'pfa_dist_finalize': (C.c_int, []),
     'pfa_dist_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
     'pfa_dist_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
+    'pfa_p2p_alloc': (C.c_int, [C.c_int64, C.c_int32, P]),
+    'pfa_p2p_open': (C.c_int, [P, C.c_int32, C.c_int32]),
+    'pfa_p2p_close': (C.c_int, []),
+    'pfa_p2p_status': (C.c_int, []),
+    'pfa_p2p_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
+    'pfa_p2p_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
     'pfa_train_log_sums': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, P, P, P]),
     'pfa_adam_clip_step': (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
                                      C.c_float, C.c_float, P, P, C.c_double, P, C.c_int32, P]),

@@ -292,7 +292,8 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     native_dp = False
     if world > 1:
         dist.broadcast(fp.flat, src=0)
-        native_dp = pdist.init_native()          # RCCL communicator inside the native library, or torch fallback
+        # RCCL communicator inside the native library and / or the one-shot peer path for this policy's bucket, else torch fallback
+        native_dp = pdist.init_native(bucket_bytes=(fp.count + 16) * 4)
     elif _cfg(config, 'force_native_dp', False):
         native_dp = pdist.init_native(force_single=True)   # 1-rank communicator: exercises the DP code path in tests
     policy.noise_seed = int(config.seed)
@@ -460,12 +461,17 @@ def _finish_evaluate(data, N, T):
     return data.stats, infos
 
 
-def _all_gather_small(dist, x, rank, world):
+def _all_gather_small(dist, x, rank, world, native=False):
     """all_gather of a tiny tensor as one all-reduce(SUM) of a zero-padded [world, ...] buffer: exact (every slot has one
-    non-zero contributor) and available for device tensors on every backend (gloo has no device all_gather)."""
+    non-zero contributor) and available for device tensors on every backend (gloo has no device all_gather).  `native`: through
+    the native communicator on the compute stream (no stream hand-off), like every other collective of the update."""
     buf = torch.zeros((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
     buf[rank] = x
-    dist.all_reduce(buf)
+    if native:
+        fn = _lib.lib().pfa_dist_all_reduce_f64 if x.dtype == torch.float64 else _lib.lib().pfa_dist_all_reduce_f32
+        _lib.check(fn(_lib.ptr(buf), buf.numel(), _lib.stream_handle()), 'all_gather_small')
+    else:
+        dist.all_reduce(buf)
     return buf
 
 
@@ -475,14 +481,14 @@ def _sharded_gae(data, dist, rank, world, stream):
     config, ex = data.config, data.experience
     L, B = _lib.lib(), ex.batch_size
     has_next = int(rank < world - 1)
-    rows = _all_gather_small(dist, ex._rdv[:, 0].contiguous(), rank, world)
+    rows = _all_gather_small(dist, ex._rdv[:, 0].contiguous(), rank, world, data.native_dp)
     if has_next:
         ex._rdv[:, B] = rows[rank + 1]
     smap = torch.empty(2, dtype=torch.float64, device=ex.device)
     args = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
     _lib.check(L.pfa_gae_shard_pass1(*args, B, has_next, float(config.gamma), float(config.gae_lambda),
                                      _lib.ptr(data.workspace), _lib.ptr(smap), stream), 'gae pass 1')
-    maps = _all_gather_small(dist, smap, rank, world)
+    maps = _all_gather_small(dist, smap, rank, world, data.native_dp)
     carry = pdist.gae_fold_later(maps, rank)
     _lib.check(L.pfa_gae_shard_pass2(*args, _lib.ptr(ex.advantages), _lib.ptr(ex.returns), B, has_next,
                                      float(config.gamma), float(config.gae_lambda), _lib.ptr(data.workspace),

@@ -59,10 +59,17 @@ int load_api() {
 
 }  // namespace
 
-int dist_world() { return g_world; }
-bool dist_ready() { return g_comm != nullptr; }
+// csrc/p2p.hip: one-shot all-reduce over peer-mapped memory for buckets that fit its slots
+bool p2p_ready();
+int p2p_world();
+bool p2p_fits(size_t bytes);
+int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream);
+
+int dist_world() { return g_comm ? g_world : (p2p_ready() ? p2p_world() : 1); }
+bool dist_ready() { return g_comm != nullptr || p2p_ready(); }
 
 int dist_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
+    if (p2p_fits(count * (f64 ? 8 : 4))) return p2p_all_reduce(buf, count, f64, stream);
     PFA_REQUIRE(g_comm != nullptr, "dist: communicator not initialised");
     PFA_CHECK_NCCL(g_api.AllReduce(buf, buf, count, f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, g_comm, stream));
     return 0;

@@ -1,0 +1,178 @@
+// p2p.hip — one-shot all-reduce for small buckets over peer-mapped device memory (no reference counterpart).
+//
+// The data-parallel update all-reduces one flat bucket per optimizer step — 38 KB for the MLP policy, 0.6 MB with the LSTM —
+// 16 times per PPO update.  At that size a ring all-reduce is pure latency: 2 (R-1) = 14 dependent hops on 8 GPUs, each bound
+// by one xGMI link.  The MI355X node is a full mesh (7 links per GPU), so every rank can instead WRITE its bucket straight
+// into a slot of every peer's memory over all 7 links at once, raise a flag there, wait for the 7 flags raised in its own
+// memory and add the R slots up locally, in rank order — one hop, and bit-identical sums on every rank (same values, same
+// order), which keeps the replicas' parameters identical without a broadcast.
+//
+// Memory: each rank owns one fine-grained device allocation [2 phases][R sources][capacity] + flags [2][R][kP2pChunks]
+// (uint64 sequence numbers), exported with hipIpcGetMemHandle and mapped by every peer.  A call splits the bucket over up to
+// kP2pChunks workgroups; workgroup w of rank r pushes chunk w into slot (phase, r) of every peer, fences, sets flag
+// (phase, r, w) = seq on every peer, waits for flags (phase, *, w) >= seq in its own memory and reduces chunk w.  Two phases
+// suffice: a rank can start call s+1 (other phase) while a slow peer still reads phase s, but not call s+2 before that peer
+// has pushed call s+1, i.e. finished reading call s.  Spins are bounded: a lost peer ends in an error, not a hung GPU.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include "common.hpp"
+
+namespace pfa {
+
+constexpr int kP2pMaxRanks = 8;
+constexpr int kP2pChunks = 64;
+constexpr int kP2pThreads = 512;
+
+struct P2pPeers {
+    char *base[kP2pMaxRanks];
+};
+struct P2pState {
+    bool ready = false;
+    int rank = 0, world = 1;
+    size_t cap_bytes = 0;   // per (phase, source) slot
+    char *local = nullptr;
+    P2pPeers peers{};
+    unsigned long long seq = 0;
+    int *status = nullptr;  // device word: set non-zero when a spin ran out
+};
+static P2pState g_p2p;
+
+__host__ __device__ inline size_t p2p_slot_offset(size_t cap, int world, int phase, int src) { return ((size_t)phase * world + src) * cap; }
+__host__ __device__ inline size_t p2p_flags_offset(size_t cap, int world) { return (size_t)2 * world * cap; }
+static size_t p2p_total_bytes(size_t cap, int world) { return p2p_flags_offset(cap, world) + (size_t)2 * world * kP2pChunks * sizeof(unsigned long long) + 256; }
+
+template <typename T>
+__global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers peers, int rank, int world, size_t cap, int phase,
+                                                                    unsigned long long seq, T *buf, long long n, int *status) {
+    const int w = blockIdx.x;
+    const long long per = (n + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)w * per, hi = lo + per < n ? lo + per : n;
+    // push this rank's chunk into its slot on every peer (own memory included: the reduction reads all R slots from one place)
+    for (int q = 0; q < world; ++q) {
+        T *dst = reinterpret_cast<T *>(peers.base[q] + p2p_slot_offset(cap, world, phase, rank));
+        for (long long i = lo + threadIdx.x; i < hi; i += kP2pThreads) __builtin_nontemporal_store(buf[i], dst + i);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if ((int)threadIdx.x < world) {
+        unsigned long long *flag = reinterpret_cast<unsigned long long *>(peers.base[threadIdx.x] + p2p_flags_offset(cap, world)) +
+                                   ((size_t)phase * world + rank) * kP2pChunks + w;
+        __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if ((int)threadIdx.x < world) {
+        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(peers.base[rank] + p2p_flags_offset(cap, world)) +
+                                         ((size_t)phase * world + threadIdx.x) * kP2pChunks + w;
+        int spin = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (++spin > (1 << 26)) {   // seconds: a peer is gone
+                atomicExch(status, 1);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    const char *mine = peers.base[rank];
+    for (long long i = lo + threadIdx.x; i < hi; i += kP2pThreads) {
+        T s = reinterpret_cast<const T *>(mine + p2p_slot_offset(cap, world, phase, 0))[i];
+        for (int r = 1; r < world; ++r) s += __builtin_nontemporal_load(reinterpret_cast<const T *>(mine + p2p_slot_offset(cap, world, phase, r)) + i);
+        buf[i] = s;
+    }
+}
+
+bool p2p_ready() { return g_p2p.ready; }
+int p2p_world() { return g_p2p.world; }
+bool p2p_fits(size_t bytes) { return g_p2p.ready && bytes <= g_p2p.cap_bytes; }
+
+int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
+    PFA_REQUIRE(g_p2p.ready, "p2p: not initialised");
+    const size_t bytes = count * (f64 ? 8 : 4);
+    PFA_REQUIRE(bytes <= g_p2p.cap_bytes, "p2p: %zu bytes exceed the slot capacity %zu", bytes, g_p2p.cap_bytes);
+    if (count == 0) return 0;
+    const unsigned long long seq = ++g_p2p.seq;
+    const int phase = (int)(seq & 1);
+    long long chunks = (long long)((bytes + 16383) / 16384);   // >= 16 KB per workgroup
+    chunks = chunks < 1 ? 1 : (chunks > kP2pChunks ? kP2pChunks : chunks);
+    ScopedKernelTimer timer("p2p_all_reduce", stream);
+    if (f64)
+        hipLaunchKernelGGL(p2p_all_reduce_kernel<double>, dim3((unsigned)chunks), dim3(kP2pThreads), 0, stream, g_p2p.peers, g_p2p.rank,
+                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (double *)buf, (long long)count, g_p2p.status);
+    else
+        hipLaunchKernelGGL(p2p_all_reduce_kernel<float>, dim3((unsigned)chunks), dim3(kP2pThreads), 0, stream, g_p2p.peers, g_p2p.rank,
+                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (float *)buf, (long long)count, g_p2p.status);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace pfa
+
+using namespace pfa;
+
+// Allocate this rank's buffer (slots of `cap_bytes` per phase and source) and export its IPC handle (64 bytes).
+extern "C" int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64_host) {
+    PFA_REQUIRE(cap_bytes >= 256 && world >= 1 && world <= kP2pMaxRanks && handle64_host, "p2p.alloc: bad arguments (world must be 1..%d)", kP2pMaxRanks);
+    PFA_REQUIRE(!g_p2p.ready && !g_p2p.local, "p2p.alloc: already allocated (pfa_p2p_close first)");
+    const size_t cap = align_up((size_t)cap_bytes, 256);
+    const size_t total = p2p_total_bytes(cap, world);
+    void *p = nullptr;
+    PFA_CHECK_HIP(hipExtMallocWithFlags(&p, total, hipDeviceMallocFinegrained));
+    PFA_CHECK_HIP(hipMemset(p, 0, total));
+    PFA_CHECK_HIP(hipDeviceSynchronize());
+    hipIpcMemHandle_t h;
+    PFA_CHECK_HIP(hipIpcGetMemHandle(&h, p));
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    std::memcpy(handle64_host, &h, 64);
+    g_p2p.local = (char *)p;
+    g_p2p.cap_bytes = cap;
+    g_p2p.world = world;
+    g_p2p.status = (int *)((char *)p + total - 64);
+    return 0;
+}
+
+// Map every peer's buffer.  `handles` = world x 64 bytes in rank order (this rank's own entry is ignored).
+extern "C" int pfa_p2p_open(const uint8_t *handles_host, int32_t rank, int32_t world) {
+    PFA_REQUIRE(handles_host && g_p2p.local && world == g_p2p.world && rank >= 0 && rank < world, "p2p.open: bad arguments / not allocated");
+    for (int q = 0; q < world; ++q) {
+        if (q == rank) {
+            g_p2p.peers.base[q] = g_p2p.local;
+            continue;
+        }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles_host + (size_t)q * 64, 64);
+        void *p = nullptr;
+        PFA_CHECK_HIP(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        g_p2p.peers.base[q] = (char *)p;
+    }
+    g_p2p.rank = rank;
+    g_p2p.seq = 0;
+    g_p2p.ready = true;
+    return 0;
+}
+
+extern "C" int pfa_p2p_close(void) {
+    if (g_p2p.ready)
+        for (int q = 0; q < g_p2p.world; ++q)
+            if (q != g_p2p.rank && g_p2p.peers.base[q]) (void)hipIpcCloseMemHandle(g_p2p.peers.base[q]);
+    if (g_p2p.local) (void)hipFree(g_p2p.local);
+    g_p2p = P2pState{};
+    return 0;
+}
+
+extern "C" int pfa_p2p_status(void) {   // 0 ok, 1 a spin ran out (a peer never arrived), -1 not initialised
+    if (!g_p2p.ready) return -1;
+    int s = 0;
+    if (hipMemcpy(&s, g_p2p.status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return s;
+}
+
+extern "C" int pfa_p2p_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream) {
+    PFA_REQUIRE(buf && count >= 0, "p2p.all_reduce: bad arguments");
+    return p2p_all_reduce(buf, (size_t)count, false, (hipStream_t)stream);
+}
+extern "C" int pfa_p2p_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream) {
+    PFA_REQUIRE(buf && count >= 0, "p2p.all_reduce: bad arguments");
+    return p2p_all_reduce(buf, (size_t)count, true, (hipStream_t)stream);
+}

@@ -91,26 +91,70 @@ def gae_fold_later(maps, rank):
     return x.reshape(1) if hasattr(x, 'reshape') else x
 
 
-_native = dict(ready=False, world=1)
+_native = dict(ready=False, world=1, rccl=False, p2p=False)
 
 
 def native_ready():
     return _native['ready']
 
 
-def init_native(force_single=False):
-    """Create this process's RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp) so the optimizer-step
-    all-reduce can be enqueued from native code on the compute stream.  The 128-byte id travels from rank 0 through
-    the already-initialised torch.distributed group.  Returns True when EVERY rank succeeded (agreement by a MIN
-    all-reduce); on any failure all ranks fall back to torch.distributed collectives.  ``PFA_NATIVE_RCCL=0`` disables.
-    ``force_single`` builds a 1-rank communicator without a process group (tests on a single GPU)."""
+def init_p2p(bucket_bytes):
+    """Open the one-shot peer-mapped all-reduce (csrc/p2p.hip) for buckets of up to ``bucket_bytes``: every rank allocates its
+    fine-grained slot buffer, the 64-byte IPC handles travel through the torch.distributed group, every rank maps its peers.
+    One node, world size <= 8.  Returns True when EVERY rank succeeded (MIN all-reduce), else closes again everywhere."""
     import ctypes as C
     import numpy as np
     import torch
     from . import _lib
-    if os.environ.get('PFA_NATIVE_RCCL', '1') == '0':
-        return False
     d, rank, w = world()
+    if w <= 1 or w > 8:
+        return False
+    L = _lib.lib()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    handle = np.zeros(64, np.uint8)
+    ok = int(L.pfa_p2p_alloc(int(bucket_bytes), w, handle.ctypes.data_as(C.c_void_p)) == 0)
+    table = torch.zeros(w, 65, dtype=torch.int32, device='cuda')     # 64 handle bytes + the rank's success flag
+    table[rank, :64] = torch.from_numpy(handle.astype(np.int32)).cuda()
+    table[rank, 64] = ok
+    d.all_reduce(table)
+    host = table.cpu().numpy()
+    ok = int(host[:, 64].min())
+    if ok:
+        handles = np.ascontiguousarray(host[:, :64].astype(np.uint8))
+        ok = int(L.pfa_p2p_open(handles.ctypes.data_as(C.c_void_p), rank, w) == 0)
+    flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
+    d.all_reduce(flag, op=d.ReduceOp.MIN)
+    ok = int(flag.item())
+    if not ok:
+        L.pfa_p2p_close()
+    else:
+        d.barrier()                                                   # nobody pushes into a buffer that is not mapped yet
+    return bool(ok)
+
+
+def init_native(force_single=False, bucket_bytes=0):
+    """Native collectives for the update: the optimizer-step all-reduce (and the few small reductions around it) are enqueued
+    from native code on the compute stream, with no stream hand-off.  Two transports, picked by ``PFA_ALLREDUCE``:
+      ``rccl`` (default)  this process's own RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp); the 128-byte id
+                          travels from rank 0 through the already-initialised torch.distributed group; ``PFA_NATIVE_RCCL=0``
+                          disables it;
+      ``p2p``             additionally the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every bucket of up to
+                          ``bucket_bytes`` — one hop over the xGMI mesh instead of a ring; larger buckets stay on RCCL.
+    Returns True when a native transport is up on EVERY rank (agreement by MIN all-reduce); otherwise all ranks use
+    torch.distributed collectives.  ``force_single`` builds a 1-rank RCCL communicator without a process group (tests)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from . import _lib
+    d, rank, w = world()
+    mode = os.environ.get('PFA_ALLREDUCE', 'rccl').lower()
+    p2p_ok = False
+    if 'p2p' in mode and w > 1 and bucket_bytes > 0:
+        p2p_ok = init_p2p(max(int(bucket_bytes), 65536))
+        _native.update(p2p=p2p_ok)
+    if os.environ.get('PFA_NATIVE_RCCL', '1') == '0':
+        _native.update(ready=p2p_ok, world=w if p2p_ok else 1)
+        return p2p_ok
     if w == 1 and not force_single:
         return False
     L = _lib.lib()
@@ -132,12 +176,14 @@ def init_native(force_single=False):
         ok = int(flag.item())
         if not ok:
             L.pfa_dist_finalize()
-    _native.update(ready=bool(ok), world=w)
-    return bool(ok)
+    _native.update(ready=bool(ok) or p2p_ok, world=w, rccl=bool(ok))
+    return bool(ok) or p2p_ok
 
 
 def finalize_native():
     from . import _lib
     if _native['ready']:
+        if _native.get('p2p'):
+            _lib.lib().pfa_p2p_close()
         _lib.lib().pfa_dist_finalize()
-        _native.update(ready=False, world=1)
+        _native.update(ready=False, world=1, rccl=False, p2p=False)

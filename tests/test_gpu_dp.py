@@ -56,25 +56,54 @@ def _loop(n_local, world, recurrent, inject=None):
     return out
 
 
-def _worker(rank, world, port, recurrent, out_dir):
+TRANSPORTS = {
+    # torch.distributed (gloo on device tensors) for every collective: the fallback path
+    'torch': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='rccl'),
+    # the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every collective of the update: IPC-mapped slots work between two
+    # processes on one device exactly as between two devices
+    'p2p': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p'),
+    # the native RCCL communicator: two ranks on ONE device are refused by RCCL ("duplicate GPU"); the refusal must be clean
+    # on both ranks (no hang, torch's own RCCL instance unharmed) and the run must continue on the fallback path
+    'rccl-refused': dict(PFA_NATIVE_RCCL='1', PFA_ALLREDUCE='rccl'),
+}
+
+
+def _worker(rank, world, port, recurrent, out_dir, transport='torch'):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', PFA_NATIVE_RCCL='0')
+                      LOCAL_RANK='0', HSA_ENABLE_IPC_MODE_LEGACY='0', **TRANSPORTS[transport])
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     sys.path.insert(0, os.path.dirname(__file__))
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     res = _loop(N_PER_RANK, world, recurrent)
+    from pufferlib_amd import dist as pdist
+    res['native'] = np.array([int(pdist.native_ready()), int(pdist._native.get('p2p', False)), int(pdist._native.get('rccl', False))])
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **res)
     dist.barrier()
+    pdist.finalize_native()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('recurrent', [False, True])
-def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent):
+def _spawn(fn, args, world, timeout_s=240):
+    """mp.spawn with a deadline: a collective that never completes must fail the test, not hang the box."""
+    import time
+    ctx = mp.spawn(fn, args=args, nprocs=world, join=False)
+    t0 = time.time()
+    while not ctx.join(timeout=5):
+        if time.time() - t0 > timeout_s:
+            for p in ctx.processes:
+                p.kill()
+            raise AssertionError(f'ranks still running after {timeout_s} s')
+
+
+@pytest.mark.parametrize('recurrent,transport', [(False, 'torch'), (True, 'torch'), (False, 'p2p'), (True, 'p2p'), (False, 'rccl-refused')])
+def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent, transport):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), recurrent, str(tmp_path)), nprocs=world, join=True)
+    _spawn(_worker, (world, _free_port(), recurrent, str(tmp_path), transport), world)
     r = [np.load(tmp_path / f'rank{q}.npz') for q in range(world)]
+    native = [tuple(int(x) for x in r[q]['native']) for q in range(world)]
+    assert native[0] == native[1] == {'torch': (0, 0, 0), 'p2p': (1, 1, 0), 'rccl-refused': (0, 0, 0)}[transport], native
     names = ('obs', 'actions', 'logprobs', 'values', 'rewards', 'dones')
     inject = [{n: np.concatenate([r[q][f'{it}.{n}'] for q in range(world)]) for n in names} for it in range(ITERS)]
     single = _loop(N_PER_RANK * world, 1, recurrent, inject=inject)
@@ -90,3 +119,45 @@ def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent):
         assert r[0][f'{it}.global_step'][0] == single[f'{it}.global_step'][0] == (it + 1) * world * rows
     # the shards really are different envs (seeds seed + r*N + i), not replicas of each other
     assert not np.array_equal(r[0]['0.obs'], r[1]['0.obs'])
+
+
+def _p2p_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pufferlib_amd import _lib, dist as pdist
+    assert pdist.init_p2p(1 << 20)
+    L = _lib.lib()
+    ok = True
+    g = torch.Generator(device='cuda').manual_seed(100 + rank)
+    for it, n in enumerate([1, 7, 9497, 9497, 153752, 262144, 3, 9497] * 4):       # many calls: both phases are reused
+        for dtype, fn in ((torch.float32, L.pfa_p2p_all_reduce_f32), (torch.float64, L.pfa_p2p_all_reduce_f64)):
+            if dtype == torch.float64 and n > 131072:
+                continue
+            x = torch.randn(n, device='cuda', dtype=dtype, generator=g)
+            mine = x.clone()
+            _lib.check(fn(_lib.ptr(x), n, _lib.stream_handle()), 'p2p all-reduce')
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            both[rank] = mine
+            ref = torch.stack(both)
+            dist.all_reduce(ref)                                       # gloo: every rank's contribution, then the rank-order sum
+            want = ref[0]
+            for q in range(1, world):
+                want = want + ref[q]
+            ok = ok and bool(torch.equal(x, want))
+    assert L.pfa_p2p_status() == 0
+    np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([int(ok)]))
+    dist.barrier()
+    L.pfa_p2p_close()
+    dist.destroy_process_group()
+
+
+def test_one_shot_peer_all_reduce_is_the_rank_order_sum_bit_for_bit(tmp_path):
+    """csrc/p2p.hip between two processes on the one GPU: f32 and f64 buckets from 1 element to 1 MB, 64 calls (phase reuse),
+    result == slot 0 + slot 1 in rank order on BOTH ranks, exactly."""
+    world = 2
+    _spawn(_p2p_worker, (world, _free_port(), str(tmp_path)), world)
+    assert all(int(np.load(tmp_path / f'ok{q}.npy')[0]) == 1 for q in range(world))
