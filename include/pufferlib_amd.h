@@ -485,6 +485,59 @@ int pfa_dist_finalize(void);
 int pfa_dist_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);   /* one-shot peer path when it is open and the bucket fits, else RCCL */
 int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * NatureCNN policy of BASELINE configs[3] — pufferlib.models.Convolutional (models.py:113-157) behind frameworks.cleanrl.Policy:
+ * Conv2d(F,32,8,s4) ReLU Conv2d(32,64,4,s2) ReLU Conv2d(64,64,3,s1) ReLU Flatten Linear(3136,512) ReLU, actor Linear(512,A),
+ * value_fn Linear(512,1); observations uint8 (F,84,84), `.float() / 255.0`.  Every product of forward and backward is a launch
+ * of one of two fp32-MFMA implicit-GEMM kernels (csrc/igemm.hip); the operand A(m, k) is an access pattern, not a buffer:
+ *   mode 0 dense            A = ptr[m * lda + k]
+ *   mode 1 im2col, f32      ptr = NHWC activations [n][IH][IW][IC]; m = (n, oy, ox), k = (ky*KW + kx)*IC + ic
+ *   mode 2 im2col, uint8    ptr = NCHW frames [n][IC][IH][IW];      m = (n, oy, ox), k = (ic*KH + ky)*KW + kx, value / 255.0
+ *   mode 3 col2im (for dX)  ptr = NHWC dOut [n][OH][OW][OC]; m = INPUT pixel (n, y, x), k = (ky*KW + kx)*OC + oc
+ * pfa_igemm_rows:    C[m][n] = epilogue(sum_k A(m,k) B[k][n]), epilogue 0 none, 1 + bias[n], 2 relu(+ bias[n]), 3 zero where
+ *                    mask[m][n] <= 0 (relu' read where the forward left it).  N a multiple of 16, K of 4.
+ * pfa_igemm_weights: out (+)= sum_m A(m,k) D[m][n] scattered to torch's parameter layout: perm 0 [k][n], 1 Linear [n][k],
+ *                    2 conv [oc=n][ic][ky][kx] from mode-1 k order, 3 the same from mode-2 k order, 4 Linear behind an NCHW
+ *                    Flatten from NHWC rows (IC, IH, IW of the operand = the flattened tensor); split over rows, f64
+ *                    reduction of the splits (deterministic).  workspace >= pfa_igemm_weights_workspace_bytes(M, K, N).
+ * pfa_colsum:        out[n] (+)= sum_m D[m][n] (bias gradients), f64, deterministic.
+ * pfa_cnn_pack_conv / pfa_cnn_transpose: torch weights -> the [k][n] matrices the loaders' patch orders need (after every
+ *                    optimizer step): forward B [k][OC]; dX B [(ky*KW+kx)*OC + oc][IC]; Linear [N][K] -> [K][N].
+ * pfa_cnn_heads_sample / pfa_cnn_heads_loss (csrc/cnn_heads.hip): decode_actions + sample_logits, and the PPO loss with its
+ *                    gradients w.r.t. the head outputs [rows][16] and the hidden vector [rows][512], for a chunk
+ *                    [q0, q0 + rows) of minibatch mb; loss_pairs16 as in pfa_ppo_mlp_grad (accumulate != 0 adds chunks up).
+ * pfa_cnn_gather_frames: the frames of such a chunk, contiguous.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t mode;
+    int32_t reserved;
+    const void *ptr;
+    int64_t lda;                                      /* dense only */
+    int32_t IC, IH, IW, OC, OH, OW, KH, KW, S;        /* conv geometry (valid padding) */
+} pfa_igemm_operand;
+int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, const float *B, int32_t ldb, int32_t N, float *C, int32_t ldc,
+                   int32_t epilogue, const float *bias, const float *mask, int32_t ldmask, pfa_stream_t stream);
+size_t pfa_igemm_weights_workspace_bytes(int64_t M, int32_t K, int32_t N);
+int pfa_igemm_weights(const pfa_igemm_operand *a, int64_t M, int32_t K, const float *D, int32_t ldd, int32_t N, float *out,
+                      int32_t perm, int32_t accumulate, void *workspace, pfa_stream_t stream);
+size_t pfa_colsum_workspace_bytes(int32_t N);
+int pfa_colsum(const float *D, int64_t M, int32_t N, int32_t ldd, float *out, int32_t accumulate, void *workspace, pfa_stream_t stream);
+int pfa_cnn_pack_conv(const float *w, const pfa_igemm_operand *geom, int32_t u8_order, float *fwd, float *dx, pfa_stream_t stream);
+int pfa_cnn_transpose(const float *w, int32_t N, int32_t K, float *out, pfa_stream_t stream);
+/* Linear(channels*hw, N) behind nn.Flatten of an NCHW tensor (models.py:133) for NHWC activations: perm_out [N][K'] with the
+ * columns in NHWC order (B of dX), t_out [K'][N] (B of the forward); pfa_igemm_weights perm 4 undoes the order for dW. */
+int pfa_cnn_pack_fc(const float *w, int32_t N, int32_t channels, int32_t hw, float *perm_out, float *t_out, pfa_stream_t stream);
+int pfa_cnn_heads_sample(const float *h, int64_t rows, const float *actor_w, const float *actor_b, const float *value_w,
+                         const float *value_b, int32_t num_actions, const float *noise, const pfa_noise_key *key, int64_t row_offset,
+                         int64_t *actions, float *logprob, float *entropy, float *value, pfa_stream_t stream);
+size_t pfa_cnn_heads_loss_workspace_bytes(void);
+int pfa_cnn_heads_loss(const float *h, const pfa_experience *exp, int64_t batch_rows, int32_t mb, int64_t q0, int64_t rows,
+                       const float *actor_w, const float *actor_b, const float *value_w, const float *value_b, int32_t num_actions,
+                       const pfa_ppo_hparams *hp, const double *adv_stats, int64_t global_mb_rows, float *dout, float *dh,
+                       float *loss_pairs16, int32_t accumulate, void *workspace, pfa_stream_t stream);
+int pfa_cnn_gather_frames(const uint8_t *frames, int64_t frame_bytes, int64_t batch_rows, int32_t mb, const pfa_ppo_hparams *hp,
+                          int64_t q0, int64_t rows, uint8_t *out, pfa_stream_t stream);
+
 /* One-shot all-reduce over peer-mapped device memory (csrc/p2p.hip) for the small buckets of the data-parallel update: every
  * rank writes its bucket into a slot of every peer's buffer over the xGMI mesh, raises a flag, waits for the peers' flags and
  * sums the slots in rank order (one hop instead of a ring's 2 (R-1); identical bits on every rank).  pfa_p2p_alloc creates

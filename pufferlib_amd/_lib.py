@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip', 'igemm.hip', 'cnn_heads.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -80,6 +80,11 @@ class SpacesConfig(C.Structure):
 class SynthConfig(C.Structure):
     _fields_ = [('num_envs', C.c_int32), ('obs_values', C.c_int32), ('obs_stride', C.c_int32), ('num_actions', C.c_int32),
                 ('episode_length', C.c_int32), ('obs_high', C.c_int32), ('seed', C.c_uint64), ('env_offset', C.c_int64)]
+
+
+class IgemmOperand(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('reserved', C.c_int32), ('ptr', C.c_void_p), ('lda', C.c_int64), ('IC', C.c_int32), ('IH', C.c_int32),
+                ('IW', C.c_int32), ('OC', C.c_int32), ('OH', C.c_int32), ('OW', C.c_int32), ('KH', C.c_int32), ('KW', C.c_int32), ('S', C.c_int32)]
 
 
 class MlpDims(C.Structure):
@@ -201,6 +206,19 @@ _SIGNATURES = {
     'pfa_dist_finalize': (C.c_int, []),
     'pfa_dist_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
     'pfa_dist_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
+    'pfa_igemm_rows': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, C.c_int32, P]),
+    'pfa_igemm_weights_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    'pfa_igemm_weights': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P]),
+    'pfa_colsum_workspace_bytes': (C.c_size_t, [C.c_int32]),
+    'pfa_colsum': (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int32, P, P]),
+    'pfa_cnn_pack_conv': (C.c_int, [P, C.POINTER(IgemmOperand), C.c_int32, P, P, P]),
+    'pfa_cnn_transpose': (C.c_int, [P, C.c_int32, C.c_int32, P, P]),
+    'pfa_cnn_pack_fc': (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
+    'pfa_cnn_heads_sample': (C.c_int, [P, C.c_int64, P, P, P, P, C.c_int32, P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
+    'pfa_cnn_heads_loss_workspace_bytes': (C.c_size_t, []),
+    'pfa_cnn_heads_loss': (C.c_int, [P, C.POINTER(Experience), C.c_int64, C.c_int32, C.c_int64, C.c_int64, P, P, P, P, C.c_int32,
+                                     C.POINTER(PpoHparams), P, C.c_int64, P, P, P, C.c_int32, P, P]),
+    'pfa_cnn_gather_frames': (C.c_int, [P, C.c_int64, C.c_int64, C.c_int32, C.POINTER(PpoHparams), C.c_int64, C.c_int64, P, P]),
     'pfa_p2p_alloc': (C.c_int, [C.c_int64, C.c_int32, P]),
     'pfa_p2p_open': (C.c_int, [P, C.c_int32, C.c_int32]),
     'pfa_p2p_close': (C.c_int, []),

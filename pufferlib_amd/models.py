@@ -67,6 +67,99 @@ class LSTMWrapper(nn.Module):
                            'pufferlib_amd.cleanrl.RecurrentPolicy / pufferlib_amd.clean_pufferl (HIP kernels)')
 
 
+class Convolutional(nn.Module):
+    """pufferlib.models.Convolutional (models.py:113-157), the CleanRL NatureCNN used for Atari: the same modules, names
+    (``network.0/2/4/7``, ``actor``, ``value_fn``) and initialisation (layer_init: orthogonal sqrt(2), actor 0.01, value 1), so
+    state_dicts are interchangeable with the reference.  Parameter container: the arithmetic runs in csrc/igemm.hip /
+    csrc/cnn_heads.hip through pufferlib_amd.cnn.Engine."""
+
+    def __init__(self, env, *args, framestack=4, flat_size=64 * 7 * 7, input_size=512, hidden_size=512, output_size=512,
+                 channels_last=False, downsample=1, **kwargs):
+        super().__init__()
+        if channels_last or downsample != 1 or hidden_size != 512 or output_size != 512 or flat_size != 64 * 7 * 7:
+            raise NotImplementedError('pufferlib_amd.models.Convolutional runs the Atari geometry: uint8 (framestack, 84, 84) frames, '
+                                      'flat_size 3136, hidden 512')
+        self.framestack = int(framestack)
+        self.network = nn.Sequential(
+            layer_init(nn.Conv2d(framestack, 32, 8, stride=4)), nn.ReLU(),
+            layer_init(nn.Conv2d(32, 64, 4, stride=2)), nn.ReLU(),
+            layer_init(nn.Conv2d(64, 64, 3, stride=1)), nn.ReLU(),
+            nn.Flatten(),
+            layer_init(nn.Linear(flat_size, hidden_size)), nn.ReLU(),
+        )
+        self.actor = layer_init(nn.Linear(hidden_size, env.single_action_space.n), std=0.01)
+        self.value_fn = layer_init(nn.Linear(output_size, 1), std=1)
+
+    def forward(self, observations):
+        raise RuntimeError('pufferlib_amd.models.Convolutional is a parameter container: call it through '
+                           'pufferlib_amd.cleanrl.Policy / pufferlib_amd.clean_pufferl (HIP kernels)')
+
+
+def find_cnn(module):
+    """The Convolutional-shaped submodule of a policy wrapper (ours or the reference's): network / actor / value_fn."""
+    for m in module.modules():
+        if all(hasattr(m, n) for n in ('network', 'actor', 'value_fn')) and isinstance(getattr(m, 'network'), nn.Sequential):
+            return m
+    return None
+
+
+class ConvParams:
+    """One flat fp32 device buffer holding the NatureCNN parameters in named_parameters() order (network.0.weight, .bias,
+    network.2.*, network.4.*, network.7.*, actor.*, value_fn.*), every module parameter re-pointed at its view: module,
+    kernels, optimizer and checkpoints see the same bytes.  The interface the trainer uses matches FlatParams."""
+    multidiscrete = False
+
+    def __init__(self, policy_module, device):
+        net = find_cnn(policy_module)
+        if net is None:
+            raise ValueError('policy has no network/actor/value_fn (models.Convolutional shape)')
+        self.net = net
+        convs = [m for m in net.network if isinstance(m, nn.Conv2d)]
+        fc = [m for m in net.network if isinstance(m, nn.Linear)]
+        if len(convs) != 3 or len(fc) != 1:
+            raise ValueError('expected three Conv2d and one Linear in network')
+        want = [((32, None, 8, 8), (4, 4)), ((64, 32, 4, 4), (2, 2)), ((64, 64, 3, 3), (1, 1))]
+        for cv, (shape, stride) in zip(convs, want):
+            ws = tuple(cv.weight.shape)
+            if ws[0] != shape[0] or ws[2:] != shape[2:] or (shape[1] is not None and ws[1] != shape[1]) or tuple(cv.stride) != stride \
+                    or tuple(cv.padding) != (0, 0):
+                raise NotImplementedError(f'conv layer {ws} stride {cv.stride}: only the NatureCNN geometry is built')
+        if tuple(fc[0].weight.shape) != (512, 3136):
+            raise NotImplementedError('Linear(3136, 512) expected behind the conv stack')
+        self.framestack = int(convs[0].weight.shape[1])
+        if (self.framestack * 8) % 4 != 0:
+            raise NotImplementedError('framestack')
+        self.num_actions = int(net.actor.weight.shape[0])
+        if self.num_actions > 15:
+            raise NotImplementedError('the head kernels take up to 15 actions')
+        self.nvec = [self.num_actions]
+        self.names = [n for n, _ in net.named_parameters()]
+        sizes = [p.numel() for _, p in net.named_parameters()]
+        self.count = int(sum(sizes))
+        self.flat = torch.zeros(self.count, dtype=torch.float32, device=device)
+        self.views = self.split(self.flat)
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                v = self.views[name]
+                v.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = v
+        self.obs_dim = self.obs_stride = self.framestack * 84 * 84
+
+    def split(self, flat):
+        out, o = {}, 0
+        for name, p in self.net.named_parameters():
+            n = p.numel()
+            out[name] = flat[o:o + n].view(p.shape)
+            o += n
+        return out
+
+    def flat_like(self):
+        return torch.zeros_like(self.flat)
+
+    def unpack_actions(self, packed):
+        return packed
+
+
 LSTM_KEYS = ['weight_ih_l0', 'weight_hh_l0', 'bias_ih_l0', 'bias_hh_l0']
 
 

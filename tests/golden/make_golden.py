@@ -19,6 +19,8 @@ Fixtures written (all small, committed):
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
+  ppo_cnn.npz        same with models.Convolutional (models.py:113-157, NatureCNN) on a stub env with uint8 (4, 84, 84) frames;
+                     frames are re-derivable from recorded frame numbers, big tensors recorded as digests (sum, |sum|, 64 samples)
   ppo_spaces.npz     same as ppo_mlp on ocean make_spaces: Dict observation emulated to 108-byte rows, Dict action emulated to
                      MultiDiscrete([2, 2]) -> models.Default's per-head decoders and sample_logits' list branch (cleanrl.py:25-47)
 """
@@ -416,7 +418,152 @@ def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2, env='squared'):
     print(f'ppo_{tag}.npz', len(out), 'arrays; losses it0', out['it0.losses'])
 
 
+def cnn_frame(counter, base_seed=777):
+    """Frame number `counter` of the stub Atari-shaped env: uint8 (4, 84, 84) from numpy's legacy generator seeded per frame
+    (the GPU test regenerates the same frames from the recorded counters instead of storing 28 KB per observation)."""
+    return np.random.RandomState(base_seed + int(counter)).randint(0, 256, (4, 84, 84)).astype(np.uint8)
+
+
+def digest(a, samples=64):
+    """Compact fingerprint of a big tensor: sum, sum of |.|, and `samples` evenly spaced elements."""
+    f = np.asarray(a, np.float64).reshape(-1)
+    idx = np.linspace(0, f.size - 1, min(samples, f.size)).astype(np.int64)
+    return np.concatenate([[f.sum(), np.abs(f).sum()], f[idx]])
+
+
+def gen_ppo_cnn(num_envs=4, horizon=16, iters=1):
+    """clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with pufferlib.models.Convolutional (models.py:113-157, the
+    NatureCNN of BASELINE configs[3]) behind frameworks.cleanrl.Policy, on a stub env with Atari-shaped observations."""
+    import gymnasium
+    import pufferlib
+    import pufferlib.emulation
+    import pufferlib.postprocess
+    import pufferlib.vector
+    import pufferlib.models
+    import pufferlib.frameworks.cleanrl
+    import clean_pufferl
+
+    class _NoUtil:
+        def __init__(self, *a, **k):
+            self.cpu_util = self.cpu_mem = self.gpu_util = self.gpu_mem = [0]
+
+        def stop(self):
+            pass
+
+    clean_pufferl.Utilization = _NoUtil
+    clean_pufferl.print_dashboard = lambda *a, **k: None
+    clean_pufferl.save_checkpoint = lambda data: None
+    counters = {'next': 0}
+
+    class FrameEnv(gymnasium.Env):
+        def __init__(self):
+            self.observation_space = gymnasium.spaces.Box(low=0, high=255, shape=(4, 84, 84), dtype=np.uint8)
+            self.action_space = gymnasium.spaces.Discrete(4)
+            self.render_mode = 'ansi'
+            self.tick = 0
+            self.frame = None
+            self.counter = -1
+
+        def _draw(self):
+            self.counter = counters['next']
+            counters['next'] += 1
+            self.frame = cnn_frame(self.counter)
+            return self.frame
+
+        def reset(self, seed=None):
+            self.tick = 0
+            return self._draw(), {}
+
+        def step(self, action):
+            reward = float(int(action) == int(self.frame[0, 0, 0]) % 4)
+            self.tick += 1
+            done = self.tick >= 5
+            return self._draw(), reward, done, False, {'score': reward} if done else {}
+
+    def make_env():
+        return pufferlib.emulation.GymnasiumPufferEnv(env=pufferlib.postprocess.EpisodeStats(FrameEnv()))
+
+    batch = num_envs * horizon
+    config = pufferlib.namespace(
+        env='frames', seed=1, torch_deterministic=True, cpu_offload=False, device='cpu',
+        total_timesteps=batch * 8, learning_rate=2.5e-4, anneal_lr=True, gamma=0.99, gae_lambda=0.95,
+        update_epochs=2, norm_adv=True, clip_coef=0.1, clip_vloss=True, vf_coef=0.5, vf_clip_coef=0.1,
+        max_grad_norm=0.5, ent_coef=0.01, target_kl=None, batch_size=batch, minibatch_size=batch // 2,
+        bptt_horizon=8, compile=False, compile_mode='reduce-overhead', checkpoint_interval=10 ** 9,
+        data_dir='/tmp/golden_experiments', exp_id='golden')
+    vec = pufferlib.vector.make(make_env, num_envs=num_envs, backend=pufferlib.vector.Serial)
+    torch.manual_seed(1)
+    net = pufferlib.models.Convolutional(vec.driver_env, framestack=4, flat_size=64 * 7 * 7)
+    policy = pufferlib.frameworks.cleanrl.Policy(net)
+    out = {}
+    for k, v in policy.state_dict().items():
+        out['w0.' + k] = digest(v.detach().numpy())
+    noise = []
+    orig_multinomial = torch.multinomial
+
+    def recording_multinomial(p, n, *a, **kw):
+        st = torch.get_rng_state()
+        res = orig_multinomial(p, n, *a, **kw)
+        st2 = torch.get_rng_state()
+        torch.set_rng_state(st)
+        q = torch.empty_like(p).exponential_(1)
+        assert torch.equal((p / q).argmax(-1, keepdim=True), res), 'multinomial != argmax(p/q)'
+        torch.set_rng_state(st2)
+        noise.append(q.numpy().copy())
+        return res
+
+    torch.multinomial = recording_multinomial
+    try:
+        data = clean_pufferl.create(config, vec, policy)
+        exp = data.experience
+        for it in range(iters):
+            noise.clear()
+            # which frame every stored observation is: envs step in index order, so observation (t, e) is the frame env e holds at recv t
+            frame_ids = []
+            orig_recv = vec.recv
+
+            def recv():
+                frame_ids.append([env.env.env.counter for env in vec.envs])
+                return orig_recv()
+            vec.recv = recv
+            clean_pufferl.evaluate(data)
+            vec.recv = orig_recv
+            out[f'it{it}.frame_ids'] = np.array(frame_ids[:horizon], np.int64)            # (T, N)
+            obs = exp.obs.numpy().reshape(batch, 4, 84, 84)
+            for t in range(horizon):
+                for e in range(num_envs):
+                    assert np.array_equal(obs[t * num_envs + e], cnn_frame(frame_ids[t][e])), (t, e)
+            out[f'it{it}.noise'] = np.stack(noise)                                        # (T, N, A)
+            out[f'it{it}.actions'] = exp.actions_np.copy().astype(np.int8)
+            out[f'it{it}.logprobs'] = exp.logprobs_np.copy()
+            out[f'it{it}.rewards'] = exp.rewards_np.copy()
+            out[f'it{it}.dones'] = exp.dones_np.copy()
+            out[f'it{it}.values'] = exp.values_np.copy()
+            out[f'it{it}.global_step'] = np.array(data.global_step, np.int64)
+            lr_used = data.optimizer.param_groups[0]['lr']
+            clean_pufferl.train(data)
+            out[f'it{it}.lr_used'] = np.array(lr_used, np.float64)
+            out[f'it{it}.advantages'] = exp.b_advantages.numpy().copy()
+            out[f'it{it}.returns'] = exp.b_returns.numpy().copy()
+            L = data.losses
+            out[f'it{it}.losses'] = np.array([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac,
+                                              L.explained_variance], np.float64)
+            for k, v in policy.state_dict().items():
+                out[f'it{it}.w.' + k] = digest(v.detach().numpy())
+    finally:
+        torch.multinomial = orig_multinomial
+    out['config'] = np.array([num_envs, horizon, config.minibatch_size, config.bptt_horizon, config.update_epochs,
+                              config.total_timesteps, iters], np.int64)
+    out['hparams'] = np.array([config.learning_rate, config.gamma, config.gae_lambda, config.clip_coef, config.vf_coef,
+                               config.vf_clip_coef, config.max_grad_norm, config.ent_coef], np.float64)
+    np.savez_compressed(os.path.join(HERE, 'ppo_cnn.npz'), **out)
+    print('ppo_cnn.npz', len(out), 'arrays; losses it0', out['it0.losses'])
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'cnn':
+        gen_ppo_cnn()
+        sys.exit(0)
     import clean_pufferl  # builds c_gae through pyximport exactly as the reference does (clean_pufferl.py:24-27)
     gen_gae(clean_pufferl.compute_gae)
     gen_squared('d3t1', 64, 3, 1, 1, 60)
@@ -433,3 +580,4 @@ if __name__ == '__main__':
     gen_ppo('mlp', use_rnn=False)
     gen_ppo('lstm', use_rnn=True)
     gen_ppo('spaces', use_rnn=False, env='spaces')
+    gen_ppo_cnn()

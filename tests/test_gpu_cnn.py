@@ -1,0 +1,100 @@
+"""NatureCNN policy (pufferlib/models.py:113-157 `Convolutional`, BASELINE configs[3]) on the fp32-MFMA implicit-GEMM kernels
+(csrc/igemm.hip, csrc/cnn_heads.hip): every layer's forward, dX and dW against torch's own conv2d / linear + autograd on the
+CPU in fp32 (the arithmetic the reference runs), heads + sampling + PPO loss against the oracle's sample_logits / loss."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(__file__))
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+class _Env:
+    def __init__(self, actions=4, framestack=4):
+        from pufferlib_amd import spaces
+        self.single_observation_space = spaces.Box(low=0, high=255, shape=(framestack, 84, 84), dtype=np.uint8)
+        self.single_action_space = spaces.Discrete(actions)
+
+
+def _net(actions=4, seed=0):
+    from pufferlib_amd import cnn, models
+    torch.manual_seed(seed)
+    net = models.Convolutional(_Env(actions))
+    ref = {k: v.detach().clone() for k, v in net.state_dict().items()}      # CPU copy before adoption
+    cp = models.ConvParams(net, 'cuda')
+    return net, ref, cp, cnn.Engine(cp, chunk=64)
+
+
+def _torch_forward(ref, frames_u8):
+    x = frames_u8.float() / 255.0
+    a1 = F.relu(F.conv2d(x, ref['network.0.weight'], ref['network.0.bias'], stride=4))
+    a2 = F.relu(F.conv2d(a1, ref['network.2.weight'], ref['network.2.bias'], stride=2))
+    a3 = F.relu(F.conv2d(a2, ref['network.4.weight'], ref['network.4.bias'], stride=1))
+    h = F.relu(F.linear(a3.flatten(1), ref['network.7.weight'], ref['network.7.bias']))
+    return a1, a2, a3, h
+
+
+@pytest.mark.parametrize('n', [3, 37])
+def test_every_layer_forward_and_backward_matches_torch(n):
+    net, ref, cp, eng = _net()
+    assert cp.count == 1686693 - 0 if cp.num_actions == 4 else True
+    g = torch.Generator().manual_seed(1)
+    frames = torch.randint(0, 256, (n, 4, 84, 84), dtype=torch.uint8, generator=g)
+    for k in ref:
+        ref[k].requires_grad_(True)
+    a1, a2, a3, h = _torch_forward(ref, frames)
+    G = torch.randn(n, 512, generator=g)
+    (h * G).sum().backward()
+    dev_frames = frames.cuda().reshape(n, -1).contiguous()
+    hd = eng.forward(dev_frames, n)
+    nhwc = lambda t, c, hw: t[:n * hw * hw].view(n, hw, hw, c).permute(0, 3, 1, 2).cpu().numpy()  # noqa: E731
+    np.testing.assert_allclose(nhwc(eng.a1, 32, 20), a1.detach().numpy(), **TOL)
+    np.testing.assert_allclose(nhwc(eng.a2, 64, 9), a2.detach().numpy(), **TOL)
+    np.testing.assert_allclose(nhwc(eng.a3, 64, 7), a3.detach().numpy(), rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(hd.cpu().numpy(), h.detach().numpy(), rtol=1e-5, atol=3e-5)
+    # backward of sum(h * G): d(pre-ReLU hidden) = G * relu'
+    eng.dh[:n] = (G * (h.detach() > 0)).cuda()
+    grads = torch.zeros(cp.count, device='cuda')
+    gv = cp.split(grads)
+    eng.backward(dev_frames, n, eng.dh, gv, False)
+    for name in ('network.7.weight', 'network.7.bias', 'network.4.weight', 'network.4.bias', 'network.2.weight', 'network.2.bias',
+                 'network.0.weight', 'network.0.bias'):
+        want = ref[name].grad.numpy()
+        scale = max(1.0, float(np.abs(want).max()))
+        np.testing.assert_allclose(gv[name].cpu().numpy() / scale, want / scale, rtol=1e-4, atol=2e-5, err_msg=name)
+    # accumulate = True adds a second chunk
+    eng.forward(dev_frames, n)
+    eng.backward(dev_frames, n, eng.dh, gv, True)
+    np.testing.assert_allclose(gv['network.2.weight'].cpu().numpy(), 2 * ref['network.2.weight'].grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_heads_sample_and_loss_match_the_oracle():
+    from oracle import ppo_torch
+    from pufferlib_amd import _lib
+    import ctypes as C
+    net, ref, cp, eng = _net(actions=6, seed=3)
+    L = _lib.lib()
+    n, A = 50, 6
+    g = torch.Generator().manual_seed(2)
+    h = torch.relu(torch.randn(n, 512, generator=g))
+    noise = torch.empty(n, A).exponential_(1, generator=g)
+    logits = F.linear(h, ref['actor.weight'], ref['actor.bias'])
+    value = F.linear(h, ref['value_fn.weight'], ref['value_fn.bias']).flatten()
+    oa, olp, oent = ppo_torch.sample_logits(logits, noise=noise)
+    v = cp.views
+    acts = torch.empty(n, dtype=torch.int64, device='cuda')
+    lp, ent, val = (torch.empty(n, device='cuda') for _ in range(3))
+    key = _lib.NoiseKey(1, 0)
+    hc, nz = h.cuda(), noise.cuda()
+    _lib.check(L.pfa_cnn_heads_sample(_lib.ptr(hc), n, _lib.ptr(v['actor.weight']), _lib.ptr(v['actor.bias']), _lib.ptr(v['value_fn.weight']),
+                                      _lib.ptr(v['value_fn.bias']), A, _lib.ptr(nz), C.byref(key), 0, _lib.ptr(acts), _lib.ptr(lp), _lib.ptr(ent),
+                                      _lib.ptr(val), None), 'sample')
+    assert torch.equal(acts.cpu(), oa)
+    np.testing.assert_allclose(lp.cpu().numpy(), olp.numpy(), **TOL)
+    np.testing.assert_allclose(ent.cpu().numpy(), oent.numpy(), **TOL)
+    np.testing.assert_allclose(val.cpu().numpy(), value.detach().numpy(), **TOL)
