@@ -298,6 +298,12 @@ int pfa_synth_async_reset(void *state, const pfa_synth_config *cfg, float *obs, 
                           uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 int pfa_synth_send(void *state, const pfa_synth_config *cfg, const int64_t *actions, float *obs, float *rewards,
                    uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+/* Frame rows (BASELINE configs[3]: uint8 (framestack, 84, 84) observations, SURVEY config C4): obs_values = obs_stride = bytes
+ * per row (a multiple of 16), obs_high = 255; same generator, state and statistics entries, uint8 live buffer. */
+int pfa_frames_async_reset(void *state, const pfa_synth_config *cfg, uint8_t *obs, float *rewards, uint8_t *terminals,
+                           uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+int pfa_frames_send(void *state, const pfa_synth_config *cfg, const int64_t *actions, uint8_t *obs, float *rewards,
+                    uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 int pfa_synth_episode_stats(void *state, const pfa_synth_config *cfg, double *out4, int32_t reset, pfa_stream_t stream);
 int pfa_synth_last_infos(void *state, const pfa_synth_config *cfg, uint8_t *finished, double *episode_return,
                          int32_t *episode_length, double *score, pfa_stream_t stream);

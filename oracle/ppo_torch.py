@@ -6,11 +6,12 @@ same torch CPU ops in the same order; it restates the *control flow and data lay
 
   pufferlib/models.py:41-62          Default.forward (encode -> relu -> decoder / value_head)
   pufferlib/models.py:84-111         LSTMWrapper.forward
+  pufferlib/models.py:113-157        Convolutional (NatureCNN) encode / decode
   pufferlib/frameworks/cleanrl.py:12-47   log_prob / entropy / sample_logits
   clean_pufferl.py:76-154            evaluate (rollout + Experience.store, :436-450)
   clean_pufferl.py:157-271           train (sort :452-464, GAE, flatten :466-482, minibatch loop)
 
-Parity status: PINNED — tests/test_oracle_golden.py replays tests/golden/ppo_{mlp,lstm}.npz (outputs of
+Parity status: PINNED — tests/test_oracle_golden.py replays tests/golden/ppo_{mlp,lstm,cnn}.npz (outputs of
 the unmodified reference) through this file and requires identical actions / experience buffers and
 post-update weights, Adam moments and losses.
 
@@ -122,6 +123,43 @@ class Policy:
         hidden = hidden.transpose(0, 1).reshape(B * TT, H)
         logits, value = self.decode(hidden)
         return logits, value, state
+
+
+class ConvPolicy:
+    """Weights of models.Convolutional (pufferlib/models.py:113-157, the CleanRL NatureCNN) as torch leaf tensors in the
+    reference's named_parameters order.  Same interface as ``Policy`` for the Trainer below."""
+    NAMES = ['network.0.weight', 'network.0.bias', 'network.2.weight', 'network.2.bias', 'network.4.weight', 'network.4.bias',
+             'network.7.weight', 'network.7.bias', 'actor.weight', 'actor.bias', 'value_fn.weight', 'value_fn.bias']
+    recurrent = False
+    heads = None
+
+    def __init__(self, weights, framestack=4, dtype=torch.float32):
+        """dtype=torch.float64 (with torch.set_default_dtype(torch.float64) around the Trainer) gives the same arithmetic in double
+        precision: the yardstick for how far fp32 summation order alone moves a result."""
+        self.names = list(self.NAMES)
+        self.framestack = framestack
+        self.params = [torch.tensor(np.asarray(weights[n]), dtype=dtype, requires_grad=True) for n in self.names]
+
+    p = Policy.p
+    state_arrays = Policy.state_arrays
+
+    # models.py:150-154: observations / 255.0 through Conv(8,4) ReLU Conv(4,2) ReLU Conv(3,1) ReLU Flatten Linear ReLU
+    def encode(self, obs):
+        F = torch.nn.functional
+        x = obs.reshape(obs.shape[0], self.framestack, 84, 84) / 255.0
+        x = torch.relu(F.conv2d(x, self.p('network.0.weight'), self.p('network.0.bias'), stride=4))
+        x = torch.relu(F.conv2d(x, self.p('network.2.weight'), self.p('network.2.bias'), stride=2))
+        x = torch.relu(F.conv2d(x, self.p('network.4.weight'), self.p('network.4.bias'), stride=1))
+        return torch.relu(F.linear(x.flatten(1), self.p('network.7.weight'), self.p('network.7.bias')))
+
+    # models.py:156-157
+    def decode(self, hidden):
+        F = torch.nn.functional
+        return F.linear(hidden, self.p('actor.weight'), self.p('actor.bias')), F.linear(hidden, self.p('value_fn.weight'), self.p('value_fn.bias'))
+
+    def forward(self, obs, state=None):
+        logits, value = self.decode(self.encode(obs))
+        return logits, value, None
 
 
 def sample_logits(logits, action=None, noise=None):

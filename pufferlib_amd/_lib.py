@@ -165,6 +165,8 @@ _SIGNATURES = {
     'pfa_synth_state_bytes': (C.c_size_t, [C.POINTER(SynthConfig)]),
     'pfa_synth_async_reset': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P, P]),
     'pfa_synth_send': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P, P, P]),
+    'pfa_frames_async_reset': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P, P]),
+    'pfa_frames_send': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P, P, P]),
     'pfa_synth_episode_stats': (C.c_int, [P, C.POINTER(SynthConfig), P, C.c_int32, P]),
     'pfa_synth_last_infos': (C.c_int, [P, C.POINTER(SynthConfig), P, P, P, P, P]),
     'pfa_multiagent_episode_stats': (C.c_int, [P, C.c_int32, P, C.c_int32, P]),

@@ -35,7 +35,7 @@ from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
 from .namespace import namespace
-from .vector import Bandit, Memory, Multiagent, Spaces, Squared, Stochastic, Synthetic
+from .vector import Bandit, Frames, Memory, Multiagent, Spaces, Squared, Stochastic, Synthetic
 
 
 def seed_everything(seed, torch_deterministic=True):
@@ -94,7 +94,7 @@ class Experience:
     """clean_pufferl.Experience (clean_pufferl.py:380-482) as device tensors in env-major order:
     row (env e, step t) at flat index e*T + t."""
 
-    def __init__(self, batch_size, bptt_horizon, minibatch_size, obs_stride, num_envs, device):
+    def __init__(self, batch_size, bptt_horizon, minibatch_size, obs_stride, num_envs, device, obs_bytes=None):
         if minibatch_size is None:
             minibatch_size = batch_size
         num_minibatches = batch_size / minibatch_size
@@ -112,7 +112,10 @@ class Experience:
             # every env must contribute whole bptt segments
             raise ValueError('batch_size / num_envs must be divisible by bptt_horizon')
         B = batch_size
-        self.obs = torch.zeros(B, obs_stride, dtype=torch.float32, device=device)
+        if obs_bytes is not None:     # frame observations stay bytes (the conv kernels read uint8): rows of obs_bytes, a multiple of 16
+            self.obs = torch.zeros(B, obs_bytes, dtype=torch.uint8, device=device)
+        else:
+            self.obs = torch.zeros(B, obs_stride, dtype=torch.float32, device=device)
         self.actions = torch.zeros(B, dtype=torch.int32, device=device)
         self.logprobs = torch.zeros(B, dtype=torch.float32, device=device)
         # one spare element behind rewards/dones/values: the halo row of the data-parallel GAE (next rank's first row)
@@ -268,6 +271,13 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         else:
             policy = Policy(policy, seed=config.seed)     # e.g. the reference's cleanrl.Policy(models.Default)
     recurrent = isinstance(policy, RecurrentPolicy)
+    from .models import find_cnn
+    conv = find_cnn(policy) is not None
+    if conv and (recurrent or host_mode or not isinstance(vecenv, Frames)):
+        raise NotImplementedError('the convolutional policy (models.Convolutional) trains on the device-resident frame vecenv '
+                                  '(vector.Frames) without an LSTM')
+    if isinstance(vecenv, Frames) and not conv:
+        raise NotImplementedError('vector.Frames shows uint8 (framestack, 84, 84) observations: use models.Convolutional')
     if recurrent and isinstance(vecenv, Stochastic):
         raise NotImplementedError('the device-resident Stochastic vecenv has a fused rollout for the MLP policy only '
                                   '(ocean.Stochastic: "do not use a policy with memory", ocean.py:534)')
@@ -303,9 +313,13 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         nmb_ = config.batch_size // (_cfg(config, 'minibatch_size', None) or config.batch_size)
         pdist.check_partition(total_agents, config.batch_size // total_agents, config.bptt_horizon, nmb_)
     experience = Experience(config.batch_size, config.bptt_horizon, _cfg(config, 'minibatch_size', None),
-                            obs_stride, total_agents, device)
+                            obs_stride, total_agents, device, obs_bytes=fp.obs_dim if conv else None)
     optimizer = HipAdam(fp, lr=config.learning_rate, eps=1e-5)
-    lstm_engine = None
+    lstm_engine = cnn_engine = None
+    if conv:
+        cnn_engine = policy.cnn_engine
+        cnn_engine.experience = experience
+        cnn_engine._alloc(min(8192, max(experience.minibatch_size, total_agents)))
     if recurrent:
         from . import lstm as plstm
         lstm_engine = plstm.Engine(fp, experience, vecenv)
@@ -313,14 +327,16 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
 
     L = _lib.lib()
     hp = _make_hparams(config, experience)
-    ws_bytes = max(L.pfa_ppo_workspace_bytes(C.byref(fp.dims), config.batch_size, C.byref(hp)),
+    # (the conv engine owns its gradient workspaces; the shared one then only serves adv_stats / GAE / log sums: any MLP shape sizes it)
+    dims = _lib.MlpDims(64, 64, 128, 4, 0) if conv else fp.dims
+    ws_bytes = max(L.pfa_ppo_workspace_bytes(C.byref(dims), config.batch_size, C.byref(hp)),
                    L.pfa_gae_workspace_bytes(config.batch_size))
     data = namespace(
         config=config, vecenv=vecenv, policy=policy, uncompiled_policy=policy, optimizer=optimizer,
         experience=experience, profile=profile, losses=losses, wandb=wandb, global_step=0, epoch=0, stats={},
         msg=msg, last_log_time=0, utilization=utilization,
         # engine state
-        flat_params=fp, rank=rank, world_size=world, native_dp=native_dp, lstm_engine=lstm_engine,
+        flat_params=fp, rank=rank, world_size=world, native_dp=native_dp, lstm_engine=lstm_engine, cnn_engine=cnn_engine,
         env_offset=env_offset, host_bridge=host_bridge,
         workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
         grads=torch.zeros(fp.count + 16, dtype=torch.float32, device=device),   # gradient + 8 loss sums as (hi, lo) float pairs
@@ -422,7 +438,9 @@ def _rollout_stepwise(data, noise, T, N):
     for t in range(T):
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step + t)
         nz = None if noise is None else noise[t]
-        if eng is None:
+        if data.cnn_engine is not None:
+            data.cnn_engine.policy_step(vecenv.obs_buf, N, nz, key, vecenv.env_offset, actions, logprob, None, value)
+        elif eng is None:
             _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(vecenv.obs_buf), N, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(nz),
                                                 C.byref(key), vecenv.env_offset, _lib.ptr(actions), _lib.ptr(logprob), None,
                                                 _lib.ptr(value), stream), 'forward_sample')
@@ -431,7 +449,8 @@ def _rollout_stepwise(data, noise, T, N):
                                               _lib.ptr(eng.lstm_h), _lib.ptr(eng.lstm_c), _lib.ptr(nz), C.byref(key),
                                               vecenv.env_offset, _lib.ptr(actions), _lib.ptr(logprob), None, _lib.ptr(value),
                                               stream), 'lstm_policy_step')
-        _lib.check(L.pfa_store_step(C.byref(exp.c), t, N, fp.obs_stride, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
+        # (frame rows are bytes: the copy moves them as obs_dim / 4 four-byte words)
+        _lib.check(L.pfa_store_step(C.byref(exp.c), t, N, fp.obs_dim // 4 if data.cnn_engine is not None else fp.obs_stride, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
                                     _lib.ptr(vecenv.terminals_u8), _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(value), stream),
                    'store_step')
         vecenv.device_send(actions)
@@ -529,8 +548,8 @@ def train(data):
     global_mb_rows = experience.minibatch_size * world
     loss_scale = 1.0 / (global_mb_rows * nmb)
     epochs_run = 0
-    if data.lstm_engine is not None:
-        eng = data.lstm_engine
+    eng = data.lstm_engine if data.lstm_engine is not None else data.cnn_engine   # multi-kernel updates: recurrent (lstm.py) / conv (cnn.py)
+    if eng is not None:
         for epoch in range(config.update_epochs):
             eng.state = None                      # lstm_state = None (clean_pufferl.py:176)
             for mb in range(nmb):
@@ -545,7 +564,7 @@ def train(data):
             if config.target_kl is not None:
                 if float(data.grads[fp.count + 8:fp.count + 10].double().sum().item()) / global_mb_rows > config.target_kl:
                     break
-    native_loop = data.lstm_engine is None and (world == 1 or data.native_dp) and config.target_kl is None
+    native_loop = eng is None and (world == 1 or data.native_dp) and config.target_kl is None
     if native_loop:
         # no early exit: the whole epoch x minibatch loop (incl. the per-step RCCL all-reduce when data parallel) is
         # enqueued by one native call on the compute stream
@@ -558,7 +577,7 @@ def train(data):
                 int(config.update_epochs), _lib.ptr(data.loss_acc), _lib.ptr(data.workspace),
                 1 if data.native_dp else 0, stream), 'ppo_train')
             opt.step_count += config.update_epochs * nmb
-    for epoch in range(0 if (native_loop or data.lstm_engine is not None) else config.update_epochs):
+    for epoch in range(0 if (native_loop or eng is not None) else config.update_epochs):
         for mb in range(nmb):
             with profile.train_forward:
                 _lib.check(L.pfa_ppo_mlp_grad(C.byref(experience.c), B, mb, _lib.ptr(fp.flat), C.byref(fp.dims),
@@ -674,6 +693,8 @@ def try_load_checkpoint(data):
     with torch.no_grad():      # copy INTO the views of the flat device buffer the kernels read
         for k, v in data.uncompiled_policy.state_dict().items():
             v.copy_(sd[k])
+    if data.cnn_engine is not None:
+        data.cnn_engine.version += 1          # the packed weight forms are stale
     data.optimizer.load_state_dict(resume['optimizer_state_dict'])
     data.global_step = resume['global_step']
     data.epoch = resume['update']

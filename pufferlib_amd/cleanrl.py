@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .models import FlatParams
+from .models import ConvParams, FlatParams, find_cnn
 
 KERNEL_STRIDES = (16, 32, 64, 96, 128)     # observation row strides (floats) every policy kernel is built for
 RECURRENT_STRIDES = KERNEL_STRIDES + (160,)  # the recurrent path also takes MiniGrid-shaped 160-byte rows (SURVEY config C3)
@@ -34,6 +34,12 @@ class Policy(torch.nn.Module):
 
     def adopt(self, obs_stride, device):
         """Move the parameters into one flat device buffer (idempotent for the same stride/device)."""
+        if find_cnn(self.policy) is not None:       # models.Convolutional: its own parameter layout and engine (cnn.py)
+            if self._flat is None or self._flat.flat.device != torch.device(device):
+                from . import cnn
+                self._flat = ConvParams(self.policy, device)
+                self.cnn_engine = cnn.Engine(self._flat, chunk=256)       # grows on demand (Engine._alloc)
+            return self._flat
         if (self._flat is None or self._flat.obs_stride != obs_stride
                 or self._flat.flat.device != torch.device(device)):
             self._flat = FlatParams(self.policy, obs_stride, device)
@@ -42,6 +48,14 @@ class Policy(torch.nn.Module):
     @property
     def flat_params(self):
         return self._flat
+
+    def __getstate__(self):
+        """Pickles (torch.save of the whole module, clean_pufferl.py:517) carry the parameters only: the flat-buffer bookkeeping
+        and the conv engine's activation buffers are rebuilt by adopt() on first use."""
+        state = dict(self.__dict__)
+        state['_flat'] = None
+        state.pop('cnn_engine', None)
+        return state
 
     def get_value(self, x, state=None):
         return self.forward(x)[3]
@@ -60,6 +74,8 @@ class Policy(torch.nn.Module):
         rows = x.shape[0]
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]
+        if find_cnn(self.policy) is not None:
+            return self._forward_cnn(x2, rows, noise)
         stride = obs_stride_for(D)
         if (x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) >= D and x2.stride(0) in KERNEL_STRIDES
                 and x2.data_ptr() % 16 == 0):   # any other dtype takes the .float() copy below, like models.Default (models.py:50)
@@ -83,6 +99,32 @@ class Policy(torch.nn.Module):
                                             C.byref(key), 0, _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(entropy),
                                             _lib.ptr(value), _lib.stream_handle()), 'mlp_forward_sample')
         return fp.unpack_actions(actions), logprob, entropy, value.unsqueeze(1)
+
+
+def _forward_cnn(self, x2, rows, noise):
+    """policy(frames) for models.Convolutional: uint8 (rows, framestack*84*84) -> (actions, logprob, entropy, value)."""
+    cp = self.adopt(0, x2.device)
+    if x2.shape[1] != cp.obs_dim:
+        raise ValueError(f'expected frames of {cp.obs_dim} bytes, got rows of {x2.shape[1]}')
+    frames = x2.to(torch.uint8).contiguous()       # the reference divides whatever it is given by 255 (models.py:152); frames are bytes
+    eng = self.cnn_engine
+    eng._alloc(min(rows, 8192))
+    dev = x2.device
+    actions = torch.empty(rows, dtype=torch.int64, device=dev)
+    logprob = torch.empty(rows, dtype=torch.float32, device=dev)
+    entropy = torch.empty(rows, dtype=torch.float32, device=dev)
+    value = torch.empty(rows, dtype=torch.float32, device=dev)
+    key = _lib.NoiseKey(self.noise_seed, self.noise_step)
+    if noise is not None:
+        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        assert noise.shape == (rows, cp.num_actions)
+    else:
+        self.noise_step += 1
+    eng.policy_step(frames, rows, noise, key, 0, actions, logprob, entropy, value)
+    return actions, logprob, entropy, value.unsqueeze(1)
+
+
+Policy._forward_cnn = _forward_cnn
 
 
 class RecurrentPolicy(torch.nn.Module):

@@ -118,8 +118,12 @@ class Engine:
     """Forward / update of the NatureCNN policy over a ConvParams buffer.  `chunk` = frames per kernel batch (bounds the
     activation memory: ~170 KB per frame with the gradients)."""
 
-    def __init__(self, cp, chunk=8192):
+    def __init__(self, cp, experience=None, chunk=8192):
         self.cp, self.dev = cp, cp.flat.device
+        self.fp = cp
+        self.experience = experience      # the trainer's buffers (uint8 obs [B][frame_bytes]) for update()
+        self.state = None                 # (no recurrent state; the trainer's epoch loop resets it for either engine)
+        self.norm_partials = torch.zeros(1024, dtype=torch.float64, device=self.dev)
         v = cp.views
         dev = self.dev
         self.conv1 = ConvLayer(v['network.0.weight'], v['network.0.bias'], 84, 84, 4, True, dev)
@@ -200,8 +204,27 @@ class Engine:
         self.conv2.backward_dx(self.d2, m, self.a1, self.d1)
         self.conv1.backward_dw(frames, m, self.d1, gv['network.0.weight'], gv['network.0.bias'], acc, self.ws, self.ws_col)
 
-    def update(self, exp_c, obs_u8, B, mb, hp, adv_stats, global_mb_rows, grads):
-        """Forward + PPO loss + backward for minibatch `mb`; writes the flat gradient (named_parameters order) + the loss tail."""
+    def update(self, mb, hp, adv_stats, global_mb_rows, grads, B):
+        """Forward + PPO loss + backward for minibatch `mb` of the trainer's experience (clean_pufferl.py:179-244 up to
+        loss.backward()); writes the flat gradient (named_parameters order) + the loss tail."""
+        return self.update_from(self.experience.c, self.experience.obs, B, mb, hp, adv_stats, global_mb_rows, grads)
+
+    def clip_adam(self, grads, opt, max_grad_norm, loss_acc, loss_scale):
+        """clip_grad_norm_ + optimizer.step() (clean_pufferl.py:240-244) on the flat buffer; the packed weight forms go stale."""
+        L = _lib.lib()
+        stream = _lib.stream_handle()
+        cp = self.cp
+        n = self.norm_partials.numel()
+        _lib.check(L.pfa_sumsq_partials(_lib.ptr(grads), cp.count, _lib.ptr(self.norm_partials), n, stream), 'sumsq')
+        opt.step_count += 1
+        g = opt.param_groups[0]
+        _lib.check(L.pfa_adam_clip_step(_lib.ptr(cp.flat), _lib.ptr(grads), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), cp.count,
+                                        float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), opt.step_count,
+                                        float(max_grad_norm), 1.0, C.c_void_p(grads.data_ptr() + 4 * cp.count), _lib.ptr(loss_acc), loss_scale,
+                                        _lib.ptr(self.norm_partials), n, stream), 'adam')
+        self.version += 1
+
+    def update_from(self, exp_c, obs_u8, B, mb, hp, adv_stats, global_mb_rows, grads):
         L = _lib.lib()
         cp = self.cp
         v = cp.views

@@ -399,6 +399,7 @@ class _DeviceVecEnv:
     DEFAULTS = ()
     SEEDED = False          # whether the env family reads the seeds async_reset is given
     AGENTS_PER_ENV = 1      # agent rows per env, env-major (PettingZoo emulation order, emulation.py:325-345)
+    OBS_U8 = False          # live observation buffer of bytes (frame envs) instead of floats
 
     @property
     def num_envs(self):
@@ -439,7 +440,7 @@ class _DeviceVecEnv:
         self.env_offset = int(env_offset)
         self.obs_dim = 1
         dev = self.device
-        self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.float32, device=dev)
+        self.obs_buf = torch.zeros(num_envs, self.obs_stride, dtype=torch.uint8 if self.OBS_U8 else torch.float32, device=dev)
         self.observations = self.obs_buf[:, :1]
         self.rewards = torch.zeros(num_envs, dtype=torch.float32, device=dev)
         self.terminals_u8 = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
@@ -836,6 +837,56 @@ class Synthetic(_DeviceVecEnv):
     def _k_infos(self):
         _lib.check(self.L.pfa_synth_last_infos(_lib.ptr(self.state), C.byref(self.cfg), *self._fin_ptrs(), _lib.stream_handle()),
                    'last_infos')
+
+
+def make_frames(framestack=4, num_actions=4, episode_length=100, **kwargs):
+    """Env creator token of the synthetic frame env (BASELINE configs[3]'s workload shape, SURVEY config C4: uint8
+    (framestack, 84, 84) observations uniform in 0..255 as the Atari wrappers hand them to the NatureCNN, atari/environment.py:14-41,
+    4 actions like Breakout)."""
+    return FramesSpec(framestack, num_actions, episode_length)
+
+
+class FramesSpec(_SimpleSpec):
+    def __init__(self, framestack=4, num_actions=4, episode_length=100):
+        super().__init__(0, 255, int(num_actions))
+        self.framestack, self.num_actions, self.episode_length = int(framestack), int(num_actions), int(episode_length)
+        self.single_observation_space = spaces.Box(low=0, high=255, shape=(self.framestack, 84, 84), dtype=np.uint8)
+        self.observation_space = self.single_observation_space
+        self.emulated = namespace(observation_dtype=np.dtype(np.uint8),
+                                  emulated_observation_dtype=np.dtype((np.uint8, (self.framestack, 84, 84))))
+
+
+class Frames(Synthetic):
+    """Device-resident synthetic frame vecenv: the byte generator of ``Synthetic`` writing uint8 (framestack, 84, 84) rows, reward 1
+    when the action equals byte 0 of the shown frame modulo the action count.  Atari itself is a third-party emulator outside the
+    reference tree (parity unpinned), so the workload keeps its observation / action shapes."""
+    FAMILY, NAMES, DEFAULTS = 'frames', ('framestack', 'num_actions', 'episode_length'), (4, 4, 100)
+    OBS_U8 = True
+
+    def _spec(self, framestack, num_actions, episode_length):
+        self.obs_stride = int(framestack) * 84 * 84            # bytes per row
+        return FramesSpec(framestack, num_actions, episode_length)
+
+    def _alloc_state(self):
+        import torch
+        sp = self.driver_env
+        self.obs_dim = self.obs_stride
+        self.observations = self.obs_buf.view(self.num_agents, sp.framestack, 84, 84)
+        self.episode_len = sp.episode_length + 1
+        self.cfg = _lib.SynthConfig(self.num_agents, self.obs_stride, self.obs_stride, sp.num_actions, sp.episode_length, 255, 0, self.env_offset)
+        nbytes = self.L.pfa_synth_state_bytes(C.byref(self.cfg))
+        if nbytes == 0:
+            raise APIUsageError(self.L.pfa_last_error().decode())
+        self.state = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+
+    def _k_reset(self, seed):
+        self.cfg.seed = int(seed)
+        self.cfg.env_offset = int(self.env_offset)
+        _lib.check(self.L.pfa_frames_async_reset(_lib.ptr(self.state), C.byref(self.cfg), *self._live(), _lib.stream_handle()), 'async_reset')
+
+    def _k_send(self, actions):
+        _lib.check(self.L.pfa_frames_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(actions), *self._live(), _lib.stream_handle()),
+                   'send')
 
 
 def make_bandit(num_actions=10, reward_scale=1, reward_noise=1, **kwargs):

@@ -1,0 +1,78 @@
+"""Helpers around tests/golden/ppo_cnn.npz (written by make_golden.gen_ppo_cnn from the unmodified reference): the frame
+generator of its stub env, the tensor digest it records, the initial weights, and a vecenv that replays the recorded rollout."""
+import numpy as np
+import torch
+
+
+def cnn_frame(counter, base_seed=777):
+    """Same as make_golden.cnn_frame: frame number `counter` of the stub env, uint8 (4, 84, 84)."""
+    return np.random.RandomState(base_seed + int(counter)).randint(0, 256, (4, 84, 84)).astype(np.uint8)
+
+
+def cnn_start_weight(name, shape, seed=4242):
+    """Same as make_golden.cnn_start_weight: the golden run's start value of parameter `name`."""
+    import zlib
+    rs = np.random.RandomState(seed + zlib.crc32(name.encode()) % 100000)
+    if name.endswith('bias'):
+        return (0.01 * rs.standard_normal(shape)).astype(np.float32)
+    gain = 0.01 if 'actor' in name else 1.0 if 'value_fn' in name else np.sqrt(2)
+    return (gain / np.sqrt(np.prod(shape[1:])) * rs.standard_normal(shape)).astype(np.float32)
+
+
+def digest(a, samples=64):
+    """Same as make_golden.digest: sum, sum |.|, `samples` evenly spaced elements (f64)."""
+    f = np.asarray(a, np.float64).reshape(-1)
+    idx = np.linspace(0, f.size - 1, min(samples, f.size)).astype(np.int64)
+    return np.concatenate([[f.sum(), np.abs(f).sum()], f[idx]])
+
+
+class _Env:
+    def __init__(self, num_actions):
+        self.single_action_space = type('Discrete', (), {'n': num_actions})()
+
+
+def container(num_actions=4):
+    """This package's models.Convolutional under torch.manual_seed(1): the golden's `init.*` digests are what the reference class
+    draws under the same seed (same modules, same construction and init order; QR rounding may differ between LAPACK builds)."""
+    from pufferlib_amd import models
+    torch.manual_seed(1)
+    return models.Convolutional(_Env(num_actions), framestack=4, flat_size=64 * 7 * 7)
+
+
+def start_weights(net):
+    """name -> the golden run's start value, for every parameter of `net`."""
+    return {k: cnn_start_weight(k, tuple(v.shape)) for k, v in net.state_dict().items()}
+
+
+class ReplayVec:
+    """recv() hands out the recorded observation / reward / done stream of the golden rollout; send() ignores the actions (the
+    test compares them to the recorded ones)."""
+
+    def __init__(self, g, it=0):
+        self.frame_ids = g[f'it{it}.frame_ids']
+        T, N = self.frame_ids.shape
+        self.num_envs = N
+        self.rewards = g[f'it{it}.rewards'].reshape(T, N)
+        self.dones = g[f'it{it}.dones'].reshape(T, N)
+        self.t = 0
+        self.observations = np.zeros((N, 4, 84, 84), np.uint8)
+
+    @classmethod
+    def blank(cls, n):
+        """Only the shape: for an oracle Trainer whose experience buffers the test fills itself."""
+        self = cls.__new__(cls)
+        self.num_envs, self.t = n, 0
+        self.observations = np.zeros((n, 4, 84, 84), np.uint8)
+        return self
+
+    def async_reset(self, seed):
+        self.t = 0
+
+    def recv(self):
+        t, N = self.t, self.num_envs
+        for e in range(N):
+            self.observations[e] = cnn_frame(self.frame_ids[t, e])
+        return (self.observations, self.rewards[t], self.dones[t].astype(bool), np.zeros(N, bool), [], np.arange(N), np.ones(N, bool))
+
+    def send(self, actions):
+        self.t += 1

@@ -424,6 +424,17 @@ def cnn_frame(counter, base_seed=777):
     return np.random.RandomState(base_seed + int(counter)).randint(0, 256, (4, 84, 84)).astype(np.uint8)
 
 
+def cnn_start_weight(name, shape, seed=4242):
+    """Start value of parameter `name` of the golden NatureCNN run: N(0, gain^2 / fan_in) weights (gain as layer_init's std:
+    sqrt(2), actor 0.01, value_fn 1), N(0, 0.01^2) biases, from numpy's legacy generator keyed by the parameter name."""
+    import zlib
+    rs = np.random.RandomState(seed + zlib.crc32(name.encode()) % 100000)
+    if name.endswith('bias'):
+        return (0.01 * rs.standard_normal(shape)).astype(np.float32)
+    gain = 0.01 if 'actor' in name else 1.0 if 'value_fn' in name else np.sqrt(2)
+    return (gain / np.sqrt(np.prod(shape[1:])) * rs.standard_normal(shape)).astype(np.float32)
+
+
 def digest(a, samples=64):
     """Compact fingerprint of a big tensor: sum, sum of |.|, and `samples` evenly spaced elements."""
     f = np.asarray(a, np.float64).reshape(-1)
@@ -496,6 +507,12 @@ def gen_ppo_cnn(num_envs=4, horizon=16, iters=1):
     net = pufferlib.models.Convolutional(vec.driver_env, framestack=4, flat_size=64 * 7 * 7)
     policy = pufferlib.frameworks.cleanrl.Policy(net)
     out = {}
+    for k, v in policy.state_dict().items():
+        out['init.' + k] = digest(v.detach().numpy())      # layer_init under torch.manual_seed(1) (QR: equal up to LAPACK rounding)
+    # the run itself starts from weights any platform can rebuild bit for bit: numpy's legacy normal stream, layer_init's scales
+    with torch.no_grad():
+        for k, v in policy.state_dict().items():
+            v.copy_(torch.from_numpy(cnn_start_weight(k[len('policy.'):], tuple(v.shape))))   # keyed by the bare parameter name
     for k, v in policy.state_dict().items():
         out['w0.' + k] = digest(v.detach().numpy())
     noise = []

@@ -1,0 +1,202 @@
+"""The NatureCNN policy (pufferlib.models.Convolutional, BASELINE configs[3]) through create / evaluate / train on the device frame
+vecenv (vector.Frames):
+
+  * the frame generator and protocol state machine of vector.Frames against an independent Philox restatement;
+  * the reference's own run (tests/golden/ppo_cnn.npz, unmodified pufferlib + clean_pufferl on CPU): rollout forward + sampling on
+    its frames with its multinomial noise (actions bit-exact), then its recorded experience through the HIP update — losses and
+    updated weights within 1e-5;
+  * device rollout + update on Philox frames against the torch-fp32 oracle trainer, two iterations (optimizer state carried)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def _make(n, **kw):
+    from pufferlib_amd import vector
+    return vector.make(vector.make_frames, env_kwargs=kw, num_envs=n, backend=vector.Frames)
+
+
+def _frame(seed, env, episode, tick, nbytes=4 * 84 * 84):
+    from oracle import c_oracle
+    chunks = np.arange(nbytes // 16, dtype=np.uint64)
+    w = c_oracle.philox4x32_10_bulk(np.uint64(env), chunks, np.uint64(episode), np.uint64(tick), seed & 0xFFFFFFFF, 0x5359 ^ (seed >> 32))
+    return np.stack(w, axis=-1).astype('<u4').view(np.uint8).reshape(-1)
+
+
+def test_frame_generator_and_protocol_state_machine():
+    n, ep = 19, 4
+    vec = _make(n, episode_length=ep)
+    assert vec.single_observation_space.shape == (4, 84, 84) and vec.single_observation_space.dtype == np.uint8
+    assert vec.single_action_space.n == 4
+    vec.async_reset(5)
+    tick, episode = np.zeros(n, int), np.zeros(n, int)
+    want_r, want_t = np.zeros(n, np.float32), np.zeros(n, bool)
+    rng = np.random.default_rng(0)
+    finished = 0
+    for t in range(2 * (ep + 1) + 2):
+        o, r, te, tr, infos, ids, mask = vec.recv()
+        assert o.dtype == torch.uint8 and tuple(o.shape) == (n, 4, 84, 84)
+        o = o.cpu().numpy().reshape(n, -1)
+        for e in (0, 7, n - 1):
+            assert np.array_equal(o[e], _frame(5, e, episode[e], tick[e])), (t, e)
+        assert np.array_equal(r.cpu().numpy(), want_r) and np.array_equal(te.cpu().numpy(), want_t), t
+        finished += len(infos)
+        for i in infos:
+            assert i['episode_length'] == ep and i['episode_return'] == i['score'] * ep
+        a = rng.integers(0, 4, n)
+        done = tick == ep
+        want_r = np.where(done, 0.0, (a == o[:, 0].astype(int) % 4)).astype(np.float32)
+        tick = np.where(done, 0, tick + 1)
+        episode = episode + done
+        want_t = (tick == ep) & ~done
+        vec.send(a)
+    assert finished == 2 * n
+    assert 100 < o.astype(np.float64).mean() < 155          # bytes are uniform 0..255
+
+
+def _trainer(n, horizon, mbs, bptt, epochs, total, hp, seed, start=None, **envkw):
+    from pufferlib_amd import clean_pufferl, cleanrl
+    from test_gpu_ppo import _config
+    import cnn_golden
+    vec = _make(n, **envkw)
+    net = cnn_golden.container()
+    if start is not None:
+        with torch.no_grad():
+            for k, v in net.state_dict().items():
+                v.copy_(torch.from_numpy(start[k]) if isinstance(start, dict) else start(k, v))
+    pol = cleanrl.Policy(net)
+    data = clean_pufferl.create(_config(n, horizon, mbs, bptt, epochs, total, hp, seed=seed, env='frames'), vec, pol)
+    return vec, pol, data
+
+
+def test_reference_run_with_convolutional_policy(golden_dir):
+    import cnn_golden
+    from pufferlib_amd import clean_pufferl
+    g = np.load(os.path.join(golden_dir, 'ppo_cnn.npz'))
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    hp = [float(x) for x in g['hparams']]
+    B = n * horizon
+    start = cnn_golden.start_weights(cnn_golden.container())
+    vec, pol, data = _trainer(n, horizon, mbs, bptt, epochs, total, hp, 1, start=start)
+    for k, v in pol.state_dict().items():
+        assert np.array_equal(cnn_golden.digest(v.cpu().numpy()), g['w0.' + k]), k
+    # rollout mode: the reference's policy(obs) on its own frames, its multinomial's exponential draws
+    frame_ids, noise = g['it0.frame_ids'], g['it0.noise']
+    frames = np.stack([[cnn_golden.cnn_frame(frame_ids[t, e]) for e in range(n)] for t in range(horizon)])   # (T, N, 4, 84, 84)
+    dev = vec.device
+    for t in range(horizon):
+        a, lp, ent, val = pol(torch.as_tensor(frames[t]).to(dev), noise=torch.as_tensor(noise[t]))
+        assert np.array_equal(a.cpu().numpy(), g['it0.actions'][t * n:(t + 1) * n]), t
+        np.testing.assert_allclose(lp.cpu().numpy(), g['it0.logprobs'][t * n:(t + 1) * n], **TOL)
+        np.testing.assert_allclose(val.cpu().numpy().reshape(-1), g['it0.values'][t * n:(t + 1) * n], **TOL)
+    # training mode: its recorded experience (storage order is step-major; ours env-major) through the HIP update
+    e = data.experience
+    em = lambda x: torch.as_tensor(np.ascontiguousarray(np.asarray(x).reshape(horizon, n, *np.asarray(x).shape[1:]).swapaxes(0, 1))  # noqa: E731
+                                   .reshape(B, *np.asarray(x).shape[1:])).to(dev)
+    e.obs.copy_(em(frames.reshape(B, -1)))
+    e.actions.copy_(em(g['it0.actions'].astype(np.int32)))
+    for dst, key in ((e.logprobs, 'logprobs'), (e.values, 'values'), (e.rewards, 'rewards'), (e.dones, 'dones')):
+        dst.copy_(em(g['it0.' + key].astype(np.float32)))
+    e.ptr = B
+    data.global_step = int(g['it0.global_step'])
+    clean_pufferl.train(data)
+    L = data.losses
+    got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance]
+    np.testing.assert_allclose(got, g['it0.losses'], **TOL)
+    for k, v in pol.state_dict().items():
+        np.testing.assert_allclose(cnn_golden.digest(v.cpu().numpy()), g['it0.w.' + k], err_msg=k, **TOL)
+
+
+def test_device_rollout_and_update_vs_oracle_trainer():
+    """Rollout forward against the torch-fp32 oracle; the update against the oracle run in DOUBLE precision on the same fp32 inputs.
+    (With 3136-term dot products and values of O(10), torch's own CPU fp32 result sits ~1.4e-5 (relative) from the double-precision
+    value of the value loss, the HIP result ~1e-7 — tools/diag_cnn_precision.py — so the fp32 oracle is held to 1e-4 of the double
+    one, and the HIP path to the 1e-5 of the spec.)"""
+    import cnn_golden
+    from oracle import c_oracle, ppo_torch
+    from pufferlib_amd import clean_pufferl
+    n, horizon, nmb, bptt, epochs = 8, 8, 2, 4, 2
+    B = n * horizon
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
+    start = cnn_golden.start_weights(cnn_golden.container())
+    vec, pol, data = _trainer(n, horizon, B // nmb, bptt, epochs, B * 10, hp, 3, start=start, episode_length=5)
+    opols = {torch.float32: ppo_torch.ConvPolicy(start), torch.float64: ppo_torch.ConvPolicy(start, dtype=torch.float64)}
+    sm = lambda x: x.view(n, horizon, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
+    keys = ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac', 'explained_variance')
+    trainers = {}
+    try:
+        for it in range(2):
+            step0 = pol.noise_step
+            stats, _ = clean_pufferl.evaluate(data)
+            e = data.experience
+            obs = sm(e.obs)                                                  # step-major (T*N, 28224) uint8
+            # the oracle's rollout forward on the device's frames with the oracle's restatement of the Philox noise stream
+            opol = opols[torch.float32]
+            acts, lps, vals = [], [], []
+            with torch.no_grad():
+                for t in range(horizon):
+                    logits, value, _ = opol.forward(torch.as_tensor(obs[t * n:(t + 1) * n]).float())
+                    q = c_oracle.philox_exp_noise(3, step0 + t, n, 4)
+                    a, lp, _ = ppo_torch.sample_logits(logits, noise=torch.as_tensor(q))
+                    acts.append(a.numpy()), lps.append(lp.numpy()), vals.append(value.reshape(-1).numpy())
+            assert np.array_equal(sm(e.actions), np.concatenate(acts)), it
+            np.testing.assert_allclose(sm(e.logprobs), np.concatenate(lps), **TOL)
+            np.testing.assert_allclose(sm(e.values), np.concatenate(vals), **TOL)
+            Lo = {}
+            for dt, opol in opols.items():
+                torch.set_default_dtype(dt)
+                new = ppo_torch.Trainer(opol, cnn_golden.ReplayVec.blank(n), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt,
+                                        update_epochs=epochs, learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3],
+                                        vf_coef=hp[4], vf_clip_coef=hp[5], max_grad_norm=hp[6], ent_coef=hp[7], total_timesteps=B * 10, seed=3)
+                if dt in trainers:
+                    new.opt = trainers[dt].opt
+                trainers[dt] = tr = new
+                tr.obs = torch.as_tensor(obs).to(dt)
+                tr.actions = sm(e.actions).astype(np.int64)
+                tr.logprobs, tr.rewards, tr.dones, tr.values = (sm(x).copy() for x in (e.logprobs, e.rewards, e.dones, e.values))
+                tr.global_step = data.global_step
+                Lo[dt] = tr.train()
+            torch.set_default_dtype(torch.float32)
+            clean_pufferl.train(data)
+            L = data.losses
+            want = [Lo[torch.float64][k] for k in keys]
+            np.testing.assert_allclose([getattr(L, k) for k in keys], want, err_msg=f'iteration {it}', **TOL)
+            np.testing.assert_allclose([Lo[torch.float32][k] for k in keys], want, rtol=1e-4, atol=1e-5, err_msg=f'fp32 oracle, iteration {it}')
+            sd = pol.state_dict()
+            for k, arr in opols[torch.float64].state_arrays().items():
+                np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=f'{k}, iteration {it}', **TOL)
+                np.testing.assert_allclose(opols[torch.float32].state_arrays()[k], arr, rtol=1e-4, atol=1e-5, err_msg=f'fp32 oracle {k}')
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert stats['episode_length'] == 5
+
+
+def test_conv_policy_checkpoint_round_trip(tmp_path):
+    from pufferlib_amd import clean_pufferl
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
+    vec, pol, data = _trainer(4, 4, 8, 2, 1, 160, hp, 2)
+    data.config.data_dir, data.config.exp_id = str(tmp_path), 'cnn'
+    clean_pufferl.evaluate(data)
+    clean_pufferl.train(data)
+    path = clean_pufferl.save_checkpoint(data)
+    assert os.path.getsize(path) < 8 << 20                   # parameters only (6.7 MB), none of the engine's activation buffers
+    want = {k: v.clone() for k, v in pol.state_dict().items()}
+    clean_pufferl.evaluate(data)
+    clean_pufferl.train(data)
+    assert any(not torch.equal(want[k], v) for k, v in pol.state_dict().items())
+    clean_pufferl.try_load_checkpoint(data)
+    for k, v in pol.state_dict().items():
+        assert torch.equal(want[k], v), k
+    loaded = torch.load(path, weights_only=False)
+    frames = vec.recv()[0]
+    a0 = loaded(frames, noise=torch.ones(4, 4))
+    a1 = pol(frames, noise=torch.ones(4, 4))
+    for x, y in zip(a0, a1):
+        assert torch.equal(x, y)

@@ -152,6 +152,36 @@ def test_ppo_replay_matches_reference(golden_dir, tag):
         assert abs(tr.opt.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-15
 
 
+def test_conv_ppo_replay_matches_reference(golden_dir):
+    """oracle ConvPolicy + Trainer against the unmodified reference's run with models.Convolutional (ppo_cnn.npz): same initial
+    weights (digests), identical actions given the recorded multinomial noise, log-probabilities / values / losses / updated weights."""
+    import cnn_golden
+    torch.set_num_threads(1)
+    g = _load(golden_dir, 'ppo_cnn.npz')
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    lr, gamma, lam, clip, vf_coef, vf_clip, mgn, ent = (float(x) for x in g['hparams'])
+    net = cnn_golden.container()
+    for k, v in net.state_dict().items():      # layer_init of the container == the reference's, up to the QR's rounding
+        np.testing.assert_allclose(cnn_golden.digest(v.numpy()), g['init.policy.' + k], rtol=1e-5, atol=1e-6, err_msg=k)
+    w0 = cnn_golden.start_weights(net)
+    for k, v in w0.items():
+        assert np.array_equal(cnn_golden.digest(v), g['w0.policy.' + k]), k
+    pol = ppo_torch.ConvPolicy(w0)
+    tr = ppo_torch.Trainer(pol, cnn_golden.ReplayVec(g), batch_size=n * horizon, minibatch_size=mbs, bptt_horizon=bptt, update_epochs=epochs,
+                           learning_rate=lr, gamma=gamma, gae_lambda=lam, clip_coef=clip, vf_coef=vf_coef, vf_clip_coef=vf_clip,
+                           max_grad_norm=mgn, ent_coef=ent, total_timesteps=total, seed=1)
+    tr.evaluate(g['it0.noise'])
+    assert np.array_equal(tr.actions, g['it0.actions'].astype(np.int64)), 'actions differ'
+    np.testing.assert_allclose(tr.logprobs, g['it0.logprobs'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tr.values, g['it0.values'], rtol=1e-5, atol=1e-6)
+    L = tr.train()
+    np.testing.assert_allclose(tr.b_advantages.numpy(), g['it0.advantages'], rtol=1e-5, atol=1e-6)
+    got = [L['policy_loss'], L['value_loss'], L['entropy'], L['old_approx_kl'], L['approx_kl'], L['clipfrac'], L['explained_variance']]
+    np.testing.assert_allclose(got, g['it0.losses'], rtol=2e-5, atol=1e-7)
+    for name, arr in pol.state_arrays().items():
+        np.testing.assert_allclose(cnn_golden.digest(arr), g['it0.w.policy.' + name], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
 def test_stochastic_oracle_replays_reference_trajectory(golden_dir):
     """ocean.Stochastic under Serial + GymnasiumPufferEnv + EpisodeStats (tests/golden/stochastic.npz from the unmodified
     reference): observations, f32 rewards, terminals, auto-reset rows and the episode infos, bit for bit."""
