@@ -36,12 +36,19 @@ D, NT = 3, 1             # obs 7x7 = 49 floats, padded to a 64-float row (256 B)
 FLOP_PER_ROW_UPDATE = 39680          # fwd 18 688 + bwd 20 992 per row per epoch (the 64-float padded row)
 FLOP_PER_ROW_USEFUL = 2 * (49 * 128 + 128 * 9) + 2 * 49 * 128 + 2 * 2 * 128 * 9   # the same on the 49 real columns: 32 000
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+# NatureCNN (workload c4; SURVEY 8d: ~18.7 MFLOP per forward sample), products of the rows-form kernel per frame:
+#   forward  conv1 2*400*256*32 + conv2 2*81*512*64 + conv3 2*49*576*64 + fc 2*3136*512          = 18 685 952
+#   dX       fc 2*3136*512 + conv3 (= its forward) + conv2 (= its forward); conv1 needs none      = 12 132 352
+# and of the weight-form kernel: dW of the four layers (= the forward products) + the heads' 2*512*16
+CNN_FWD_FLOP = 2 * (400 * 256 * 32 + 81 * 512 * 64 + 49 * 576 * 64 + 3136 * 512)
+CNN_DX_FLOP = 2 * (3136 * 512 + 49 * 576 * 64 + 81 * 512 * 64)
+CNN_DW_FLOP = CNN_FWD_FLOP + 2 * 512 * 16
 
 
-def make_config(total_timesteps):
+def make_config(total_timesteps, env='squared'):
     from pufferlib_amd import namespace
     B = NUM_ENVS * HORIZON
-    return namespace(env='squared', seed=1, torch_deterministic=True, device='cuda', total_timesteps=total_timesteps,
+    return namespace(env=env, seed=1, torch_deterministic=True, device='cuda', total_timesteps=total_timesteps,
                      learning_rate=2.5e-4, anneal_lr=True, gamma=0.99, gae_lambda=0.95, update_epochs=EPOCHS,
                      norm_adv=True, clip_coef=0.1, clip_vloss=True, vf_coef=0.5, vf_clip_coef=0.1, max_grad_norm=0.5,
                      ent_coef=0.01, target_kl=None, batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT,
@@ -113,6 +120,58 @@ def cpu_baseline(budget_s=24.0):
                                         box='8-core Xeon @ 2.1 GHz, survey container (no GPU)', source='BASELINE.md section 2'))
 
 
+def cpu_baseline_c4(n=32, horizon=16):
+    """The oracle port of the conv-policy path (torch-fp32 ConvPolicy + the restated trainer) on a bounded sample of the c4
+    workload's shape: `n` envs x `horizon` steps of uint8 (4, 84, 84) frames (numpy generator), 4 minibatches x 4 epochs."""
+    import numpy as np
+    import torch
+    from oracle import ppo_torch
+    cores_avail = os.cpu_count() or 1
+    cores = min(cores_avail, 16)
+    torch.set_num_threads(cores)
+    B = n * horizon
+    rs = np.random.RandomState(0)
+
+    class FrameVec:
+        num_envs = n
+        observations = np.zeros((n, 4, 84, 84), np.uint8)
+
+        def async_reset(self, seed):
+            pass
+
+        def recv(self):
+            self.observations[:] = rs.randint(0, 256, self.observations.shape, dtype=np.uint8)
+            return (self.observations, rs.randint(0, 2, n).astype(np.float32), np.zeros(n, bool), np.zeros(n, bool), [], np.arange(n), np.ones(n, bool))
+
+        def send(self, actions):
+            pass
+
+    shapes = {'network.0.weight': (32, 4, 8, 8), 'network.0.bias': (32,), 'network.2.weight': (64, 32, 4, 4), 'network.2.bias': (64,),
+              'network.4.weight': (64, 64, 3, 3), 'network.4.bias': (64,), 'network.7.weight': (512, 3136), 'network.7.bias': (512,),
+              'actor.weight': (4, 512), 'actor.bias': (4,), 'value_fn.weight': (1, 512), 'value_fn.bias': (1,)}
+    w = {k: (rs.standard_normal(sh) * (0.01 if len(sh) == 1 else 1.0 / np.sqrt(np.prod(sh[1:])))).astype(np.float32) for k, sh in shapes.items()}
+    tr = ppo_torch.Trainer(ppo_torch.ConvPolicy(w), FrameVec(), batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT, update_epochs=EPOCHS,
+                           learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, vf_coef=0.5, vf_clip_coef=0.1, max_grad_norm=0.5,
+                           ent_coef=0.01, total_timesteps=B * 1000, seed=1)
+
+    def one():
+        tr.evaluate(rs.exponential(size=(horizon, n, 4)).astype('float32'))
+        tr.train()
+
+    one()
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        one()
+        iters += 1
+        if time.perf_counter() - t0 > 15.0 or iters >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=iters * B / dt, unit='env_steps/s', cores=cores, cores_available=cores_avail, cpu_model=_cpu_model(), kind='port',
+                sample=f'{iters} evaluate+train iteration(s) of {n} envs x {horizon} steps of uint8 (4,84,84) frames (batch {B}, {NMB} minibatches x '
+                       f'{EPOCHS} epochs) after 1 warm-up; torch-fp32 NatureCNN on {cores} threads')
+
+
 def self_check(data, pol):
     """One more (untimed) evaluate + train, the train replayed by the torch-fp32 oracle trainer on the device rollout's
     experience at the FULL bench size (one epoch = 4 optimizer steps over all 524 288 rows, to bound the host time): losses and
@@ -166,10 +225,12 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--policy', choices=['mlp', 'lstm'], default='mlp',
                     help="'lstm' = LSTMWrapper(128) on the same envs (BASELINE configs[2]'s policy; not the headline metric)")
-    ap.add_argument('--workload', choices=['squared', 'c3'], default='squared',
+    ap.add_argument('--horizon', type=int, default=None, help='rollout steps per batch (default 128; 32 for c4)')
+    ap.add_argument('--workload', choices=['squared', 'c3', 'c4'], default='squared',
                     help="'c3' = BASELINE configs[2] / SURVEY config C3: MiniGrid-shaped 160-byte rows, 7 actions, 100-step episodes from the "
                          "device-side synthetic generator (the simulator is third-party: env parity unpinned), LSTM(128) policy, bptt 16; "
-                         "not the headline metric")
+                         "not the headline metric; 'c4' = BASELINE configs[3] / SURVEY config C4: 8192 envs of uint8 (4,84,84) frames from the "
+                         "device-side generator (Atari is a third-party emulator: env parity unpinned), NatureCNN policy; not the headline metric")
     ap.add_argument('--no-breakdown', action='store_true', help='skip the extra (untimed) per-kernel breakdown pass')
     args = ap.parse_args()
 
@@ -196,10 +257,19 @@ def main():
         torch.cuda.set_device(0)
 
     from pufferlib_amd import _lib, clean_pufferl, cleanrl, models, vector
+    global NUM_ENVS, HORIZON
+    if args.workload == 'c4':
+        NUM_ENVS, HORIZON = 8192, 32
+    if args.horizon:
+        HORIZON = args.horizon
     L = _lib.lib()
     K, W = args.steps, args.warmup
     per_gpu = NUM_ENVS * HORIZON
-    if args.workload == 'c3':
+    if args.workload == 'c4':
+        args.policy = 'cnn'
+        vec = vector.make(vector.make_frames, env_kwargs=dict(framestack=4, num_actions=4, episode_length=100), num_envs=NUM_ENVS,
+                          backend=vector.Frames)
+    elif args.workload == 'c3':
         args.policy = 'lstm'
         vec = vector.make(vector.make_synthetic, env_kwargs=dict(obs_values=160, num_actions=7, episode_length=100, obs_high=10),
                           num_envs=NUM_ENVS, backend=vector.Synthetic)
@@ -208,9 +278,12 @@ def main():
                           backend=vector.Squared, obs_stride=64)
     if args.policy == 'lstm':
         pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+    elif args.policy == 'cnn':
+        pol = cleanrl.Policy(models.Convolutional(vec.driver_env, framestack=4))
     else:
         pol = cleanrl.Policy(models.Default(vec.driver_env))
-    data = clean_pufferl.create(make_config(per_gpu * world * (K + W) * 4), vec, pol)
+    data = clean_pufferl.create(make_config(per_gpu * world * (K + W) * 4, env={'c4': 'frames', 'c3': 'synthetic'}.get(args.workload, 'squared')),
+                                vec, pol)
 
     def barrier():
         if world > 1:
@@ -221,7 +294,7 @@ def main():
         clean_pufferl.evaluate(data)
         clean_pufferl.train(data)
     # dominant kernel of the update: the fused fwd/loss/bwd kernel (MLP) or the BPTT kernel (LSTM)
-    dominant = 'ppo_mlp_grad' if args.policy == 'mlp' else 'lstm_seq_bwd'
+    dominant = {'mlp': 'ppo_mlp_grad', 'lstm': 'lstm_seq_bwd', 'cnn': 'igemm_rows'}[args.policy]
     L.pfa_timing_select(dominant.encode())
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
@@ -259,6 +332,7 @@ def main():
     if rank == 0 and not args.no_breakdown:
         L.pfa_timing_enable(0)
         names = (('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
+                 else ('igemm_rows', 'igemm_weights', 'gae', 'adam_clip') if args.policy == 'cnn'
                  else (('rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'), 'squared_tape', 'gae', 'lstm_seq_fwd',
                        'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
         for name in names:
@@ -276,6 +350,12 @@ def main():
         # algorithmic flop per minibatch row: DESIGN.md section 4 (MLP fwd+bwd) / section 7 (BPTT product [dxe | dh] = dG Wcat)
         flop_row = FLOP_PER_ROW_UPDATE if args.policy == 'mlp' else 2 * 512 * 256
         achieved = flop_row * rows_per_launch / (avg_ms * 1e-3) / 1e12 if launches else 0.0
+        if args.policy == 'cnn':
+            # the rows-form kernel runs every forward and dX product of the step (launches of different shapes): algorithmic flop of
+            # all of them over their summed duration.  Rollout: B forwards; update: EPOCHS x B x (forward + dX)
+            step_flop = per_gpu * (CNN_FWD_FLOP + EPOCHS * (CNN_FWD_FLOP + CNN_DX_FLOP))
+            achieved = step_flop * K / (total_ms * 1e-3) / 1e12 if launches else 0.0
+            flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
         traffic = None
         pmc = os.path.join(REPO, 'profiles', 'pmc_summary.json')
         if os.path.exists(pmc):
@@ -284,11 +364,16 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            'metric': 'env steps/sec end-to-end PPO (rollout+GAE+update), 4096 envs' + (' [configs[2] workload]' if args.workload == 'c3' else ''),
+            'metric': (f'env steps/sec end-to-end PPO (rollout+GAE+update), {NUM_ENVS} envs'
+                       + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')),
             'value': value, 'unit': 'env_steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': (f'synthetic MiniGrid-shaped rows (160 bytes as 160 f32, 7 actions, 100-step episodes), {NUM_ENVS} envs/GPU x '
+            'config': {'workload': (f'synthetic Atari-shaped frames (uint8 (4,84,84), 4 actions, 100-step episodes), {NUM_ENVS} envs/GPU x {HORIZON} steps, '
+                                    f'NatureCNN (models.Convolutional), {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[3]; env parity '
+                                    'unpinned: third-party emulator' + (', sharded' if world > 1 else '') + ')')
+                       if args.workload == 'c4' else
+                       (f'synthetic MiniGrid-shaped rows (160 bytes as 160 f32, 7 actions, 100-step episodes), {NUM_ENVS} envs/GPU x '
                                     f'{HORIZON} steps, MLP 128 + LSTM 128, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[2]; '
                                     'env parity unpinned: third-party simulator' + (', sharded' if world > 1 else '') + ')')
                        if args.workload == 'c3' else
@@ -308,7 +393,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline_c4() if args.workload == 'c4' else cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         from pufferlib_amd import dist as pdist

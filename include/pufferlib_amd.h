@@ -499,16 +499,20 @@ int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
  *   mode 0 dense            A = ptr[m * lda + k]
  *   mode 1 im2col, f32      ptr = NHWC activations [n][IH][IW][IC]; m = (n, oy, ox), k = (ky*KW + kx)*IC + ic
  *   mode 2 im2col, uint8    ptr = NCHW frames [n][IC][IH][IW];      m = (n, oy, ox), k = (ic*KH + ky)*KW + kx, value / 255.0
- *   mode 3 col2im (for dX)  ptr = NHWC dOut [n][OH][OW][OC]; m = INPUT pixel (n, y, x), k = (ky*KW + kx)*OC + oc
- * pfa_igemm_rows:    C[m][n] = epilogue(sum_k A(m,k) B[k][n]), epilogue 0 none, 1 + bias[n], 2 relu(+ bias[n]), 3 zero where
- *                    mask[m][n] <= 0 (relu' read where the forward left it).  N a multiple of 16, K of 4.
+ *   mode 3 col2im (for dX)  ptr = NHWC dOut [n][OH][OW][OC]; m = INPUT pixel (n, y, x); runs as S*S phases (y mod S, x mod S), each
+ *                           contracting over the (KH/S)(KW/S) taps that reach it: k = (jy*(KW/S) + jx)*OC + oc, tap (py + jy*S, px + jx*S)
+ * pfa_igemm_rows:    C[m][n] = epilogue(sum_k A(m,k) B[n][k]) with B row-major [N][ldb] (k contiguous; mode 3: [S*S][N][ldb], K =
+ *                    KH*KW*OC in total), epilogue 0 none, 1 + bias[n], 2 relu(+ bias[n]), 3 zero where mask[m][n] <= 0 (relu' read
+ *                    where the forward left it).  N a multiple of 16, the contraction length (per phase) of 16.
  * pfa_igemm_weights: out (+)= sum_m A(m,k) D[m][n] scattered to torch's parameter layout: perm 0 [k][n], 1 Linear [n][k],
  *                    2 conv [oc=n][ic][ky][kx] from mode-1 k order, 3 the same from mode-2 k order, 4 Linear behind an NCHW
- *                    Flatten from NHWC rows (IC, IH, IW of the operand = the flattened tensor); split over rows, f64
- *                    reduction of the splits (deterministic).  workspace >= pfa_igemm_weights_workspace_bytes(M, K, N).
- * pfa_colsum:        out[n] (+)= sum_m D[m][n] (bias gradients), f64, deterministic.
- * pfa_cnn_pack_conv / pfa_cnn_transpose: torch weights -> the [k][n] matrices the loaders' patch orders need (after every
- *                    optimizer step): forward B [k][OC]; dX B [(ky*KW+kx)*OC + oc][IC]; Linear [N][K] -> [K][N].
+ *                    Flatten from NHWC rows (IC, IH, IW of the operand = the flattened tensor); bias_out (nullable) (+)= the column
+ *                    sums of D (the bias gradient, from the same pass over D); split over rows, f64 reduction of the splits
+ *                    (deterministic).  workspace >= pfa_igemm_weights_workspace_bytes(M, K, N).
+ * pfa_colsum:        out[n] (+)= sum_m D[m][n] on its own, f64, deterministic.
+ * pfa_cnn_pack_conv / pfa_cnn_transpose: torch weights -> the matrices the loaders' patch orders need (after every optimizer
+ *                    step): forward B [OC][k] (nullable: mode 2's order is torch's own), dX B [S*S][IC][(KH/S)(KW/S)*OC];
+ *                    Linear [N][K] -> [K][N] (B of its dX).
  * pfa_cnn_heads_sample / pfa_cnn_heads_loss (csrc/cnn_heads.hip): decode_actions + sample_logits, and the PPO loss with its
  *                    gradients w.r.t. the head outputs [rows][16] and the hidden vector [rows][512], for a chunk
  *                    [q0, q0 + rows) of minibatch mb; loss_pairs16 as in pfa_ppo_mlp_grad (accumulate != 0 adds chunks up).
@@ -525,13 +529,13 @@ int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, const float
                    int32_t epilogue, const float *bias, const float *mask, int32_t ldmask, pfa_stream_t stream);
 size_t pfa_igemm_weights_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int pfa_igemm_weights(const pfa_igemm_operand *a, int64_t M, int32_t K, const float *D, int32_t ldd, int32_t N, float *out,
-                      int32_t perm, int32_t accumulate, void *workspace, pfa_stream_t stream);
+                      int32_t perm, int32_t accumulate, float *bias_out, void *workspace, pfa_stream_t stream);
 size_t pfa_colsum_workspace_bytes(int32_t N);
 int pfa_colsum(const float *D, int64_t M, int32_t N, int32_t ldd, float *out, int32_t accumulate, void *workspace, pfa_stream_t stream);
 int pfa_cnn_pack_conv(const float *w, const pfa_igemm_operand *geom, int32_t u8_order, float *fwd, float *dx, pfa_stream_t stream);
 int pfa_cnn_transpose(const float *w, int32_t N, int32_t K, float *out, pfa_stream_t stream);
 /* Linear(channels*hw, N) behind nn.Flatten of an NCHW tensor (models.py:133) for NHWC activations: perm_out [N][K'] with the
- * columns in NHWC order (B of dX), t_out [K'][N] (B of the forward); pfa_igemm_weights perm 4 undoes the order for dW. */
+ * columns in NHWC order (B of the forward), t_out [K'][N] (B of dX); pfa_igemm_weights perm 4 undoes the order for dW. */
 int pfa_cnn_pack_fc(const float *w, int32_t N, int32_t channels, int32_t hw, float *perm_out, float *t_out, pfa_stream_t stream);
 int pfa_cnn_heads_sample(const float *h, int64_t rows, const float *actor_w, const float *actor_b, const float *value_w,
                          const float *value_b, int32_t num_actions, const float *noise, const pfa_noise_key *key, int64_t row_offset,

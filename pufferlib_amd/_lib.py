@@ -210,7 +210,7 @@ _SIGNATURES = {
     'pfa_dist_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
     'pfa_igemm_rows': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, C.c_int32, P]),
     'pfa_igemm_weights_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    'pfa_igemm_weights': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P]),
+    'pfa_igemm_weights': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, P]),
     'pfa_colsum_workspace_bytes': (C.c_size_t, [C.c_int32]),
     'pfa_colsum': (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, C.c_int32, P, P]),
     'pfa_cnn_pack_conv': (C.c_int, [P, C.POINTER(IgemmOperand), C.c_int32, P, P, P]),

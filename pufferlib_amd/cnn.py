@@ -36,13 +36,19 @@ class ConvLayer:
         self.K = ic * kh * kw
         self.u8 = u8_input
         self.geom = (ic, ih, iw, oc, self.OH, self.OW, kh, kw, stride)
-        self.w_fwd = torch.empty(self.K, oc, device=device)                      # [k][oc] in the loader's patch order
-        self.w_dx = None if u8_input else torch.empty(kh * kw * oc, ic, device=device)   # [(ky, kx, oc)][ic]
+        # forward B [oc][k] in the loader's patch order: the first layer's order (ic, ky, kx) is torch's own, so the weight serves
+        self.w_fwd = weight.view(oc, self.K) if u8_input else torch.empty(oc, self.K, device=device)
+        # dX B [phase][ic][(jy, jx, oc)] (no dX for the first layer)
+        self.phases = stride * stride
+        self.KP = (kh // stride) * (kw // stride) * oc if not u8_input else 0
+        self.w_dx = None if u8_input else torch.empty(self.phases, ic, self.KP, device=device)
 
     def pack(self):
+        if self.u8:
+            return
         L = _lib.lib()
-        _lib.check(L.pfa_cnn_pack_conv(_lib.ptr(self.w), C.byref(_operand(0, self.w, 0, self.geom)), 1 if self.u8 else 0, _lib.ptr(self.w_fwd),
-                                       _lib.ptr(self.w_dx), _lib.stream_handle()), 'pack_conv')
+        _lib.check(L.pfa_cnn_pack_conv(_lib.ptr(self.w), C.byref(_operand(0, self.w, 0, self.geom)), 0, _lib.ptr(self.w_fwd), _lib.ptr(self.w_dx),
+                                       _lib.stream_handle()), 'pack_conv')
 
     def out_rows(self, n):
         return n * self.OH * self.OW
@@ -50,24 +56,20 @@ class ConvLayer:
     def forward(self, x, n, out):
         """out [n*OH*OW][OC] = relu(conv(x) + bias)."""
         a = _operand(MODE_IM2COL_U8 if self.u8 else MODE_IM2COL_F32, x, 0, self.geom)
-        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), self.out_rows(n), self.K, _lib.ptr(self.w_fwd), self.OC, self.OC, _lib.ptr(out), self.OC,
+        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), self.out_rows(n), self.K, _lib.ptr(self.w_fwd), self.K, self.OC, _lib.ptr(out), self.OC,
                                              EPI_BIAS_RELU, _lib.ptr(self.b), None, 0, _lib.stream_handle()), 'conv_forward')
 
     def backward_dx(self, dout, n, act_in, dx):
         """dx [n*IH*IW][IC] = conv_transpose(dout) masked by relu'(act_in) — act_in is the (post-ReLU) activation this layer read."""
         a = _operand(MODE_COL2IM, dout, 0, self.geom)
-        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), n * self.IH * self.IW, self.KH * self.KW * self.OC, _lib.ptr(self.w_dx), self.IC, self.IC,
+        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), n * self.IH * self.IW, self.KH * self.KW * self.OC, _lib.ptr(self.w_dx), self.KP, self.IC,
                                              _lib.ptr(dx), self.IC, EPI_MASK, None, _lib.ptr(act_in), self.IC, _lib.stream_handle()), 'conv_dx')
 
-    def backward_dw(self, x, n, dout, gw, gb, accumulate, ws, ws_col):
+    def backward_dw(self, x, n, dout, gw, gb, accumulate, ws):
         """gw (torch layout [OC][IC][KH][KW]) (+)= dout^T im2col(x); gb (+)= column sums of dout."""
-        L = _lib.lib()
         a = _operand(MODE_IM2COL_U8 if self.u8 else MODE_IM2COL_F32, x, 0, self.geom)
-        rows = self.out_rows(n)
-        _lib.check(L.pfa_igemm_weights(C.byref(a), rows, self.K, _lib.ptr(dout), self.OC, self.OC, _lib.ptr(gw), 3 if self.u8 else 2,
-                                       1 if accumulate else 0, _lib.ptr(ws), _lib.stream_handle()), 'conv_dw')
-        _lib.check(L.pfa_colsum(_lib.ptr(dout), rows, self.OC, self.OC, _lib.ptr(gb), 1 if accumulate else 0, _lib.ptr(ws_col),
-                                _lib.stream_handle()), 'conv_db')
+        _lib.check(_lib.lib().pfa_igemm_weights(C.byref(a), self.out_rows(n), self.K, _lib.ptr(dout), self.OC, self.OC, _lib.ptr(gw),
+                                                3 if self.u8 else 2, 1 if accumulate else 0, _lib.ptr(gb), _lib.ptr(ws), _lib.stream_handle()), 'conv_dw')
 
     def dw_workspace(self, n):
         return _lib.lib().pfa_igemm_weights_workspace_bytes(self.out_rows(n), self.K, self.OC)
@@ -79,8 +81,8 @@ class LinearLayer:
     def __init__(self, weight, bias, relu, flatten, device):
         self.w, self.b, self.relu, self.flatten = weight, bias, relu, flatten
         self.N, self.K = weight.shape
-        self.w_t = torch.empty(self.K, self.N, device=device)          # forward B [k][n]
-        self.w_p = torch.empty(self.N, self.K, device=device) if flatten else None   # dX B [n][k'] (columns in NHWC order)
+        self.w_t = torch.empty(self.K, self.N, device=device)          # dX B [k][n]
+        self.w_p = torch.empty(self.N, self.K, device=device) if flatten else None   # forward B [n][k'] (columns in NHWC order)
 
     def pack(self):
         L = _lib.lib()
@@ -92,23 +94,20 @@ class LinearLayer:
 
     def forward(self, x, rows, out):
         a = _operand(MODE_DENSE, x, self.K)
-        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), rows, self.K, _lib.ptr(self.w_t), self.N, self.N, _lib.ptr(out), self.N,
+        wb = self.w_p if self.flatten else self.w
+        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), rows, self.K, _lib.ptr(wb), self.K, self.N, _lib.ptr(out), self.N,
                                              EPI_BIAS_RELU if self.relu else EPI_BIAS, _lib.ptr(self.b), None, 0, _lib.stream_handle()), 'linear_forward')
 
     def backward_dx(self, dout, rows, act_in, dx):
         a = _operand(MODE_DENSE, dout, self.N)
-        wb = self.w_p if self.flatten else self.w
-        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), rows, self.N, _lib.ptr(wb), self.K, self.K, _lib.ptr(dx), self.K, EPI_MASK, None,
+        _lib.check(_lib.lib().pfa_igemm_rows(C.byref(a), rows, self.N, _lib.ptr(self.w_t), self.N, self.K, _lib.ptr(dx), self.K, EPI_MASK, None,
                                              _lib.ptr(act_in), self.K, _lib.stream_handle()), 'linear_dx')
 
-    def backward_dw(self, x, rows, dout, gw, gb, accumulate, ws, ws_col):
-        L = _lib.lib()
+    def backward_dw(self, x, rows, dout, gw, gb, accumulate, ws):
         geom = (self.flatten[0], self.flatten[1], self.flatten[2], 0, 0, 0, 0, 0, 0) if self.flatten else (0,) * 9
         a = _operand(MODE_DENSE, x, self.K, geom)
-        _lib.check(L.pfa_igemm_weights(C.byref(a), rows, self.K, _lib.ptr(dout), self.N, self.N, _lib.ptr(gw), 4 if self.flatten else 1,
-                                       1 if accumulate else 0, _lib.ptr(ws), _lib.stream_handle()), 'linear_dw')
-        _lib.check(L.pfa_colsum(_lib.ptr(dout), rows, self.N, self.N, _lib.ptr(gb), 1 if accumulate else 0, _lib.ptr(ws_col),
-                                _lib.stream_handle()), 'linear_db')
+        _lib.check(_lib.lib().pfa_igemm_weights(C.byref(a), rows, self.K, _lib.ptr(dout), self.N, self.N, _lib.ptr(gw), 4 if self.flatten else 1,
+                                                1 if accumulate else 0, _lib.ptr(gb), _lib.ptr(ws), _lib.stream_handle()), 'linear_dw')
 
     def dw_workspace(self, rows):
         return _lib.lib().pfa_igemm_weights_workspace_bytes(rows, self.K, self.N)
@@ -156,7 +155,6 @@ class Engine:
         ws = max([self.conv1.dw_workspace(n), self.conv2.dw_workspace(n), self.conv3.dw_workspace(n), self.fc.dw_workspace(n),
                   L.pfa_igemm_weights_workspace_bytes(n, 512, 16)])
         self.ws = torch.empty(ws, dtype=torch.uint8, device=dev)
-        self.ws_col = torch.empty(L.pfa_colsum_workspace_bytes(512), dtype=torch.uint8, device=dev)
         self.ws_loss = torch.empty(L.pfa_cnn_heads_loss_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.g16 = torch.empty(16, 512, device=dev)
         self.gb16 = torch.empty(16, device=dev)
@@ -196,13 +194,13 @@ class Engine:
     def backward(self, frames, m, dh_pre, gv, acc):
         """Back-propagate d loss / d (pre-ReLU hidden) [m][512] through Linear(3136,512) and the three conv layers of the chunk
         whose forward just ran (activations a1/a2/a3 live); weight / bias gradients into the views `gv` (accumulate = acc)."""
-        self.fc.backward_dw(self.a3, m, dh_pre, gv['network.7.weight'], gv['network.7.bias'], acc, self.ws, self.ws_col)
+        self.fc.backward_dw(self.a3, m, dh_pre, gv['network.7.weight'], gv['network.7.bias'], acc, self.ws)
         self.fc.backward_dx(dh_pre, m, self.a3, self.d3)            # d3 masked by relu'(a3)
-        self.conv3.backward_dw(self.a2, m, self.d3, gv['network.4.weight'], gv['network.4.bias'], acc, self.ws, self.ws_col)
+        self.conv3.backward_dw(self.a2, m, self.d3, gv['network.4.weight'], gv['network.4.bias'], acc, self.ws)
         self.conv3.backward_dx(self.d3, m, self.a2, self.d2)
-        self.conv2.backward_dw(self.a1, m, self.d2, gv['network.2.weight'], gv['network.2.bias'], acc, self.ws, self.ws_col)
+        self.conv2.backward_dw(self.a1, m, self.d2, gv['network.2.weight'], gv['network.2.bias'], acc, self.ws)
         self.conv2.backward_dx(self.d2, m, self.a1, self.d1)
-        self.conv1.backward_dw(frames, m, self.d1, gv['network.0.weight'], gv['network.0.bias'], acc, self.ws, self.ws_col)
+        self.conv1.backward_dw(frames, m, self.d1, gv['network.0.weight'], gv['network.0.bias'], acc, self.ws)
 
     def update(self, mb, hp, adv_stats, global_mb_rows, grads, B):
         """Forward + PPO loss + backward for minibatch `mb` of the trainer's experience (clean_pufferl.py:179-244 up to
@@ -243,9 +241,8 @@ class Engine:
                                             1 if acc else 0, _lib.ptr(self.ws_loss), stream), 'cnn_heads_loss')
             # heads: dW = dout^T h ([16][512]: rows < A actor, row A value_fn), db = column sums of dout
             a = _operand(MODE_DENSE, h, 512)
-            _lib.check(L.pfa_igemm_weights(C.byref(a), m, 512, _lib.ptr(self.dout), 16, 16, _lib.ptr(self.g16), 1, 1 if acc else 0, _lib.ptr(self.ws),
-                                           stream), 'heads_dw')
-            _lib.check(L.pfa_colsum(_lib.ptr(self.dout), m, 16, 16, _lib.ptr(self.gb16), 1 if acc else 0, _lib.ptr(self.ws_col), stream), 'heads_db')
+            _lib.check(L.pfa_igemm_weights(C.byref(a), m, 512, _lib.ptr(self.dout), 16, 16, _lib.ptr(self.g16), 1, 1 if acc else 0,
+                                           _lib.ptr(self.gb16), _lib.ptr(self.ws), stream), 'heads_dw')
             dh_pre = self.dh                       # already w.r.t. the pre-ReLU hidden (masked in the heads kernel)
             self.backward(self.frames, m, dh_pre, gv, acc)
         A = cp.num_actions

@@ -4,19 +4,25 @@
 //
 // Every product of the forward pass and of loss.backward() is one of two contractions over v_mfma_f32_16x16x4_f32 (exact fp32
 // FMA chains; the 1e-5 parity target rules out bf16):
-//   rows form   C[m][n]  = sum_k A(m, k) * B[k][n]            forward conv / linear (m = output pixel or sample, k = patch index)
-//                                                             and dX (m = INPUT pixel, k = (ky, kx, oc), A = gathered dOut)
-//   weight form G[k][n]  = sum_m A(m, k) * D[m][n]            dW (contraction over the rows of the minibatch, split over row chunks)
+//   rows form   C[m][n]  = sum_k A(m, k) * B[n][k]            forward conv / linear (m = output pixel or sample, k = patch index)
+//                                                             and dX (m = INPUT pixel, k = (tap, oc), A = gathered dOut)
+//   weight form G[k][n]  = sum_m A(m, k) * D[m][n]            dW (+ column sums of D = the bias gradient), split over row chunks
 // A(m, k) is never materialised: the tile loader computes the address of the patch element (implicit im2col / col2im), so a conv
-// layer reads its input once per k-slab from L2/HBM and nothing else.  Activations are NHWC f32 (the patch index runs
-// (ky, kx, ic) with ic contiguous: 16-float runs per row), the first layer reads the uint8 NCHW frames directly ((ic, ky, kx) with
-// kx contiguous: 4-byte runs) and applies `/ 255.0` on the way in.  Weights are re-packed into the [k][n] matrices these orders
-// need after every optimizer step (pfa_cnn_pack); gradients leave in torch's parameter layout.
+// layer reads its input once per k-slab from L2/HBM and nothing else.  Activations are NHWC f32 (patch index (ky, kx, ic), ic
+// contiguous); the first layer reads the uint8 NCHW frames directly ((ic, ky, kx), kx contiguous: one aligned 32-bit word = four
+// patch elements) and applies `/ 255.0` on the way in.  dX of a stride-S layer runs as S*S phases (input pixels with equal
+// (y mod S, x mod S) share the (KH/S)(KW/S) kernel taps that reach them), so no multiply is spent on the structural zeros of a
+// transposed strided convolution.
 //
-// Tiling (both forms): 256 threads = 4 waves, k-slabs of 16 double-buffered in LDS k-major ([k][tile width], row stride == 16
-// mod 32 floats so that the MFMA fragment reads — lane (c, g) reads [4 kk + g][16 a + c] — are conflict-free), global loads of
-// slab s+1 in flight under the MFMAs of slab s.  rows form: 128 x (32 | 64) output tile, wave w owns rows 32w..32w+31.
-// weight form: (64 | 128) x (32 | 64) tile of G per workgroup and a chunk of rows, partial sums reduced in f64 (deterministic).
+// Address arithmetic is the cost that competes with the MFMAs (VALU and MFMA issue from the same SIMD port and do not overlap),
+// so it is incremental: a thread keeps the (tap, channel) decomposition of its fixed k-quad (rows form) or its fixed row pair's
+// (n, oy, ox) (weight form) and advances it by one slab with adds and compares; divisions happen once per tile.
+//
+// Tiling: 256 threads = 4 waves, k-slabs of 16, double-buffered in LDS, global loads of slab s+1 in flight under the MFMAs of
+// slab s.  rows form: (64 MI) x (16 NI) output tile, both operands row-major in LDS with a 20-float row stride; lane (c, g) reads
+// ONE float4 per 16 x 16 fragment and slab (row c, columns 4g..4g+3 — the MFMA's k-slot g then stands for k = 4g + kk in step kk,
+// for A and B alike), 2 lanes per bank.  weight form: 128 x (16 NI) tile of G per workgroup and a chunk of rows; the partial sums
+// of the row splits are reduced in f64 in a fixed order (deterministic) and scattered into torch's parameter layout.
 #include "common.hpp"
 #include "mlp_tile.hpp"
 
@@ -24,6 +30,7 @@ namespace pfa {
 
 constexpr int kIgThreads = 256;
 constexpr int kIgBK = 16;
+constexpr int kIgLS = kIgBK + 4;   // LDS row stride (floats) of a [row][16 k] slab
 
 enum IgAMode : int { kADense = 0, kAIm2colF32 = 1, kAIm2colU8 = 2, kACol2im = 3 };
 enum IgEpilogue : int { kEpiNone = 0, kEpiBias = 1, kEpiBiasRelu = 2, kEpiMask = 3 };
@@ -36,123 +43,340 @@ struct IgGeom {
 struct IgA {
     int mode;
     const void *ptr;   // dense: float [M][lda]; im2col f32: NHWC input; im2col u8: NCHW frames; col2im: dOut NHWC [N][OH][OW][OC]
-    long long lda;
+    int lda;
     IgGeom g;
+    int JH, JW, HP, WP;   // col2im: taps per phase (KH/S, KW/S) and pixels per phase and frame (IH/S, IW/S)
 };
 
-// Per-row part of the address (computed once per tile row): returns the element offset of patch element k = 0 and a validity
-// descriptor the k part needs.
+// x / 255.0f for x = 0..255, correctly rounded without the division sequence: one Newton step on x * (1/255) reproduces
+// IEEE division for all 256 inputs (checked exhaustively, tests/test_host_logic.py).
+__device__ __forceinline__ float ig_div255(float x) {
+    const float r = 1.0f / 255.0f;
+    const float q = x * r;
+    return fmaf(fmaf(-q, 255.0f, x), r, q);
+}
+
+// -------------------------------------------------------------------------------------------------- the k part of an address
+// Where patch elements k .. k+3 sit relative to a row's base element, kept incrementally (k advances by one slab at a time).
+struct IgK {
+    int off;          // element offset to add to the row base
+    int p, q, ch;     // running decomposition: im2col f32 (ky, kx, ic) / u8 (ic, ky, kx) / col2im (jy, jx, oc)
+};
+
+template <int MODE>
+__device__ __forceinline__ IgK ig_k_init(const IgA &a, int k) {
+    IgK s;
+    if (MODE == kADense) {
+        s.p = s.q = s.ch = 0;
+        s.off = k;
+    } else if (MODE == kAIm2colF32) {   // k = (ky*KW + kx)*IC + ic
+        const int pix = k / a.g.IC;
+        s.ch = k - pix * a.g.IC;
+        s.p = pix / a.g.KW;
+        s.q = pix - s.p * a.g.KW;
+        s.off = (s.p * a.g.IW + s.q) * a.g.IC + s.ch;
+    } else if (MODE == kAIm2colU8) {    // k = (ic*KH + ky)*KW + kx
+        s.ch = k % a.g.KW;
+        const int t = k / a.g.KW;
+        s.q = t % a.g.KH;
+        s.p = t / a.g.KH;
+        s.off = (s.p * a.g.IH + s.q) * a.g.IW + s.ch;
+    } else {                              // k = (jy*JW + jx)*OC + oc; the row base is dOut pixel (yy, xx): tap (jy, jx) reads (yy-jy, xx-jx)
+        const int pix = k / a.g.OC;
+        s.ch = k - pix * a.g.OC;
+        s.p = pix / a.JW;
+        s.q = pix - s.p * a.JW;
+        s.off = -(s.p * a.g.OW + s.q) * a.g.OC + s.ch;
+    }
+    return s;
+}
+
+template <int MODE>
+__device__ __forceinline__ void ig_k_advance(const IgA &a, IgK &s) {   // k += 16
+    if (MODE == kADense) {
+        s.off += kIgBK;
+    } else if (MODE == kAIm2colF32) {
+        s.ch += kIgBK;
+        while (s.ch >= a.g.IC) {
+            s.ch -= a.g.IC;
+            if (++s.q == a.g.KW) {
+                s.q = 0;
+                ++s.p;
+            }
+        }
+        s.off = (s.p * a.g.IW + s.q) * a.g.IC + s.ch;
+    } else if (MODE == kAIm2colU8) {
+        s.ch += kIgBK;
+        while (s.ch >= a.g.KW) {
+            s.ch -= a.g.KW;
+            if (++s.q == a.g.KH) {
+                s.q = 0;
+                ++s.p;
+            }
+        }
+        s.off = (s.p * a.g.IH + s.q) * a.g.IW + s.ch;
+    } else {
+        s.ch += kIgBK;
+        while (s.ch >= a.g.OC) {
+            s.ch -= a.g.OC;
+            if (++s.q == a.JW) {
+                s.q = 0;
+                ++s.p;
+            }
+        }
+        s.off = -(s.p * a.g.OW + s.q) * a.g.OC + s.ch;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ the row part of an address
 struct IgRow {
-    long long base;   // element offset (dense: m*lda; im2col: (n, oy*S, ox*S) corner; col2im: n*OH*OW*OC)
-    int y, x;         // col2im: input pixel coordinates
-    bool ok;
+    int base;        // element offset of the row's first patch element (col2im: of dOut pixel (yy, xx), possibly outside the image)
+    int y, x;        // col2im: (yy, xx); tap (jy, jx) reads dOut pixel (yy - jy, xx - jx) when that is inside the image
 };
 
-__device__ __forceinline__ IgRow ig_row(const IgA &a, long long m, long long M) {
+// rows form, col2im: m = (n, yy, xx) counts the input pixels of phase (py, px): y = yy*S + py, x = xx*S + px
+template <int MODE>
+__device__ __forceinline__ IgRow ig_row(const IgA &a, int m) {
     IgRow r;
-    r.ok = m < M;
     r.y = r.x = 0;
-    r.base = 0;
-    if (!r.ok) return r;
-    if (a.mode == kADense) {
+    if (MODE == kADense) {
         r.base = m * a.lda;
-    } else if (a.mode == kAIm2colF32) {
+    } else if (MODE == kAIm2colF32 || MODE == kAIm2colU8) {
         const int ohw = a.g.OH * a.g.OW;
-        const long long n = m / ohw;
-        const int rem = (int)(m - n * ohw), oy = rem / a.g.OW, ox = rem - oy * a.g.OW;
-        r.base = ((n * a.g.IH + (long long)oy * a.g.S) * a.g.IW + (long long)ox * a.g.S) * a.g.IC;
-    } else if (a.mode == kAIm2colU8) {
-        const int ohw = a.g.OH * a.g.OW;
-        const long long n = m / ohw;
-        const int rem = (int)(m - n * ohw), oy = rem / a.g.OW, ox = rem - oy * a.g.OW;
-        r.base = (n * a.g.IC * a.g.IH + (long long)oy * a.g.S) * a.g.IW + (long long)ox * a.g.S;
-    } else {   // col2im: m = input pixel (n, y, x)
-        const int ihw = a.g.IH * a.g.IW;
-        const long long n = m / ihw;
-        const int rem = (int)(m - n * ihw);
-        r.y = rem / a.g.IW;
-        r.x = rem - r.y * a.g.IW;
-        r.base = n * a.g.OH * a.g.OW * a.g.OC;
+        const int n = m / ohw, rem = m - n * ohw, oy = rem / a.g.OW, ox = rem - oy * a.g.OW;
+        r.base = MODE == kAIm2colF32 ? ((n * a.g.IH + oy * a.g.S) * a.g.IW + ox * a.g.S) * a.g.IC
+                                       : (n * a.g.IC * a.g.IH + oy * a.g.S) * a.g.IW + ox * a.g.S;
+    } else {
+        const int hw = a.HP * a.WP;
+        const int n = m / hw, rem = m - n * hw, yy = rem / a.WP, xx = rem - yy * a.WP;
+        r.base = ((n * a.g.OH + yy) * a.g.OW + xx) * a.g.OC;
+        r.y = yy;
+        r.x = xx;
     }
     return r;
 }
 
-// Four consecutive patch elements k .. k+3 (k % 4 == 0) of a row.
-__device__ __forceinline__ float4 ig_load4(const IgA &a, const IgRow &r, int k) {
-    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!r.ok) return z;
-    if (a.mode == kADense) {
-        return *reinterpret_cast<const float4 *>((const float *)a.ptr + r.base + k);
-    } else if (a.mode == kAIm2colF32) {   // k = (ky*KW + kx)*IC + ic, IC % 4 == 0
-        const int pix = k / a.g.IC, ic = k - pix * a.g.IC, ky = pix / a.g.KW, kx = pix - ky * a.g.KW;
-        return *reinterpret_cast<const float4 *>((const float *)a.ptr + r.base + ((long long)ky * a.g.IW + kx) * a.g.IC + ic);
-    } else if (a.mode == kAIm2colU8) {    // k = (ic*KH + ky)*KW + kx, KW % 4 == 0; observations.float() / 255.0 (models.py:150)
-        const int kx = k % a.g.KW, t = k / a.g.KW, ky = t % a.g.KH, ic = t / a.g.KH;
-        const uint8_t *p = (const uint8_t *)a.ptr + r.base + ((long long)ic * a.g.IH + ky) * a.g.IW + kx;
-        return make_float4((float)p[0] / 255.0f, (float)p[1] / 255.0f, (float)p[2] / 255.0f, (float)p[3] / 255.0f);
-    } else {                              // k = (ky*KW + kx)*OC + oc: dOut[n][(y-ky)/S][(x-kx)/S][oc] where that is a pixel
-        const int pix = k / a.g.OC, oc = k - pix * a.g.OC, ky = pix / a.g.KW, kx = pix - ky * a.g.KW;
-        const int dy = r.y - ky, dx = r.x - kx;
-        if (dy < 0 || dx < 0) return z;
-        const int oy = dy / a.g.S, ox = dx / a.g.S;
-        if (oy * a.g.S != dy || ox * a.g.S != dx || oy >= a.g.OH || ox >= a.g.OW) return z;
-        return *reinterpret_cast<const float4 *>((const float *)a.ptr + r.base + ((long long)oy * a.g.OW + ox) * a.g.OC + oc);
+#ifdef PFA_IG_BOUNDS   // debug builds (tools/experiments/igemm_index_check.hip): record the first out-of-range access instead of making it
+__device__ long long ig_dbg_limits[3];   // elements of A, B, C
+__device__ int ig_dbg[8];                // [0] hits, [1] operand (0 A, 1 B, 2 C), [2] index lo, [3] index hi, [4] blockIdx.x, [5] threadIdx.x, [6] aux
+__device__ __forceinline__ bool ig_dbg_bad(int operand, long long idx, long long span, int aux) {
+    if (idx >= 0 && idx + span <= ig_dbg_limits[operand]) return false;
+    if (atomicAdd(&ig_dbg[0], 1) == 0) {
+        ig_dbg[1] = operand;
+        ig_dbg[2] = (int)(idx & 0xFFFFFFFF);
+        ig_dbg[3] = (int)(idx >> 32);
+        ig_dbg[4] = blockIdx.x;
+        ig_dbg[5] = threadIdx.x;
+        ig_dbg[6] = aux;
     }
+    return true;
+}
+#define IG_DBG_BAD(op, idx, span, aux) ig_dbg_bad(op, idx, span, aux)
+#else
+#define IG_DBG_BAD(op, idx, span, aux) false
+#endif
+
+template <int MODE>
+__device__ __forceinline__ float4 ig_load4(const IgA &a, const IgRow &r, const IgK &k) {
+    if (MODE == kAIm2colU8) {   // observations.float() / 255.0 (models.py:150); four bytes = one aligned word
+        const uint32_t w = *reinterpret_cast<const uint32_t *>((const uint8_t *)a.ptr + (r.base + k.off));
+        return make_float4(ig_div255((float)(w & 0xFFu)), ig_div255((float)((w >> 8) & 0xFFu)), ig_div255((float)((w >> 16) & 0xFFu)),
+                           ig_div255((float)(w >> 24)));
+    }
+    if (MODE == kACol2im && ((unsigned)(r.y - k.p) >= (unsigned)a.g.OH || (unsigned)(r.x - k.q) >= (unsigned)a.g.OW))
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (IG_DBG_BAD(0, (long long)r.base + k.off, 4, k.off)) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4 *>((const float *)a.ptr + (r.base + k.off));
 }
 
 // ------------------------------------------------------------------------------------------------------------------ rows form
-// C[m][n] = epilogue(sum_k A(m, k) B[k][n]); B row-major [K][ldb]; C row-major [M][ldc].  grid = (ceil(M/128), N / (16 NI)).
-template <int NI>
-__global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, long long M, int K, const float *__restrict__ B, int ldb,
+// C[row(m)][n] = epilogue(sum_k A(m, k) B[n][k]); B row-major [N][ldb] (k contiguous); C row-major, row stride ldc.
+// grid = (ceil(M / (64 MI)), N / (16 NI), phases); col2im: blockIdx.z = phase, M = pixels per phase, B = B0 + phase * N * ldb.
+template <int MODE, int MI, int NI>
+__global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, int M, int K, const float *__restrict__ B, int ldb, int N,
                                                                   float *__restrict__ Cout, int ldc, int epi, const float *__restrict__ bias,
                                                                   const float *__restrict__ mask, int ldmask) {
-    constexpr int TM = 128, TN = 16 * NI, SA = TM + 16, SB = TN % 32 == 0 ? TN + 16 : TN + 32;
-    constexpr int kStage = kIgBK * (SA + SB);
-    __shared__ float lds[2 * kStage];
+    constexpr int TM = 64 * MI, TN = 16 * NI;
+    constexpr int kStage = (TM + TN) * kIgLS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    const long long m0 = (long long)blockIdx.x * TM;
-    const int n0 = blockIdx.y * TN;
-    // A slab: 128 rows x 16 k: thread -> (row = idx / 4, quad = idx % 4), two rows per thread
-    IgRow rows[2];
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const int py = MODE == kACol2im ? (int)blockIdx.z / A.g.S : 0, px = MODE == kACol2im ? (int)blockIdx.z % A.g.S : 0;
+    B += (size_t)blockIdx.z * N * ldb;
+    // loader role: slab row (tid >> 2) + 64 q, k-quad (tid & 3) * 4
+    const int lr = tid >> 2, kq = (tid & 3) * 4;
+    IgRow rows[MI];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) rows[q] = ig_row(A, m0 + (tid + q * kIgThreads) / 4, M);
-    const int kq = (tid & 3) * 4;
+    for (int q = 0; q < MI; ++q) {
+        const int m = m0 + lr + 64 * q;
+        rows[q] = ig_row<MODE>(A, m < M ? m : M - 1);      // rows past the end repeat the last one; the epilogue drops them
+    }
+    IgK kc = ig_k_init<MODE>(A, kq);
+    const float *bp = B + (size_t)(n0 + (lr < TN ? lr : 0)) * ldb + kq;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int stages = K / kIgBK;
+    float4 ra[MI], rb;
+    auto fetch = [&]() {   // the slab the cursor points at, then advance
+#pragma unroll
+        for (int q = 0; q < MI; ++q) ra[q] = ig_load4<MODE>(A, rows[q], kc);
+        if (lr < TN && !IG_DBG_BAD(1, bp - B, 4, lr)) rb = *reinterpret_cast<const float4 *>(bp);
+        ig_k_advance<MODE>(A, kc);
+        bp += kIgBK;
+    };
+    auto stash = [&](int buf) {
+        float *la = lds + buf * kStage, *lb = la + TM * kIgLS;
+#pragma unroll
+        for (int q = 0; q < MI; ++q) *reinterpret_cast<float4 *>(la + (lr + 64 * q) * kIgLS + kq) = ra[q];
+        if (lr < TN) *reinterpret_cast<float4 *>(lb + lr * kIgLS + kq) = rb;
+    };
+    fetch();
+    stash(0);
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < stages) fetch();
+        const float *la = lds + buf * kStage + (wv * 16 * MI + c) * kIgLS + 4 * g;
+        const float *lb = lds + buf * kStage + TM * kIgLS + c * kIgLS + 4 * g;
+        float4 fa[MI], fb[NI];
+#pragma unroll
+        for (int a = 0; a < MI; ++a) fa[a] = *reinterpret_cast<const float4 *>(la + a * 16 * kIgLS);
+#pragma unroll
+        for (int b = 0; b < NI; ++b) fb[b] = *reinterpret_cast<const float4 *>(lb + b * 16 * kIgLS);
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                acc[a][b] = mfma16(fa[a].x, fb[b].x, acc[a][b]);
+                acc[a][b] = mfma16(fa[a].y, fb[b].y, acc[a][b]);
+                acc[a][b] = mfma16(fa[a].z, fb[b].z, acc[a][b]);
+                acc[a][b] = mfma16(fa[a].w, fb[b].w, acc[a][b]);
+            }
+        if (s + 1 < stages) stash(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wv * 16 * MI + a * 16 + 4 * g + r;
+            if (m >= M) continue;
+            size_t orow = (size_t)m;
+            if (MODE == kACol2im) {   // phase-local pixel -> input pixel
+                const int hw = A.HP * A.WP;
+                const int n = m / hw, rem = m - n * hw, yy = rem / A.WP, xx = rem - yy * A.WP;
+                orow = ((size_t)n * A.g.IH + (size_t)(yy * A.g.S + py)) * A.g.IW + (size_t)(xx * A.g.S + px);
+            }
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                const int n = n0 + b * 16 + c;
+                float v = acc[a][b][r];
+                if (epi == kEpiBias || epi == kEpiBiasRelu) v += bias[n];
+                if (epi == kEpiBiasRelu) v = fmaxf(v, 0.0f);
+                if (epi == kEpiMask) v = mask[orow * ldmask + n] > 0.0f ? v : 0.0f;   // relu' of the layer input, read where it was produced
+                if (IG_DBG_BAD(2, (long long)(orow * ldc + n), 1, m)) continue;
+                Cout[orow * ldc + n] = v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- weight form
+// partial[split][k][n] = sum over the split's rows of A(m, k) D[m][n], and (k-tile 0 only) colpart[split][n] = sum of D[m][n];
+// grid = ((K / 128 rounded up) * (N / (16 NI)), splits).  Wave w owns k rows 32w .. 32w+31 of the 128 x (16 NI) tile.
+struct IgM {   // (n, oy, ox) of a row of an im2col operand, advanced by 16 rows per slab
+    int n, oy, ox;
+};
+template <int MODE>
+__device__ __forceinline__ int ig_m_base(const IgA &a, const IgM &r) {
+    return MODE == kAIm2colF32 ? ((r.n * a.g.IH + r.oy * a.g.S) * a.g.IW + r.ox * a.g.S) * a.g.IC
+                                 : (r.n * a.g.IC * a.g.IH + r.oy * a.g.S) * a.g.IW + r.ox * a.g.S;
+}
+
+template <int MODE, int NI>
+__global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int M, int K, const float *__restrict__ D, int ldd, int N,
+                                                                     int rows_per_split, float *__restrict__ partial, double *__restrict__ colpart) {
+    constexpr int TK = 128, TN = 16 * NI, SA = TK + 16, SB = TN % 32 == 0 ? TN + 16 : TN + 32;
+    constexpr int kStage = kIgBK * (SA + SB);
+    constexpr int kDThreads = kIgBK * TN / 4;
+    __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int tiles_n = N / TN;
+    const int ktile = blockIdx.x / tiles_n, k0 = ktile * TK, n0 = (blockIdx.x % tiles_n) * TN;
+    const int m_lo = blockIdx.y * rows_per_split;
+    const int m_hi = m_lo + rows_per_split < M ? m_lo + rows_per_split : M;
+    const int stages = m_hi > m_lo ? (m_hi - m_lo + kIgBK - 1) / kIgBK : 0;
+    // loader role: A rows (tid >> 5) and + 8 of the slab, k-quad (tid & 31) * 4 — the k part is fixed for the whole kernel
+    const int ar = tid >> 5, ak = k0 + (tid & 31) * 4;
+    const bool k_ok = ak < K;
+    const IgK kc = ig_k_init<MODE>(A, k_ok ? ak : 0);
+    IgM rm[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int m = m_lo + ar + 8 * q;
+        if (MODE == kADense) {
+            rm[q].n = m;
+            rm[q].oy = rm[q].ox = 0;
+        } else {
+            const int ohw = A.g.OH * A.g.OW;
+            rm[q].n = m / ohw;
+            const int rem = m - rm[q].n * ohw;
+            rm[q].oy = rem / A.g.OW;
+            rm[q].ox = rem - rm[q].oy * A.g.OW;
+        }
+    }
+    const int dr = tid / (TN / 4), dc = (tid % (TN / 4)) * 4;
     f32x4 acc[2][NI];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int stages = (K + kIgBK - 1) / kIgBK;
+    double colsum = 0.0;
     float4 ra[2], rb;
-    constexpr int kB4 = kIgBK * TN / 4;   // float4 of a B slab (<= 256)
-    auto fetch = [&](int s) {
-        const int k0 = s * kIgBK;
+    int mrow = m_lo;   // first row of the slab the cursors point at
+    auto fetch = [&]() {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) ra[q] = k0 + kq < K ? ig_load4(A, rows[q], k0 + kq) : make_float4(0.f, 0.f, 0.f, 0.f);
-        rb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < kB4) {
-            const int row = tid / (TN / 4), col = (tid % (TN / 4)) * 4;
-            if (k0 + row < K) rb = *reinterpret_cast<const float4 *>(B + (size_t)(k0 + row) * ldb + n0 + col);
+        for (int q = 0; q < 2; ++q) {
+            ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k_ok && mrow + ar + 8 * q < m_hi) {
+                IgRow r;
+                r.y = r.x = 0;
+                r.base = MODE == kADense ? rm[q].n * A.lda : ig_m_base<MODE>(A, rm[q]);
+                ra[q] = ig_load4<MODE>(A, r, kc);
+            }
+            if (MODE == kADense) {
+                rm[q].n += kIgBK;
+            } else {
+                rm[q].ox += kIgBK;
+                while (rm[q].ox >= A.g.OW) {
+                    rm[q].ox -= A.g.OW;
+                    if (++rm[q].oy == A.g.OH) {
+                        rm[q].oy = 0;
+                        ++rm[q].n;
+                    }
+                }
+            }
         }
+        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < kDThreads && mrow + dr < m_hi) rb = *reinterpret_cast<const float4 *>(D + (size_t)(mrow + dr) * ldd + n0 + dc);
+        mrow += kIgBK;
     };
     auto stash = [&](int buf) {
         float *la = lds + buf * kStage, *lb = la + kIgBK * SA;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {   // transpose into k-major: la[k][m]
-            const int m = (tid + q * kIgThreads) / 4;
-            la[(kq + 0) * SA + m] = ra[q].x;
-            la[(kq + 1) * SA + m] = ra[q].y;
-            la[(kq + 2) * SA + m] = ra[q].z;
-            la[(kq + 3) * SA + m] = ra[q].w;
-        }
-        if (tid < kB4) *reinterpret_cast<float4 *>(lb + (tid / (TN / 4)) * SB + (tid % (TN / 4)) * 4) = rb;
+        for (int q = 0; q < 2; ++q) *reinterpret_cast<float4 *>(la + (ar + 8 * q) * SA + (tid & 31) * 4) = ra[q];
+        if (tid < kDThreads) *reinterpret_cast<float4 *>(lb + dr * SB + dc) = rb;
     };
-    fetch(0);
-    stash(0);
+    if (stages > 0) {
+        fetch();
+        stash(0);
+    }
     __syncthreads();
     for (int s = 0; s < stages; ++s) {
         const int buf = s & 1;
-        if (s + 1 < stages) fetch(s + 1);
+        if (s + 1 < stages) fetch();
         const float *la = lds + buf * kStage + wv * 32 + c;
         const float *lb = lds + buf * kStage + kIgBK * SA + c;
 #pragma unroll
@@ -167,126 +391,47 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, long l
 #pragma unroll
                 for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
         }
-        if (s + 1 < stages) stash(buf ^ 1);
-        __syncthreads();
-    }
+        if (ktile == 0 && tid < TN) {   // bias gradient: column sums of this slab of D (rows past the split are zero in LDS)
+            const float *lcol = lds + buf * kStage + kIgBK * SA + tid;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long m = m0 + wv * 32 + a * 16 + 4 * g + r;
-            if (m >= M) continue;
-#pragma unroll
-            for (int b = 0; b < NI; ++b) {
-                const int n = n0 + b * 16 + c;
-                float v = acc[a][b][r];
-                if (epi == kEpiBias || epi == kEpiBiasRelu) v += bias[n];
-                if (epi == kEpiBiasRelu) v = fmaxf(v, 0.0f);
-                if (epi == kEpiMask) v = mask[(size_t)m * ldmask + n] > 0.0f ? v : 0.0f;   // relu' of the layer input, read where it was produced
-                Cout[(size_t)m * ldc + n] = v;
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------------------- weight form
-// partial[split][k][n] = sum over the split's rows of A(m, k) D[m][n]; grid = ((K / (16 MI*WR)) * (N / (16 NI*WC)), splits).
-template <int WR, int WC, int MI, int NI>
-__global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, long long M, int K, const float *__restrict__ D, int ldd, int N,
-                                                                     long long rows_per_split, float *__restrict__ partial) {
-    constexpr int TK = WR * MI * 16, TN = WC * NI * 16, SA = TK % 32 == 0 ? TK + 16 : TK + 32, SB = TN % 32 == 0 ? TN + 16 : TN + 32;
-    constexpr int kStage = kIgBK * (SA + SB);
-    constexpr int kA4 = kIgBK * TK / 4, kB4 = kIgBK * TN / 4;
-    constexpr int kLA = (kA4 + kIgThreads - 1) / kIgThreads, kLB = (kB4 + kIgThreads - 1) / kIgThreads;
-    __shared__ float lds[2 * kStage];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int wr = wv / WC, wc = wv % WC;
-    const int tiles_n = N / TN;
-    const int k0 = (blockIdx.x / tiles_n) * TK, n0 = (blockIdx.x % tiles_n) * TN;
-    const long long m_lo = (long long)blockIdx.y * rows_per_split;
-    const long long m_hi = m_lo + rows_per_split < M ? m_lo + rows_per_split : M;
-    const int stages = (int)((m_hi - m_lo + kIgBK - 1) / kIgBK);
-    f32x4 acc[MI][NI];
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
-#pragma unroll
-        for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float4 ra[kLA], rb[kLB];
-    auto fetch = [&](int s) {
-        const long long mb = m_lo + (long long)s * kIgBK;
-#pragma unroll
-        for (int q = 0; q < kLA; ++q) {
-            const int idx = tid + q * kIgThreads;
-            const int row = idx / (TK / 4), col = (idx % (TK / 4)) * 4;
-            ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < kA4 && mb + row < m_hi && k0 + col < K) ra[q] = ig_load4(A, ig_row(A, mb + row, M), k0 + col);
-        }
-#pragma unroll
-        for (int q = 0; q < kLB; ++q) {
-            const int idx = tid + q * kIgThreads;
-            const int row = idx / (TN / 4), col = (idx % (TN / 4)) * 4;
-            rb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < kB4 && mb + row < m_hi) rb[q] = *reinterpret_cast<const float4 *>(D + (size_t)(mb + row) * ldd + n0 + col);
-        }
-    };
-    auto stash = [&](int buf) {
-        float *la = lds + buf * kStage, *lb = la + kIgBK * SA;
-#pragma unroll
-        for (int q = 0; q < kLA; ++q) {
-            const int idx = tid + q * kIgThreads;
-            if (idx < kA4) *reinterpret_cast<float4 *>(la + (idx / (TK / 4)) * SA + (idx % (TK / 4)) * 4) = ra[q];
-        }
-#pragma unroll
-        for (int q = 0; q < kLB; ++q) {
-            const int idx = tid + q * kIgThreads;
-            if (idx < kB4) *reinterpret_cast<float4 *>(lb + (idx / (TN / 4)) * SB + (idx % (TN / 4)) * 4) = rb[q];
-        }
-    };
-    if (stages > 0) {
-        fetch(0);
-        stash(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < stages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < stages) fetch(s + 1);
-        const float *la = lds + buf * kStage + wr * MI * 16 + c;
-        const float *lb = lds + buf * kStage + kIgBK * SA + wc * NI * 16 + c;
-#pragma unroll
-        for (int kk = 0; kk < kIgBK / 4; ++kk) {
-            float fa[MI], fb[NI];
-#pragma unroll
-            for (int a = 0; a < MI; ++a) fa[a] = la[(4 * kk + g) * SA + 16 * a];
-#pragma unroll
-            for (int b = 0; b < NI; ++b) fb[b] = lb[(4 * kk + g) * SB + 16 * b];
-#pragma unroll
-            for (int a = 0; a < MI; ++a)
-#pragma unroll
-                for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
+            for (int r = 0; r < kIgBK; ++r) colsum += (double)lcol[r * SB];
         }
         if (s + 1 < stages) stash(buf ^ 1);
         __syncthreads();
     }
     float *out = partial + (size_t)blockIdx.y * K * N;
 #pragma unroll
-    for (int a = 0; a < MI; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < NI; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = k0 + (wr * MI + a) * 16 + 4 * g + r;
-                if (k < K) out[(size_t)k * N + n0 + (wc * NI + b) * 16 + c] = acc[a][b][r];
+                const int k = k0 + (wv * 2 + a) * 16 + 4 * g + r;
+                if (k < K) out[(size_t)k * N + n0 + b * 16 + c] = acc[a][b][r];
             }
+    if (ktile == 0 && tid < TN) colpart[(size_t)blockIdx.y * N + n0 + tid] = colsum;
 }
 
 // Sum of the split partials (f64, fixed order) scattered into the gradient in torch's layout.  perm: 0 = out[k*N + n] (a
 // transposed Linear: [K][N] kept), 1 = Linear weight [n][k], 2 = conv weight [oc = n][ic][ky][kx] from k = (ky*KW + kx)*IC + ic,
-// 3 = conv weight from k = (ic*KH + ky)*KW + kx (the uint8 first layer).  accumulate: += (micro-batches of one minibatch).
-__global__ void __launch_bounds__(256) igemm_weights_reduce_kernel(const float *__restrict__ partial, int splits, int K, int N, float *__restrict__ out,
-                                                                  int perm, IgGeom g, int accumulate) {
+// 3 = conv weight from k = (ic*KH + ky)*KW + kx (the uint8 first layer).  Elements K*N .. K*N + N - 1: the bias gradient from the
+// column-sum partials.  accumulate: += (micro-batches of one minibatch).
+__global__ void __launch_bounds__(256) igemm_weights_reduce_kernel(const float *__restrict__ partial, const double *__restrict__ colpart, int splits, int K,
+                                                                  int N, float *__restrict__ out, float *__restrict__ bias_out, int perm, IgGeom g,
+                                                                  int accumulate) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)K * N) return;
+    const long long kn = (long long)K * N;
+    if (i >= kn + N) return;
+    if (i >= kn) {
+        if (bias_out == nullptr) return;
+        const int n = (int)(i - kn);
+        double s = 0.0;
+        for (int q = 0; q < splits; ++q) s += colpart[(size_t)q * N + n];
+        bias_out[n] = (accumulate ? bias_out[n] : 0.0f) + (float)s;
+        return;
+    }
     double s = 0.0;
-    for (int q = 0; q < splits; ++q) s += (double)partial[(size_t)q * K * N + i];
+    for (int q = 0; q < splits; ++q) s += (double)partial[(size_t)q * kn + i];
     const int k = (int)(i / N), n = (int)(i - (long long)k * N);
     long long p;
     if (perm == 0) p = i;
@@ -303,7 +448,7 @@ __global__ void __launch_bounds__(256) igemm_weights_reduce_kernel(const float *
     out[p] = (accumulate ? out[p] : 0.0f) + (float)s;
 }
 
-// Column sums (bias gradients): out[n] (+)= sum_m D[m][n]; two deterministic stages.
+// Column sums on their own (a bias gradient without a weight gradient next to it): out[n] (+)= sum_m D[m][n]; two deterministic stages.
 constexpr int kIgColChunks = 256;
 __global__ void __launch_bounds__(256) ig_colsum_partial_kernel(const float *__restrict__ D, long long M, int N, int ldd, double *__restrict__ partial) {
     const long long per = (M + kIgColChunks - 1) / kIgColChunks;
@@ -325,8 +470,9 @@ __global__ void __launch_bounds__(256) ig_colsum_final_kernel(const double *__re
     out[n] = (accumulate ? out[n] : 0.0f) + (float)s;
 }
 
-// Weight re-packing after an optimizer step: conv [OC][IC][KH][KW] -> forward B [k][OC] in the patch order of the layer's loader,
-// and dX B [(ky*KW + kx)*OC + oc][IC]; Linear [N][K] -> [K][N] (forward) — its own layout serves dX.
+// Weight re-packing after an optimizer step.  Conv [OC][IC][KH][KW] -> forward B [OC][k] with k in the loader's patch order
+// (the uint8 first layer's order IS torch's: no packing needed, fwd may be null), and dX B [phase][IC][(jy*JW + jx)*OC + oc] with
+// phase = py*S + px and kernel tap (ky, kx) = (py + jy*S, px + jx*S).
 __global__ void __launch_bounds__(256) ig_pack_conv_kernel(const float *__restrict__ w, IgGeom g, int u8_order, float *__restrict__ fwd,
                                                           float *__restrict__ dx) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -338,12 +484,16 @@ __global__ void __launch_bounds__(256) ig_pack_conv_kernel(const float *__restri
     t /= g.KH;
     const int ic = (int)(t % g.IC), oc = (int)(t / g.IC);
     const float v = w[i];
-    const long long kf = u8_order ? ((long long)ic * g.KH + ky) * g.KW + kx : ((long long)ky * g.KW + kx) * g.IC + ic;
-    fwd[kf * g.OC + oc] = v;
-    if (dx) dx[(((long long)ky * g.KW + kx) * g.OC + oc) * g.IC + ic] = v;
+    const int K = g.IC * g.KH * g.KW;
+    if (fwd) fwd[(long long)oc * K + (u8_order ? ((long long)ic * g.KH + ky) * g.KW + kx : ((long long)ky * g.KW + kx) * g.IC + ic)] = v;
+    if (dx) {
+        const int JH = g.KH / g.S, JW = g.KW / g.S, py = ky % g.S, px = kx % g.S, jy = ky / g.S, jx = kx / g.S;
+        const long long KP = (long long)JH * JW * g.OC;
+        dx[((long long)(py * g.S + px) * g.IC + ic) * KP + ((long long)jy * JW + jx) * g.OC + oc] = v;
+    }
 }
 // Linear(C*H*W, N) behind nn.Flatten (models.py:133): torch's column index is NCHW (c*H*W + y*W + x), our activation rows are NHWC
-// ((y*W + x)*C + c).  perm_out [N][K'] (columns re-ordered; B of dX) and t_out [K'][N] (B of the forward).
+// ((y*W + x)*C + c).  perm_out [N][K'] (columns re-ordered: B of the forward) and t_out [K'][N] (B of dX).
 __global__ void __launch_bounds__(256) ig_pack_fc_kernel(const float *__restrict__ w, int N, int Cc, int HW, float *__restrict__ perm_out,
                                                         float *__restrict__ t_out) {
     const int K = Cc * HW;
@@ -362,24 +512,66 @@ __global__ void __launch_bounds__(256) ig_transpose_kernel(const float *__restri
     out[(size_t)k * N + n] = w[i];
 }
 
-static int ig_check_a(const pfa_igemm_operand *a, int K) {
+static int ig_check_a(const pfa_igemm_operand *a, int64_t M, int K) {
     PFA_REQUIRE(a && a->ptr, "igemm: null A operand");
     PFA_REQUIRE(a->mode >= 0 && a->mode <= 3, "igemm: bad A mode %d", a->mode);
-    PFA_REQUIRE(K % 4 == 0, "igemm: K must be a multiple of 4 (got %d)", K);
-    if (a->mode == kADense) PFA_REQUIRE(a->lda % 4 == 0 && a->lda >= K, "igemm: dense lda must be a multiple of 4 and >= K");
+    PFA_REQUIRE(K >= 4 && K % 4 == 0, "igemm: K must be a multiple of 4 (got %d)", K);
+    PFA_REQUIRE(((uintptr_t)a->ptr & 15) == 0, "igemm: the A operand must be 16-byte aligned");
+    if (a->mode == kADense) {
+        PFA_REQUIRE(a->lda % 4 == 0 && a->lda >= K, "igemm: dense lda must be a multiple of 4 and >= K");
+        PFA_REQUIRE(M * a->lda < (1ll << 31), "igemm: operand too large for 32-bit element offsets (split the rows)");
+        return 0;
+    }
+    PFA_REQUIRE(a->S >= 1 && a->KH >= 1 && a->KW >= 1 && a->OH == (a->IH - a->KH) / a->S + 1 && a->OW == (a->IW - a->KW) / a->S + 1,
+                "igemm: inconsistent conv geometry");
+    const int64_t frames = a->mode == kACol2im ? M / ((int64_t)a->IH * a->IW) + 1 : M / ((int64_t)a->OH * a->OW) + 1;
+    PFA_REQUIRE(frames * a->IC * a->IH * a->IW < (1ll << 31) && frames * a->OC * a->OH * a->OW < (1ll << 31),
+                "igemm: operand too large for 32-bit element offsets (split the rows)");
     if (a->mode == kAIm2colF32) PFA_REQUIRE(a->IC % 4 == 0 && K == a->KH * a->KW * a->IC, "igemm: im2col f32 needs IC %% 4 == 0 and K == KH*KW*IC");
-    if (a->mode == kAIm2colU8) PFA_REQUIRE(a->KW % 4 == 0 && K == a->KH * a->KW * a->IC, "igemm: im2col u8 needs KW %% 4 == 0 and K == IC*KH*KW");
-    if (a->mode == kACol2im) PFA_REQUIRE(a->OC % 4 == 0 && K == a->KH * a->KW * a->OC, "igemm: col2im needs OC %% 4 == 0 and K == KH*KW*OC");
+    if (a->mode == kAIm2colU8)
+        PFA_REQUIRE(a->KW % 4 == 0 && a->IW % 4 == 0 && a->S % 4 == 0 && (a->IC * a->IH * a->IW) % 4 == 0 && K == a->KH * a->KW * a->IC,
+                    "igemm: im2col u8 needs KW, IW, S multiples of 4 (aligned 4-byte patch runs) and K == IC*KH*KW");
+    if (a->mode == kACol2im)
+        PFA_REQUIRE(a->OC % 4 == 0 && K == a->KH * a->KW * a->OC && a->KH % a->S == 0 && a->KW % a->S == 0 && a->IH % a->S == 0 && a->IW % a->S == 0 &&
+                        true,
+                    "igemm: col2im needs OC %% 4 == 0, K == KH*KW*OC, and KH, KW, IH, IW multiples of the stride");
     return 0;
 }
 static IgA ig_make_a(const pfa_igemm_operand *a) {
     IgA r;
     r.mode = a->mode;
     r.ptr = a->ptr;
-    r.lda = a->lda;
+    r.lda = (int)a->lda;
     r.g = IgGeom{a->IC, a->IH, a->IW, a->OC, a->OH, a->OW, a->KH, a->KW, a->S};
+    r.JH = r.JW = r.HP = r.WP = 0;
+    if (a->mode == kACol2im) {
+        r.JH = a->KH / a->S;
+        r.JW = a->KW / a->S;
+        r.HP = a->IH / a->S;
+        r.WP = a->IW / a->S;
+    }
     return r;
 }
+
+// Launch plan of the weight form, shared by the workspace query and the launch: tile width over n, number of (k, n) tiles, row
+// splits (>= 2048 rows each, about 2048 workgroups in all, at most 512) and rows per split (a multiple of the k-slab).
+struct IgWeightPlan {
+    int tn, tiles, splits;
+    int rows_per_split;
+};
+static IgWeightPlan ig_weight_plan(int64_t M, int K, int N) {
+    IgWeightPlan p;
+    p.tn = N % 64 == 0 ? 64 : N % 32 == 0 ? 32 : 16;
+    p.tiles = ((K + 127) / 128) * (N / p.tn);
+    int64_t s = (M + 2047) / 2048;
+    const int64_t cap = 2048 / p.tiles + 1;
+    if (s > cap) s = cap;
+    if (s > 512) s = 512;
+    p.splits = (int)(s < 1 ? 1 : s);
+    p.rows_per_split = (int)((((M + p.splits - 1) / p.splits) + 15) / 16 * 16);
+    return p;
+}
+static size_t ig_partial_bytes(const IgWeightPlan &p, int K, int N) { return align_up((size_t)p.splits * (size_t)K * (size_t)N * sizeof(float), 256); }
 
 }  // namespace pfa
 
@@ -387,74 +579,91 @@ using namespace pfa;
 
 extern "C" int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, const float *B, int32_t ldb, int32_t N, float *C, int32_t ldc,
                               int32_t epilogue, const float *bias, const float *mask, int32_t ldmask, pfa_stream_t stream) {
-    if (int rc = ig_check_a(a, K)) return rc;
-    PFA_REQUIRE(M >= 0 && B && C && N >= 16 && N % 16 == 0 && ldb >= N && ldb % 4 == 0 && ldc >= N, "igemm.rows: bad shapes (N must be a multiple of 16)");
+    if (int rc = ig_check_a(a, M, K)) return rc;
+    PFA_REQUIRE(M >= 0 && M < (1ll << 31) && B && C && N >= 16 && N % 16 == 0 && ldc >= N, "igemm.rows: bad shapes (N must be a multiple of 16)");
+    PFA_REQUIRE(((uintptr_t)B & 15) == 0 && ldb % 4 == 0, "igemm.rows: B must be 16-byte aligned with ldb a multiple of 4");
     PFA_REQUIRE(epilogue >= 0 && epilogue <= 3, "igemm.rows: bad epilogue");
     PFA_REQUIRE((epilogue != kEpiBias && epilogue != kEpiBiasRelu) || bias, "igemm.rows: bias epilogue without a bias vector");
     PFA_REQUIRE(epilogue != kEpiMask || (mask && ldmask >= N), "igemm.rows: mask epilogue without a mask");
     if (M == 0) return 0;
     const IgA A = ig_make_a(a);
-    const unsigned gm = (unsigned)((M + 127) / 128);
+    int phases = 1, Kp = K;
+    long long Mp = M;
+    if (A.mode == kACol2im) {   // S*S phases of M / (S*S) pixels, each contracting over its own K / (S*S) taps x channels
+        phases = A.g.S * A.g.S;
+        PFA_REQUIRE(M % ((long long)A.g.IH * A.g.IW) == 0, "igemm.rows: col2im rows must be whole frames");
+        Mp = M / phases;
+        Kp = K / phases;
+    }
+    PFA_REQUIRE(Kp % kIgBK == 0 && ldb >= Kp, "igemm.rows: the contraction length (per phase) must be a multiple of 16 and ldb >= it");
     ScopedKernelTimer timer("igemm_rows", (hipStream_t)stream);
-    if (N % 64 == 0)
-        hipLaunchKernelGGL(igemm_rows_kernel<4>, dim3(gm, N / 64), dim3(kIgThreads), 0, (hipStream_t)stream, A, (long long)M, (int)K, B, (int)ldb, C,
-                           (int)ldc, (int)epilogue, bias, mask, (int)ldmask);
-    else if (N % 32 == 0)
-        hipLaunchKernelGGL(igemm_rows_kernel<2>, dim3(gm, N / 32), dim3(kIgThreads), 0, (hipStream_t)stream, A, (long long)M, (int)K, B, (int)ldb, C,
-                           (int)ldc, (int)epilogue, bias, mask, (int)ldmask);
-    else
-        hipLaunchKernelGGL(igemm_rows_kernel<1>, dim3(gm, N / 16), dim3(kIgThreads), 0, (hipStream_t)stream, A, (long long)M, (int)K, B, (int)ldb, C,
-                           (int)ldc, (int)epilogue, bias, mask, (int)ldmask);
+#define PFA_IG_ROWS(MODE, MI, NI)                                                                                                          \
+    hipLaunchKernelGGL((igemm_rows_kernel<MODE, MI, NI>), dim3((unsigned)((Mp + 64 * MI - 1) / (64 * MI)), N / (16 * NI), phases), \
+                       dim3(kIgThreads), 0, (hipStream_t)stream, A, (int)Mp, (int)Kp, B, (int)ldb, (int)N, C, (int)ldc, (int)epilogue, \
+                       bias, mask, (int)ldmask)
+#define PFA_IG_ROWS_MODE(MI, NI)                   \
+    switch (A.mode) {                              \
+        case kADense: PFA_IG_ROWS(kADense, MI, NI); break;           \
+        case kAIm2colF32: PFA_IG_ROWS(kAIm2colF32, MI, NI); break;   \
+        case kAIm2colU8: PFA_IG_ROWS(kAIm2colU8, MI, NI); break;     \
+        default: PFA_IG_ROWS(kACol2im, MI, NI); break;               \
+    }
+    if (N % 64 == 0) {
+        PFA_IG_ROWS_MODE(2, 4)
+    } else if (N % 32 == 0) {
+        PFA_IG_ROWS_MODE(4, 2)
+    } else {
+        PFA_IG_ROWS_MODE(4, 1)
+    }
+#undef PFA_IG_ROWS_MODE
+#undef PFA_IG_ROWS
     PFA_LAUNCH_CHECK();
     return 0;
 }
 
-static int ig_splits(int64_t M, int tiles) {
-    int64_t s = (M + 2047) / 2048;          // >= 2048 rows per split
-    const int64_t cap = 2048 / (tiles > 0 ? tiles : 1) + 1;
-    if (s > cap) s = cap;
-    if (s > 512) s = 512;
-    return (int)(s < 1 ? 1 : s);
-}
-
 extern "C" size_t pfa_igemm_weights_workspace_bytes(int64_t M, int32_t K, int32_t N) {
-    const int tiles = ((K + 63) / 64) * ((N + 31) / 32);
-    return (size_t)ig_splits(M, tiles) * (size_t)K * (size_t)N * sizeof(float) + 256;
+    if (M < 1 || K < 4 || N < 16 || N % 16 != 0) return 0;
+    const IgWeightPlan p = ig_weight_plan(M, K, N);
+    return ig_partial_bytes(p, K, N) + (size_t)p.splits * (size_t)N * sizeof(double) + 256;
 }
 
 extern "C" int pfa_igemm_weights(const pfa_igemm_operand *a, int64_t M, int32_t K, const float *D, int32_t ldd, int32_t N, float *out,
-                                 int32_t perm, int32_t accumulate, void *workspace, pfa_stream_t stream) {
-    if (int rc = ig_check_a(a, K)) return rc;
-    PFA_REQUIRE(M >= 1 && D && out && workspace && N >= 16 && N % 16 == 0 && ldd >= N && ldd % 4 == 0, "igemm.weights: bad shapes");
+                                 int32_t perm, int32_t accumulate, float *bias_out, void *workspace, pfa_stream_t stream) {
+    if (int rc = ig_check_a(a, M, K)) return rc;
+    PFA_REQUIRE(a->mode != kACol2im, "igemm.weights: the col2im operand belongs to the rows form");
+    PFA_REQUIRE(M >= 1 && M < (1ll << 31) && D && out && workspace && N >= 16 && N % 16 == 0 && ldd >= N && ldd % 4 == 0 && ((uintptr_t)D & 15) == 0,
+                "igemm.weights: bad shapes");
     PFA_REQUIRE(perm >= 0 && perm <= 4, "igemm.weights: bad permutation");
     const IgA A = ig_make_a(a);
+    const IgWeightPlan p = ig_weight_plan(M, K, N);
     float *partial = (float *)workspace;
-    int splits;
-    long long rps;
-    ScopedKernelTimer timer("igemm_weights", (hipStream_t)stream);
-    if (N % 64 == 0) {          // 128 x 64 tiles: WR=4 (MI=2) x WC=1 (NI=4)
-        const int tiles = ((K + 127) / 128) * (N / 64);
-        splits = ig_splits(M, tiles);
-        rps = (((M + splits - 1) / splits) + 15) / 16 * 16;
-        hipLaunchKernelGGL((igemm_weights_kernel<4, 1, 2, 4>), dim3(tiles, splits), dim3(kIgThreads), 0, (hipStream_t)stream, A, (long long)M, (int)K, D,
-                           (int)ldd, (int)N, rps, partial);
-    } else if (N % 32 == 0) {   // 128 x 32
-        const int tiles = ((K + 127) / 128) * (N / 32);
-        splits = ig_splits(M, tiles);
-        rps = (((M + splits - 1) / splits) + 15) / 16 * 16;
-        hipLaunchKernelGGL((igemm_weights_kernel<4, 1, 2, 2>), dim3(tiles, splits), dim3(kIgThreads), 0, (hipStream_t)stream, A, (long long)M, (int)K, D,
-                           (int)ldd, (int)N, rps, partial);
-    } else {                    // 128 x 16
-        const int tiles = ((K + 127) / 128) * (N / 16);
-        splits = ig_splits(M, tiles);
-        rps = (((M + splits - 1) / splits) + 15) / 16 * 16;
-        hipLaunchKernelGGL((igemm_weights_kernel<4, 1, 2, 1>), dim3(tiles, splits), dim3(kIgThreads), 0, (hipStream_t)stream, A, (long long)M, (int)K, D,
-                           (int)ldd, (int)N, rps, partial);
+    double *colpart = (double *)((char *)workspace + ig_partial_bytes(p, K, N));
+    const dim3 grid(p.tiles, p.splits);
+    {
+        ScopedKernelTimer timer("igemm_weights", (hipStream_t)stream);
+#define PFA_IG_WEIGHTS(MODE, NI)                                                                                                                 \
+    hipLaunchKernelGGL((igemm_weights_kernel<MODE, NI>), grid, dim3(kIgThreads), 0, (hipStream_t)stream, A, (int)M, (int)K, D, (int)ldd, (int)N, \
+                       p.rows_per_split, partial, colpart)
+#define PFA_IG_WEIGHTS_MODE(NI)                                        \
+    switch (A.mode) {                                                  \
+        case kADense: PFA_IG_WEIGHTS(kADense, NI); break;              \
+        case kAIm2colF32: PFA_IG_WEIGHTS(kAIm2colF32, NI); break;      \
+        default: PFA_IG_WEIGHTS(kAIm2colU8, NI); break;                \
     }
-    PFA_LAUNCH_CHECK();
-    const long long total = (long long)K * N;
-    hipLaunchKernelGGL(igemm_weights_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, splits, (int)K,
-                       (int)N, out, (int)perm, A.g, (int)accumulate);
+        if (p.tn == 64) {
+            PFA_IG_WEIGHTS_MODE(4)
+        } else if (p.tn == 32) {
+            PFA_IG_WEIGHTS_MODE(2)
+        } else {
+            PFA_IG_WEIGHTS_MODE(1)
+        }
+#undef PFA_IG_WEIGHTS_MODE
+#undef PFA_IG_WEIGHTS
+        PFA_LAUNCH_CHECK();
+    }
+    const long long total = (long long)K * N + N;
+    hipLaunchKernelGGL(igemm_weights_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, colpart, p.splits,
+                       (int)K, (int)N, out, bias_out, (int)perm, A.g, (int)accumulate);
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -473,8 +682,9 @@ extern "C" int pfa_colsum(const float *D, int64_t M, int32_t N, int32_t ldd, flo
 }
 
 extern "C" int pfa_cnn_pack_conv(const float *w, const pfa_igemm_operand *geom, int32_t u8_order, float *fwd, float *dx, pfa_stream_t stream) {
-    PFA_REQUIRE(w && geom && fwd, "cnn.pack_conv: null buffer");
+    PFA_REQUIRE(w && geom && (fwd || dx), "cnn.pack_conv: null buffer");
     const IgA A = ig_make_a(geom);
+    PFA_REQUIRE(!dx || (A.g.S >= 1 && A.g.KH % A.g.S == 0 && A.g.KW % A.g.S == 0), "cnn.pack_conv: the dX form needs KH, KW multiples of the stride");
     const long long total = (long long)A.g.OC * A.g.IC * A.g.KH * A.g.KW;
     hipLaunchKernelGGL(ig_pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, A.g, (int)u8_order, fwd, dx);
     PFA_LAUNCH_CHECK();

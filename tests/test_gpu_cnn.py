@@ -98,3 +98,29 @@ def test_heads_sample_and_loss_match_the_oracle():
     np.testing.assert_allclose(lp.cpu().numpy(), olp.numpy(), **TOL)
     np.testing.assert_allclose(ent.cpu().numpy(), oent.numpy(), **TOL)
     np.testing.assert_allclose(val.cpu().numpy(), value.detach().numpy(), **TOL)
+
+
+@pytest.mark.parametrize('M,K,N', [(700000, 512, 64), (8192, 3136, 512), (3000000, 256, 32), (8192, 512, 16)])
+def test_weight_form_at_full_chunk_sizes_stays_inside_its_workspace(M, K, N):
+    """The weight-gradient contraction at the row counts of an 8192-frame chunk (row splits at their caps): the workspace the query
+    sizes is the one the launch uses (guard bytes behind it stay untouched), result against an fp64 matmul."""
+    import ctypes as C
+    from pufferlib_amd import _lib, cnn
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(M % 1000)
+    a = torch.randn(M, K, device='cuda', generator=g) * 0.1
+    d = torch.randn(M, N, device='cuda', generator=g) * 0.1
+    nbytes = L.pfa_igemm_weights_workspace_bytes(M, K, N)
+    ws = torch.full((nbytes + 4096,), 0xA5, dtype=torch.uint8, device='cuda')
+    out = torch.empty(N, K, device='cuda')
+    bias = torch.empty(N, device='cuda')
+    op = cnn._operand(cnn.MODE_DENSE, a, K)
+    _lib.check(L.pfa_igemm_weights(C.byref(op), M, K, _lib.ptr(d), N, N, _lib.ptr(out), 1, 0, _lib.ptr(bias), _lib.ptr(ws), _lib.stream_handle()),
+               'weights')
+    torch.cuda.synchronize()
+    assert bool((ws[nbytes:] == 0xA5).all()), 'the launch wrote past the workspace it asked for'
+    want = (d.double().t() @ a.double())
+    err = (out.double() - want).abs().max().item()
+    assert err <= 1e-5 * want.abs().max().item() + 1e-5, err
+    wb = d.double().sum(0)
+    assert (bias.double() - wb).abs().max().item() <= 1e-5 * wb.abs().max().item() + 1e-5

@@ -134,11 +134,13 @@ def test_device_rollout_and_update_vs_oracle_trainer():
     try:
         for it in range(2):
             step0 = pol.noise_step
+            w_before = {k[len('policy.'):]: v.clone() for k, v in pol.state_dict().items()}
             stats, _ = clean_pufferl.evaluate(data)
             e = data.experience
             obs = sm(e.obs)                                                  # step-major (T*N, 28224) uint8
-            # the oracle's rollout forward on the device's frames with the oracle's restatement of the Philox noise stream
-            opol = opols[torch.float32]
+            # the oracle's rollout forward (the weights the device holds now) on the device's frames, with the oracle's restatement
+            # of the Philox noise stream
+            opol = ppo_torch.ConvPolicy({k: v.cpu().numpy() for k, v in w_before.items()})
             acts, lps, vals = [], [], []
             with torch.no_grad():
                 for t in range(horizon):
@@ -168,11 +170,13 @@ def test_device_rollout_and_update_vs_oracle_trainer():
             L = data.losses
             want = [Lo[torch.float64][k] for k in keys]
             np.testing.assert_allclose([getattr(L, k) for k in keys], want, err_msg=f'iteration {it}', **TOL)
-            np.testing.assert_allclose([Lo[torch.float32][k] for k in keys], want, rtol=1e-4, atol=1e-5, err_msg=f'fp32 oracle, iteration {it}')
+            if it == 0:      # the yardstick itself: fp32 and fp64 oracle agree to fp32 summation noise while they share their weights
+                np.testing.assert_allclose([Lo[torch.float32][k] for k in keys], want, rtol=1e-4, atol=1e-5, err_msg='fp32 oracle')
             sd = pol.state_dict()
             for k, arr in opols[torch.float64].state_arrays().items():
                 np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=f'{k}, iteration {it}', **TOL)
-                np.testing.assert_allclose(opols[torch.float32].state_arrays()[k], arr, rtol=1e-4, atol=1e-5, err_msg=f'fp32 oracle {k}')
+                if it == 0:
+                    np.testing.assert_allclose(opols[torch.float32].state_arrays()[k], arr, rtol=1e-4, atol=1e-5, err_msg=f'fp32 oracle {k}')
     finally:
         torch.set_default_dtype(torch.float32)
     assert stats['episode_length'] == 5
