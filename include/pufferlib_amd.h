@@ -498,20 +498,21 @@ int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
  * of one of two fp32-MFMA implicit-GEMM kernels (csrc/igemm.hip); the operand A(m, k) is an access pattern, not a buffer:
  *   mode 0 dense            A = ptr[m * lda + k]
  *   mode 1 im2col, f32      ptr = NHWC activations [n][IH][IW][IC]; m = (n, oy, ox), k = (ky*KW + kx)*IC + ic
- *   mode 2 im2col, uint8    ptr = NCHW frames [n][IC][IH][IW];      m = (n, oy, ox), k = (ic*KH + ky)*KW + kx, value / 255.0
+ *   mode 2 im2col, uint8    ptr = NCHW frames [n][IC][IH][IW];      m = (n, oy, ox), k = (ic*KH + ky)*KW + kx, the byte as a float 0..255
+ *                           (`observations / 255.0`, models.py:150, rides in the other operand: pack_conv / perm 3 below)
  *   mode 3 col2im (for dX)  ptr = NHWC dOut [n][OH][OW][OC]; m = INPUT pixel (n, y, x); runs as S*S phases (y mod S, x mod S), each
  *                           contracting over the (KH/S)(KW/S) taps that reach it: k = (jy*(KW/S) + jx)*OC + oc, tap (py + jy*S, px + jx*S)
  * pfa_igemm_rows:    C[m][n] = epilogue(sum_k A(m,k) B[n][k]) with B row-major [N][ldb] (k contiguous; mode 3: [S*S][N][ldb], K =
  *                    KH*KW*OC in total), epilogue 0 none, 1 + bias[n], 2 relu(+ bias[n]), 3 zero where mask[m][n] <= 0 (relu' read
  *                    where the forward left it).  N a multiple of 16, the contraction length (per phase) of 16.
  * pfa_igemm_weights: out (+)= sum_m A(m,k) D[m][n] scattered to torch's parameter layout: perm 0 [k][n], 1 Linear [n][k],
- *                    2 conv [oc=n][ic][ky][kx] from mode-1 k order, 3 the same from mode-2 k order, 4 Linear behind an NCHW
+ *                    2 conv [oc=n][ic][ky][kx] from mode-1 k order, 3 the same from mode-2 k order divided by 255, 4 Linear behind an NCHW
  *                    Flatten from NHWC rows (IC, IH, IW of the operand = the flattened tensor); bias_out (nullable) (+)= the column
  *                    sums of D (the bias gradient, from the same pass over D); split over rows, f64 reduction of the splits
  *                    (deterministic).  workspace >= pfa_igemm_weights_workspace_bytes(M, K, N).
  * pfa_colsum:        out[n] (+)= sum_m D[m][n] on its own, f64, deterministic.
  * pfa_cnn_pack_conv / pfa_cnn_transpose: torch weights -> the matrices the loaders' patch orders need (after every optimizer
- *                    step): forward B [OC][k] (nullable: mode 2's order is torch's own), dX B [S*S][IC][(KH/S)(KW/S)*OC];
+ *                    step): forward B [OC][k] (u8_order: torch's own order, weights / 255), dX B [S*S][IC][(KH/S)(KW/S)*OC] (nullable);
  *                    Linear [N][K] -> [K][N] (B of its dX).
  * pfa_cnn_heads_sample / pfa_cnn_heads_loss (csrc/cnn_heads.hip): decode_actions + sample_logits, and the PPO loss with its
  *                    gradients w.r.t. the head outputs [rows][16] and the hidden vector [rows][512], for a chunk

@@ -36,19 +36,17 @@ class ConvLayer:
         self.K = ic * kh * kw
         self.u8 = u8_input
         self.geom = (ic, ih, iw, oc, self.OH, self.OW, kh, kw, stride)
-        # forward B [oc][k] in the loader's patch order: the first layer's order (ic, ky, kx) is torch's own, so the weight serves
-        self.w_fwd = weight.view(oc, self.K) if u8_input else torch.empty(oc, self.K, device=device)
+        # forward B [oc][k] in the loader's patch order (the first layer: torch's own order, weights / 255 — its loader hands out bytes)
+        self.w_fwd = torch.empty(oc, self.K, device=device)
         # dX B [phase][ic][(jy, jx, oc)] (no dX for the first layer)
         self.phases = stride * stride
         self.KP = (kh // stride) * (kw // stride) * oc if not u8_input else 0
         self.w_dx = None if u8_input else torch.empty(self.phases, ic, self.KP, device=device)
 
     def pack(self):
-        if self.u8:
-            return
         L = _lib.lib()
-        _lib.check(L.pfa_cnn_pack_conv(_lib.ptr(self.w), C.byref(_operand(0, self.w, 0, self.geom)), 0, _lib.ptr(self.w_fwd), _lib.ptr(self.w_dx),
-                                       _lib.stream_handle()), 'pack_conv')
+        _lib.check(L.pfa_cnn_pack_conv(_lib.ptr(self.w), C.byref(_operand(0, self.w, 0, self.geom)), 1 if self.u8 else 0, _lib.ptr(self.w_fwd),
+                                       _lib.ptr(self.w_dx), _lib.stream_handle()), 'pack_conv')
 
     def out_rows(self, n):
         return n * self.OH * self.OW

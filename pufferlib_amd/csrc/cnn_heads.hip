@@ -179,11 +179,15 @@ __global__ void __launch_bounds__(256) cnn_heads_loss_kernel(const float *h, lon
 }
 
 // loss_pairs16 (+)= the (hi, lo) pairs of the chunk's six sums (a minibatch is processed in chunks: accumulate != 0 adds)
-__global__ void cnn_stats_final_kernel(const double *partial, int nblocks, float *loss_pairs16, int accumulate) {
-    const int i = threadIdx.x;
-    if (i >= 8) return;
-    double s = accumulate ? (double)loss_pairs16[2 * i] + (double)loss_pairs16[2 * i + 1] : 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 8 + i];
+__global__ void cnn_stats_final_kernel(const double *partial, int nblocks, float *loss_pairs16, int accumulate) {   // one wave
+    const int i = threadIdx.x & 7, part = threadIdx.x >> 3;   // 8 sums x 8 interleaved block ranges
+    double s = 0.0;
+    for (int b = part; b < nblocks; b += 8) s += partial[(size_t)b * 8 + i];
+    s += __shfl_xor(s, 8, 64);      // fixed combination order
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (threadIdx.x >= 8) return;
+    if (accumulate) s += (double)loss_pairs16[2 * i] + (double)loss_pairs16[2 * i + 1];
     const float hi = (float)s;
     loss_pairs16[2 * i] = hi;
     loss_pairs16[2 * i + 1] = (float)(s - (double)hi);

@@ -10,7 +10,8 @@
 // A(m, k) is never materialised: the tile loader computes the address of the patch element (implicit im2col / col2im), so a conv
 // layer reads its input once per k-slab from L2/HBM and nothing else.  Activations are NHWC f32 (patch index (ky, kx, ic), ic
 // contiguous); the first layer reads the uint8 NCHW frames directly ((ic, ky, kx), kx contiguous: one aligned 32-bit word = four
-// patch elements) and applies `/ 255.0` on the way in.  dX of a stride-S layer runs as S*S phases (input pixels with equal
+// patch elements) as floats 0..255 — the `/ 255.0` is folded into its packed weights (forward) and into the reduction of its
+// weight gradient, one VALU conversion per element instead of four.  dX of a stride-S layer runs as S*S phases (input pixels with equal
 // (y mod S, x mod S) share the (KH/S)(KW/S) kernel taps that reach them), so no multiply is spent on the structural zeros of a
 // transposed strided convolution.
 //
@@ -47,14 +48,6 @@ struct IgA {
     IgGeom g;
     int JH, JW, HP, WP;   // col2im: taps per phase (KH/S, KW/S) and pixels per phase and frame (IH/S, IW/S)
 };
-
-// x / 255.0f for x = 0..255, correctly rounded without the division sequence: one Newton step on x * (1/255) reproduces
-// IEEE division for all 256 inputs (checked exhaustively, tests/test_host_logic.py).
-__device__ __forceinline__ float ig_div255(float x) {
-    const float r = 1.0f / 255.0f;
-    const float q = x * r;
-    return fmaf(fmaf(-q, 255.0f, x), r, q);
-}
 
 // -------------------------------------------------------------------------------------------------- the k part of an address
 // Where patch elements k .. k+3 sit relative to a row's base element, kept incrementally (k advances by one slab at a time).
@@ -178,10 +171,9 @@ __device__ __forceinline__ bool ig_dbg_bad(int operand, long long idx, long long
 
 template <int MODE>
 __device__ __forceinline__ float4 ig_load4(const IgA &a, const IgRow &r, const IgK &k) {
-    if (MODE == kAIm2colU8) {   // observations.float() / 255.0 (models.py:150); four bytes = one aligned word
-        const uint32_t w = *reinterpret_cast<const uint32_t *>((const uint8_t *)a.ptr + (r.base + k.off));
-        return make_float4(ig_div255((float)(w & 0xFFu)), ig_div255((float)((w >> 8) & 0xFFu)), ig_div255((float)((w >> 16) & 0xFFu)),
-                           ig_div255((float)(w >> 24)));
+    if (MODE == kAIm2colU8) {   // four bytes = one aligned word, as floats 0..255; the `/ 255.0` of models.py:150 rides in the other operand
+        const uint32_t w = *reinterpret_cast<const uint32_t *>((const uint8_t *)a.ptr + (r.base + k.off));   // (packed weights / dW scale)
+        return make_float4((float)(w & 0xFFu), (float)((w >> 8) & 0xFFu), (float)((w >> 16) & 0xFFu), (float)(w >> 24));
     }
     if (MODE == kACol2im && ((unsigned)(r.y - k.p) >= (unsigned)a.g.OH || (unsigned)(r.x - k.q) >= (unsigned)a.g.OW))
         return make_float4(0.f, 0.f, 0.f, 0.f);
@@ -219,26 +211,23 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, int M,
 #pragma unroll
         for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int stages = K / kIgBK;
+    // global -> register prefetch one slab deep (two deep was measured: the extra registers cost occupancy, 60 vs 80 TFLOP/s),
+    // register -> LDS double buffer
     float4 ra[MI], rb;
-    auto fetch = [&]() {   // the slab the cursor points at, then advance
+    auto fetch = [&](float4(&fa)[MI], float4 &fb) {   // the slab the cursor points at, then advance
 #pragma unroll
-        for (int q = 0; q < MI; ++q) ra[q] = ig_load4<MODE>(A, rows[q], kc);
-        if (lr < TN && !IG_DBG_BAD(1, bp - B, 4, lr)) rb = *reinterpret_cast<const float4 *>(bp);
+        for (int q = 0; q < MI; ++q) fa[q] = ig_load4<MODE>(A, rows[q], kc);
+        if (lr < TN && !IG_DBG_BAD(1, bp - B, 4, lr)) fb = *reinterpret_cast<const float4 *>(bp);
         ig_k_advance<MODE>(A, kc);
         bp += kIgBK;
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const float4(&fa)[MI], const float4 &fb) {
         float *la = lds + buf * kStage, *lb = la + TM * kIgLS;
 #pragma unroll
-        for (int q = 0; q < MI; ++q) *reinterpret_cast<float4 *>(la + (lr + 64 * q) * kIgLS + kq) = ra[q];
-        if (lr < TN) *reinterpret_cast<float4 *>(lb + lr * kIgLS + kq) = rb;
+        for (int q = 0; q < MI; ++q) *reinterpret_cast<float4 *>(la + (lr + 64 * q) * kIgLS + kq) = fa[q];
+        if (lr < TN) *reinterpret_cast<float4 *>(lb + lr * kIgLS + kq) = fb;
     };
-    fetch();
-    stash(0);
-    __syncthreads();
-    for (int s = 0; s < stages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < stages) fetch();
+    auto multiply = [&](int buf) {
         const float *la = lds + buf * kStage + (wv * 16 * MI + c) * kIgLS + 4 * g;
         const float *lb = lds + buf * kStage + TM * kIgLS + c * kIgLS + 4 * g;
         float4 fa[MI], fb[NI];
@@ -246,30 +235,58 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, int M,
         for (int a = 0; a < MI; ++a) fa[a] = *reinterpret_cast<const float4 *>(la + a * 16 * kIgLS);
 #pragma unroll
         for (int b = 0; b < NI; ++b) fb[b] = *reinterpret_cast<const float4 *>(lb + b * 16 * kIgLS);
+        // step kk of the slab uses component kk of every fragment; consecutive MFMAs go to different accumulators
 #pragma unroll
         for (int a = 0; a < MI; ++a)
 #pragma unroll
-            for (int b = 0; b < NI; ++b) {
-                acc[a][b] = mfma16(fa[a].x, fb[b].x, acc[a][b]);
-                acc[a][b] = mfma16(fa[a].y, fb[b].y, acc[a][b]);
-                acc[a][b] = mfma16(fa[a].z, fb[b].z, acc[a][b]);
-                acc[a][b] = mfma16(fa[a].w, fb[b].w, acc[a][b]);
-            }
-        if (s + 1 < stages) stash(buf ^ 1);
+            for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a].x, fb[b].x, acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a].y, fb[b].y, acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a].z, fb[b].z, acc[a][b]);
+#pragma unroll
+        for (int a = 0; a < MI; ++a)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a].w, fb[b].w, acc[a][b]);
+    };
+    fetch(ra, rb);
+    stash(0, ra, rb);
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        if (s + 1 < stages) fetch(ra, rb);
+        multiply(s & 1);
+        if (s + 1 < stages) stash((s & 1) ^ 1, ra, rb);
         __syncthreads();
     }
 #pragma unroll
-    for (int a = 0; a < MI; ++a)
+    for (int a = 0; a < MI; ++a) {
+        int en = 0, eyy = 0, exx = 0;
+        if (MODE == kACol2im) {   // phase-local pixel of the first of this lane's four rows; the next ones by carry
+            const int m = m0 + wv * 16 * MI + a * 16 + 4 * g, hw = A.HP * A.WP;
+            en = m / hw;
+            const int rem = m - en * hw;
+            eyy = rem / A.WP;
+            exx = rem - eyy * A.WP;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = m0 + wv * 16 * MI + a * 16 + 4 * g + r;
-            if (m >= M) continue;
             size_t orow = (size_t)m;
-            if (MODE == kACol2im) {   // phase-local pixel -> input pixel
-                const int hw = A.HP * A.WP;
-                const int n = m / hw, rem = m - n * hw, yy = rem / A.WP, xx = rem - yy * A.WP;
-                orow = ((size_t)n * A.g.IH + (size_t)(yy * A.g.S + py)) * A.g.IW + (size_t)(xx * A.g.S + px);
+            if (MODE == kACol2im) {   // -> input pixel
+                orow = ((size_t)en * A.g.IH + (size_t)(eyy * A.g.S + py)) * A.g.IW + (size_t)(exx * A.g.S + px);
+                if (++exx == A.WP) {
+                    exx = 0;
+                    if (++eyy == A.HP) {
+                        eyy = 0;
+                        ++en;
+                    }
+                }
             }
+            if (m >= M) continue;
 #pragma unroll
             for (int b = 0; b < NI; ++b) {
                 const int n = n0 + b * 16 + c;
@@ -281,6 +298,7 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, int M,
                 Cout[orow * ldc + n] = v;
             }
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- weight form
@@ -308,23 +326,29 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
     const int m_lo = blockIdx.y * rows_per_split;
     const int m_hi = m_lo + rows_per_split < M ? m_lo + rows_per_split : M;
     const int stages = m_hi > m_lo ? (m_hi - m_lo + kIgBK - 1) / kIgBK : 0;
-    // loader role: A rows (tid >> 5) and + 8 of the slab, k-quad (tid & 31) * 4 — the k part is fixed for the whole kernel
-    const int ar = tid >> 5, ak = k0 + (tid & 31) * 4;
-    const bool k_ok = ak < K;
-    const IgK kc = ig_k_init<MODE>(A, k_ok ? ak : 0);
-    IgM rm[2];
+    // loader role: A row (tid >> 4) of the slab, k-quads (tid & 15) * 4 and + 64 — the k part is fixed for the whole kernel, the row
+    // part is one cursor per thread
+    const int ar = tid >> 4, aq = (tid & 15) * 4;
+    bool k_ok[2];
+    IgK kc[2];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int m = m_lo + ar + 8 * q;
+    for (int j = 0; j < 2; ++j) {
+        const int ak = k0 + aq + 64 * j;
+        k_ok[j] = ak < K;
+        kc[j] = ig_k_init<MODE>(A, k_ok[j] ? ak : 0);
+    }
+    IgM rm;
+    {
+        const int m = m_lo + ar;
         if (MODE == kADense) {
-            rm[q].n = m;
-            rm[q].oy = rm[q].ox = 0;
+            rm.n = m;
+            rm.oy = rm.ox = 0;
         } else {
             const int ohw = A.g.OH * A.g.OW;
-            rm[q].n = m / ohw;
-            const int rem = m - rm[q].n * ohw;
-            rm[q].oy = rem / A.g.OW;
-            rm[q].ox = rem - rm[q].oy * A.g.OW;
+            rm.n = m / ohw;
+            const int rem = m - rm.n * ohw;
+            rm.oy = rem / A.g.OW;
+            rm.ox = rem - rm.oy * A.g.OW;
         }
     }
     const int dr = tid / (TN / 4), dc = (tid % (TN / 4)) * 4;
@@ -335,48 +359,37 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
         for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     double colsum = 0.0;
     float4 ra[2], rb;
-    int mrow = m_lo;   // first row of the slab the cursors point at
-    auto fetch = [&]() {
+    int mrow = m_lo;          // first row of the slab the cursors point at
+    auto fetch = [&](float4(&fa)[2], float4 &fb) {
+        IgRow r;
+        r.y = r.x = 0;
+        r.base = MODE == kADense ? rm.n * A.lda : ig_m_base<MODE>(A, rm);
+        const bool row_ok = mrow + ar < m_hi;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            ra[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k_ok && mrow + ar + 8 * q < m_hi) {
-                IgRow r;
-                r.y = r.x = 0;
-                r.base = MODE == kADense ? rm[q].n * A.lda : ig_m_base<MODE>(A, rm[q]);
-                ra[q] = ig_load4<MODE>(A, r, kc);
-            }
-            if (MODE == kADense) {
-                rm[q].n += kIgBK;
-            } else {
-                rm[q].ox += kIgBK;
-                while (rm[q].ox >= A.g.OW) {
-                    rm[q].ox -= A.g.OW;
-                    if (++rm[q].oy == A.g.OH) {
-                        rm[q].oy = 0;
-                        ++rm[q].n;
-                    }
+        for (int j = 0; j < 2; ++j) fa[j] = (row_ok && k_ok[j]) ? ig_load4<MODE>(A, r, kc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == kADense) {
+            rm.n += kIgBK;
+        } else {
+            rm.ox += kIgBK;
+            while (rm.ox >= A.g.OW) {
+                rm.ox -= A.g.OW;
+                if (++rm.oy == A.g.OH) {
+                    rm.oy = 0;
+                    ++rm.n;
                 }
             }
         }
-        rb = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < kDThreads && mrow + dr < m_hi) rb = *reinterpret_cast<const float4 *>(D + (size_t)(mrow + dr) * ldd + n0 + dc);
+        fb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < kDThreads && mrow + dr < m_hi) fb = *reinterpret_cast<const float4 *>(D + (size_t)(mrow + dr) * ldd + n0 + dc);
         mrow += kIgBK;
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](int buf, const float4(&fa)[2], const float4 &fb) {
         float *la = lds + buf * kStage, *lb = la + kIgBK * SA;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) *reinterpret_cast<float4 *>(la + (ar + 8 * q) * SA + (tid & 31) * 4) = ra[q];
-        if (tid < kDThreads) *reinterpret_cast<float4 *>(lb + dr * SB + dc) = rb;
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4 *>(la + ar * SA + aq + 64 * j) = fa[j];
+        if (tid < kDThreads) *reinterpret_cast<float4 *>(lb + dr * SB + dc) = fb;
     };
-    if (stages > 0) {
-        fetch();
-        stash(0);
-    }
-    __syncthreads();
-    for (int s = 0; s < stages; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < stages) fetch();
+    auto multiply = [&](int buf) {
         const float *la = lds + buf * kStage + wv * 32 + c;
         const float *lb = lds + buf * kStage + kIgBK * SA + c;
 #pragma unroll
@@ -396,7 +409,16 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
 #pragma unroll
             for (int r = 0; r < kIgBK; ++r) colsum += (double)lcol[r * SB];
         }
-        if (s + 1 < stages) stash(buf ^ 1);
+    };
+    if (stages > 0) {
+        fetch(ra, rb);
+        stash(0, ra, rb);
+    }
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        if (s + 1 < stages) fetch(ra, rb);
+        multiply(s & 1);
+        if (s + 1 < stages) stash((s & 1) ^ 1, ra, rb);
         __syncthreads();
     }
     float *out = partial + (size_t)blockIdx.y * K * N;
@@ -414,24 +436,32 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
 
 // Sum of the split partials (f64, fixed order) scattered into the gradient in torch's layout.  perm: 0 = out[k*N + n] (a
 // transposed Linear: [K][N] kept), 1 = Linear weight [n][k], 2 = conv weight [oc = n][ic][ky][kx] from k = (ky*KW + kx)*IC + ic,
-// 3 = conv weight from k = (ic*KH + ky)*KW + kx (the uint8 first layer).  Elements K*N .. K*N + N - 1: the bias gradient from the
-// column-sum partials.  accumulate: += (micro-batches of one minibatch).
+// 3 = conv weight from k = (ic*KH + ky)*KW + kx, divided by 255 (the uint8 first layer: its loader hands out raw bytes).  Elements
+// K*N .. K*N + N - 1: the bias gradient from the column-sum partials.  accumulate: += (micro-batches of one minibatch).
+// 64 elements per workgroup, the splits dealt round-robin to its four waves and combined as (w0 + w1) + (w2 + w3).
 __global__ void __launch_bounds__(256) igemm_weights_reduce_kernel(const float *__restrict__ partial, const double *__restrict__ colpart, int splits, int K,
                                                                   int N, float *__restrict__ out, float *__restrict__ bias_out, int perm, IgGeom g,
                                                                   int accumulate) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ double sh[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
     const long long kn = (long long)K * N;
-    if (i >= kn + N) return;
+    double s = 0.0;
+    if (i < kn) {
+        for (int q = sl; q < splits; q += 4) s += (double)partial[(size_t)q * kn + i];
+    } else if (i < kn + N) {
+        for (int q = sl; q < splits; q += 4) s += colpart[(size_t)q * N + (i - kn)];
+    }
+    sh[sl][e] = s;
+    __syncthreads();
+    if (sl != 0 || i >= kn + N) return;
+    s = (sh[0][e] + sh[1][e]) + (sh[2][e] + sh[3][e]);
     if (i >= kn) {
         if (bias_out == nullptr) return;
         const int n = (int)(i - kn);
-        double s = 0.0;
-        for (int q = 0; q < splits; ++q) s += colpart[(size_t)q * N + n];
         bias_out[n] = (accumulate ? bias_out[n] : 0.0f) + (float)s;
         return;
     }
-    double s = 0.0;
-    for (int q = 0; q < splits; ++q) s += (double)partial[(size_t)q * kn + i];
     const int k = (int)(i / N), n = (int)(i - (long long)k * N);
     long long p;
     if (perm == 0) p = i;
@@ -441,6 +471,7 @@ __global__ void __launch_bounds__(256) igemm_weights_reduce_kernel(const float *
         p = (((long long)n * g.IC + ic) * g.KH + ky) * g.KW + kx;
     } else if (perm == 3) {
         p = (long long)n * K + k;   // (ic, ky, kx) IS torch's order within an output channel
+        s /= 255.0;
     } else {   // 4: Linear behind nn.Flatten of an NCHW tensor whose activations we keep NHWC: k = (y*IW + x)*IC + c -> c*IH*IW + y*IW + x
         const int pix = k / g.IC, cch = k - pix * g.IC;
         p = (long long)n * K + (long long)cch * g.IH * g.IW + pix;
@@ -471,7 +502,7 @@ __global__ void __launch_bounds__(256) ig_colsum_final_kernel(const double *__re
 }
 
 // Weight re-packing after an optimizer step.  Conv [OC][IC][KH][KW] -> forward B [OC][k] with k in the loader's patch order
-// (the uint8 first layer's order IS torch's: no packing needed, fwd may be null), and dX B [phase][IC][(jy*JW + jx)*OC + oc] with
+// (the uint8 first layer keeps torch's order and takes the / 255 of the observations), and dX B [phase][IC][(jy*JW + jx)*OC + oc] with
 // phase = py*S + px and kernel tap (ky, kx) = (py + jy*S, px + jx*S).
 __global__ void __launch_bounds__(256) ig_pack_conv_kernel(const float *__restrict__ w, IgGeom g, int u8_order, float *__restrict__ fwd,
                                                           float *__restrict__ dx) {
@@ -485,7 +516,10 @@ __global__ void __launch_bounds__(256) ig_pack_conv_kernel(const float *__restri
     const int ic = (int)(t % g.IC), oc = (int)(t / g.IC);
     const float v = w[i];
     const int K = g.IC * g.KH * g.KW;
-    if (fwd) fwd[(long long)oc * K + (u8_order ? ((long long)ic * g.KH + ky) * g.KW + kx : ((long long)ky * g.KW + kx) * g.IC + ic)] = v;
+    if (fwd) {   // the uint8 loader hands out raw bytes: its weights carry the `/ 255.0` of models.py:150
+        if (u8_order) fwd[(long long)oc * K + ((long long)ic * g.KH + ky) * g.KW + kx] = v / 255.0f;
+        else fwd[(long long)oc * K + ((long long)ky * g.KW + kx) * g.IC + ic] = v;
+    }
     if (dx) {
         const int JH = g.KH / g.S, JW = g.KW / g.S, py = ky % g.S, px = kx % g.S, jy = ky / g.S, jx = kx / g.S;
         const long long KP = (long long)JH * JW * g.OC;
@@ -611,7 +645,7 @@ extern "C" int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, 
     if (N % 64 == 0) {
         PFA_IG_ROWS_MODE(2, 4)
     } else if (N % 32 == 0) {
-        PFA_IG_ROWS_MODE(4, 2)
+        PFA_IG_ROWS_MODE(2, 2)   // (128 x 32 beats 256 x 32: the smaller stage keeps more workgroups per CU)
     } else {
         PFA_IG_ROWS_MODE(4, 1)
     }
@@ -662,7 +696,7 @@ extern "C" int pfa_igemm_weights(const pfa_igemm_operand *a, int64_t M, int32_t 
         PFA_LAUNCH_CHECK();
     }
     const long long total = (long long)K * N + N;
-    hipLaunchKernelGGL(igemm_weights_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, colpart, p.splits,
+    hipLaunchKernelGGL(igemm_weights_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, (hipStream_t)stream, partial, colpart, p.splits,
                        (int)K, (int)N, out, bias_out, (int)perm, A.g, (int)accumulate);
     PFA_LAUNCH_CHECK();
     return 0;

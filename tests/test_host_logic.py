@@ -185,15 +185,3 @@ def test_errors_are_also_the_reference_classes_once_pufferlib_exceptions_is_load
             sys.modules.pop('pufferlib.exceptions', None)
         else:
             sys.modules['pufferlib.exceptions'] = saved
-
-
-def test_newton_step_division_by_255_is_exact_for_every_byte():
-    """csrc/igemm.hip ig_div255: q = x * r, q' = fma(fma(-q, 255, x), r, q) with r = fl(1/255) must equal IEEE x / 255 for the 256
-    inputs the uint8 loader can see (the products below are exact in double, so the double evaluation is the fp32 fma)."""
-    x = np.arange(256, dtype=np.float32)
-    r = np.float32(1.0) / np.float32(255.0)
-    q0 = (x * r).astype(np.float32)
-    e = (x.astype(np.float64) - q0.astype(np.float64) * 255.0).astype(np.float32)
-    q = (q0.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
-    assert np.array_equal(q, (x / np.float32(255.0)).astype(np.float32))
-    assert not np.array_equal(q0, q)          # the bare multiplication is not enough
