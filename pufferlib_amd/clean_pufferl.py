@@ -273,9 +273,14 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     recurrent = isinstance(policy, RecurrentPolicy)
     from .models import find_cnn
     conv = find_cnn(policy) is not None
-    if conv and (recurrent or host_mode or not isinstance(vecenv, Frames)):
-        raise NotImplementedError('the convolutional policy (models.Convolutional) trains on the device-resident frame vecenv '
-                                  '(vector.Frames) without an LSTM')
+    if conv:
+        space = vecenv.single_observation_space
+        if recurrent:
+            raise NotImplementedError('the convolutional policy (models.Convolutional) trains without an LSTM here')
+        if not (host_mode or isinstance(vecenv, Frames)):
+            raise NotImplementedError('models.Convolutional reads uint8 (framestack, 84, 84) frames: a host vecenv or vector.Frames')
+        if np.dtype(space.dtype) != np.uint8 or tuple(space.shape[-2:]) != (84, 84):
+            raise NotImplementedError(f'models.Convolutional reads uint8 (framestack, 84, 84) frames, the env shows {space.dtype} {space.shape}')
     if isinstance(vecenv, Frames) and not conv:
         raise NotImplementedError('vector.Frames shows uint8 (framestack, 84, 84) observations: use models.Convolutional')
     if recurrent and isinstance(vecenv, Stochastic):
@@ -288,8 +293,9 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         from . import hostpath
         _lib.require_gpu()
         device = torch.device('cuda', torch.cuda.current_device())
-        obs_stride = hostpath.obs_stride_for(int(np.prod(vecenv.single_observation_space.shape)), recurrent)
-        host_bridge = hostpath.HostBridge(vecenv, obs_stride, device)
+        obs_values = int(np.prod(vecenv.single_observation_space.shape))
+        obs_stride = obs_values if conv else hostpath.obs_stride_for(obs_values, recurrent)     # frames stay bytes
+        host_bridge = hostpath.HostBridge(vecenv, obs_stride, device, frames=conv)
     else:
         device = vecenv.device
         obs_stride = vecenv.obs_stride

@@ -25,21 +25,24 @@ from .cleanrl import obs_stride_for  # noqa: F401  (re-exported: create() and th
 class HostBridge:
     """Pinned staging buffers of one host vecenv and their device mirrors."""
 
-    def __init__(self, vecenv, obs_stride, device):
+    def __init__(self, vecenv, obs_stride, device, frames=False):
+        """`frames`: the observations stay bytes (uint8 rows of obs_stride = prod(shape) bytes, for the conv policy) instead of being
+        cast to padded float rows."""
         space = vecenv.single_observation_space
         self.obs_dim = int(np.prod(space.shape))
         self.obs_stride = obs_stride
+        obs_dtype = torch.uint8 if frames else torch.float32
         self.total_agents = int(vecenv.num_agents)
         n = int(getattr(vecenv, 'agents_per_batch', self.total_agents))
         self.max_rows = n
         pin = dict(pin_memory=True)
-        self.obs_pin = torch.zeros(n, obs_stride, dtype=torch.float32, **pin)
+        self.obs_pin = torch.zeros(n, obs_stride, dtype=obs_dtype, **pin)
         self.rew_pin = torch.zeros(n, dtype=torch.float32, **pin)
         self.done_pin = torch.zeros(n, dtype=torch.uint8, **pin)
         self.mask_pin = torch.zeros(n, dtype=torch.uint8, **pin)
         self.ids_pin = torch.zeros(n, dtype=torch.int32, **pin)
         self.act_pin = torch.zeros(n, dtype=torch.int64, **pin)
-        self.obs = torch.zeros(n, obs_stride, dtype=torch.float32, device=device)
+        self.obs = torch.zeros(n, obs_stride, dtype=obs_dtype, device=device)
         self.rew = torch.zeros(n, dtype=torch.float32, device=device)
         self.done = torch.zeros(n, dtype=torch.uint8, device=device)
         self.mask = torch.zeros(n, dtype=torch.uint8, device=device)
@@ -123,7 +126,9 @@ def evaluate(data):
             actions = torch.empty(n, dtype=torch.int64, device=bridge.obs.device)
             logprob = torch.empty(n, device=bridge.obs.device)
             value = torch.empty(n, device=bridge.obs.device)
-            if eng is None:
+            if data.cnn_engine is not None:                          # models.Convolutional on the staged uint8 frames
+                data.cnn_engine.policy_step(bridge.obs, n, noise, key, row0, actions, logprob, None, value)
+            elif eng is None:
                 _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(bridge.obs), n, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(noise),
                                                     C.byref(key), row0, _lib.ptr(actions), _lib.ptr(logprob), None, _lib.ptr(value),
                                                     stream), 'forward_sample')
@@ -141,7 +146,9 @@ def evaluate(data):
                 eng.lstm_c[0].index_copy_(0, idx, c)
             policy.noise_step += 1
         with profile.eval_misc:
-            _lib.check(L.pfa_store_rows(C.byref(experience.c), n, bridge.total_agents, fp.obs_stride, _lib.ptr(bridge.obs),
+            # (frame rows are bytes: the copy moves them as obs_dim / 4 four-byte words)
+            _lib.check(L.pfa_store_rows(C.byref(experience.c), n, bridge.total_agents,
+                                        fp.obs_dim // 4 if data.cnn_engine is not None else fp.obs_stride, _lib.ptr(bridge.obs),
                                         _lib.ptr(bridge.rew), _lib.ptr(bridge.done), _lib.ptr(actions), _lib.ptr(logprob),
                                         _lib.ptr(value), _lib.ptr(bridge.ids), _lib.ptr(bridge.mask), _lib.ptr(bridge.counters),
                                         _lib.ptr(bridge.stored_dropped), stream), 'store_rows')

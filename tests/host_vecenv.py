@@ -259,3 +259,55 @@ class HostByteRows:
 
     def close(self):
         pass
+
+
+class HostFrames:
+    """Host vecenv with Atari-shaped observations (uint8 (4, 84, 84), 4 actions): numpy frames, reward 1 when the action equals
+    byte 0 of the shown frame modulo 4, episodes of `episode_length` steps, Serial's protocol (the send after a terminal row is
+    the reset row; finished episodes report an info dict)."""
+
+    def __init__(self, num_envs, episode_length=5, seed=0):
+        from pufferlib_amd import spaces
+        self.single_observation_space = spaces.Box(low=0, high=255, shape=(4, 84, 84), dtype=np.uint8)
+        self.single_action_space = spaces.Discrete(4)
+        self.driver_env = self
+        self.num_envs = self.num_agents = self.agents_per_batch = num_envs
+        self.emulated = True
+        self.episode_length = episode_length
+        self.rng = np.random.RandomState(seed)
+        self.obs = np.zeros((num_envs, 4, 84, 84), np.uint8)
+        self.rew = np.zeros(num_envs, np.float32)
+        self.term = np.zeros(num_envs, bool)
+        self.tick = np.zeros(num_envs, int)
+        self.ret = np.zeros(num_envs)
+        self.infos = []
+
+    def _draw(self, idx):
+        self.obs[idx] = self.rng.randint(0, 256, (len(idx), 4, 84, 84)).astype(np.uint8)
+
+    def async_reset(self, seed=42):
+        self._draw(np.arange(self.num_envs))
+        self.rew[:] = 0
+        self.term[:] = False
+        self.tick[:] = 0
+        self.ret[:] = 0
+        self.infos = []
+
+    def recv(self):
+        n = self.num_envs
+        return self.obs.copy(), self.rew.copy(), self.term.copy(), np.zeros(n, bool), self.infos, np.arange(n), np.ones(n, bool)
+
+    def send(self, actions):
+        a = np.asarray(actions).reshape(-1)
+        done = self.term.copy()
+        hit = (a == self.obs[:, 0, 0, 0].astype(int) % 4) & ~done
+        self.rew = np.where(done, 0.0, hit).astype(np.float32)
+        self.ret = np.where(done, 0.0, self.ret + hit)
+        self.tick = np.where(done, 0, self.tick + 1)
+        self.term = (self.tick >= self.episode_length) & ~done
+        self.infos = [dict(episode_return=float(self.ret[i]), episode_length=int(self.tick[i]), score=float(self.ret[i] / self.tick[i]))
+                      for i in np.nonzero(self.term)[0]]
+        self._draw(np.arange(self.num_envs))
+
+    def close(self):
+        pass

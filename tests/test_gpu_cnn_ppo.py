@@ -61,11 +61,15 @@ def test_frame_generator_and_protocol_state_machine():
     assert 100 < o.astype(np.float64).mean() < 155          # bytes are uniform 0..255
 
 
-def _trainer(n, horizon, mbs, bptt, epochs, total, hp, seed, start=None, **envkw):
+def _trainer(n, horizon, mbs, bptt, epochs, total, hp, seed, start=None, host=False, **envkw):
     from pufferlib_amd import clean_pufferl, cleanrl
     from test_gpu_ppo import _config
     import cnn_golden
-    vec = _make(n, **envkw)
+    if host:                      # a host vecenv speaking the reference's protocol (hostpath.py): frames arrive as numpy uint8
+        from host_vecenv import HostFrames
+        vec = HostFrames(n, **envkw)
+    else:
+        vec = _make(n, **envkw)
     net = cnn_golden.container()
     if start is not None:
         with torch.no_grad():
@@ -117,8 +121,9 @@ def test_reference_run_with_convolutional_policy(golden_dir):
         np.testing.assert_allclose(got[:2], want[:2], rtol=0, atol=1e-5 * max(1.0, want[1]), err_msg=k + ' (sums)')
 
 
-def test_device_rollout_and_update_vs_oracle_trainer():
-    """Rollout forward against the torch-fp32 oracle; the update against the oracle run in DOUBLE precision on the same fp32 inputs.
+@pytest.mark.parametrize('host', [False, True])
+def test_device_rollout_and_update_vs_oracle_trainer(host):
+    """(host = True: the same against a host vecenv handing out numpy frames, through hostpath.evaluate.)  Rollout forward against the torch-fp32 oracle; the update against the oracle run in DOUBLE precision on the same fp32 inputs.
     (With 3136-term dot products and values of O(10), torch's own CPU fp32 result sits ~1.4e-5 (relative) from the double-precision
     value of the value loss, the HIP result ~1e-7 — tools/diag_cnn_precision.py — so the fp32 oracle is held to 1e-4 of the double
     one, and the HIP path to the 1e-5 of the spec.)"""
@@ -129,7 +134,7 @@ def test_device_rollout_and_update_vs_oracle_trainer():
     B = n * horizon
     hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
     start = cnn_golden.start_weights(cnn_golden.container())
-    vec, pol, data = _trainer(n, horizon, B // nmb, bptt, epochs, B * 10, hp, 3, start=start, episode_length=5)
+    vec, pol, data = _trainer(n, horizon, B // nmb, bptt, epochs, B * 10, hp, 3, start=start, host=host, episode_length=5)
     opols = {torch.float32: ppo_torch.ConvPolicy(start), torch.float64: ppo_torch.ConvPolicy(start, dtype=torch.float64)}
     sm = lambda x: x.view(n, horizon, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
     keys = ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac', 'explained_variance')
@@ -177,9 +182,9 @@ def test_device_rollout_and_update_vs_oracle_trainer():
                 np.testing.assert_allclose([Lo[torch.float32][k] for k in keys], want, rtol=1e-4, atol=1e-5, err_msg='fp32 oracle')
             sd = pol.state_dict()
             for k, arr in opols[torch.float64].state_arrays().items():
+                # (the fp32 oracle's own weights are not held to the double ones: where a gradient is ~1e-5 = Adam's eps, its fp32
+                # summation noise moves the normalised step by up to 30 % of lr — seen: 2.8e-4 on network.0.weight at lr 1e-3)
                 np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=f'{k}, iteration {it}', **TOL)
-                if it == 0:
-                    np.testing.assert_allclose(opols[torch.float32].state_arrays()[k], arr, rtol=1e-4, atol=1e-5, err_msg=f'fp32 oracle {k}')
     finally:
         torch.set_default_dtype(torch.float32)
     assert stats['episode_length'] == 5
