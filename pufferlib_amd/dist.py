@@ -98,6 +98,9 @@ def native_ready():
     return _native['ready']
 
 
+P2P_MAX_BUCKET = 1 << 20
+
+
 def init_p2p(bucket_bytes):
     """Open the one-shot peer-mapped all-reduce (csrc/p2p.hip) for buckets of up to ``bucket_bytes``: every rank allocates its
     fine-grained slot buffer, the 64-byte IPC handles travel through the torch.distributed group, every rank maps its peers.
@@ -149,7 +152,8 @@ def init_native(force_single=False, bucket_bytes=0):
     d, rank, w = world()
     mode = os.environ.get('PFA_ALLREDUCE', 'rccl').lower()
     p2p_ok = False
-    if 'p2p' in mode and w > 1 and bucket_bytes > 0:
+    # one hop pays for latency-bound buckets; a multi-MB bucket (the conv policy's 6.7 MB) is bandwidth-bound and stays on RCCL
+    if 'p2p' in mode and w > 1 and 0 < bucket_bytes <= P2P_MAX_BUCKET:
         p2p_ok = init_p2p(max(int(bucket_bytes), 65536))
         _native.update(p2p=p2p_ok)
     if os.environ.get('PFA_NATIVE_RCCL', '1') == '0':
