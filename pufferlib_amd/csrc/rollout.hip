@@ -17,6 +17,18 @@
 
 namespace pfa {
 
+#ifdef PFA_PROBES   // tools/probe_rollout.py: s_memtime stamps of workgroup 0's waves over a window of steps
+__device__ unsigned long long *g_rtrace = nullptr;
+__device__ int g_rtrace_t0 = 0, g_rtrace_steps = 0;
+#define PFA_RSTAMP(t, k)                                                                                            \
+    do {                                                                                                            \
+        if (g_rtrace && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (t) >= g_rtrace_t0 && (t) < g_rtrace_t0 + g_rtrace_steps) \
+            g_rtrace[(((size_t)(threadIdx.x >> 6)) * g_rtrace_steps + ((t) - g_rtrace_t0)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PFA_RSTAMP(t, k) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // standalone forward + sample over `rows` observation rows
 // ---------------------------------------------------------------------------------------------
@@ -99,14 +111,26 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
+        PFA_RSTAMP(t, 0);
         // Experience.store of the observation rows (clean_pufferl.py:443), env-major: row (e, t) at e*T + t
         unstage_rows<DP>(xs, ex.obs + (size_t)t * DP, (long long)blockIdx.x * EPW, v.n, (size_t)T * DP, EPW);
+        PFA_RSTAMP(t, 1);
         forward_slice<DP>(w, xs, part);
+        PFA_RSTAMP(t, 2);
         __syncthreads();
+        PFA_RSTAMP(t, 3);
         const float q = env_ok ? noise_lane(noise ? noise + ((size_t)t * v.n + e) * a : nullptr, seed, step0 + t,
                                             (uint64_t)(env_offset + e), lo, a)
                                : 1.0f;
+#ifdef PFA_PROBES
+        if (q == -12345.678f) PFA_RSTAMP(t, 7);   // (never true) pins the stamp behind the noise
+#endif
+        PFA_RSTAMP(t, 4);
         const LaneSample sm = sample_lanes(part, le, lo, a, q);
+#ifdef PFA_PROBES
+        if (sm.value == 12345.678f) PFA_RSTAMP(t, 7);
+#endif
+        PFA_RSTAMP(t, 5);
         if (owner) {
             const size_t row = (size_t)e * T + t;
             ex.rewards[row] = reward;
@@ -129,7 +153,9 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
                 squared_step(v, s, grid, tc, sm.action, reward, terminal, fin, fr, fl, fs);
             }
         }
+        PFA_RSTAMP(t, 6);
         __syncthreads();
+        PFA_RSTAMP(t, 7);
     }
 
     // write back: env state + the live buffers the next recv() returns
@@ -170,6 +196,15 @@ static int check_dims(const pfa_mlp_dims *d) {
 }  // namespace pfa
 
 using namespace pfa;
+
+#ifdef PFA_PROBES
+extern "C" int pfa_probe_set_rollout_trace(unsigned long long *buf, int t0, int steps) {
+    PFA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rtrace), &buf, sizeof(buf)));
+    PFA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rtrace_t0), &t0, sizeof(t0)));
+    PFA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rtrace_steps), &steps, sizeof(steps)));
+    return 0;
+}
+#endif
 
 extern "C" int64_t pfa_mlp_param_count(const pfa_mlp_dims *dims) {
     if (check_dims(dims)) return -1;
@@ -212,8 +247,10 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     SquaredView v = squared_view(state, *cfg);
     const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
     ScopedKernelTimer timer("rollout_mlp_squared", (hipStream_t)stream);
-    // 16 envs per workgroup.  An 8-env variant (two workgroups per CU at N = 4096) measured slower: the step is issue-bound,
-    // not latency-bound.
+    // 16 envs per workgroup.  Two restructurings measured no better (round 2, tools/probe_rollout.py): an 8-env variant (two
+    // workgroups per CU at N = 4096) was slower, and four helper waves taking the observation / scalar stores and the next
+    // step's Philox noise off the policy waves (bit-exact, barriers without the store-acknowledge wait) left the launch at
+    // 0.334 vs 0.331 ms — what bounds a step is the dependent chain forward -> sample -> env step itself.
     const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
     PFA_DISPATCH_DP(dims->obs_stride,
                     hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, v,
