@@ -393,7 +393,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)
-            out['cpu_baseline'] = cpu_baseline_c4() if args.workload == 'c4' else cpu_baseline()
+            if args.workload == 'c4':
+                out['cpu_baseline'] = cpu_baseline_c4()
+            elif args.policy == 'mlp':          # the headline configuration; the recurrent side workloads carry none
+                out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
         from pufferlib_amd import dist as pdist
