@@ -192,7 +192,12 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, int M,
     constexpr int kStage = (TM + TN) * kIgLS;
     __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); neighbouring row tiles read overlapping patches of the
+    // same frames, so the tile index is permuted to give every XCD one contiguous run of tiles (grid.x is a multiple of 8).
+    const int per_xcd = gridDim.x >> 3;
+    const int tile_m = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int m0 = tile_m * TM, n0 = blockIdx.y * TN;
+    if (m0 >= M) return;
     const int py = MODE == kACol2im ? (int)blockIdx.z / A.g.S : 0, px = MODE == kACol2im ? (int)blockIdx.z % A.g.S : 0;
     B += (size_t)blockIdx.z * N * ldb;
     // loader role: slab row (tid >> 2) + 64 q, k-quad (tid & 3) * 4
@@ -632,7 +637,7 @@ extern "C" int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, 
     PFA_REQUIRE(Kp % kIgBK == 0 && ldb >= Kp, "igemm.rows: the contraction length (per phase) must be a multiple of 16 and ldb >= it");
     ScopedKernelTimer timer("igemm_rows", (hipStream_t)stream);
 #define PFA_IG_ROWS(MODE, MI, NI)                                                                                                          \
-    hipLaunchKernelGGL((igemm_rows_kernel<MODE, MI, NI>), dim3((unsigned)((Mp + 64 * MI - 1) / (64 * MI)), N / (16 * NI), phases), \
+    hipLaunchKernelGGL((igemm_rows_kernel<MODE, MI, NI>), dim3((unsigned)(((Mp + 64 * MI - 1) / (64 * MI) + 7) / 8 * 8), N / (16 * NI), phases), \
                        dim3(kIgThreads), 0, (hipStream_t)stream, A, (int)Mp, (int)Kp, B, (int)ldb, (int)N, C, (int)ldc, (int)epilogue, \
                        bias, mask, (int)ldmask)
 #define PFA_IG_ROWS_MODE(MI, NI)                   \
