@@ -185,3 +185,29 @@ def test_errors_are_also_the_reference_classes_once_pufferlib_exceptions_is_load
             sys.modules.pop('pufferlib.exceptions', None)
         else:
             sys.modules['pufferlib.exceptions'] = saved
+
+
+def test_conv_params_flat_buffer_layout_and_aliasing():
+    """models.ConvParams: one flat buffer in the reference's named_parameters order (models.py:126-140), every module parameter a
+    view of it; the frame vecenv's creator token and spaces."""
+    import torch
+    from pufferlib_amd import models, vector
+    spec = vector.make_frames(framestack=4, num_actions=4, episode_length=7)
+    assert spec.single_observation_space.shape == (4, 84, 84) and spec.single_observation_space.dtype == np.uint8
+    assert spec.single_action_space.n == 4 and spec.episode_length == 7
+    net = models.Convolutional(spec, framestack=4)
+    before = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    cp = models.ConvParams(net, 'cpu')
+    assert cp.count == 1686693 and cp.obs_dim == 4 * 84 * 84 and cp.num_actions == 4
+    assert cp.names == ['network.0.weight', 'network.0.bias', 'network.2.weight', 'network.2.bias', 'network.4.weight', 'network.4.bias',
+                        'network.7.weight', 'network.7.bias', 'actor.weight', 'actor.bias', 'value_fn.weight', 'value_fn.bias']
+    o = 0
+    for name, p in net.named_parameters():
+        assert torch.equal(p.detach(), before[name])                                    # values kept
+        assert p.data_ptr() == cp.flat.data_ptr() + 4 * o                              # and they now alias the flat buffer, in order
+        o += p.numel()
+    cp.flat.zero_()
+    assert all(float(p.abs().sum()) == 0.0 for p in net.parameters())
+    assert models.find_cnn(torch.nn.Sequential(net)) is net and models.find_cnn(torch.nn.Linear(2, 2)) is None
+    with pytest.raises(NotImplementedError):
+        models.Convolutional(spec, framestack=4, hidden_size=256)
