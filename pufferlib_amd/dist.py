@@ -130,19 +130,39 @@ def init_p2p(bucket_bytes):
     ok = int(flag.item())
     if not ok:
         L.pfa_p2p_close()
-    else:
-        d.barrier()                                                   # nobody pushes into a buffer that is not mapped yet
-    return bool(ok)
+        return False
+    d.barrier()                                                       # nobody pushes into a buffer that is not mapped yet
+    # Self-test before anything depends on the transport: a few all-reduces of integer-valued data (exact in any order) against
+    # torch.distributed's result.  The kernel's spins are bounded, so a peer that cannot be reached shows up as a status word or
+    # a wrong sum here — and the update then stays on RCCL / torch.distributed — instead of as a hang in the first optimizer step.
+    good = 1
+    for n, dtype, fn in ((1024, torch.float32, L.pfa_p2p_all_reduce_f32), (37, torch.float64, L.pfa_p2p_all_reduce_f64),
+                         (min(int(bucket_bytes) // 4, 1 << 18), torch.float32, L.pfa_p2p_all_reduce_f32)):
+        x = ((torch.arange(n, device='cuda') % 251) * (rank + 1)).to(dtype)
+        want = x.clone()
+        d.all_reduce(want)
+        if fn(x.data_ptr(), n, _lib.stream_handle()) != 0:
+            good = 0
+        torch.cuda.synchronize()
+        if good and (L.pfa_p2p_status() != 0 or not torch.equal(x, want)):
+            good = 0
+    flag = torch.tensor([good], dtype=torch.int32, device='cuda')
+    d.all_reduce(flag, op=d.ReduceOp.MIN)
+    if not int(flag.item()):
+        L.pfa_p2p_close()
+        return False
+    return True
 
 
 def init_native(force_single=False, bucket_bytes=0):
     """Native collectives for the update: the optimizer-step all-reduce (and the few small reductions around it) are enqueued
     from native code on the compute stream, with no stream hand-off.  Two transports, picked by ``PFA_ALLREDUCE``:
-      ``rccl`` (default)  this process's own RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp); the 128-byte id
+      ``rccl``            this process's own RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp); the 128-byte id
                           travels from rank 0 through the already-initialised torch.distributed group; ``PFA_NATIVE_RCCL=0``
                           disables it;
-      ``p2p``             additionally the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every bucket of up to
-                          ``bucket_bytes`` — one hop over the xGMI mesh instead of a ring; larger buckets stay on RCCL.
+      ``p2p`` (default)   additionally the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every bucket of up to
+                          ``bucket_bytes`` (<= 1 MiB) — one hop over the xGMI mesh instead of a ring; it is opened only if its
+                          self-test against torch.distributed passes on every rank; larger buckets stay on RCCL.
     Returns True when a native transport is up on EVERY rank (agreement by MIN all-reduce); otherwise all ranks use
     torch.distributed collectives.  ``force_single`` builds a 1-rank RCCL communicator without a process group (tests)."""
     import ctypes as C
@@ -150,7 +170,7 @@ def init_native(force_single=False, bucket_bytes=0):
     import torch
     from . import _lib
     d, rank, w = world()
-    mode = os.environ.get('PFA_ALLREDUCE', 'rccl').lower()
+    mode = os.environ.get('PFA_ALLREDUCE', 'p2p').lower()          # 'p2p' = peer path for small buckets + RCCL; 'rccl' = RCCL only
     p2p_ok = False
     # one hop pays for latency-bound buckets; a multi-MB bucket (the conv policy's 6.7 MB) is bandwidth-bound and stays on RCCL
     if 'p2p' in mode and w > 1 and 0 < bucket_bytes <= P2P_MAX_BUCKET:
