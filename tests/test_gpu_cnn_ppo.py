@@ -212,3 +212,26 @@ def test_conv_policy_checkpoint_round_trip(tmp_path):
     a1 = pol(frames, noise=torch.ones(4, 4))
     for x, y in zip(a0, a1):
         assert torch.equal(x, y)
+
+
+def test_update_in_several_chunks_equals_one_chunk():
+    """cnn.Engine.update walks a minibatch in chunks (gradients, bias gradients and loss sums accumulate across chunks, the bench
+    runs 8 of them): the same update with 32-row minibatches as one chunk and as chunks of 16 and of 8 + ragged policy_step chunks."""
+    import cnn_golden
+    from pufferlib_amd import clean_pufferl
+    hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
+    start = cnn_golden.start_weights(cnn_golden.container())
+    out = []
+    for chunk in (None, 16, 8):
+        vec, pol, data = _trainer(8, 8, 32, 4, 2, 640, hp, 3, start=start, episode_length=5)
+        if chunk is not None:
+            data.cnn_engine.chunk = chunk            # buffers stay sized for 32 rows; the loops step by `chunk`
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+        L = data.losses
+        out.append((data.experience.actions.clone(), data.experience.values.clone(), data.flat_params.flat.clone(),
+                    np.array([L.policy_loss, L.value_loss, L.entropy, L.approx_kl, L.clipfrac])))
+    for acts, vals, flat, losses in out[1:]:
+        assert torch.equal(acts, out[0][0]) and torch.equal(vals, out[0][1])          # rollout forward: rows are independent
+        np.testing.assert_allclose(losses, out[0][3], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(flat.cpu().numpy(), out[0][2].cpu().numpy(), rtol=1e-5, atol=1e-6)
