@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
                 f32x4 gi, gf, gg, go;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float tc = tanhf(acn[r]);
+                    const float tc = tanh_f(acn[r]);
                     const float dhx = adh[r] + dhrec[rt][sub][r];  // heads path + recurrent path
                     const float d_o = dhx * tc;
                     const float d_c = dhx * ao[r] * (1.0f - tc * tc) + dc[rt][sub][r];

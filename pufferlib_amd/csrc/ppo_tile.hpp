@@ -70,6 +70,23 @@ __device__ __forceinline__ float gmax(float x) {
     }
 }
 
+// exp / log of the loss on the hardware transcendentals (v_exp_f32 / v_log_f32, 1 ulp) with the argument's rounding repaired:
+// five instructions instead of the library's ~15.  The loss is VALU work on the MFMA waves' issue port, so its
+// instruction count is launch time.  exp(x) = 2^(t + e) with t = fl(x log2e) and e = the product's rounding error + x times the
+// constant's low part; 2^(t+e) = 2^t (1 + e ln2) to first order (|e| < 2^-23 |t|).  Relative error ~2 ulp over the loss's range
+// (x <= 0 in the softmax, |x| small in the ratio) — the library forms are not bit-identical to torch's vectorised ones either.
+__device__ __forceinline__ float loss_exp(float x) {
+    const float kL = 1.44269502162933349609375f, kLl = 1.92596298909109e-8f;   // log2(e) = kL + kLl
+    const float t = x * kL;
+    const float e = fmaf(x, kLl, fmaf(x, kL, -t));
+    const float r = __builtin_amdgcn_exp2f(t);
+    return fmaf(r, e * 0.693147182464599609375f, r);
+}
+__device__ __forceinline__ float loss_log(float x) {   // x in [1, 16] here (sum of exp(logit - max))
+    const float l2 = __builtin_amdgcn_logf(x);           // v_log_f32 = log2
+    return fmaf(l2, 0.693147182464599609375f, l2 * -1.904654323148236e-9f);   // ln2 = hi + lo
+}
+
 struct RowScalars {
     int action;
     float old_logprob, old_value, adv, ret, weight;  // weight 0 for rows of a padding tile
@@ -86,7 +103,7 @@ struct LossOut {
 // code the headline workload runs, unchanged.
 template <bool MH, bool SWAP = false>
 __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScalars &rs, int a, uint32_t heads, int g,
-                                                 const pfa_ppo_hparams &hp, float adv_mean, float adv_den, float inv_rows) {
+                                                 const pfa_ppo_hparams &hp, float adv_mean, float adv_rden, float inv_rows) {
     float nl[4], p[4], hent[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
     bool chosen[4];
     if constexpr (MH) {
@@ -113,12 +130,12 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
             float ev[4], se = 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                ev[r] = mem[r] ? expf(out[r] - lmax) : 0.0f;
+                ev[r] = mem[r] ? loss_exp(out[r] - lmax) : 0.0f;
                 se += ev[r];
             }
             se += __shfl_xor(se, 16, 64);
             se += __shfl_xor(se, 32, 64);
-            const float lse = lmax + logf(se), inv_se = 1.0f / se;
+            const float lse = lmax + loss_log(se), inv_se = __builtin_amdgcn_rcpf(se);
             const int act = start + (int)(((uint32_t)rs.action >> (4 * h)) & 15u);
             float he = 0.0f;
 #pragma unroll
@@ -152,12 +169,12 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
     float ev[4], se = 0.0f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        ev[r] = 4 * g + r < a ? expf(out[r] - lmax) : 0.0f;
+        ev[r] = 4 * g + r < a ? loss_exp(out[r] - lmax) : 0.0f;
         se += ev[r];
     }
     se = gsum<SWAP>(se);
-    const float lse = lmax + logf(se);
-    const float inv_se = 1.0f / se;
+    const float lse = lmax + loss_log(se);
+    const float inv_se = __builtin_amdgcn_rcpf(se);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int o = 4 * g + r;
@@ -176,8 +193,8 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
     }
 
     const float logratio = new_logprob - rs.old_logprob;
-    const float ratio = expf(logratio);
-    const float adv = hp.norm_adv ? (rs.adv - adv_mean) / adv_den : rs.adv;
+    const float ratio = loss_exp(logratio);
+    const float adv = hp.norm_adv ? (rs.adv - adv_mean) * adv_rden : rs.adv;   // adv_rden = 1 / (std + 1e-8), taken once per launch
     const float lo = 1.0f - hp.clip_coef, hi = 1.0f + hp.clip_coef;
     const float pg1 = -adv * ratio;
     const float pg2 = -adv * fminf(fmaxf(ratio, lo), hi);

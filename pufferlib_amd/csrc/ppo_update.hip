@@ -177,6 +177,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             adv_den = (float)sqrt(var) + 1e-8f;
         }
         const float inv_rows = (float)(1.0 / global_rows);
+        const float adv_rden = 1.0f / adv_den;
 
         f32x4 acc_dw2[kMT];
         float db2[4], stats[6];
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 lo.dout = out * rs.weight;
                 lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs.adv;
             } else {
-                lo = ppo_loss_tile<MH, !MH>(out, rs, a, heads, g, hp, adv_mean, adv_den, inv_rows);   // one head: permlane-swap reductions
+                lo = ppo_loss_tile<MH, !MH>(out, rs, a, heads, g, hp, adv_mean, adv_rden, inv_rows);   // one head: permlane-swap reductions
             }
             const f32x4 dout = lo.dout;
 #pragma unroll
