@@ -252,8 +252,9 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.0f);   // (compiles to canonicalise + max; a one-instruction
-                                                                               // inline-asm v_max loses the MFMA->VALU hazard wait states)
+                for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.0f);   // (canonicalise + max = 2 instructions.  Measured: an
+                        // inline-asm v_max loses the MFMA->VALU hazard wait states; the integer form max(bits, 0) is exact and one
+                        // instruction but shifts the block's schedule: 66.8 instead of 64.7 us per launch)
             f32x4 out;
             {
                 f32x4 o[4] = {f32x4{bo[0], bo[1], bo[2], bo[3]}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
