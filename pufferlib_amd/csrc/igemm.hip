@@ -22,7 +22,8 @@
 // Tiling: 256 threads = 4 waves, k-slabs of 16, double-buffered in LDS, global loads of slab s+1 in flight under the MFMAs of
 // slab s.  rows form: (64 MI) x (16 NI) output tile, both operands row-major in LDS with a 20-float row stride; lane (c, g) reads
 // ONE float4 per 16 x 16 fragment and slab (row c, columns 4g..4g+3 — the MFMA's k-slot g then stands for k = 4g + kk in step kk,
-// for A and B alike), 2 lanes per bank.  weight form: 128 x (16 NI) tile of G per workgroup and a chunk of rows; the partial sums
+// for A and B alike), 2 lanes per bank.  weight form: (64 KJ) x (16 NI) tile of G per workgroup (KJ = 2..4: the height that pads K
+// least) and a chunk of rows; the partial sums
 // of the row splits are reduced in f64 in a fixed order (deterministic) and scattered into torch's parameter layout.
 #include "common.hpp"
 #include "mlp_tile.hpp"
@@ -318,10 +319,10 @@ __device__ __forceinline__ int ig_m_base(const IgA &a, const IgM &r) {
                                  : (r.n * a.g.IC * a.g.IH + r.oy * a.g.S) * a.g.IW + r.ox * a.g.S;
 }
 
-template <int MODE, int NI>
+template <int MODE, int KJ, int NI>
 __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int M, int K, const float *__restrict__ D, int ldd, int N,
                                                                      int rows_per_split, float *__restrict__ partial, double *__restrict__ colpart) {
-    constexpr int TK = 128, TN = 16 * NI, SA = TK + 16, SB = TN % 32 == 0 ? TN + 16 : TN + 32;
+    constexpr int TK = 64 * KJ, TN = 16 * NI, SA = TK + 16, SB = TN % 32 == 0 ? TN + 16 : TN + 32;
     constexpr int kStage = kIgBK * (SA + SB);
     constexpr int kDThreads = kIgBK * TN / 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
@@ -331,13 +332,13 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
     const int m_lo = blockIdx.y * rows_per_split;
     const int m_hi = m_lo + rows_per_split < M ? m_lo + rows_per_split : M;
     const int stages = m_hi > m_lo ? (m_hi - m_lo + kIgBK - 1) / kIgBK : 0;
-    // loader role: A row (tid >> 4) of the slab, k-quads (tid & 15) * 4 and + 64 — the k part is fixed for the whole kernel, the row
-    // part is one cursor per thread
+    // loader role: A row (tid >> 4) of the slab, k-quads (tid & 15) * 4 + 64 j, j < KJ — the k part is fixed for the whole kernel,
+    // the row part is one cursor per thread.  Wave w owns k rows 16 KJ w .. 16 KJ (w + 1) - 1 of the tile (KJ fragments).
     const int ar = tid >> 4, aq = (tid & 15) * 4;
-    bool k_ok[2];
-    IgK kc[2];
+    bool k_ok[KJ];
+    IgK kc[KJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < KJ; ++j) {
         const int ak = k0 + aq + 64 * j;
         k_ok[j] = ak < K;
         kc[j] = ig_k_init<MODE>(A, k_ok[j] ? ak : 0);
@@ -357,21 +358,21 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
         }
     }
     const int dr = tid / (TN / 4), dc = (tid % (TN / 4)) * 4;
-    f32x4 acc[2][NI];
+    f32x4 acc[KJ][NI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < KJ; ++a)
 #pragma unroll
         for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     double colsum = 0.0;
-    float4 ra[2], rb;
+    float4 ra[KJ], rb;
     int mrow = m_lo;          // first row of the slab the cursors point at
-    auto fetch = [&](float4(&fa)[2], float4 &fb) {
+    auto fetch = [&](float4(&fa)[KJ], float4 &fb) {
         IgRow r;
         r.y = r.x = 0;
         r.base = MODE == kADense ? rm.n * A.lda : ig_m_base<MODE>(A, rm);
         const bool row_ok = mrow + ar < m_hi;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fa[j] = (row_ok && k_ok[j]) ? ig_load4<MODE>(A, r, kc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < KJ; ++j) fa[j] = (row_ok && k_ok[j]) ? ig_load4<MODE>(A, r, kc[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == kADense) {
             rm.n += kIgBK;
         } else {
@@ -388,24 +389,24 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
         if (tid < kDThreads && mrow + dr < m_hi) fb = *reinterpret_cast<const float4 *>(D + (size_t)(mrow + dr) * ldd + n0 + dc);
         mrow += kIgBK;
     };
-    auto stash = [&](int buf, const float4(&fa)[2], const float4 &fb) {
+    auto stash = [&](int buf, const float4(&fa)[KJ], const float4 &fb) {
         float *la = lds + buf * kStage, *lb = la + kIgBK * SA;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4 *>(la + ar * SA + aq + 64 * j) = fa[j];
+        for (int j = 0; j < KJ; ++j) *reinterpret_cast<float4 *>(la + ar * SA + aq + 64 * j) = fa[j];
         if (tid < kDThreads) *reinterpret_cast<float4 *>(lb + dr * SB + dc) = fb;
     };
     auto multiply = [&](int buf) {
-        const float *la = lds + buf * kStage + wv * 32 + c;
+        const float *la = lds + buf * kStage + wv * 16 * KJ + c;
         const float *lb = lds + buf * kStage + kIgBK * SA + c;
 #pragma unroll
         for (int kk = 0; kk < kIgBK / 4; ++kk) {
-            float fa[2], fb[NI];
+            float fa[KJ], fb[NI];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fa[a] = la[(4 * kk + g) * SA + 16 * a];
+            for (int a = 0; a < KJ; ++a) fa[a] = la[(4 * kk + g) * SA + 16 * a];
 #pragma unroll
             for (int b = 0; b < NI; ++b) fb[b] = lb[(4 * kk + g) * SB + 16 * b];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < KJ; ++a)
 #pragma unroll
                 for (int b = 0; b < NI; ++b) acc[a][b] = mfma16(fa[a], fb[b], acc[a][b]);
         }
@@ -428,12 +429,12 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
     }
     float *out = partial + (size_t)blockIdx.y * K * N;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < KJ; ++a)
 #pragma unroll
         for (int b = 0; b < NI; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = k0 + (wv * 2 + a) * 16 + 4 * g + r;
+                const int k = k0 + (wv * KJ + a) * 16 + 4 * g + r;
                 if (k < K) out[(size_t)k * N + n0 + b * 16 + c] = acc[a][b][r];
             }
     if (ktile == 0 && tid < TN) colpart[(size_t)blockIdx.y * N + n0 + tid] = colsum;
@@ -593,19 +594,29 @@ static IgA ig_make_a(const pfa_igemm_operand *a) {
 }
 
 // Launch plan of the weight form, shared by the workspace query and the launch: tile width over n, number of (k, n) tiles, row
-// splits (>= 2048 rows each, about 2048 workgroups in all, at most 512) and rows per split (a multiple of the k-slab).
+// splits (>= 2048 rows each, about 2048 workgroups in all, at most 1024) and rows per split (a multiple of the k-slab).
 struct IgWeightPlan {
-    int tn, tiles, splits;
+    int tn, kj, tiles, splits;   // tile = (64 kj) x tn
     int rows_per_split;
 };
 static IgWeightPlan ig_weight_plan(int64_t M, int K, int N) {
     IgWeightPlan p;
     p.tn = N % 64 == 0 ? 64 : N % 32 == 0 ? 32 : 16;
-    p.tiles = ((K + 127) / 128) * (N / p.tn);
+    // tile height over k: the one of 256 / 192 / 128 that pads K least (ties: the taller — more MFMAs per loaded D row and barrier)
+    p.kj = 2;
+    int best = (K + 127) / 128 * 128;
+    for (int kj = 3; kj <= 4; ++kj) {
+        const int padded = (K + 64 * kj - 1) / (64 * kj) * (64 * kj);
+        if (padded <= best) {
+            best = padded;
+            p.kj = kj;
+        }
+    }
+    p.tiles = ((K + 64 * p.kj - 1) / (64 * p.kj)) * (N / p.tn);
     int64_t s = (M + 2047) / 2048;
     const int64_t cap = 2048 / p.tiles + 1;
     if (s > cap) s = cap;
-    if (s > 512) s = 512;
+    if (s > 1024) s = 1024;
     p.splits = (int)(s < 1 ? 1 : s);
     p.rows_per_split = (int)((((M + p.splits - 1) / p.splits) + 15) / 16 * 16);
     return p;
@@ -680,14 +691,18 @@ extern "C" int pfa_igemm_weights(const pfa_igemm_operand *a, int64_t M, int32_t 
     const dim3 grid(p.tiles, p.splits);
     {
         ScopedKernelTimer timer("igemm_weights", (hipStream_t)stream);
-#define PFA_IG_WEIGHTS(MODE, NI)                                                                                                                 \
-    hipLaunchKernelGGL((igemm_weights_kernel<MODE, NI>), grid, dim3(kIgThreads), 0, (hipStream_t)stream, A, (int)M, (int)K, D, (int)ldd, (int)N, \
+#define PFA_IG_WEIGHTS(MODE, KJ, NI)                                                                                                             \
+    hipLaunchKernelGGL((igemm_weights_kernel<MODE, KJ, NI>), grid, dim3(kIgThreads), 0, (hipStream_t)stream, A, (int)M, (int)K, D, (int)ldd, (int)N, \
                        p.rows_per_split, partial, colpart)
+#define PFA_IG_WEIGHTS_KJ(MODE, NI)                                  \
+    if (p.kj == 4) PFA_IG_WEIGHTS(MODE, 4, NI);                      \
+    else if (p.kj == 3) PFA_IG_WEIGHTS(MODE, 3, NI);                 \
+    else PFA_IG_WEIGHTS(MODE, 2, NI);
 #define PFA_IG_WEIGHTS_MODE(NI)                                        \
     switch (A.mode) {                                                  \
-        case kADense: PFA_IG_WEIGHTS(kADense, NI); break;              \
-        case kAIm2colF32: PFA_IG_WEIGHTS(kAIm2colF32, NI); break;      \
-        default: PFA_IG_WEIGHTS(kAIm2colU8, NI); break;                \
+        case kADense: PFA_IG_WEIGHTS_KJ(kADense, NI) break;            \
+        case kAIm2colF32: PFA_IG_WEIGHTS_KJ(kAIm2colF32, NI) break;    \
+        default: PFA_IG_WEIGHTS_KJ(kAIm2colU8, NI) break;              \
     }
         if (p.tn == 64) {
             PFA_IG_WEIGHTS_MODE(4)
@@ -696,6 +711,7 @@ extern "C" int pfa_igemm_weights(const pfa_igemm_operand *a, int64_t M, int32_t 
         } else {
             PFA_IG_WEIGHTS_MODE(1)
         }
+#undef PFA_IG_WEIGHTS_KJ
 #undef PFA_IG_WEIGHTS_MODE
 #undef PFA_IG_WEIGHTS
         PFA_LAUNCH_CHECK();
