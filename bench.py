@@ -11,7 +11,8 @@ optimizer step over RCCL.  Inputs are synthetic by construction (the env IS the 
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     dominant kernel ppo_mlp_grad (fp32 MFMA bound): algorithmic FLOPs per launch / average launch
-               duration measured with HIP events on the launch stream over the timed region
+               duration measured with HIP events on the launch stream over the timed region (every 5th launch
+               bracketed: the event packets serialise the queue)
   cpu_baseline the CPU oracle port (C env + torch-fp32 policy/update, oracle/) timed on a bounded sample of
                the same workload on this box's host cores (rank 0, N = 1 only)
 """
@@ -296,6 +297,12 @@ def main():
     # dominant kernel of the update: the fused fwd/loss/bwd kernel (MLP) or the BPTT kernel (LSTM)
     dominant = {'mlp': 'ppo_mlp_grad', 'lstm': 'lstm_seq_bwd', 'cnn': 'igemm_rows'}[args.policy]
     L.pfa_timing_select(dominant.encode())
+    # The event pair around a launch serialises the queue (~7 us of dispatch bubble each: 16 bracketed launches per step cost
+    # the headline 7 %, measured).  The dominant kernel's launches all have the same shape in the MLP / LSTM updates, so every
+    # 5th one is bracketed (5 is coprime to the 16 launches of a step: every epoch x minibatch position gets sampled); the conv
+    # update's launches differ in shape and are all bracketed.
+    event_stride = 1 if args.policy == 'cnn' else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '5'))
+    L.pfa_timing_stride(event_stride)
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
     barrier()
@@ -331,7 +338,7 @@ def main():
         barrier()
     if rank == 0 and not args.no_breakdown:
         L.pfa_timing_enable(0)
-        names = (('rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
+        names = (('philox_exp_noise', 'rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
                  else ('igemm_rows', 'igemm_weights', 'gae', 'adam_clip') if args.policy == 'cnn'
                  else (('rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'), 'squared_tape', 'gae', 'lstm_seq_fwd',
                        'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
@@ -386,7 +393,7 @@ def main():
                          'frac_useful': (achieved * FLOP_PER_ROW_USEFUL / FLOP_PER_ROW_UPDATE / PEAK_FP32_MFMA_TFLOPS
                                          if args.policy == 'mlp' else None),   # on the 49 real columns (32 000 FLOP/row)
                          'traffic': traffic,
-                         'avg_launch_ms': avg_ms, 'launches': launches,
+                         'avg_launch_ms': avg_ms, 'launches': launches, 'bracketed': f'every {event_stride}. launch of the timed region' if event_stride > 1 else 'every launch of the timed region',
                          'flop_per_launch': flop_row * rows_per_launch},
             'kernel_ms_per_step': breakdown,
         }

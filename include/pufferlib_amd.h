@@ -32,6 +32,7 @@ const char *pfa_last_error(void);
  * the launch count and the summed device time in ms (HOST pointers). */
 int pfa_timing_enable(int mode);
 int pfa_timing_select(const char *kernel); /* the kernel mode 1 times (default "ppo_mlp_grad") */
+int pfa_timing_stride(int every);          /* mode 1 brackets every `every`-th launch of that kernel (default 1 = all) */
 int pfa_timing_reset(void);
 int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms_host);
 
@@ -139,6 +140,14 @@ int pfa_mlp_forward_sample(const float *obs, int64_t rows, const float *params, 
                            const float *noise, const pfa_noise_key *key, int64_t row_offset,
                            int64_t *actions, float *logprob, float *entropy, float *value,
                            pfa_stream_t stream);
+
+/* The Exp(1) action noise of a whole rollout in one launch: out[t][r][j] (f32 [steps][rows][A]) = the draw the Philox
+ * stream above makes for (row row_offset + r, step key->step + t, column j) — bit for bit what the policy steps draw in
+ * place when their `noise` is null, so handing `out` to them as the explicit tensor changes nothing but where the
+ * arithmetic runs (off the fused rollout's per-step critical path).  Stands in for torch.multinomial's internal
+ * exponential_ draw (frameworks/cleanrl.py:25-47 sample_logits -> torch.multinomial). */
+int pfa_philox_exp_noise(float *out, int64_t steps, int64_t rows, int32_t num_actions, const pfa_noise_key *key,
+                         int64_t row_offset, pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Experience — clean_pufferl.Experience (clean_pufferl.py:380-482) kept ENV-MAJOR on device:

@@ -115,6 +115,7 @@ _SIGNATURES = {
     'pfa_last_error': (C.c_char_p, []),
     'pfa_timing_enable': (C.c_int, [C.c_int]),
     'pfa_timing_select': (C.c_int, [C.c_char_p]),
+    'pfa_timing_stride': (C.c_int, [C.c_int]),
     'pfa_timing_reset': (C.c_int, []),
     'pfa_timing_read': (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'pfa_gae_workspace_bytes': (C.c_size_t, [C.c_int64]),
@@ -132,6 +133,7 @@ _SIGNATURES = {
     'pfa_mlp_param_count': (C.c_int64, [C.POINTER(MlpDims)]),
     'pfa_mlp_forward_sample': (C.c_int, [P, C.c_int64, P, C.POINTER(MlpDims), P, C.POINTER(NoiseKey), C.c_int64,
                                          P, P, P, P, P]),
+    'pfa_philox_exp_noise': (C.c_int, [P, C.c_int64, C.c_int64, C.c_int32, C.POINTER(NoiseKey), C.c_int64, P]),
     'pfa_rollout_mlp_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), C.POINTER(Experience),
                                           P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
     'pfa_stochastic_state_bytes': (C.c_size_t, [C.c_int32]),

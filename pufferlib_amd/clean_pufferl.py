@@ -30,7 +30,7 @@ from threading import Thread
 import numpy as np
 import torch
 
-from . import _lib, utils
+from . import _lib, readback, utils
 from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
 from .models import FlatParams
@@ -48,7 +48,7 @@ def seed_everything(seed, torch_deterministic=True):
 
 
 def make_losses():
-    return namespace(policy_loss=0, value_loss=0, entropy=0, old_approx_kl=0, approx_kl=0, clipfrac=0,
+    return readback.LazyLosses(policy_loss=0, value_loss=0, entropy=0, old_approx_kl=0, approx_kl=0, clipfrac=0,
                      explained_variance=0)
 
 
@@ -351,6 +351,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         log_sums=torch.zeros(10, dtype=torch.float64, device=device),
         noise=None,            # optional explicit Exp(1) tensor [T][N][A] for the next evaluate() (parity tests)
         tape_stream=torch.cuda.Stream(device=device),   # reset-target tape is drawn one rollout ahead, off the critical path
+        _rb_eval=readback.Pending(), _rb_train=readback.Pending(),   # deferred stats / loss readbacks (readback.py)
     )
     return data
 
@@ -405,6 +406,14 @@ def evaluate(data):
         if data.lstm_engine is not None:
             data.lstm_engine.rollout(T, noise, policy.noise_seed, policy.noise_step, vecenv.env_offset)
         else:
+            if noise is None:
+                # the whole rollout's Philox action noise in one launch (same numbers the kernel would draw in place): keeps 40
+                # quarter-rate integer multiplies per step off the rollout's dependent chain; the kernel prefetches a step ahead
+                if getattr(data, '_noise_buf', None) is None or tuple(data._noise_buf.shape) != (T, N, fp.num_actions):
+                    data._noise_buf = torch.empty(T, N, fp.num_actions, dtype=torch.float32, device=vecenv.device)
+                noise = data._noise_buf
+                _lib.check(L.pfa_philox_exp_noise(_lib.ptr(noise), T, N, fp.num_actions, C.byref(key), vecenv.env_offset,
+                                                  _lib.stream_handle()), 'philox_exp_noise')
             _lib.check(L.pfa_rollout_mlp_squared(
                 _lib.ptr(vecenv.state), C.byref(vecenv.cfg), _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(experience.c),
                 _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
@@ -415,7 +424,7 @@ def evaluate(data):
         # The tape does not depend on actions: draw the NEXT rollout's reset rounds on the side stream while THIS
         # rollout runs (its small workgroup co-resides with the rollout's).  The ring slots it writes belong to the
         # rollout before this one, which `start_point` guarantees has finished.
-        if 3 * (vecenv._rounds_needed(T) + 1) <= vecenv.tape_rounds:
+        if 3 * (vecenv._rounds_needed(T) + 1) <= vecenv.tape_rounds and os.environ.get('PFA_TAPE_PREFETCH', '1') != '0':
             with torch.cuda.stream(data.tape_stream):
                 data.tape_stream.wait_event(start_point)
                 vecenv.ensure_tape(T)
@@ -477,13 +486,21 @@ def _finish_evaluate(data, N, T):
         elif data.world_size > 1:
             dist, _, _ = _dist()
             dist.all_reduce(st)
-        st = st.cpu().numpy()                            # the one sync of evaluate()
-        if st.shape[0] > 4 and st[4] != 0:
-            raise RuntimeError('reset-target tape underrun: an env reset before its tape round was drawn (host bookkeeping of '
-                               'ensure_tape / the side-stream prefetch is wrong); the rollout replayed stale targets')
-        data.stats = vecenv.stats_from_sums(st)
-        infos = {k: [v] for k, v in data.stats.items()}
-    return data.stats, infos
+        # The sums ride a pinned buffer behind the rollout; the host waits for them here (default) or, with
+        # PFA_LAZY_READBACK=1, when the dicts are first read — at the latest at the end of the next evaluate() (readback.py).
+        stats, infos = readback.LazyDict(data._rb_eval), readback.LazyDict(data._rb_eval)
+        means = vecenv.stats_from_sums
+
+        def finish(host, stats=stats, infos=infos, means=means):
+            if host.shape[0] > 4 and host[4] != 0:
+                raise RuntimeError('reset-target tape underrun: an env reset before its tape round was drawn (host bookkeeping of '
+                                   'ensure_tape / the side-stream prefetch is wrong); the rollout replayed stale targets')
+            m = means(host)
+            stats.fill(m)
+            infos.fill({k: [v] for k, v in m.items()})
+        data.stats = stats
+        data._rb_eval.submit(st, finish)
+    return stats, infos
 
 
 def _all_gather_small(dist, x, rank, world, native=False):
@@ -621,15 +638,18 @@ def train(data):
             ev_sums = data.log_sums[6:10].clone()
             dist.all_reduce(ev_sums)
             data.log_sums[6:10] = ev_sums
-        acc = data.log_sums.cpu().numpy()                       # the one sync of train()
-        s_y, s_yy, s_a, s_aa = acc[6:10]
+        # one D2H of 10 f64 (the one sync of train(); with PFA_LAZY_READBACK=1 data.losses fills in when it is first read)
         Bg = B * world
-        var_y = s_yy / Bg - (s_y / Bg) ** 2
-        var_res = s_aa / Bg - (s_a / Bg) ** 2                    # y_true - y_pred = advantages
-        ev = float('nan') if var_y == 0 else 1 - var_res / var_y
-        (losses.policy_loss, losses.value_loss, losses.entropy, losses.old_approx_kl, losses.approx_kl,
-         losses.clipfrac) = (float(x) for x in acc[:6])
-        losses.explained_variance = ev
+
+        def finish(acc, losses=losses, Bg=Bg):
+            s_y, s_yy, s_a, s_aa = acc[6:10]
+            var_y = s_yy / Bg - (s_y / Bg) ** 2
+            var_res = s_aa / Bg - (s_a / Bg) ** 2                    # y_true - y_pred = advantages
+            ev = float('nan') if var_y == 0 else 1 - var_res / var_y
+            losses.fill(policy_loss=float(acc[0]), value_loss=float(acc[1]), entropy=float(acc[2]), old_approx_kl=float(acc[3]),
+                        approx_kl=float(acc[4]), clipfrac=float(acc[5]), explained_variance=ev)
+        losses.attach(data._rb_train)
+        data._rb_train.submit(data.log_sums, finish)
         data.epoch += 1
 
         done_training = data.global_step >= config.total_timesteps

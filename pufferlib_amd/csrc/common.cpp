@@ -25,6 +25,8 @@ struct TimedKernel {
     size_t used = 0;
 };
 static int g_timing = 0;  // 0 off, 1 the selected (dominant) kernel only, 2 every instrumented kernel
+static int g_stride = 1;  // mode 1: bracket every g_stride-th launch of the selected kernel (the event packets serialise the queue)
+static long long g_seen = 0;
 static std::string g_selected = "ppo_mlp_grad";
 static std::map<std::string, TimedKernel> g_timed;
 
@@ -33,6 +35,7 @@ bool timing_enabled() { return g_timing != 0; }
 // Returns the stop event (to be recorded after the launch) or nullptr when timing is off.
 void *timing_begin(const char *name, hipStream_t stream) {
     if (g_timing == 0 || (g_timing == 1 && g_selected != name)) return nullptr;
+    if (g_timing == 1 && g_stride > 1 && (g_seen++ % g_stride) != 0) return nullptr;
     TimedKernel &k = g_timed[name];
     if (k.used == k.pairs.size()) {
         hipEvent_t a, b;
@@ -53,6 +56,11 @@ extern "C" const char *pfa_last_error(void) { return pfa::g_err; }
 
 extern "C" int pfa_timing_enable(int on) {
     pfa::g_timing = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return 0;
+}
+extern "C" int pfa_timing_stride(int every) {
+    pfa::g_stride = every < 1 ? 1 : every;
+    pfa::g_seen = 0;
     return 0;
 }
 extern "C" int pfa_timing_select(const char *kernel) {

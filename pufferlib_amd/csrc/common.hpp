@@ -52,4 +52,13 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` is a workgroup-scope fence over every address space: on
+// gfx9 it also waits (vmcnt(0)) for the acknowledgement of the global stores issued so far, which a kernel that never reads
+// them back does not need.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 }  // namespace pfa

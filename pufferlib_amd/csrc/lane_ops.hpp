@@ -43,7 +43,7 @@ __device__ __forceinline__ void row16_argmax(float &best, int &idx) {
     {                                                           \
         const float ob = dpp_f<CTRL>(best);                     \
         const int oi = dpp_i<CTRL>(idx);                        \
-        const bool take = ob > best || (ob == best && oi < idx); \
+        const bool take = (ob > best) | ((ob == best) & (oi < idx)); /* bitwise: no exec-mask branches */ \
         best = take ? ob : best;                                \
         idx = take ? oi : idx;                                  \
     }

@@ -66,10 +66,7 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
 // ---------------------------------------------------------------------------------------------
 // fused persistent rollout
 //
-// One workgroup of 4 wavefronts owns EPW (16 or 8) envs for all T steps.  The per-step chain env -> forward -> sample
-// -> env is latency-bound, so when N/16 would leave fewer than two workgroups per CU the launch uses EPW = 8 (half
-// the MFMA tile is padding, which is free here) and two workgroups per CU hide each other's latencies.
-// Per step:
+// One workgroup of 4 wavefronts owns 16 envs for all T steps.  Per step:
 //   all 256 threads   store the 16 observation rows (LDS -> experience, one float4 each at obs_stride 64)
 //   wave w            forward_slice: 2 x KS MFMAs against W1 fragments held in registers + its 8 head MFMAs
 //   barrier
@@ -77,8 +74,18 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
 //   thread (e, 0)     Experience.store of the scalars, then send(): env step or tape reset, rewriting row e of the
 //                     LDS observation tile
 //   barrier
+// The chain env -> forward -> sample -> env is latency-bound (one wave per SIMD, 128 dependent steps), so everything that
+// does not depend on the previous step is taken off it:
+//   * the Exp(1) noise of step t+1 is loaded into a register while step t runs when the caller hands the rollout a noise
+//     tensor (clean_pufferl.evaluate draws the whole rollout's Philox noise with pfa_philox_exp_noise in one launch: 40
+//     quarter-rate integer multiplies per step and wave otherwise);
+//   * NT1 (one target, every ocean default): the next reset's target is fetched from the tape right after the previous
+//     reset (a dependent HBM round trip every episode otherwise), the tape's fill level is read once at launch, and the env
+//     step is the single-target form of squared_env.hpp (reward table, no integer or f64 division, two-cell grid clear);
+//   * the two per-step barriers order LDS only (`lds_barrier`, common.hpp): a `__syncthreads()` also waits for the acknowledgement of
+//     the experience stores just issued, which nothing in this kernel reads back.
 // ---------------------------------------------------------------------------------------------
-template <int DP, int EPW>
+template <int DP, int EPW, bool NT1>
 __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(SquaredView v, const float *params, int a,
                                                                           pfa_experience ex, const float *noise,
                                                                           uint64_t seed, uint64_t step0, long long env_offset,
@@ -87,7 +94,11 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
     constexpr int XS = XTile<DP>::XS;
     __shared__ float xs[XTile<DP>::kFloats];
     __shared__ float part[kRollWaves][kOut * 16];  // partial out^T[o][row] per wave
-    __shared__ uint16_t tg[16 * kMaxTargets];
+    __shared__ uint16_t tg[NT1 ? 1 : 16 * kMaxTargets];
+    // One wave per SIMD on a dependent chain: whatever shares the CU (the reset-tape workgroup drawn on the side stream while
+    // this kernel runs) must not win issue slots from it — the launch lasts as long as its slowest workgroup.
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ RewardTable rtab;
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;  // sampling role: local env, output index
     const int e = blockIdx.x * EPW + le;
     const bool env_ok = le < EPW && e < v.n;
@@ -99,15 +110,37 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
 
     // recv(): the live buffers are the current observation / reward / terminal of every env
     stage_rows<DP>(live_obs, (long long)blockIdx.x * EPW, v.n, xs, EPW);
+    if (NT1) rtab.build(v.d);
     SquaredEnv s;
+    Target1 t1;
     float reward = 0.0f;
     bool terminal = false;
+    long long filled = 0;        // NT1: tape rounds drawn when this launch started (the host guarantees they cover it)
+    uint16_t next_cell = 0;      // NT1: target of this env's next reset (tape round s.rounds), fetched ahead of the reset
+    uint32_t slot = 0;           // NT1: s.rounds % tape_rounds, kept incrementally
+    const size_t tape_n = (size_t)v.n;
     if (owner) {
         squared_load(v, e, s);
-        for (int t = 0; t < v.nt; ++t) tg[le * kMaxTargets + t] = v.tgt[(size_t)t * v.n + e];
+        if (NT1) {
+            t1.set(v.tgt[e], v.g);
+            filled = v.hdr->rounds_filled;
+            slot = s.rounds % (uint32_t)v.tape_rounds;
+            next_cell = v.tape[(size_t)slot * tape_n + e];
+        } else {
+            for (int t = 0; t < v.nt; ++t) tg[le * kMaxTargets + t] = v.tgt[(size_t)t * v.n + e];
+        }
         reward = live_rew[e];
         terminal = live_term[e] != 0;
     }
+    // explicit noise rows [T][N][a]: this lane's column, one step ahead
+    const bool noise_lane_ok = env_ok && lo < a;
+    const float *nz = noise && noise_lane_ok ? noise + (size_t)e * a + lo : nullptr;
+    const size_t nz_step = (size_t)v.n * a;
+    float q_next = nz ? nz[0] : 1.0f;
+    // Everything loaded so far (weight fragments, env state, first noise value) lands before the loop: a load still in flight at
+    // the loop header makes the compiler's first in-loop wait a vmcnt(0), which then also waits for the experience stores of
+    // every step (s_waitcnt vmcnt(0) expcnt(7) lgkmcnt(15) on gfx9).
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 
     for (int t = 0; t < T; ++t) {
@@ -117,11 +150,13 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
         PFA_RSTAMP(t, 1);
         forward_slice<DP>(w, xs, part);
         PFA_RSTAMP(t, 2);
-        __syncthreads();
+        lds_barrier();
         PFA_RSTAMP(t, 3);
-        const float q = env_ok ? noise_lane(noise ? noise + ((size_t)t * v.n + e) * a : nullptr, seed, step0 + t,
-                                            (uint64_t)(env_offset + e), lo, a)
-                               : 1.0f;
+        // (vmcnt is one in-order counter: every wait for a loaded value also waits for the stores issued before it.  The
+        // prefetched noise and tape values are therefore consumed HERE and at the top of the owner block — where the youngest
+        // outstanding store is a forward pass old — and this step's stores and prefetches are issued after those points.)
+        const float q = noise ? q_next
+                              : (env_ok ? noise_lane(nullptr, seed, step0 + t, (uint64_t)(env_offset + e), lo, a) : 1.0f);
 #ifdef PFA_PROBES
         if (q == -12345.678f) PFA_RSTAMP(t, 7);   // (never true) pins the stamp behind the noise
 #endif
@@ -132,36 +167,58 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
 #endif
         PFA_RSTAMP(t, 5);
         if (owner) {
+            const float stored_reward = reward;
+            const bool stored_terminal = terminal;
+            // send(): vector.py:144-151
+            float *grid = xs + le * XS;
+            if (NT1) {
+                if (s.done) {
+                    if ((long long)s.rounds >= filled) v.hdr->underrun = 1;
+                    squared_reset_nt1(v, s, grid, t1, next_cell, reward, terminal);
+                    s.rounds += 1;
+                    slot = slot + 1 == (uint32_t)v.tape_rounds ? 0u : slot + 1;
+                } else {
+                    squared_step_nt1(v, s, grid, t1, rtab, sm.action, reward, terminal);
+                }
+            } else {
+                uint16_t *tc = tg + le * kMaxTargets;
+                if (s.done) {
+                    if ((long long)s.rounds >= v.hdr->rounds_filled) v.hdr->underrun = 1;
+                    const uint16_t *tr = v.tape + (size_t)(s.rounds % (uint32_t)v.tape_rounds) * v.nt * v.n;
+                    squared_reset(v, e, s, grid, tr, tc, reward, terminal);
+                    s.rounds += 1;
+                } else {
+                    bool fin;
+                    double fr, fs;
+                    int fl;
+                    squared_step(v, s, grid, tc, sm.action, reward, terminal, fin, fr, fl, fs);
+                }
+            }
+            // Experience.store of the scalars (clean_pufferl.py:443-449): what recv() returned for this step + the policy's outputs
             const size_t row = (size_t)e * T + t;
-            ex.rewards[row] = reward;
-            ex.dones[row] = terminal ? 1.0f : 0.0f;
+            ex.rewards[row] = stored_reward;
+            ex.dones[row] = stored_terminal ? 1.0f : 0.0f;
             ex.actions[row] = sm.action;
             ex.logprobs[row] = sm.logprob;
             ex.values[row] = sm.value;
-            // send(): vector.py:144-151
-            float *grid = xs + le * XS;
-            uint16_t *tc = tg + le * kMaxTargets;
-            if (s.done) {
-                if ((long long)s.rounds >= v.hdr->rounds_filled) v.hdr->underrun = 1;
-                const uint16_t *tr = v.tape + (size_t)(s.rounds % (uint32_t)v.tape_rounds) * v.nt * v.n;
-                squared_reset(v, e, s, grid, tr, tc, reward, terminal);
-                s.rounds += 1;
-            } else {
-                bool fin;
-                double fr, fs;
-                int fl;
-                squared_step(v, s, grid, tc, sm.action, reward, terminal, fin, fr, fl, fs);
-            }
+            // the next reset's target, re-fetched every step (a conditional fetch would make next_cell a phi whose copy waits for
+            // the load at once); the value a reset consumes was requested at least one whole step earlier
+            if (NT1) next_cell = v.tape[(size_t)slot * tape_n + e];
         }
+        if (nz && t + 1 < T) q_next = nz[(size_t)(t + 1) * nz_step];
         PFA_RSTAMP(t, 6);
-        __syncthreads();
+        lds_barrier();
         PFA_RSTAMP(t, 7);
     }
 
     // write back: env state + the live buffers the next recv() returns
     if (owner) {
         squared_store(v, e, s);
-        for (int t = 0; t < v.nt; ++t) v.tgt[(size_t)t * v.n + e] = tg[le * kMaxTargets + t];
+        if (NT1) {
+            v.tgt[e] = t1.cell;
+        } else {
+            for (int t = 0; t < v.nt; ++t) v.tgt[(size_t)t * v.n + e] = tg[le * kMaxTargets + t];
+        }
         v.fin[e] = 0;
         live_rew[e] = reward;
         live_term[e] = terminal ? 1 : 0;
@@ -169,6 +226,27 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
         live_mask[e] = 1;
     }
     unstage_rows<DP>(xs, live_obs, (long long)blockIdx.x * EPW, v.n, (size_t)DP, EPW);
+}
+
+// The whole rollout's action noise in one launch: out[t][r][j] = the Exp(1) draw noise_lane() makes in place for
+// (row row_offset + r, step key.step + t, column j) — one Philox call per four columns.
+__global__ void __launch_bounds__(256) philox_exp_noise_kernel(float *out, long long steps, long long rows, int a, int groups,
+                                                               uint64_t seed, uint64_t step0, long long row_offset) {
+    const long long total = steps * rows * groups;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j4 = (int)(i % groups);
+        const long long tr = i / groups;
+        const long long r = tr % rows, t = tr / rows;
+        const uint64_t step = step0 + (uint64_t)t, row = (uint64_t)(row_offset + r);
+        const u32x4 w = philox4x32_10((uint32_t)row, (uint32_t)j4, (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                                      (uint32_t)(seed >> 32));
+        float *o = out + (size_t)tr * a + 4 * j4;
+        const int left = a - 4 * j4;
+        o[0] = -logf(philox_uniform(w.x));
+        if (left > 1) o[1] = -logf(philox_uniform(w.y));
+        if (left > 2) o[2] = -logf(philox_uniform(w.z));
+        if (left > 3) o[3] = -logf(philox_uniform(w.w));
+    }
 }
 
 static int check_dims(const pfa_mlp_dims *d) {
@@ -230,6 +308,22 @@ extern "C" int pfa_mlp_forward_sample(const float *obs, int64_t rows, const floa
     return 0;
 }
 
+extern "C" int pfa_philox_exp_noise(float *out, int64_t steps, int64_t rows, int32_t num_actions, const pfa_noise_key *key,
+                                    int64_t row_offset, pfa_stream_t stream) {
+    PFA_REQUIRE(steps >= 0 && rows >= 0, "philox noise: negative shape");
+    PFA_REQUIRE(num_actions >= 1 && num_actions <= 15, "philox noise: num_actions must be in 1..15 (got %d)", num_actions);
+    if (steps == 0 || rows == 0) return 0;
+    PFA_REQUIRE(out && key, "philox noise: null buffer");
+    const int groups = (num_actions + 3) / 4;
+    const long long total = (long long)steps * rows * groups;
+    const unsigned grid = (unsigned)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    ScopedKernelTimer timer("philox_exp_noise", (hipStream_t)stream);
+    hipLaunchKernelGGL(philox_exp_noise_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, out, (long long)steps, (long long)rows,
+                       (int)num_actions, groups, key->seed, key->step, (long long)row_offset);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cfg, const float *params,
                                        const pfa_mlp_dims *dims, const pfa_experience *exp, const float *noise,
                                        const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards,
@@ -247,15 +341,20 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     SquaredView v = squared_view(state, *cfg);
     const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
     ScopedKernelTimer timer("rollout_mlp_squared", (hipStream_t)stream);
-    // 16 envs per workgroup.  Two restructurings measured no better (round 2, tools/probe_rollout.py): an 8-env variant (two
-    // workgroups per CU at N = 4096) was slower, and four helper waves taking the observation / scalar stores and the next
-    // step's Philox noise off the policy waves (bit-exact, barriers without the store-acknowledge wait) left the launch at
-    // 0.334 vs 0.331 ms — what bounds a step is the dependent chain forward -> sample -> env step itself.
+    // 16 envs per workgroup (an 8-env variant — two workgroups per CU at N = 4096 — and four helper waves for the stores and the
+    // noise both measured no better in round 2: tools/probe_rollout.py); the single-target env form when it applies.
     const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
-    PFA_DISPATCH_DP(dims->obs_stride,
-                    hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, v,
-                                       params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
-                                       terminals, truncations, masks));
+    if (cfg->num_targets == 1) {
+        PFA_DISPATCH_DP(dims->obs_stride,
+                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, true>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
+                                           v, params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
+                                           terminals, truncations, masks));
+    } else {
+        PFA_DISPATCH_DP(dims->obs_stride,
+                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, false>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
+                                           v, params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
+                                           terminals, truncations, masks));
+    }
     PFA_LAUNCH_CHECK();
     return 0;
 }

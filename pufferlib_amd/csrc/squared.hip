@@ -235,6 +235,193 @@ __global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tape fill, single-target form (num_targets == 1: random.sample(pop, 1) is ONE _randbelow, so word w yields a draw iff
+// (w >> (32 - bits)) < n_pop, independently of every other word).  The work then splits into
+//   (1) the only sequential part: the raw MT19937 words.  x[k+624] = twist(x[k], x[k+1], x[k+397]) lets 227 consecutive
+//       words be computed at once; ONE wavefront slides that 227-word window over an LDS ring (no workgroup barriers, one
+//       SIMD slot: it runs under the rollout without slowing it) and streams the raw words to scratch — `squared_tape_words`;
+//   (2) everything else in parallel over all words: temper, test, count (`squared_tape_count`), then exclusive offsets,
+//       compaction into (round, env) tape slots, and the stream state after the last word consumed (`squared_tape_select`).
+// The number of words the draws will need is only known statistically (acceptance n_pop / 2^bits), so (1) produces the
+// expectation + 2 % + 6 blocks (>= 15 sigma at every size); if the words still run out, `underrun` is raised — never silent.
+// Scratch = the per-env seeding area `seed_mt` (u32[624][N]), idle between async_resets.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMtStep = kMtN - kMtM;        // 227
+constexpr int kTapeLin = 12288;             // words of LDS the raw stream slides through (48 KB)
+constexpr int kSelWords = 16;               // consecutive words per thread in the parallel passes
+constexpr int kSelThreads = 256;
+constexpr int kSelChunk = kSelWords * kSelThreads;
+
+struct TapeJob {          // written by the words kernel, read by the parallel passes (hdr itself is rewritten by the last pass)
+    long long first_round;
+    long long need;       // draws to produce
+    long long avail;      // words available from the stream position on
+    int idx0;             // index of the next word inside block 0 (may be 624)
+    int blocks;           // regenerated blocks after block 0
+};
+
+__global__ void __launch_bounds__(64) squared_tape_words_kernel(SquaredView v, uint32_t *raw, TapeJob *job, int rounds, int blocks) {
+    // The stream is laid out LINEARLY in LDS (x[base + i] at lin[w + i]) so that every operand of a step sits at a constant
+    // offset from one moving pointer; when the window reaches the end, its last 624 words move back to the front.
+    __shared__ uint32_t lin[kTapeLin];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < kMtN; i += 64) {
+        const uint32_t w = v.hdr->mt[i];
+        lin[i] = w;
+        raw[i] = w;
+    }
+    if (lane == 0) {
+        const int idx0 = v.hdr->mt_idx;
+        job->first_round = v.hdr->rounds_filled;
+        job->need = (long long)rounds * v.n;
+        job->idx0 = idx0;
+        job->blocks = blocks;
+        job->avail = (long long)(blocks + 1) * kMtN - idx0;
+    }
+    lds_barrier();
+    // new words x[624 + k], k in [0, blocks*624), in whole 227-word steps (the last step may run past the end: the scratch has
+    // the slack, the extra words are simply more of the same stream).  Lane l owns words j = 64 r + l (r < 4; r = 3: l < 35) of
+    // every step.  The `far` operand x[k + 397] of a step is the word the SAME (r, lane) slot produced one step earlier
+    // (k + 397 - 624 = k - 227), so the step-to-step dependency stays in registers; `cur` / `nxt` were written at least two
+    // steps back and are fetched one step ahead.  One wavefront, LDS operations complete in issue order: no barrier in the loop.
+    const int steps = (blocks * kMtN + kMtStep - 1) / kMtStep;
+    uint32_t far[4], cur[4], nxt[4];
+    const uint32_t *src = lin + lane;      // &x[base + lane]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {          // (r = 3, lanes >= 35: slots this lane does not own — read, never stored)
+        far[r] = src[r * 64 + kMtM];
+        cur[r] = src[r * 64];
+        nxt[r] = src[r * 64 + 1];
+    }
+    uint32_t *out = raw + kMtN + lane;     // &raw[624 + base + lane]
+    int w = 0;                             // window start inside lin (uniform)
+    for (int st = 0; st < steps; ++st) {
+        uint32_t cur1[4], nxt1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {      // operands of step st + 1: written in step st - 1 or earlier
+            cur1[r] = src[kMtStep + r * 64];
+            nxt1[r] = src[kMtStep + r * 64 + 1];
+        }
+        uint32_t *dst = lin + w + kMtN + lane;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t x = mt_twist(cur[r], nxt[r], far[r]);
+            if (r < 3 || lane < kMtStep - 192) {
+                dst[r * 64] = x;
+                out[r * 64] = x;
+            }
+            far[r] = x;
+            cur[r] = cur1[r];
+            nxt[r] = nxt1[r];
+        }
+        w += kMtStep;
+        out += kMtStep;
+        if (w + kMtN + 2 * kMtStep + 64 > kTapeLin) {     // (uniform) move the window back to the front
+            for (int i = lane; i < kMtN; i += 64) lin[i] = lin[w + i];
+            w = 0;
+        }
+        src = lin + w + lane;
+    }
+}
+
+__device__ __forceinline__ uint32_t tape_accept_mask(const uint32_t *raw, const TapeJob &job, long long p0, int bits, int n_pop,
+                                                     uint32_t cand[kSelWords]) {
+    // words p0 .. p0+15 of the stream (position p <-> raw[idx0 + p]); bit i set <=> word p0+i exists and is accepted
+    uint32_t mask = 0;
+#pragma unroll
+    for (int i = 0; i < kSelWords; ++i) {
+        const long long p = p0 + i;
+        uint32_t c = 0xffffffffu;
+        if (p < job.avail) c = mt_temper(raw[job.idx0 + p]) >> (32 - bits);
+        cand[i] = c;
+        if (c < (uint32_t)n_pop) mask |= 1u << i;
+    }
+    return mask;
+}
+
+__global__ void __launch_bounds__(kSelThreads) squared_tape_count_kernel(SquaredView v, const uint32_t *raw, const TapeJob *jobp,
+                                                                         int *counts) {
+    __shared__ int wsum[kSelThreads / 64];
+    const TapeJob job = *jobp;
+    const int n_pop = 8 * v.d, bits = 32 - __clz(n_pop);
+    uint32_t cand[kSelWords];
+    const long long p0 = (long long)blockIdx.x * kSelChunk + (long long)threadIdx.x * kSelWords;
+    int c = __popc(tape_accept_mask(raw, job, p0, bits, n_pop, cand));
+    for (int off = 32; off; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+__global__ void __launch_bounds__(kSelThreads) squared_tape_select_kernel(SquaredView v, const uint32_t *raw, const TapeJob *jobp,
+                                                                          const int *counts, int rounds) {
+    __shared__ long long s_red[kSelThreads / 64];
+    __shared__ int s_wave[kSelThreads / 64];
+    __shared__ long long s_last;     // stream position of the word that produced the last draw (-1: not in this workgroup)
+    const TapeJob job = *jobp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int n_pop = 8 * v.d, bits = 32 - __clz(n_pop);
+    // draws produced by the workgroups before this one
+    long long before = 0;
+    for (int i = tid; i < (int)blockIdx.x; i += kSelThreads) before += counts[i];
+    for (int off = 32; off; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0) s_red[wv] = before;
+    if (tid == 0) s_last = -1;
+    __syncthreads();
+    before = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const bool tail = blockIdx.x == gridDim.x - 1;
+    if (before >= job.need) return;   // (uniform) the stream position was fixed by an earlier workgroup
+    uint32_t cand[kSelWords];
+    const long long p0 = (long long)blockIdx.x * kSelChunk + (long long)tid * kSelWords;
+    const uint32_t mask = tape_accept_mask(raw, job, p0, bits, n_pop, cand);
+    // exclusive prefix of the per-thread counts over the workgroup
+    const int mine = __popc(mask);
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int wave_base = 0, total = 0;
+    for (int q = 0; q < kSelThreads / 64; ++q) {
+        wave_base += q < wv ? s_wave[q] : 0;
+        total += s_wave[q];
+    }
+    long long pos = before + wave_base + incl - mine;
+#pragma unroll
+    for (int i = 0; i < kSelWords; ++i) {
+        if ((mask >> i) & 1u) {
+            if (pos < job.need) {
+                const long long round = job.first_round + pos / v.n;
+                const int env = (int)(pos % v.n);
+                v.tape[(size_t)(round % v.tape_rounds) * v.n + env] = (uint16_t)perimeter_cell((int)cand[i], v.g);
+                if (pos == job.need - 1) s_last = p0 + i;
+            }
+            ++pos;
+        }
+    }
+    __syncthreads();
+    const long long last = s_last;
+    if (last >= 0) {
+        // the stream after the last consumed word: the block that holds the next word and the index inside it (an index of 624
+        // = "regenerate first" stays on the old block, as CPython and the one-workgroup kernel leave it)
+        const long long consumed = last + 1, at = job.idx0 + consumed;
+        long long blk = at / kMtN;
+        int idx = (int)(at % kMtN);
+        if (idx == 0 && blk > 0) { blk -= 1; idx = kMtN; }
+        for (int i = tid; i < kMtN; i += kSelThreads) v.hdr->mt[i] = raw[blk * kMtN + i];
+        if (tid == 0) {
+            v.hdr->mt_idx = idx;
+            v.hdr->words += (unsigned long long)consumed;
+            v.hdr->rounds_filled = job.first_round + rounds;
+        }
+    } else if (tail && before + total < job.need && tid == 0) {
+        v.hdr->underrun = 1;     // the margin of extra words did not cover the rejections: reported, never silent
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // send: Serial.send (vector.py:137-156), one thread per env
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) squared_send_kernel(SquaredView v, const long long *actions, float *obs,
@@ -361,6 +548,30 @@ extern "C" int pfa_squared_fill_tape(void *state, const pfa_squared_config *cfg,
     if (rounds == 0) return 0;
     SquaredView v = squared_view(state, *cfg);
     ScopedKernelTimer timer("squared_tape", (hipStream_t)stream);
+    if (cfg->num_targets == 1) {
+        // single-target form: one wavefront of raw words + two parallel passes (see above); needs room in the seeding scratch
+        const int n_pop = 8 * cfg->distance_to_target;
+        int bits = 0;
+        while ((1 << bits) <= n_pop) ++bits;                       // n_pop.bit_length()
+        const double need = (double)rounds * cfg->num_envs;
+        const double words = need * (double)(1 << bits) / n_pop * 1.02 + 6.0 * kMtN;
+        const long long blocks = (long long)(words / kMtN) + 1;
+        const long long chunks = ((blocks + 1) * kMtN + kSelChunk - 1) / kSelChunk;
+        const long long scratch_words = (long long)kMtN * cfg->num_envs;
+        const long long used = (blocks + 1) * kMtN + kMtStep + chunks + 64;    // raw words (+ one step of slack), counts, job
+        if (used <= scratch_words && blocks < (1 << 21)) {
+            uint32_t *raw = v.seed_mt;
+            int *counts = (int *)(raw + (blocks + 1) * kMtN + kMtStep);
+            TapeJob *job = (TapeJob *)(((uintptr_t)(counts + chunks) + 15) & ~(uintptr_t)15);
+            hipLaunchKernelGGL(squared_tape_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, v, raw, job, (int)rounds, (int)blocks);
+            hipLaunchKernelGGL(squared_tape_count_kernel, dim3((unsigned)chunks), dim3(kSelThreads), 0, (hipStream_t)stream, v,
+                               (const uint32_t *)raw, (const TapeJob *)job, counts);
+            hipLaunchKernelGGL(squared_tape_select_kernel, dim3((unsigned)chunks), dim3(kSelThreads), 0, (hipStream_t)stream, v,
+                               (const uint32_t *)raw, (const TapeJob *)job, (const int *)counts, (int)rounds);
+            PFA_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipLaunchKernelGGL(squared_tape_kernel, dim3(1), dim3(kTapeThreads), 0, (hipStream_t)stream, v, (int)rounds);
     PFA_LAUNCH_CHECK();
     return 0;

@@ -227,4 +227,98 @@ __device__ __forceinline__ void squared_step(const SquaredView &v, SquaredEnv &s
     s.done = done;      // emulation.py:226
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-target form (num_targets == 1, every ocean default) for the fused rollout, where the env step sits on the
+// rollout's per-step critical path.  Same statements as squared_reset / squared_step above, with what is constant per
+// launch or per episode taken out of the step: the target's (x, y) lives in registers (no `c / g` per step), the reward
+// 1 - k/d comes from a table of the 2d+1 possible Chebyshev distances built once per launch with the same f64 division
+// (`RewardTable`: bit-identical by construction), and a reset clears the two cells that can be non-zero (agent, target
+// marker) instead of the whole grid.  The fused-vs-stepwise test (which runs the general form) pins the equivalence.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxRewardDist = 32;   // table entries; distances beyond it (never reached: k <= 2d <= 10) take the division
+
+struct RewardTable {
+    double rd[kMaxRewardDist];
+    float rf[kMaxRewardDist];
+    __device__ __forceinline__ void build(int d) {   // all threads of the workgroup; caller barriers before use
+        for (int k = threadIdx.x; k < kMaxRewardDist; k += blockDim.x) {
+            const double r = 1.0 - (double)k / (double)d;   // ocean.py:477 in python-float arithmetic
+            rd[k] = r;
+            rf[k] = (float)r;                               // emulation.py:221
+        }
+    }
+};
+
+struct Target1 {
+    int tx, ty;
+    uint16_t cell;
+    __device__ __forceinline__ void set(uint16_t c, int g) {
+        cell = c;
+        tx = c / g;
+        ty = c - tx * g;
+    }
+};
+
+template <typename GridPtr>
+__device__ __forceinline__ void squared_reset_nt1(const SquaredView &v, SquaredEnv &s, GridPtr grid, Target1 &tg, uint16_t new_cell,
+                                                  float &reward, bool &terminal) {
+    const int g = v.g, d = v.d;
+    grid[s.x * g + s.y] = 0.0f;       // the only cells a finished episode leaves non-zero: the agent and the target marker
+    grid[tg.cell] = 0.0f;
+    grid[d * g + d] = -1.0f;
+    s.x = d;
+    s.y = d;
+    s.tick = 0;
+    tg.set(new_cell, g);
+    grid[new_cell] = 1.0f;
+    s.rem = 1u;
+    s.done = false;
+    s.ep_ret = 0.0;
+    s.ep_len = 0;
+    reward = 0.0f;
+    terminal = false;
+}
+
+template <typename GridPtr>
+__device__ __forceinline__ void squared_step_nt1(const SquaredView &v, SquaredEnv &s, GridPtr grid, const Target1 &tg,
+                                                 const RewardTable &rt, int action, float &reward, bool &terminal) {
+    const int g = v.g, d = v.d;
+    int x = s.x, y = s.y;
+    grid[x * g + y] = 0.0f;
+    int dx, dy;
+    squared_move(action & 7, dx, dy);
+    x += dx;
+    y += dy;
+    const int ddx = x > tg.tx ? x - tg.tx : tg.tx - x, ddy = y > tg.ty ? y - tg.ty : tg.ty - y;
+    const int min_dist = s.rem ? (ddx > ddy ? ddx : ddy) : (1 << 30);
+    double r;
+    float rf;
+    if (min_dist < kMaxRewardDist) {
+        r = rt.rd[min_dist];
+        rf = rt.rf[min_dist];
+    } else {
+        r = 1.0 - (double)min_dist / (double)d;
+        rf = (float)r;
+    }
+    if (min_dist == 0) s.rem = 0u;                          // targets.remove; marker stays drawn (:495-498)
+    const int ox = x > d ? x - d : d - x, oy = y > d ? y - d : d - y;
+    if ((ox > oy ? ox : oy) >= d) { x = d; y = d; }         // teleport home on the perimeter (:500-504)
+    s.x = x;
+    s.y = y;
+    grid[x * g + y] = -1.0f;
+    s.tick += 1;
+    const bool done = s.tick >= d;                          // max_ticks = num_targets * d
+    s.ep_ret += r;
+    s.ep_len += 1;
+    if (done) {
+        s.acc_cnt += 1;
+        s.acc_ret += s.ep_ret;
+        s.acc_len += s.ep_len;
+        s.acc_score += s.rem ? 0.0 : 1.0;                   // (1 - len(targets)) / 1
+    }
+    reward = rf;
+    terminal = done;
+    s.done = done;
+}
+
 }  // namespace pfa

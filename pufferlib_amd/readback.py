@@ -1,0 +1,134 @@
+"""Device -> host readbacks of the trainer's two per-iteration reports, immediate (default) or deferred.
+
+The reference's ``evaluate`` ends by averaging the episode infos it collected and ``train`` ends by turning the loss
+tensors into python floats (clean_pufferl.py:127-152, 249-270).  On the device path both are one small f64 vector copied
+into a pinned host buffer behind the kernels that produce it.  By default the host waits for that copy at once, exactly
+where the reference has its numbers (two stream syncs per iteration).
+
+``PFA_LAZY_READBACK=1`` defers the wait: the caller gets a *lazy* container back and the first access to the numbers
+(``data.stats['score']``, ``data.losses.policy_loss``, ``dict(infos)``, printing, pickling, the dashboard) waits for the
+copy's event and fills the container in; a readback is also resolved before its buffer is reused one iteration later, so
+the host never runs more than one iteration ahead of the device and an error carried by the numbers (the reset-tape
+underrun flag) surfaces at most one ``evaluate()`` late.  It removes the two host round trips per iteration from the
+device's timeline — and measured no gain on MI355X for the headline workload (round 2: 351 M env steps/s deferred against
+356 M immediate): the iteration is matrix-pipe- and power-bound, and every kernel runs ~2 % slower when the queue never
+drains, which is what the ~0.05 ms of host bubbles per 1.5 ms iteration buys back.  It stays as an option for hosts with
+a slow Python side; the GPU test suite passes in both modes.
+"""
+import os
+
+from .namespace import Namespace
+
+
+def eager():
+    return os.environ.get('PFA_LAZY_READBACK', '0') in ('', '0')
+
+
+class Pending:
+    """One in-flight readback: ``submit`` enqueues the copy of ``src`` (device tensor) into this object's pinned buffer on
+    the current stream and records the event; ``resolve`` waits for it once and hands the host array to ``finish``."""
+
+    def __init__(self):
+        self.host = None
+        self.event = None
+        self.finish = None
+
+    def submit(self, src, finish):
+        import torch
+        self.resolve()                      # the buffer is about to be reused
+        if self.host is None or self.host.shape != src.shape or self.host.dtype != src.dtype:
+            self.host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+            self.event = torch.cuda.Event()
+        self.host.copy_(src, non_blocking=True)
+        self.event.record(torch.cuda.current_stream(src.device))
+        self.finish = finish
+        if eager():
+            self.resolve()
+        return self
+
+    @property
+    def outstanding(self):
+        return self.finish is not None
+
+    def resolve(self):
+        finish = self.finish
+        if finish is None:
+            return
+        self.finish = None
+        self.event.synchronize()
+        finish(self.host.numpy().copy())
+
+
+class LazyDict(dict):
+    """A dict whose contents arrive with a ``Pending`` readback: every read or write first resolves it.  Behaves as a plain
+    dict afterwards (and compares, prints, copies and pickles as one)."""
+    __slots__ = ('_pending',)
+
+    def __init__(self, pending=None):
+        dict.__init__(self)
+        self._pending = pending
+
+    def _force(self):
+        p = self._pending
+        if p is not None:
+            self._pending = None
+            p.resolve()
+
+    def fill(self, values):
+        """Called by the readback's continuation (no forcing: this IS the resolution)."""
+        self._pending = None
+        dict.update(self, values)
+
+    def __reduce__(self):
+        self._force()
+        return (dict, (dict(dict.items(self)),))
+
+
+def _forcing(name):
+    base = getattr(dict, name)
+
+    def method(self, *args, **kwargs):
+        self._force()
+        for other in args:                  # d1 == d2, d1 | d2, d1.update(d2): dict's C code reads the operand's storage directly
+            if isinstance(other, LazyDict):
+                other._force()
+        return base(self, *args, **kwargs)
+    method.__name__ = name
+    method.__doc__ = base.__doc__
+    return method
+
+
+for _name in ('__getitem__', '__setitem__', '__delitem__', '__iter__', '__len__', '__contains__', '__repr__', '__eq__', '__ne__',
+              '__or__', '__ror__', '__ior__', '__reversed__', 'keys', 'values', 'items', 'get', 'copy', 'update', 'pop', 'popitem',
+              'setdefault', 'clear'):
+    setattr(LazyDict, _name, _forcing(_name))
+del _name
+
+
+class LazyLosses(Namespace):
+    """``data.losses`` (clean_pufferl.py:369-378: a namespace of python floats) whose fields arrive with a ``Pending``
+    readback.  Attribute, item and iteration access resolve it first."""
+    __slots__ = ('_pending',)
+
+    def __init__(self, **fields):
+        object.__setattr__(self, '_pending', None)
+        Namespace.__init__(self, **fields)
+
+    def attach(self, pending):
+        object.__setattr__(self, '_pending', pending)
+
+    def fill(self, **values):
+        object.__setattr__(self, '_pending', None)
+        object.__getattribute__(self, '__dict__').update(values)
+
+    def __getattribute__(self, name):
+        if name == '__dict__' or not name.startswith('_'):
+            if name not in ('attach', 'fill'):
+                p = object.__getattribute__(self, '_pending')
+                if p is not None:
+                    object.__setattr__(self, '_pending', None)
+                    p.resolve()
+        return object.__getattribute__(self, name)
+
+    def __repr__(self):
+        return 'namespace(' + ', '.join(f'{k}={v!r}' for k, v in self.__dict__.items()) + ')'

@@ -382,3 +382,36 @@ def test_gpu_utilisation_counter_for_the_dashboard():
     time.sleep(0.1)
     u.stop()
     assert len(u.gpu_util) >= 1 and len(u.gpu_mem) == len(u.gpu_util) and 0 < u.gpu_mem[-1] <= 1
+
+
+def test_deferred_readback_mode_gives_the_same_numbers(monkeypatch):
+    """PFA_LAZY_READBACK=1 (readback.py): stats and losses arrive through lazy containers one event later; three
+    evaluate()+train() iterations give bit-identical statistics, losses and weights to the immediate mode, nothing is waited
+    for until the numbers are read, and the readbacks of an iteration are resolved by the end of the next."""
+    from pufferlib_amd import clean_pufferl, readback
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    n, horizon = 256, 32
+    runs = []
+    for lazy in (False, True):
+        monkeypatch.setenv('PFA_LAZY_READBACK', '1' if lazy else '0')
+        torch.manual_seed(3)
+        vec, pol = _make(n)
+        data = clean_pufferl.create(_config(n, horizon, n * horizon // 4, 16, 2, n * horizon * 8, hp, seed=5), vec, pol)
+        out = []
+        for it in range(3):
+            stats, infos = clean_pufferl.evaluate(data)
+            if lazy:
+                assert isinstance(stats, readback.LazyDict) and data._rb_eval.outstanding      # nothing waited for yet
+            clean_pufferl.train(data)
+            if lazy:
+                assert data._rb_train.outstanding
+                if it:
+                    assert not prev_stats._pending and len(prev_stats) == 3                       # resolved by this evaluate()
+                prev_stats = stats
+            out.append((stats, infos, data.losses))
+        final = [(dict(s), dict(i), dict(l)) for s, i, l in out]
+        assert not data._rb_eval.outstanding and not data._rb_train.outstanding
+        runs.append((final, data.flat_params.flat.clone()))
+    assert repr(runs[0][0]) == repr(runs[1][0])          # (repr: an explained_variance of nan still compares equal)
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert set(runs[0][0][-1][0]) == {'episode_return', 'episode_length', 'score'} and runs[0][0][-1][2]['value_loss'] > 0

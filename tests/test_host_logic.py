@@ -211,3 +211,78 @@ def test_conv_params_flat_buffer_layout_and_aliasing():
     assert models.find_cnn(torch.nn.Sequential(net)) is net and models.find_cnn(torch.nn.Linear(2, 2)) is None
     with pytest.raises(NotImplementedError):
         models.Convolutional(spec, framestack=4, hidden_size=256)
+
+
+class _FakePending:
+    """Stands in for readback.Pending on a box without a GPU: counts resolutions, runs the continuation once."""
+
+    def __init__(self, fn):
+        self.fn, self.n = fn, 0
+
+    def resolve(self):
+        if self.fn is not None:
+            fn, self.fn = self.fn, None
+            self.n += 1
+            fn()
+
+
+def test_deferred_readback_containers_resolve_on_first_use():
+    """readback.LazyDict / LazyLosses: nothing is waited for until the numbers are read; every way of reading them (item,
+    attribute, iteration, unpacking, pickling, printing, truthiness) resolves exactly once and then behaves like the plain
+    dict / namespace the reference returns (clean_pufferl.py:127-152, 369-378)."""
+    import pickle
+    from pufferlib_amd import readback as rb
+
+    def lazy_dict(values):
+        d = rb.LazyDict()
+        p = _FakePending(lambda: d.fill(values))
+        d._pending = p
+        return d, p
+
+    d, p = lazy_dict({'a': 1.0, 'b': 2.0})
+    assert p.n == 0
+    assert d['a'] == 1.0 and p.n == 1 and len(d) == 2 and dict(d) == {'a': 1.0, 'b': 2.0} and p.n == 1
+    d, p = lazy_dict({'x': 3})
+    assert {**d} == {'x': 3} and p.n == 1
+    d, p = lazy_dict({'x': 3})
+    assert pickle.loads(pickle.dumps(d)) == {'x': 3} and type(pickle.loads(pickle.dumps(d))) is dict
+    d, p = lazy_dict({})
+    assert not d and p.n == 1
+    d, p = lazy_dict({'k': 1})
+    assert [k for k in d] == ['k'] and 'k' in d and d.get('z', 7) == 7 and list(d.items()) == [('k', 1)] and p.n == 1
+    d, p = lazy_dict({'k': 1})
+    assert repr(d) == "{'k': 1}" and d == {'k': 1}
+    d, p = lazy_dict({'k': 1})
+    d2, p2 = lazy_dict({'k': 1})
+    assert d == d2 and p.n == 1 and p2.n == 1    # both operands resolve (dict.__eq__ reads the other's storage directly)
+    d, p = lazy_dict({'k': 1})
+    d['j'] = 2                                   # a write resolves first, so the readback cannot overwrite it later
+    assert dict(d) == {'k': 1, 'j': 2}
+
+    def lazy_losses(**values):
+        ns = rb.LazyLosses(**{k: 0 for k in values})
+        p = _FakePending(lambda: ns.fill(**values))
+        ns.attach(p)
+        return ns, p
+
+    ns, p = lazy_losses(policy_loss=1.5, value_loss=2.5)
+    assert p.n == 0
+    assert ns.policy_loss == 1.5 and p.n == 1 and ns['value_loss'] == 2.5 and dict(ns) == {'policy_loss': 1.5, 'value_loss': 2.5}
+    ns, p = lazy_losses(policy_loss=9.0)
+    assert list(ns.items()) == [('policy_loss', 9.0)] and p.n == 1
+    ns, p = lazy_losses(policy_loss=9.0)
+    assert 'policy_loss=9.0' in repr(ns)
+    ns.policy_loss = 4
+    assert ns.policy_loss == 4 and len(ns) == 1
+
+
+def test_deferred_readback_error_surfaces_at_resolution():
+    """The tape-underrun check travels with the readback: it raises where the statistics are first read."""
+    from pufferlib_amd import readback as rb
+    d = rb.LazyDict()
+
+    def boom():
+        raise RuntimeError('reset-target tape underrun')
+    d._pending = _FakePending(boom)
+    with pytest.raises(RuntimeError, match='underrun'):
+        d.get('score')
