@@ -431,3 +431,35 @@ def test_vectorised_philox_equals_the_c_restatement():
                 u = ((w >> 8).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -24)
                 n = min(4, cols - 4 * j)
                 assert np.array_equal(got[e, 4 * j:4 * j + n], (-np.log(u))[:n]), (seed, step, e, j)
+
+
+@pytest.mark.parametrize('seed,pre,need,n_pop', [(1, 0, 1000, 24), (2, 7, 5000, 24), (3, 623, 4096 * 33, 24), (4, 100, 3000, 16),
+                                                  (5, 0, 777, 40), (6, 5, 624 * 3, 8), (7, 311, 1, 24)])
+def test_parallel_form_of_the_squared_tape_equals_cpython_random(seed, pre, need, n_pop):
+    """oracle/squared_tape.py (the algorithm of csrc/squared.hip's single-target tape kernels: sliding 227-word MT19937 window,
+    parallel accept / prefix / select, generator state handed back) against CPython itself: the draws of
+    random.sample(range(n_pop), 1) in order, and random.getstate() afterwards — block AND index, incl. the convention that an
+    index of 624 stays on the old block.  Sizes: the headline fill (4096 envs x 33 rounds), power-of-two and non-power-of-two
+    populations (acceptance 1/2 .. 3/4 .. 5/8), a start on the last word of a block, a single draw."""
+    from oracle import squared_tape
+    random.seed(seed)
+    for _ in range(pre):
+        random.getrandbits(32)
+    st = random.getstate()[1]
+    want = [random.sample(range(n_pop), 1)[0] for _ in range(need)]
+    after = random.getstate()[1]
+    draws, block, idx, consumed = squared_tape.fill(st[:624], st[624], need, n_pop)
+    assert draws.tolist() == want
+    assert idx == after[624] and block.tolist() == list(after[:624])
+    assert consumed >= need
+
+
+def test_squared_tape_raw_words_are_successive_mt19937_blocks():
+    from oracle import squared_tape
+    random.seed(11)
+    st = random.getstate()[1]
+    raw = squared_tape.raw_words(np.array(st[:624], dtype=np.uint32), 120)      # crosses the linear window's wrap several times
+    for j in range(1, 121):
+        for _ in range(624):
+            random.getrandbits(32)
+        assert raw[624 * j:624 * (j + 1)].tolist() == list(random.getstate()[1][:624]), j
