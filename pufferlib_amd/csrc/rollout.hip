@@ -32,7 +32,7 @@ __device__ int g_rtrace_t0 = 0, g_rtrace_steps = 0;
 // ---------------------------------------------------------------------------------------------
 // standalone forward + sample over `rows` observation rows
 // ---------------------------------------------------------------------------------------------
-template <int DP>
+template <int DP, int KS>
 __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const float *obs, long long rows, const float *params,
                                                                          int a, uint32_t heads, const float *noise,
                                                                          uint64_t seed, uint64_t step, long long row_offset,
@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
                                                                          float *value) {
     __shared__ float xs[XTile<DP>::kFloats];
     __shared__ float part[kRollWaves][kOut * 16];
-    SliceFrags<DP> w;
+    SliceFrags<DP, KS> w;
     w.load(params, a);
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
     const long long tiles = (rows + 15) / 16;
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
         __syncthreads();
         stage_rows<DP>(obs, tile * 16, rows, xs);
         __syncthreads();
-        forward_slice<DP>(w, xs, part);
+        forward_slice<DP, KS>(w, xs, part);
         __syncthreads();
         const long long row = tile * 16 + le;
         const bool ok = row < rows;
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
 //   * the two per-step barriers order LDS only (`lds_barrier`, common.hpp): a `__syncthreads()` also waits for the acknowledgement of
 //     the experience stores just issued, which nothing in this kernel reads back.
 // ---------------------------------------------------------------------------------------------
-template <int DP, int EPW, bool NT1>
+template <int DP, int EPW, bool NT1, int KS>
 __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(SquaredView v, const float *params, int a,
                                                                           pfa_experience ex, const float *noise,
                                                                           uint64_t seed, uint64_t step0, long long env_offset,
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
     const bool owner = lo == 0 && env_ok;  // the thread that carries env `e`
     const int T = ex.horizon_T;
 
-    SliceFrags<DP> w;
+    SliceFrags<DP, KS> w;
     w.load(params, a);
 
     // recv(): the live buffers are the current observation / reward / terminal of every env
@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
         // Experience.store of the observation rows (clean_pufferl.py:443), env-major: row (e, t) at e*T + t
         unstage_rows<DP>(xs, ex.obs + (size_t)t * DP, (long long)blockIdx.x * EPW, v.n, (size_t)T * DP, EPW);
         PFA_RSTAMP(t, 1);
-        forward_slice<DP>(w, xs, part);
+        forward_slice<DP, KS>(w, xs, part);
         PFA_RSTAMP(t, 2);
         lds_barrier();
         PFA_RSTAMP(t, 3);
@@ -262,13 +262,16 @@ static int check_dims(const pfa_mlp_dims *d) {
     return 0;
 }
 
-#define PFA_DISPATCH_DP(dp, CALL)                 \
-    switch (dp) {                                 \
-        case 16: { constexpr int DP = 16; CALL; } break;   \
-        case 32: { constexpr int DP = 32; CALL; } break;   \
-        case 64: { constexpr int DP = 64; CALL; } break;   \
-        case 96: { constexpr int DP = 96; CALL; } break;   \
-        default: { constexpr int DP = 128; CALL; } break;  \
+// DP = observation row stride, KS = forward k-steps: the 7x7 grid's 49 columns need 13 of the 64-float row's 16 (rollout_tile.hpp)
+#define PFA_DISPATCH_DP(dims_, CALL)                                                                     \
+    if ((dims_)->obs_stride == 64 && (dims_)->obs_dim > 48 && (dims_)->obs_dim <= 52) {                  \
+        constexpr int DP = 64, KS = 13; CALL;                                                            \
+    } else switch ((dims_)->obs_stride) {                                                                \
+        case 16: { constexpr int DP = 16, KS = 4; CALL; } break;                                          \
+        case 32: { constexpr int DP = 32, KS = 8; CALL; } break;                                          \
+        case 64: { constexpr int DP = 64, KS = 16; CALL; } break;                                         \
+        case 96: { constexpr int DP = 96, KS = 24; CALL; } break;                                         \
+        default: { constexpr int DP = 128, KS = 32; CALL; } break;                                        \
     }
 
 }  // namespace pfa
@@ -300,8 +303,8 @@ extern "C" int pfa_mlp_forward_sample(const float *obs, int64_t rows, const floa
     const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
     const int64_t tiles = (rows + 15) / 16;
     const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
-    PFA_DISPATCH_DP(dims->obs_stride,
-                    hipLaunchKernelGGL(mlp_forward_sample_kernel<DP>, dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, obs,
+    PFA_DISPATCH_DP(dims,
+                    hipLaunchKernelGGL((mlp_forward_sample_kernel<DP, KS>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, obs,
                                        (long long)rows, params, dims->num_actions, dims->heads, noise, seed, step, (long long)row_offset,
                                        (long long *)actions, logprob, entropy, value));
     PFA_LAUNCH_CHECK();
@@ -345,13 +348,13 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     // noise both measured no better in round 2: tools/probe_rollout.py); the single-target env form when it applies.
     const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
     if (cfg->num_targets == 1) {
-        PFA_DISPATCH_DP(dims->obs_stride,
-                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, true>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
+        PFA_DISPATCH_DP(dims,
+                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, true, KS>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
                                            v, params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
                                            terminals, truncations, masks));
     } else {
-        PFA_DISPATCH_DP(dims->obs_stride,
-                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, false>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
+        PFA_DISPATCH_DP(dims,
+                        hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, false, KS>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
                                            v, params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
                                            terminals, truncations, masks));
     }

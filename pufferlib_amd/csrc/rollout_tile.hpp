@@ -21,9 +21,13 @@ constexpr int kRollThreads = 256;
 constexpr int kRollWaves = 4;
 constexpr int kMW = kMT / kRollWaves;  // hidden tiles per wave
 
-template <int DP>
+// KS = k-steps (4 observation columns each) the forward issues.  Default: the whole padded row.  A launch whose true feature
+// count fits fewer steps passes the smaller number: the dropped products are pad weight x pad observation = +0 added to the
+// accumulator (like the gradient kernel's KKU, ppo_update.hip), and every rollout-mode kernel of a policy takes the same KS,
+// so the protocol path and the fused path stay bit-identical.
+template <int DP, int KS = DP / 4>
 struct SliceFrags {
-    float w1f[kMW][DP / 4], b1f[kMW][4], w2f[kMW][4], bo[4];
+    float w1f[kMW][KS], b1f[kMW][4], w2f[kMW][4], bo[4];
     __device__ __forceinline__ void load(const float *params, int a) {
         const MlpOffsets off = mlp_offsets(DP, a);
         const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
@@ -31,7 +35,7 @@ struct SliceFrags {
         for (int i = 0; i < kMW; ++i) {
             const int m = kMW * wv + i;
 #pragma unroll
-            for (int kk = 0; kk < DP / 4; ++kk) w1f[i][kk] = params[off.w1 + (16 * m + c) * DP + 4 * kk + g];
+            for (int kk = 0; kk < KS; ++kk) w1f[i][kk] = params[off.w1 + (16 * m + c) * DP + 4 * kk + g];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 b1f[i][r] = params[off.b1 + 16 * m + 4 * g + r];
@@ -74,15 +78,15 @@ __device__ __forceinline__ void unstage_rows(const float *xs, float *dst, long l
 }
 
 // This wave's slice of models.Default.forward (models.py:41-62) for the 16 rows in xs -> part[wave][o*16 + row].
-template <int DP>
-__device__ __forceinline__ void forward_slice(const SliceFrags<DP> &w, const float *xs, float (*part)[kOut * 16]) {
+template <int DP, int KS = DP / 4>
+__device__ __forceinline__ void forward_slice(const SliceFrags<DP, KS> &w, const float *xs, float (*part)[kOut * 16]) {
     constexpr int XS = XTile<DP>::XS;
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
     f32x4 h[kMW];
 #pragma unroll
     for (int i = 0; i < kMW; ++i) h[i] = f32x4{w.b1f[i][0], w.b1f[i][1], w.b1f[i][2], w.b1f[i][3]};
 #pragma unroll
-    for (int kk = 0; kk < DP / 4; ++kk) {
+    for (int kk = 0; kk < KS; ++kk) {
         const float b = xs[c * XS + 4 * kk + g];
 #pragma unroll
         for (int i = 0; i < kMW; ++i) h[i] = mfma16(w.w1f[i][kk], b, h[i]);
