@@ -463,39 +463,49 @@ __global__ void __launch_bounds__(256) squared_send_kernel(SquaredView v, const 
 // deterministic fixed-order reduction of the per-env episode accumulators
 __global__ void __launch_bounds__(256) squared_stats_kernel(SquaredView v, double *out4, int reset) {
     __shared__ double sh[4][256];
-    // thread t sums envs t, t+256, ... in that order (the order is part of the result: f64 sums of python floats).  Eight envs'
-    // loads are issued together before their stores: one memory round trip per eight envs instead of one per env (the resets
-    // may alias the loads as far as the compiler knows, which serialised the loop: 8.4 us at 4096 envs).
+    // thread t sums envs t, t+256, ... in that order (the order is part of the result: f64 sums of python floats).  Whole batches of
+    // eight envs issue their loads together before their stores — one memory round trip per eight envs instead of one per env (the
+    // resets may alias the loads as far as the compiler knows, which serialises the plain loop); the tail runs the plain loop.
     double a[4] = {0, 0, 0, 0};
     constexpr int kBatch = 8;
-    for (int e0 = threadIdx.x; e0 < v.n; e0 += 256 * kBatch) {
+    int e0 = threadIdx.x;
+    for (; e0 + 256 * (kBatch - 1) < v.n; e0 += 256 * kBatch) {
         int cnt[kBatch];
         long long len[kBatch];
         double ret[kBatch], score[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
             const int e = e0 + 256 * k;
-            const bool on = e < v.n;
-            cnt[k] = on ? v.acc_cnt[e] : 0;
-            ret[k] = on ? v.acc_ret[e] : 0.0;
-            len[k] = on ? v.acc_len[e] : 0;
-            score[k] = on ? v.acc_score[e] : 0.0;
+            cnt[k] = v.acc_cnt[e];
+            ret[k] = v.acc_ret[e];
+            len[k] = v.acc_len[e];
+            score[k] = v.acc_score[e];
         }
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
             const int e = e0 + 256 * k;
-            if (e < v.n) {
-                a[0] += (double)cnt[k];
-                a[1] += ret[k];
-                a[2] += (double)len[k];
-                a[3] += score[k];
-                if (reset) {
-                    v.acc_cnt[e] = 0;
-                    v.acc_ret[e] = 0.0;
-                    v.acc_len[e] = 0;
-                    v.acc_score[e] = 0.0;
-                }
+            a[0] += (double)cnt[k];
+            a[1] += ret[k];
+            a[2] += (double)len[k];
+            a[3] += score[k];
+            if (reset) {
+                v.acc_cnt[e] = 0;
+                v.acc_ret[e] = 0.0;
+                v.acc_len[e] = 0;
+                v.acc_score[e] = 0.0;
             }
+        }
+    }
+    for (int e = e0; e < v.n; e += 256) {
+        a[0] += (double)v.acc_cnt[e];
+        a[1] += v.acc_ret[e];
+        a[2] += (double)v.acc_len[e];
+        a[3] += v.acc_score[e];
+        if (reset) {
+            v.acc_cnt[e] = 0;
+            v.acc_ret[e] = 0.0;
+            v.acc_len[e] = 0;
+            v.acc_score[e] = 0.0;
         }
     }
     for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] = a[q];
