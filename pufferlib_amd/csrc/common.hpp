@@ -52,9 +52,10 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-// Workgroup barrier that orders LDS traffic only.  `__syncthreads()` is a workgroup-scope fence over every address space: on
-// gfx9 it also waits (vmcnt(0)) for the acknowledgement of the global stores issued so far, which a kernel that never reads
-// them back does not need.
+// Workgroup barrier that orders LDS traffic only: `s_waitcnt lgkmcnt(0); s_barrier`, never a wait on the vector-memory counter.
+// (hipcc 7.2 compiles `__syncthreads()` to the same two instructions on gfx950 in the default non-tgsplit mode — checked in the
+// ISA — so this states the intent rather than working around the compiler: the kernels that use it keep experience stores in
+// flight across their barriers and must not start waiting for them if a fence over every address space ever gets stricter.)
 __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();

@@ -82,8 +82,11 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
 //   * NT1 (one target, every ocean default): the next reset's target is fetched from the tape right after the previous
 //     reset (a dependent HBM round trip every episode otherwise), the tape's fill level is read once at launch, and the env
 //     step is the single-target form of squared_env.hpp (reward table, no integer or f64 division, two-cell grid clear);
-//   * the two per-step barriers order LDS only (`lds_barrier`, common.hpp): a `__syncthreads()` also waits for the acknowledgement of
-//     the experience stores just issued, which nothing in this kernel reads back.
+//   * no full drain of the vector-memory counter inside the loop: the weight fragments loaded before the loop used to be "in
+//     flight" at the loop header as far as the compiler could tell, so the first wait of every step was a `vmcnt(0)` — which
+//     also waits for the acknowledgement of the observation-row stores issued a few instructions earlier and of the previous
+//     step's scalar stores.  One explicit drain before the loop removes it; the two per-step barriers order LDS only
+//     (`lds_barrier`, common.hpp).
 // ---------------------------------------------------------------------------------------------
 template <int DP, int EPW, bool NT1, int KS>
 __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(SquaredView v, const float *params, int a,
