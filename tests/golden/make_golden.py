@@ -19,6 +19,8 @@ Fixtures written (all small, committed):
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
+  ppo_mp.npz         same as ppo_mlp over the reference's own pufferlib.vector.Multiprocessing backend (vector.py:218-447) in
+                     EnvPool mode (8 of 16 envs per recv): every recv() batch, the noise, the actions sent back, the sorted experience
   ppo_cnn.npz        same with models.Convolutional (models.py:113-157, NatureCNN) on a stub env with uint8 (4, 84, 84) frames;
                      frames are re-derivable from recorded frame numbers, big tensors recorded as digests (sum, |sum|, 64 samples)
   ppo_spaces.npz     same as ppo_mlp on ocean make_spaces: Dict observation emulated to 108-byte rows, Dict action emulated to
@@ -418,6 +420,135 @@ def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2, env='squared'):
     print(f'ppo_{tag}.npz', len(out), 'arrays; losses it0', out['it0.losses'])
 
 
+def gen_ppo_mp(num_envs=16, num_workers=4, batch_envs=8, horizon=32, iters=2, attempts=20):
+    """clean_pufferl.create/evaluate/train over the reference's OWN pufferlib.vector.Multiprocessing backend (vector.py:218-447:
+    worker processes, shared-memory buffers, `batch_envs` of the `num_envs` envs per recv = EnvPool mode) on ocean squared.
+    Recorded per recv(): what the backend handed out (observations, rewards, terminals, env ids, masks, infos), the multinomial
+    noise and the actions sent back; per iteration: the experience in the order sort_training_data leaves it, advantages, losses,
+    weights.  Which workers answer a recv() depends on timing; the run is repeated until every env contributes exactly `horizon`
+    rows to every batch (the schedule the device trainer's env-major experience assumes, hostpath.py) — the CONTENT does not
+    depend on timing (each env's trajectory follows from its own recorded actions)."""
+    import json
+    import pufferlib
+    import pufferlib.vector
+    import pufferlib.models
+    import pufferlib.frameworks.cleanrl
+    import pufferlib.environments.ocean as ocean
+    import clean_pufferl
+
+    class _NoUtil:
+        def __init__(self, *a, **k):
+            self.cpu_util = self.cpu_mem = self.gpu_util = self.gpu_mem = [0]
+
+        def stop(self):
+            pass
+
+    clean_pufferl.Utilization = _NoUtil
+    clean_pufferl.print_dashboard = lambda *a, **k: None
+    clean_pufferl.save_checkpoint = lambda data: None
+    batch = num_envs * horizon
+    for attempt in range(attempts):
+        config = pufferlib.namespace(
+            env='squared', seed=1, torch_deterministic=True, cpu_offload=False, device='cpu',
+            total_timesteps=batch * 8, learning_rate=2.5e-4, anneal_lr=True, gamma=0.99, gae_lambda=0.95,
+            update_epochs=2, norm_adv=True, clip_coef=0.1, clip_vloss=True, vf_coef=0.5, vf_clip_coef=0.1,
+            max_grad_norm=0.5, ent_coef=0.01, target_kl=None, batch_size=batch, minibatch_size=batch // 4,
+            bptt_horizon=8, compile=False, compile_mode='reduce-overhead', checkpoint_interval=10 ** 9,
+            data_dir='/tmp/golden_experiments', exp_id='golden')
+        vec = pufferlib.vector.make(ocean.env_creator('squared'), num_envs=num_envs, num_workers=num_workers,
+                                    batch_size=batch_envs, backend=pufferlib.vector.Multiprocessing)
+        torch.manual_seed(1)
+        policy = pufferlib.frameworks.cleanrl.Policy(pufferlib.models.Default(vec.driver_env, hidden_size=128))
+        out = {}
+        for k, v in policy.state_dict().items():
+            out['w0.' + k] = v.detach().numpy().copy()
+        noise, recvs, sends = [], [], []
+        orig_multinomial, orig_recv, orig_send = torch.multinomial, vec.recv, vec.send
+
+        def recording_multinomial(p, n, *a, **kw):
+            st = torch.get_rng_state()
+            res = orig_multinomial(p, n, *a, **kw)
+            st2 = torch.get_rng_state()
+            torch.set_rng_state(st)
+            q = torch.empty_like(p).exponential_(1)
+            assert torch.equal((p / q).argmax(-1, keepdim=True), res), 'multinomial != argmax(p/q)'
+            torch.set_rng_state(st2)
+            noise.append(q.numpy().copy())
+            return res
+
+        def recording_recv():
+            o, r, d, t, info, env_id, mask = orig_recv()
+            recvs.append((np.array(o).copy(), np.array(r).copy(), np.array(d).copy(), np.array(t).copy(),
+                          [dict(pufferlib.utils.unroll_nested_dict(i)) for i in info], np.array(env_id).copy(), np.array(mask).copy()))
+            return o, r, d, t, info, env_id, mask
+
+        def recording_send(actions):
+            sends.append(np.array(actions).copy())
+            return orig_send(actions)
+
+        torch.multinomial, vec.recv, vec.send = recording_multinomial, recording_recv, recording_send
+        even = True
+        try:
+            data = clean_pufferl.create(config, vec, policy)
+            exp = data.experience
+            first = 0
+            for it in range(iters):
+                clean_pufferl.evaluate(data)
+                k1 = len(recvs)
+                ids = np.concatenate([r[5][r[6].astype(bool)] for r in recvs[first:k1]])[:batch]
+                even = even and np.array_equal(np.bincount(ids, minlength=num_envs), np.full(num_envs, horizon))
+                even = even and [int(r[5][0]) for r in recvs[:k1]] == [batch_envs * (j % (num_envs // batch_envs)) for j in range(k1)]   # canonical turn order: fixtures must regenerate bit for bit
+                out[f'it{it}.recvs'] = np.array([first, k1], np.int64)
+                first = k1
+                # the experience as sort_training_data orders it (train() sorts; same stable (env, step) order here)
+                order = np.asarray(sorted(range(len(exp.sort_keys)), key=exp.sort_keys.__getitem__))
+                out[f'it{it}.obs'] = exp.obs.numpy().reshape(batch, -1)[order].astype(np.int8)
+                out[f'it{it}.actions'] = exp.actions_np[order].astype(np.int8)
+                out[f'it{it}.logprobs'] = exp.logprobs_np[order].copy()
+                out[f'it{it}.rewards'] = exp.rewards_np[order].copy()
+                out[f'it{it}.dones'] = exp.dones_np[order].copy()
+                out[f'it{it}.values'] = exp.values_np[order].copy()
+                out[f'it{it}.global_step'] = np.array(data.global_step, np.int64)
+                out[f'it{it}.stats'] = np.array([data.stats.get('episode_return', np.nan), data.stats.get('episode_length', np.nan),
+                                                 data.stats.get('score', np.nan)], np.float64)
+                lr_used = data.optimizer.param_groups[0]['lr']
+                clean_pufferl.train(data)
+                out[f'it{it}.lr_used'] = np.array(lr_used, np.float64)
+                out[f'it{it}.advantages'] = exp.b_advantages.numpy().copy()
+                out[f'it{it}.returns'] = exp.b_returns.numpy().copy()
+                L = data.losses
+                out[f'it{it}.losses'] = np.array([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
+                                                 np.float64)      # (explained_variance depends on the arrival order: not recorded)
+                for k, v in policy.state_dict().items():
+                    out[f'it{it}.w.' + k] = v.detach().numpy().copy()
+        finally:
+            torch.multinomial = orig_multinomial
+            vec.close()
+        if not even:
+            print(f'ppo_mp attempt {attempt}: uneven arrival schedule, retrying')
+            continue
+        K = len(recvs)
+        assert len(noise) == K == len(sends)
+        out['recv.obs'] = np.stack([r[0].reshape(batch_envs, -1) for r in recvs]).astype(np.int8)
+        out['recv.rewards'] = np.stack([r[1] for r in recvs]).astype(np.float32)
+        out['recv.terminals'] = np.stack([r[2] for r in recvs]).astype(np.uint8)
+        out['recv.truncations'] = np.stack([r[3] for r in recvs]).astype(np.uint8)
+        out['recv.env_id'] = np.stack([r[5] for r in recvs]).astype(np.int32)
+        out['recv.mask'] = np.stack([r[6] for r in recvs]).astype(np.uint8)
+        out['recv.infos'] = np.array(json.dumps([r[4] for r in recvs]))
+        out['recv.noise'] = np.stack(noise).astype(np.float32)            # [recv][batch_envs][A]
+        out['send.actions'] = np.stack(sends).astype(np.int8)
+        out['config'] = np.array([num_envs, horizon, config.minibatch_size, config.bptt_horizon, config.update_epochs,
+                                  config.total_timesteps, iters, batch_envs, num_workers], np.int64)
+        out['hparams'] = np.array([config.learning_rate, config.gamma, config.gae_lambda, config.clip_coef, config.vf_coef,
+                                   config.vf_clip_coef, config.max_grad_norm, config.ent_coef], np.float64)
+        np.savez_compressed(os.path.join(HERE, 'ppo_mp.npz'), **out)
+        print('ppo_mp.npz', len(out), 'arrays;', K, 'recvs; env-id blocks of the first recvs:',
+              [int(r[5][0]) for r in recvs[:8]], '; losses it0', out['it0.losses'])
+        return
+    raise RuntimeError('ppo_mp: no even arrival schedule in %d attempts' % attempts)
+
+
 def cnn_frame(counter, base_seed=777):
     """Frame number `counter` of the stub Atari-shaped env: uint8 (4, 84, 84) from numpy's legacy generator seeded per frame
     (the GPU test regenerates the same frames from the recorded counters instead of storing 28 KB per observation)."""
@@ -581,6 +712,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'cnn':
         gen_ppo_cnn()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'mp':
+        gen_ppo_mp()
+        sys.exit(0)
     import clean_pufferl  # builds c_gae through pyximport exactly as the reference does (clean_pufferl.py:24-27)
     gen_gae(clean_pufferl.compute_gae)
     gen_squared('d3t1', 64, 3, 1, 1, 60)
@@ -597,4 +731,5 @@ if __name__ == '__main__':
     gen_ppo('mlp', use_rnn=False)
     gen_ppo('lstm', use_rnn=True)
     gen_ppo('spaces', use_rnn=False, env='spaces')
+    gen_ppo_mp()
     gen_ppo_cnn()

@@ -196,3 +196,88 @@ def test_uneven_async_pool_fast_workers_return_more_often():
             ref.send(acts[rows, t].astype(np.int64))
     clean_pufferl.train(data)
     assert torch.isfinite(data.flat_params.flat).all()
+
+
+class _ReplayPool:
+    """A host vecenv that hands out, recv by recv, exactly what the REFERENCE's pufferlib.vector.Multiprocessing backend handed
+    the reference trainer in tests/golden/ppo_mp.npz (EnvPool mode: 8 of 16 envs per recv, shared-memory worker processes), and
+    checks that every send() carries the actions the reference sent."""
+
+    def __init__(self, g):
+        import json
+        from pufferlib_amd import vector
+        self.g = g
+        n, _, _, _, _, _, _, per, _ = (int(x) for x in g['config'])
+        self.driver_env = vector.SquaredSpec(3, 1)
+        self.single_observation_space = self.driver_env.single_observation_space
+        self.single_action_space = self.driver_env.single_action_space
+        self.num_envs = self.num_agents = n
+        self.agents_per_batch = per
+        self.agent_ids = np.arange(n)
+        self.emulated = True
+        self.infos = json.loads(str(g['recv.infos']))
+        self.k = 0
+
+    def async_reset(self, seed=42):
+        pass
+
+    def recv(self):
+        g, k = self.g, self.k
+        assert k < len(g['recv.obs']), 'the trainer asked for more batches than the reference run consumed'
+        return (g['recv.obs'][k].astype(np.float32).reshape(-1, 7, 7), g['recv.rewards'][k], g['recv.terminals'][k].astype(bool),
+                g['recv.truncations'][k].astype(bool), self.infos[k], g['recv.env_id'][k].astype(np.int64), g['recv.mask'][k].astype(bool))
+
+    def send(self, actions):
+        assert np.array_equal(np.asarray(actions).reshape(-1), self.g['send.actions'][self.k].astype(np.int64)), self.k
+        self.k += 1
+
+    def close(self):
+        pass
+
+
+def test_host_path_replays_the_reference_run_over_its_multiprocessing_backend(golden_dir):
+    """create -> evaluate -> train on the batches the unmodified reference received from its own Multiprocessing backend
+    (tests/golden/ppo_mp.npz, generated by tests/golden/make_golden.py::gen_ppo_mp): same actions back to every recv (bit-exact,
+    under the recorded multinomial noise), the env-major experience equals what the reference's store + sort_training_data
+    left (exact for observations / rewards / dones / actions, 1e-5 for log-probabilities and values), and advantages, returns,
+    losses and weights after each update match to 1e-5.  (explained_variance is left out: the reference's formula pairs rows
+    by ARRIVAL position, which for a pool depends on worker timing.)"""
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from test_gpu_ppo import TOL, _config, _load_weights
+    g = np.load(os.path.join(golden_dir, 'ppo_mp.npz'))
+    n, horizon, mbs, bptt, epochs, total, iters, per, _ = (int(x) for x in g['config'])
+    vec = _ReplayPool(g)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    _load_weights(pol, g, 'w0.')
+    data = clean_pufferl.create(_config(n, horizon, mbs, bptt, epochs, total, [float(x) for x in g['hparams']]), vec, pol)
+    exp = data.experience
+    A = 8
+    for it in range(iters):
+        k0, k1 = (int(x) for x in g[f'it{it}.recvs'])
+        assert vec.k == k0
+        assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_used'])) < 1e-12
+        noise = torch.ones(k1 - k0, n, A)
+        for k in range(k0, k1):                                   # rows of recv k belong to the agents it reported
+            noise[k - k0, torch.as_tensor(g['recv.env_id'][k].astype(np.int64))] = torch.as_tensor(g['recv.noise'][k])
+        data.noise = noise
+        stats, _ = clean_pufferl.evaluate(data)
+        assert vec.k == k1 and data.host_rows_dropped == 0
+        assert np.array_equal(exp.actions.cpu().numpy(), g[f'it{it}.actions'].astype(np.int32))
+        assert np.array_equal(exp.obs.cpu().numpy()[:, :49], g[f'it{it}.obs'].astype(np.float32))
+        assert np.array_equal(exp.rewards.cpu().numpy(), g[f'it{it}.rewards'])
+        assert np.array_equal(exp.dones.cpu().numpy(), g[f'it{it}.dones'])
+        np.testing.assert_allclose(exp.logprobs.cpu().numpy(), g[f'it{it}.logprobs'], **TOL)
+        np.testing.assert_allclose(exp.values.cpu().numpy(), g[f'it{it}.values'], **TOL)
+        assert data.global_step == int(g[f'it{it}.global_step'])
+        np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']], g[f'it{it}.stats'], rtol=1e-9)
+        clean_pufferl.train(data)
+        for m in range(exp.num_minibatches):
+            idx = exp.minibatch_rows_index(m)
+            np.testing.assert_allclose(exp.advantages[idx].cpu().numpy(), g[f'it{it}.advantages'][m], **TOL)
+            np.testing.assert_allclose(exp.returns[idx].cpu().numpy(), g[f'it{it}.returns'][m], **TOL)
+        L = data.losses
+        got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=1e-5, atol=1e-5)
+        sd = pol.state_dict()
+        for k in sd:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'it{it}.w.{k}'], err_msg=k, **TOL)

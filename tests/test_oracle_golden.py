@@ -463,3 +463,39 @@ def test_squared_tape_raw_words_are_successive_mt19937_blocks():
         for _ in range(624):
             random.getrandbits(32)
         assert raw[624 * j:624 * (j + 1)].tolist() == list(random.getstate()[1][:624]), j
+
+
+def test_multiprocessing_backend_run_is_consistent_and_oracle_policy_reproduces_it(golden_dir):
+    """tests/golden/ppo_mp.npz — the unmodified reference trained over its OWN pufferlib.vector.Multiprocessing backend
+    (vector.py:218-447, EnvPool mode: 8 of 16 envs per recv) — pinned two ways: (1) the experience the reference sorted
+    (sort_training_data, clean_pufferl.py:452-464) is exactly its recv() batches re-ordered by (env id, arrival), which is the
+    env-major layout the device trainer writes directly; (2) the oracle's restatement of models.Default + sample_logits
+    reproduces every action the reference sent back (bit-exact) and its log-probabilities / values (1e-5) from the recorded
+    observations and multinomial noise."""
+    g = np.load(os.path.join(golden_dir, 'ppo_mp.npz'))
+    n, horizon, _, _, _, _, iters, per, workers = (int(x) for x in g['config'])
+    ids, mask = g['recv.env_id'], g['recv.mask'].astype(bool)
+    assert mask.all() and ids.shape[1] == per and n // per == 2
+    assert [int(r[0]) for r in ids] == [per * (k % 2) for k in range(len(ids))]          # the two worker blocks answer in turn
+    for it in range(iters):
+        k0, k1 = (int(x) for x in g[f'it{it}.recvs'])
+        env = ids[k0:k1].reshape(-1)
+        order = np.lexsort((np.arange(env.size), env))                                   # stable (env id, arrival) order
+        assert np.array_equal(np.bincount(env), np.full(n, horizon))
+        for key, src in (('obs', 'recv.obs'), ('rewards', 'recv.rewards'), ('dones', 'recv.terminals')):
+            flat = g[src][k0:k1].reshape(env.size, -1)
+            assert np.array_equal(flat[order].reshape(g[f'it{it}.{key}'].shape).astype(np.float32),
+                                  g[f'it{it}.{key}'].astype(np.float32)), key
+        assert np.array_equal(g['send.actions'][k0:k1].reshape(-1)[order], g[f'it{it}.actions'])
+        # the oracle policy with the weights this iteration started from
+        sd = {k[len('w0.'):] if it == 0 else k[len(f'it{it - 1}.w.'):]: g[k] for k in g.files
+              if k.startswith('w0.' if it == 0 else f'it{it - 1}.w.')}
+        pol = ppo_torch.Policy.from_reference_state_dict(sd)
+        with torch.no_grad():
+            for k in range(k0, k1):
+                logits, value, _ = pol.forward(torch.as_tensor(g['recv.obs'][k].astype(np.float32)))
+                action, logprob, _ = ppo_torch.sample_logits(logits, noise=torch.as_tensor(g['recv.noise'][k]))
+                assert np.array_equal(action.numpy(), g['send.actions'][k].astype(np.int64)), k
+                rows = np.nonzero(np.isin(order, np.arange((k - k0) * per, (k - k0 + 1) * per)))[0]   # where this recv's rows landed
+                np.testing.assert_allclose(logprob.numpy(), g[f'it{it}.logprobs'][rows][np.argsort(order[rows])], rtol=1e-5, atol=1e-5)
+                np.testing.assert_allclose(value.flatten().numpy(), g[f'it{it}.values'][rows][np.argsort(order[rows])], rtol=1e-5, atol=1e-5)
