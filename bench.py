@@ -116,9 +116,13 @@ def cpu_baseline(budget_s=24.0):
     return dict(value=iters * B / dt, unit='env_steps/s', cores=cores, cores_available=cores_avail, cpu_model=_cpu_model(), kind='port',
                 sample=f'{iters} evaluate+train iteration(s) of {n} envs x {HORIZON} steps (batch {B}, {NMB} minibatches x {EPOCHS} '
                        f'epochs: the bench configuration itself) after 1 warm-up; C env on 1 core, torch-fp32 on {cores} threads',
-                reference_measured=dict(value=47.8e3, unit='env_steps/s', config='the unmodified reference (clean_pufferl + '
-                                        'pufferlib.vector.Serial + c_gae), squared 4096 envs x 128, MLP, 1 iteration',
-                                        box='8-core Xeon @ 2.1 GHz, survey container (no GPU)', source='BASELINE.md section 2'))
+                reference_measured=dict(value=74.0e3, unit='env_steps/s', config='the unmodified reference (clean_pufferl + '
+                                        'pufferlib.vector.Serial + c_gae), squared 4096 envs x 128, MLP, 4 minibatches x 4 epochs, 3 iterations '
+                                        'after a warm-up', best_vectoriser=dict(value=112.5e3, backend='pufferlib.vector.Multiprocessing, 4 workers '
+                                        '+ 4 torch threads (the best split of the 8 cores)'),
+                                        box='8-core Xeon @ 2.1 GHz, build container (no GPU)',
+                                        source='profiles/r02_reference_cpu_timing.json (tools/time_reference.py); BASELINE.md section 2 has the '
+                                               'survey container\'s single-iteration figure, 47.8e3'))
 
 
 def cpu_baseline_c4(n=32, horizon=16):
