@@ -499,3 +499,33 @@ def test_multiprocessing_backend_run_is_consistent_and_oracle_policy_reproduces_
                 rows = np.nonzero(np.isin(order, np.arange((k - k0) * per, (k - k0 + 1) * per)))[0]   # where this recv's rows landed
                 np.testing.assert_allclose(logprob.numpy(), g[f'it{it}.logprobs'][rows][np.argsort(order[rows])], rtol=1e-5, atol=1e-5)
                 np.testing.assert_allclose(value.flatten().numpy(), g[f'it{it}.values'][rows][np.argsort(order[rows])], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('d', [1, 2, 3, 4, 5])
+def test_single_target_form_of_the_squared_step_equals_the_general_form(d):
+    """oracle/squared_nt1.py: the single-target env step of the fused rollout (csrc/squared_env.hpp squared_step_nt1 /
+    squared_reset_nt1: reward table, kept target coordinates, two-cell clear at a reset) against the general restatement of
+    ocean.py:448-513, 300 episodes of random actions per grid size: identical grids after every step and reset, rewards equal
+    as float32 bit patterns, same dones and scores."""
+    from oracle import squared_nt1
+    rs = np.random.RandomState(d)
+    g = 2 * d + 1
+    perimeter = [(x, y) for x in range(g) for y in range(g) if x in (0, g - 1) or y in (0, g - 1)]   # ocean.py:444-446
+    a, b = squared_nt1.General(d), squared_nt1.SingleTarget(d)
+    # the device env enters the rollout from async_reset's freshly drawn grid: same starting state for both forms
+    first = perimeter[rs.randint(len(perimeter))]
+    a.reset(first)
+    b.grid[:] = a.grid
+    b.pos, b.target, b.tick, b.rem = a.pos, first, 0, 1
+    for episode in range(300):
+        done = False
+        while not done:
+            act = int(rs.randint(8))
+            ra, done, sa = a.step(act)
+            rb, db, sb = b.step(act)
+            assert ra.tobytes() == np.float32(rb).tobytes() and done == db and sa == sb, (episode, act)
+            assert np.array_equal(a.grid, b.grid), (episode, act)
+        t = perimeter[rs.randint(len(perimeter))]
+        a.reset(t)
+        b.reset(t)
+        assert np.array_equal(a.grid, b.grid), episode
