@@ -222,6 +222,74 @@ def self_check(data, pol):
                 tolerance=1e-5, checker='oracle/ppo_torch.py + oracle/puffer_oracle.c')
 
 
+def _free_port():
+    import socket
+    so = socket.socket()
+    so.bind(('127.0.0.1', 0))
+    port = so.getsockname()[1]
+    so.close()
+    return port
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` as a plain command (no torchrun): re-run this file as N ranks, one per GPU, under
+    torch.distributed.run on 127.0.0.1 and hand its exit code back.  The torchrun form the contract names keeps working (it
+    arrives with WORLD_SIZE set and never gets here).  On a box with fewer GPUs than ranks the ranks share devices and the
+    process group is gloo (PFA_DIST_BACKEND=gloo): a functional run of the N-rank path, flagged `ranks_share_devices` in the
+    JSON line — not a scaling measurement."""
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit('bench.py: no GPU visible')
+    if ndev < args.gpus and 'PFA_DIST_BACKEND' not in env:
+        print(f'[bench] {args.gpus} ranks on {ndev} device(s): ranks share devices, process group gloo (not a scaling run)', file=sys.stderr)
+        env['PFA_DIST_BACKEND'] = 'gloo'
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def source_build_id():
+    from pufferlib_amd import _lib
+    return _lib.source_hash()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from profiles/pmc_summary.json — only when that file was generated (tools/make_pmc_summary.py,
+    same gpurun job as the rocprofv3 --pmc passes) from the kernel sources this library was built from; a summary of another
+    build is refused (traffic null, the reason in traffic_source) instead of silently going stale."""
+    pmc = os.path.join(REPO, 'profiles', 'pmc_summary.json')
+    if not os.path.exists(pmc):
+        return None, 'no profiles/pmc_summary.json'
+    try:
+        doc = json.load(open(pmc))
+    except Exception as e:
+        return None, f'unreadable pmc_summary.json: {e}'
+    have, want = doc.get('_build'), source_build_id()
+    entry = doc.get(kernel, {})
+    if have != want:
+        return None, f'refused: pmc_summary.json was collected on kernel-source build {have}, this library is build {want}'
+    if entry.get('carried_over'):
+        return None, f'refused: the {kernel} entry of pmc_summary.json was carried over from an earlier build'
+    return entry.get('hbm_bytes_per_launch'), f"{entry.get('source', 'profiles/pmc_summary.json')} [build {have}]"
+
+
+def extra_workload(flags, timeout_s=600):
+    """A short run of one of the side workloads (BASELINE configs[2] / configs[3]) as its own process; its JSON line, trimmed."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--no-cpu-baseline', '--no-breakdown', '--no-extra'] + flags
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+        line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][-1]
+        d = json.loads(line)
+        return {k: d[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline') if k in d}
+    except Exception as e:  # a side workload never takes the headline line down with it
+        return dict(flags=flags, error=f'{type(e).__name__}: {e}')
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -237,7 +305,12 @@ def main():
                          "not the headline metric; 'c4' = BASELINE configs[3] / SURVEY config C4: 8192 envs of uint8 (4,84,84) frames from the "
                          "device-side generator (Atari is a third-party emulator: env parity unpinned), NatureCNN policy; not the headline metric")
     ap.add_argument('--no-breakdown', action='store_true', help='skip the extra (untimed) per-kernel breakdown pass')
+    ap.add_argument('--no-extra', action='store_true', help="skip the short configs[2] / configs[3] side runs appended to the N = 1 headline line")
+    ap.add_argument('--sustained-seconds', type=float, default=3.0,
+                    help='after the K timed steps: an extra leg of at least this many seconds of the same loop, reported as sustained_value (0 = skip)')
     args = ap.parse_args()
+    if args.gpus > 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 and 'RANK' not in os.environ:
+        sys.exit(self_spawn(args))
 
     import torch
     import torch.distributed as dist
@@ -252,7 +325,11 @@ def main():
         # PFA_DIST_BACKEND=gloo lets the multi-rank path be exercised on a box with fewer GPUs than ranks (ranks then share
         # devices); the driver's runs use the default: nccl (= RCCL), one rank per GPU
         backend = os.environ.get('PFA_DIST_BACKEND', 'nccl')
-        dev_index = local_rank % torch.cuda.device_count()
+        ndev = torch.cuda.device_count()
+        if ndev < world and backend == 'nccl':
+            raise SystemExit(f'bench.py: {world} ranks but {ndev} GPU(s) visible; RCCL needs one device per rank '
+                             '(PFA_DIST_BACKEND=gloo runs the ranks on shared devices for a functional check)')
+        dev_index = local_rank % ndev
         torch.cuda.set_device(dev_index)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{dev_index}'))
@@ -317,10 +394,35 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     L.pfa_timing_enable(0)
+    rank_ms = [dt / K * 1e3]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        t = torch.zeros(world, dtype=torch.float64, device='cuda')
+        t[rank] = dt
+        dist.all_reduce(t)                       # every rank's own wall time of the timed region
+        rank_ms = [float(x) / K * 1e3 for x in t.cpu()]
+        dt = max(float(x) for x in t.cpu())      # the contract's MAX over ranks
+
+    # sustained leg (untimed by the contract, reported next to it): the same loop for >= --sustained-seconds, so that a
+    # sampler with a seconds-scale period (the driver's rocm-smi poll) sees the device busy; iteration count agreed on rank 0
+    sustained = None
+    if args.sustained_seconds > 0:
+        n_sus = max(int(args.sustained_seconds / max(dt / K, 1e-6)) + 1, K)
+        if world > 1:
+            tn = torch.tensor([n_sus], dtype=torch.int64, device='cuda')
+            dist.broadcast(tn, src=0)
+            n_sus = int(tn.item())
+        barrier()
+        ts = time.perf_counter()
+        for _ in range(n_sus):
+            clean_pufferl.evaluate(data)
+            clean_pufferl.train(data)
+        barrier()
+        dts = time.perf_counter() - ts
+        if world > 1:
+            tt = torch.tensor([dts], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dts = float(tt.item())
+        sustained = dict(steps=n_sus, seconds=dts, value=world * per_gpu * n_sus / dts, ms_per_step=dts / n_sus * 1e3)
 
     def kernel_ms(name):
         n, ms = C.c_int64(0), C.c_double(0.0)
@@ -367,13 +469,7 @@ def main():
             step_flop = per_gpu * (CNN_FWD_FLOP + EPOCHS * (CNN_FWD_FLOP + CNN_DX_FLOP))
             achieved = step_flop * K / (total_ms * 1e-3) / 1e12 if launches else 0.0
             flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
-        traffic = None
-        pmc = os.path.join(REPO, 'profiles', 'pmc_summary.json')
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(dominant, {}).get('hbm_bytes_per_launch')
-            except Exception:
-                traffic = None
+        traffic, traffic_source = pmc_traffic(dominant)
         out = {
             'metric': (f'env steps/sec end-to-end PPO (rollout+GAE+update), {NUM_ENVS} envs'
                        + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')),
@@ -396,11 +492,49 @@ def main():
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'frac_useful': (achieved * FLOP_PER_ROW_USEFUL / FLOP_PER_ROW_UPDATE / PEAK_FP32_MFMA_TFLOPS
                                          if args.policy == 'mlp' else None),   # on the 49 real columns (32 000 FLOP/row)
-                         'traffic': traffic,
+                         'traffic': traffic, 'traffic_source': traffic_source, 'traffic_build': source_build_id(),
                          'avg_launch_ms': avg_ms, 'launches': launches, 'bracketed': f'every {event_stride}. launch of the timed region' if event_stride > 1 else 'every launch of the timed region',
                          'flop_per_launch': flop_row * rows_per_launch},
             'kernel_ms_per_step': breakdown,
+            'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'per_rank': [round(x, 4) for x in rank_ms]},
         }
+        if args.policy == 'mlp':
+            # the MFMA instructions the instantiated kernel really issues per 16-row tile (csrc/ppo_update.hip: forward KKU x 8, heads
+            # 32, dW2v 32, dh DHK x 8, dW1 KTM x 32): the padded SURVEY figure above is the contract's `frac`, this is the executed one
+            mfma_tile = int(L.pfa_ppo_mlp_grad_mfma_per_tile(49, 64, 8))
+            out['roofline']['mfma_per_tile'] = mfma_tile
+            out['roofline']['frac_executed'] = (mfma_tile * 2048 / 16 * rows_per_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+                                                if launches else 0.0)
+        # north_star asks for the HBM side next to the MFMA side: the rollout kernel is the path's HBM-facing kernel (it writes the
+        # experience rows, SURVEY 8d: 280 B per env step), and the end-to-end figure is 1420 B per env step
+        roll = breakdown.get({'mlp': 'rollout_mlp_squared', 'lstm': 'rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'}.get(args.policy, ''))
+        if roll and roll['ms_per_step'] > 0 and args.workload == 'squared':
+            gbs = 280.0 * per_gpu / (roll['ms_per_step'] * 1e-3) / 1e9
+            out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'rollout_mlp_squared' if args.policy == 'mlp' else 'rollout_lstm_squared',
+                                   'achieved': gbs, 'peak': 8000.0, 'unit': 'GB/s', 'frac': gbs / 8000.0,
+                                   'bytes_per_launch': 280 * per_gpu, 'avg_launch_ms': roll['ms_per_step'],
+                                   'timing': 'HIP events in the untimed breakdown pass',
+                                   'traffic': pmc_traffic('rollout_mlp_squared')[0] if args.policy == 'mlp' else None,
+                                   'end_to_end': {'bytes_per_env_step': 1420, 'achieved': 1420.0 * value / world / 1e9, 'unit': 'GB/s per GPU',
+                                                  'frac': 1420.0 * value / world / 1e9 / 8000.0}}
+        if sustained is not None:
+            out['sustained_value'] = sustained['value']
+            out['sustained'] = sustained
+        if world > 1:
+            from pufferlib_amd import dist as pdist
+            info = pdist.transport_info()
+            bucket_bytes = int(data.grads.numel()) * 4
+            on_p2p = info['p2p'] and bucket_bytes <= info['p2p_slot_bytes']
+            out['dist'] = {'backend': os.environ.get('PFA_DIST_BACKEND', 'nccl'), 'devices_visible': torch.cuda.device_count(),
+                           'ranks_share_devices': torch.cuda.device_count() < world,
+                           'native_collectives': bool(data.native_dp),
+                           'transport': {'grad_bucket': ('p2p' if on_p2p else 'rccl' if (data.native_dp and info['rccl']) else 'torch'),
+                                         'grad_bucket_bytes': bucket_bytes,
+                                         'small_reductions': ('p2p' if info['p2p'] else 'rccl' if (data.native_dp and info['rccl']) else 'torch')},
+                           'rccl_nranks': info['rccl_nranks'], 'p2p_selftest_passed': info['p2p_selftest'], 'p2p_status': info['p2p_status'],
+                           'allreduce_calls': {'p2p': info['p2p_calls'], 'rccl_native': info['rccl_calls']},
+                           'collectives_per_step': 'GAE halo + affine maps (2 tiny), advantage sums (1), gradient bucket per optimizer step '
+                                                   f'({EPOCHS * NMB}), stats/EV sums (2)'}
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)
@@ -408,6 +542,13 @@ def main():
                 out['cpu_baseline'] = cpu_baseline_c4()
             elif args.policy == 'mlp':          # the headline configuration; the recurrent side workloads carry none
                 out['cpu_baseline'] = cpu_baseline()
+        if world == 1 and args.workload == 'squared' and args.policy == 'mlp' and not args.no_extra:
+            # BASELINE configs[2] / configs[3] as short side runs (own processes, after everything of the headline is measured):
+            # not the metric, but driver-run instead of builder-run numbers for the recurrent and the conv path
+            del data, vec, pol
+            torch.cuda.empty_cache()
+            out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),
+                                      extra_workload(['--workload', 'c4', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0'])]
         print(json.dumps(out), flush=True)
     if world > 1:
         from pufferlib_amd import dist as pdist

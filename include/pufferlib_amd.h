@@ -368,6 +368,9 @@ int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_p
 int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
                      const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
                      int64_t global_mb_rows, float *grads, void *workspace, pfa_stream_t stream);
+/* MFMA instructions (v_mfma_f32_16x16x4_f32, 2048 FLOP each) the gradient kernel instantiated for these dimensions issues per
+ * 16-row tile: what bench.py's roofline.frac_executed is computed from.  0 = unsupported dimensions. */
+int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_stride, int32_t num_actions);
 /* clip_grad_norm_(max_grad_norm) + Adam(eps) step (:240-244; torch.optim.Adam single-tensor semantics, bias
  * correction with `step` = 1-based optimizer step count).  grad_scale multiplies grads first.
  * If loss_sums (the 16-float tail above) / losses (f64[8]) are given: losses[i] += sum_i * loss_scale for i < 6, i.e. the running
@@ -499,6 +502,9 @@ int pfa_dist_init(const uint8_t *id128_host, int32_t rank, int32_t world);
 int pfa_dist_finalize(void);
 int pfa_dist_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);   /* one-shot peer path when it is open and the bucket fits, else RCCL */
 int pfa_dist_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
+/* out8: [0] RCCL communicator up, [1] its ncclCommCount, [2] peer path open, [3] its world size, [4] its slot capacity (bytes),
+ * [5] all-reduces sent over the peer path, [6] all-reduces sent over RCCL, [7] pfa_p2p_status. */
+int pfa_dist_info(int64_t *out8);
 
 /* ------------------------------------------------------------------------------------------
  * NatureCNN policy of BASELINE configs[3] — pufferlib.models.Convolutional (models.py:113-157) behind frameworks.cleanrl.Policy:
@@ -563,7 +569,9 @@ int pfa_cnn_gather_frames(const uint8_t *frames, int64_t frame_bytes, int64_t ba
  * sums the slots in rank order (one hop instead of a ring's 2 (R-1); identical bits on every rank).  pfa_p2p_alloc creates
  * this rank's fine-grained buffer (slots of cap_bytes) and returns its 64-byte IPC handle; the caller gathers all handles
  * (any transport) and passes them, rank order, to pfa_p2p_open.  Once open, pfa_dist_all_reduce_* and the native train loop
- * use it for every bucket that fits.  World size <= 8 (one node).  pfa_p2p_status: 0 ok, 1 a peer never arrived. */
+ * use it for every bucket that fits.  World size <= 8 (one node).  The flag waits are bounded (PFA_P2P_TIMEOUT_MS, default
+ * 30 000): a wait that runs out fills its part of the bucket with NaN and raises the status word.  pfa_p2p_status (a plain
+ * host read, no synchronisation): 0 ok, 1 a peer never arrived, -1 not open. */
 int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64_host);
 int pfa_p2p_open(const uint8_t *handles_host, int32_t rank, int32_t world);
 int pfa_p2p_close(void);

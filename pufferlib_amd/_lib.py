@@ -29,6 +29,17 @@ def _stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """16 hex digits over every kernel source and header of the library, in build order: the identity profiles/pmc_summary.json is
+    stamped with when the counters are collected and bench.py compares before it quotes them."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950: cross-compiles without a GPU.  One object per source, then link."""
     if not force and not _stale():
@@ -210,6 +221,8 @@ _SIGNATURES = {
     'pfa_dist_finalize': (C.c_int, []),
     'pfa_dist_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
     'pfa_dist_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
+    'pfa_dist_info': (C.c_int, [P]),
+    'pfa_ppo_mlp_grad_mfma_per_tile': (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     'pfa_igemm_rows': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, C.c_int32, P]),
     'pfa_igemm_weights_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     'pfa_igemm_weights': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, P]),

@@ -641,7 +641,9 @@ def train(data):
         # one D2H of 10 f64 (the one sync of train(); with PFA_LAZY_READBACK=1 data.losses fills in when it is first read)
         Bg = B * world
 
-        def finish(acc, losses=losses, Bg=Bg):
+        def finish(acc, losses=losses, Bg=Bg, check_peers=bool(data.native_dp)):
+            if check_peers:
+                pdist.raise_if_peer_lost()           # the peer all-reduce's bounded waits: a lost rank is an error here, never a stale sum
             s_y, s_yy, s_a, s_aa = acc[6:10]
             var_y = s_yy / Bg - (s_y / Bg) ** 2
             var_res = s_aa / Bg - (s_a / Bg) ** 2                    # y_true - y_pred = advantages

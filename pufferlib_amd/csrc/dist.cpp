@@ -24,12 +24,14 @@ struct Api {
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(ncclComm_t, int *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 Api g_api;
 ncclComm_t g_comm = nullptr;
 int g_rank = 0, g_world = 1;
+unsigned long long g_rccl_calls = 0;
 
 int load_api() {
     if (g_api.handle) return 0;
@@ -41,6 +43,7 @@ int load_api() {
     g_api.CommDestroy = (decltype(g_api.CommDestroy))dlsym(h, "ncclCommDestroy");
     g_api.AllReduce = (decltype(g_api.AllReduce))dlsym(h, "ncclAllReduce");
     g_api.GetErrorString = (decltype(g_api.GetErrorString))dlsym(h, "ncclGetErrorString");
+    g_api.CommCount = (decltype(g_api.CommCount))dlsym(h, "ncclCommCount");
     PFA_REQUIRE(g_api.GetUniqueId && g_api.CommInitRank && g_api.CommDestroy && g_api.AllReduce,
                 "dist: librccl is missing a required symbol");
     g_api.handle = h;
@@ -64,6 +67,8 @@ bool p2p_ready();
 int p2p_world();
 bool p2p_fits(size_t bytes);
 int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream);
+unsigned long long p2p_calls();
+size_t p2p_capacity();
 
 int dist_world() { return g_comm ? g_world : (p2p_ready() ? p2p_world() : 1); }
 bool dist_ready() { return g_comm != nullptr || p2p_ready(); }
@@ -72,6 +77,7 @@ int dist_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
     if (p2p_fits(count * (f64 ? 8 : 4))) return p2p_all_reduce(buf, count, f64, stream);
     PFA_REQUIRE(g_comm != nullptr, "dist: communicator not initialised");
     PFA_CHECK_NCCL(g_api.AllReduce(buf, buf, count, f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, g_comm, stream));
+    ++g_rccl_calls;
     return 0;
 }
 
@@ -110,6 +116,24 @@ extern "C" int pfa_dist_finalize(void) {
     }
     g_world = 1;
     g_rank = 0;
+    return 0;
+}
+
+// What is actually up, for the bench line and the logs: out[0] RCCL communicator present, [1] its ncclCommCount (0 if none),
+// [2] peer path open, [3] its world size, [4] its slot capacity in bytes, [5] all-reduces that went over the peer path,
+// [6] all-reduces that went over RCCL, [7] pfa_p2p_status (0 ok, 1 a wait ran out, -1 closed).
+extern "C" int pfa_dist_info(int64_t *out8) {
+    PFA_REQUIRE(out8 != nullptr, "dist.info: null buffer");
+    int n = 0;
+    if (g_comm && g_api.CommCount && g_api.CommCount(g_comm, &n) != kNcclSuccess) n = -1;
+    out8[0] = g_comm != nullptr;
+    out8[1] = g_comm ? n : 0;
+    out8[2] = p2p_ready();
+    out8[3] = p2p_ready() ? p2p_world() : 0;
+    out8[4] = (int64_t)p2p_capacity();
+    out8[5] = (int64_t)p2p_calls();
+    out8[6] = (int64_t)g_rccl_calls;
+    out8[7] = pfa_p2p_status();
     return 0;
 }
 

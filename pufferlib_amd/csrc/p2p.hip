@@ -12,9 +12,16 @@
 // kP2pChunks workgroups; workgroup w of rank r pushes chunk w into slot (phase, r) of every peer, fences, sets flag
 // (phase, r, w) = seq on every peer, waits for flags (phase, *, w) >= seq in its own memory and reduces chunk w.  Two phases
 // suffice: a rank can start call s+1 (other phase) while a slow peer still reads phase s, but not call s+2 before that peer
-// has pushed call s+1, i.e. finished reading call s.  Spins are bounded: a lost peer ends in an error, not a hung GPU.
+// has pushed call s+1, i.e. finished reading call s.
+//
+// A lost peer ends in an error, not a hung GPU and not a silently wrong sum: the flag wait is bounded in wall-clock time
+// (100 MHz counter; default 30 s, PFA_P2P_TIMEOUT_MS), and a wait that runs out (a) raises the status word — host-pinned
+// memory, so the host reads it without a copy or a synchronisation (pfa_p2p_status; clean_pufferl.train() checks it after
+// every update and raises) — and (b) POISONS the chunk it could not complete with NaN, so that losses, weights and every
+// isfinite check downstream fail even where nobody looks at the status.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -35,7 +42,9 @@ struct P2pState {
     char *local = nullptr;
     P2pPeers peers{};
     unsigned long long seq = 0;
-    int *status = nullptr;  // device word: set non-zero when a spin ran out
+    int *status = nullptr;         // host-pinned word (device-visible): set non-zero when a wait ran out
+    long long timeout_ticks = 0;   // of the 100 MHz wall clock
+    unsigned long long calls = 0;
 };
 static P2pState g_p2p;
 
@@ -45,7 +54,10 @@ static size_t p2p_total_bytes(size_t cap, int world) { return p2p_flags_offset(c
 
 template <typename T>
 __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers peers, int rank, int world, size_t cap, int phase,
-                                                                    unsigned long long seq, T *buf, long long n, int *status) {
+                                                                    unsigned long long seq, T *buf, long long n, int *status,
+                                                                    long long timeout_ticks) {
+    __shared__ int timed_out;
+    if (threadIdx.x == 0) timed_out = 0;
     const int w = blockIdx.x;
     const long long per = (n + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)w * per, hi = lo + per < n ? lo + per : n;
@@ -64,10 +76,12 @@ __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers pe
     if ((int)threadIdx.x < world) {
         const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(peers.base[rank] + p2p_flags_offset(cap, world)) +
                                          ((size_t)phase * world + threadIdx.x) * kP2pChunks + w;
+        const long long t0 = (long long)wall_clock64();
         int spin = 0;
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-            if (++spin > (1 << 26)) {   // seconds: a peer is gone
-                atomicExch(status, 1);
+            if ((++spin & 1023) == 0 && (long long)wall_clock64() - t0 > timeout_ticks) {   // the peer is gone (or stalled past the budget)
+                __hip_atomic_store(status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                timed_out = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(2);
@@ -75,6 +89,11 @@ __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers pe
     }
     __syncthreads();
     __threadfence_system();
+    if (timed_out) {   // never hand back a partial sum
+        T nan_v = (T)__builtin_nanf("");
+        for (long long i = lo + threadIdx.x; i < hi; i += kP2pThreads) buf[i] = nan_v;
+        return;
+    }
     const char *mine = peers.base[rank];
     for (long long i = lo + threadIdx.x; i < hi; i += kP2pThreads) {
         T s = reinterpret_cast<const T *>(mine + p2p_slot_offset(cap, world, phase, 0))[i];
@@ -84,6 +103,8 @@ __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers pe
 }
 
 bool p2p_ready() { return g_p2p.ready; }
+unsigned long long p2p_calls() { return g_p2p.calls; }
+size_t p2p_capacity() { return g_p2p.ready ? g_p2p.cap_bytes : 0; }
 int p2p_world() { return g_p2p.world; }
 bool p2p_fits(size_t bytes) { return g_p2p.ready && bytes <= g_p2p.cap_bytes; }
 
@@ -93,16 +114,17 @@ int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
     PFA_REQUIRE(bytes <= g_p2p.cap_bytes, "p2p: %zu bytes exceed the slot capacity %zu", bytes, g_p2p.cap_bytes);
     if (count == 0) return 0;
     const unsigned long long seq = ++g_p2p.seq;
+    ++g_p2p.calls;
     const int phase = (int)(seq & 1);
     long long chunks = (long long)((bytes + 16383) / 16384);   // >= 16 KB per workgroup
     chunks = chunks < 1 ? 1 : (chunks > kP2pChunks ? kP2pChunks : chunks);
     ScopedKernelTimer timer("p2p_all_reduce", stream);
     if (f64)
         hipLaunchKernelGGL(p2p_all_reduce_kernel<double>, dim3((unsigned)chunks), dim3(kP2pThreads), 0, stream, g_p2p.peers, g_p2p.rank,
-                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (double *)buf, (long long)count, g_p2p.status);
+                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (double *)buf, (long long)count, g_p2p.status, g_p2p.timeout_ticks);
     else
         hipLaunchKernelGGL(p2p_all_reduce_kernel<float>, dim3((unsigned)chunks), dim3(kP2pThreads), 0, stream, g_p2p.peers, g_p2p.rank,
-                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (float *)buf, (long long)count, g_p2p.status);
+                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (float *)buf, (long long)count, g_p2p.status, g_p2p.timeout_ticks);
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -128,7 +150,16 @@ extern "C" int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64
     g_p2p.local = (char *)p;
     g_p2p.cap_bytes = cap;
     g_p2p.world = world;
-    g_p2p.status = (int *)((char *)p + total - 64);
+    void *st = nullptr;
+    PFA_CHECK_HIP(hipHostMalloc(&st, 64, hipHostMallocMapped));
+    *(volatile int *)st = 0;
+    g_p2p.status = (int *)st;
+    long long ms = 30000;
+    if (const char *e = std::getenv("PFA_P2P_TIMEOUT_MS")) {
+        const long long v = std::atoll(e);
+        if (v > 0) ms = v;
+    }
+    g_p2p.timeout_ticks = ms * 100000;   // wall_clock64: 100 MHz
     return 0;
 }
 
@@ -157,15 +188,14 @@ extern "C" int pfa_p2p_close(void) {
         for (int q = 0; q < g_p2p.world; ++q)
             if (q != g_p2p.rank && g_p2p.peers.base[q]) (void)hipIpcCloseMemHandle(g_p2p.peers.base[q]);
     if (g_p2p.local) (void)hipFree(g_p2p.local);
+    if (g_p2p.status) (void)hipHostFree(g_p2p.status);
     g_p2p = P2pState{};
     return 0;
 }
 
-extern "C" int pfa_p2p_status(void) {   // 0 ok, 1 a spin ran out (a peer never arrived), -1 not initialised
-    if (!g_p2p.ready) return -1;
-    int s = 0;
-    if (hipMemcpy(&s, g_p2p.status, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    return s;
+extern "C" int pfa_p2p_status(void) {   // 0 ok, 1 a wait ran out (a peer never arrived), -1 not initialised.  A plain host read.
+    if (!g_p2p.ready || !g_p2p.status) return -1;
+    return *(volatile int *)g_p2p.status;
 }
 
 extern "C" int pfa_p2p_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream) {

@@ -812,6 +812,17 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     return 0;
 }
 
+// MFMA instructions per 16-row tile of the instantiation pfa_ppo_mlp_grad dispatches for these dimensions (see the switch there):
+// forward KKU x kMT, heads 4 x kMT, dW2v 4 x kMT, dh 4 x kMT, dW1 KTM x 4 x kMT.
+extern "C" int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_stride, int32_t num_actions) {
+    if (num_actions < 1 || num_actions > 15) return 0;
+    if (obs_stride != 16 && obs_stride != 32 && obs_stride != 64 && obs_stride != 96 && obs_stride != 128) return 0;
+    int kku = obs_stride / 4, ktm = obs_stride / 16;
+    if (obs_stride == 64 && (obs_dim + 3) / 4 == 13) kku = 13;
+    if (obs_stride == 64 && obs_dim == 49) ktm = 3;
+    return kku * kMT + 3 * 4 * kMT + ktm * 4 * kMT;
+}
+
 extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, float lr,
                                   float beta1, float beta2, float eps, int64_t step, float max_grad_norm, float grad_scale,
                                   const float *loss_sums, double *losses, double loss_scale, const double *norm_partials,

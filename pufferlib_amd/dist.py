@@ -91,7 +91,7 @@ def gae_fold_later(maps, rank):
     return x.reshape(1) if hasattr(x, 'reshape') else x
 
 
-_native = dict(ready=False, world=1, rccl=False, p2p=False)
+_native = dict(ready=False, world=1, rccl=False, p2p=False, p2p_selftest=None)
 
 
 def native_ready():
@@ -148,6 +148,7 @@ def init_p2p(bucket_bytes):
             good = 0
     flag = torch.tensor([good], dtype=torch.int32, device='cuda')
     d.all_reduce(flag, op=d.ReduceOp.MIN)
+    _native['p2p_selftest'] = bool(int(flag.item()))
     if not int(flag.item()):
         L.pfa_p2p_close()
         return False
@@ -204,10 +205,31 @@ def init_native(force_single=False, bucket_bytes=0):
     return bool(ok) or p2p_ok
 
 
+def transport_info():
+    """What the update's collectives actually run on (bench.py prints it; tests assert on it): RCCL communicator and its
+    ncclCommCount, the peer path, how many all-reduces each has carried so far, and the peer path's status word."""
+    import ctypes as C
+    from . import _lib
+    out = (C.c_int64 * 8)()
+    _lib.check(_lib.lib().pfa_dist_info(out), 'dist_info')
+    return dict(native=bool(_native['ready']), rccl=bool(out[0]), rccl_nranks=int(out[1]), p2p=bool(out[2]), p2p_world=int(out[3]),
+                p2p_slot_bytes=int(out[4]), p2p_calls=int(out[5]), rccl_calls=int(out[6]), p2p_status=int(out[7]),
+                p2p_selftest=_native.get('p2p_selftest'))
+
+
+def raise_if_peer_lost():
+    """The peer all-reduce's waits are bounded (csrc/p2p.hip): when one ran out the bucket was filled with NaN and the status word
+    raised.  Called where train()/evaluate() read their results back, so a dead or stalled rank ends the run with an error."""
+    from . import _lib
+    if _native.get('p2p') and _lib.lib().pfa_p2p_status() > 0:
+        raise RuntimeError('data-parallel all-reduce over the peer path timed out waiting for a rank (PFA_P2P_TIMEOUT_MS); '
+                           'the gradients of this update are invalid')
+
+
 def finalize_native():
     from . import _lib
     if _native['ready']:
         if _native.get('p2p'):
             _lib.lib().pfa_p2p_close()
         _lib.lib().pfa_dist_finalize()
-        _native.update(ready=False, world=1, rccl=False, p2p=False)
+        _native.update(ready=False, world=1, rccl=False, p2p=False, p2p_selftest=None)

@@ -139,9 +139,9 @@ def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent, tran
     assert not np.array_equal(r[0]['0.obs'], r[1]['0.obs'])
 
 
-def _p2p_worker(rank, world, port, out_dir):
+def _p2p_worker(rank, world, port, out_dir, sizes=(1, 7, 9497, 9497, 153752, 262144, 3, 9497), reps=4):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='20000')
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -151,7 +151,7 @@ def _p2p_worker(rank, world, port, out_dir):
     L = _lib.lib()
     ok = True
     g = torch.Generator(device='cuda').manual_seed(100 + rank)
-    for it, n in enumerate([1, 7, 9497, 9497, 153752, 262144, 3, 9497] * 4):       # many calls: both phases are reused
+    for it, n in enumerate(list(sizes) * reps):       # many calls: both phases are reused
         for dtype, fn in ((torch.float32, L.pfa_p2p_all_reduce_f32), (torch.float64, L.pfa_p2p_all_reduce_f64)):
             if dtype == torch.float64 and n > 131072:
                 continue
@@ -167,6 +167,8 @@ def _p2p_worker(rank, world, port, out_dir):
                 want = want + ref[q]
             ok = ok and bool(torch.equal(x, want))
     assert L.pfa_p2p_status() == 0
+    info = pdist.transport_info()
+    assert info['p2p'] and info['p2p_world'] == world and info['p2p_calls'] > 0 and info['p2p_selftest'] is True, info
     np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([int(ok)]))
     dist.barrier()
     L.pfa_p2p_close()
@@ -179,3 +181,48 @@ def test_one_shot_peer_all_reduce_is_the_rank_order_sum_bit_for_bit(tmp_path):
     world = 2
     _spawn(_p2p_worker, (world, _free_port(), str(tmp_path)), world)
     assert all(int(np.load(tmp_path / f'ok{q}.npy')[0]) == 1 for q in range(world))
+
+
+def test_eight_ranks_on_one_gpu_run_the_full_slot_and_flag_logic(tmp_path):
+    """R = 8 — the node size the peer path is built for — before it ever meets xGMI: eight processes on the one GPU, every rank
+    pushing into seven peers' slots and waiting on seven flags per chunk, MLP- and LSTM-sized buckets, phase reuse; rank-order sums
+    bit for bit on every rank."""
+    world = 8
+    _spawn(_p2p_worker, (world, _free_port(), str(tmp_path), (1, 9497, 153752, 5, 9497), 3), world, timeout_s=420)
+    assert all(int(np.load(tmp_path / f'ok{q}.npy')[0]) == 1 for q in range(world))
+
+
+def _p2p_lost_peer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='700')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pufferlib_amd import _lib, dist as pdist
+    assert pdist.init_p2p(1 << 16)                     # self-test passes: both ranks are there
+    L = _lib.lib()
+    res = dict(status_before=L.pfa_p2p_status())
+    if rank == 0:                                      # rank 1 never joins this all-reduce
+        x = torch.ones(5000, device='cuda')
+        _lib.check(L.pfa_p2p_all_reduce_f32(_lib.ptr(x), x.numel(), _lib.stream_handle()), 'p2p all-reduce')
+        torch.cuda.synchronize()                       # returns: the wait is bounded
+        res.update(status=L.pfa_p2p_status(), all_nan=bool(torch.isnan(x).all()))
+        try:
+            pdist._native['p2p'] = True
+            pdist.raise_if_peer_lost()
+            res['raised'] = False
+        except RuntimeError:
+            res['raised'] = True
+        np.savez(os.path.join(out_dir, 'lost.npz'), **{k: np.array([int(v)]) for k, v in res.items()})
+    dist.barrier()
+    L.pfa_p2p_close()
+    dist.destroy_process_group()
+
+
+def test_lost_peer_is_an_error_not_a_stale_sum(tmp_path):
+    """a rank that never arrives must not leave the others with whatever was in the slots.  The wait is bounded
+    in wall-clock time, the bucket comes back all-NaN, the status word is raised and clean_pufferl's readback check raises."""
+    _spawn(_p2p_lost_peer_worker, (2, _free_port(), str(tmp_path)), 2, timeout_s=180)
+    r = np.load(tmp_path / 'lost.npz')
+    assert int(r['status_before'][0]) == 0 and int(r['status'][0]) == 1 and int(r['all_nan'][0]) == 1 and int(r['raised'][0]) == 1

@@ -286,3 +286,35 @@ def test_deferred_readback_error_surfaces_at_resolution():
     d._pending = _FakePending(boom)
     with pytest.raises(RuntimeError, match='underrun'):
         d.get('score')
+
+
+def test_bench_self_spawn_builds_the_torchrun_command(monkeypatch):
+    """`python bench.py --gpus N` (no torchrun) re-runs itself as N ranks; with fewer devices than ranks the ranks share devices over gloo."""
+    import argparse
+    import os
+    import subprocess
+    import sys as _sys
+    import torch
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _sys.path.insert(0, repo)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen.update(cmd=cmd, env=env)
+        return 0
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(_sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2'])
+    monkeypatch.delenv('PFA_DIST_BACKEND', raising=False)
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 8)
+    assert bench.self_spawn(argparse.Namespace(gpus=4)) == 0
+    cmd = seen['cmd']
+    assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=4' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and cmd[-6:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and 'PFA_DIST_BACKEND' not in seen['env']
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 1)
+    assert bench.self_spawn(argparse.Namespace(gpus=4)) == 0
+    assert seen['env']['PFA_DIST_BACKEND'] == 'gloo'
+    monkeypatch.setattr(torch.cuda, 'device_count', lambda: 0)
+    with pytest.raises(SystemExit):
+        bench.self_spawn(argparse.Namespace(gpus=2))
