@@ -32,6 +32,7 @@ HORIZON = 128
 NMB = 4
 EPOCHS = 4
 BPTT = 16
+SUSTAINED_CAP = 20000    # most steps the sustained leg may run: total_timesteps (the lr-anneal horizon) is sized to hold them
 D, NT = 3, 1             # obs 7x7 = 49 floats, padded to a 64-float row (256 B)
 # SURVEY.md §8d algorithmic figures (MLP, obs row 64 f32, 8 actions, hidden 128)
 FLOP_PER_ROW_UPDATE = 39680          # fwd 18 688 + bwd 20 992 per row per epoch (the 64-float padded row)
@@ -364,7 +365,7 @@ def main():
         pol = cleanrl.Policy(models.Convolutional(vec.driver_env, framestack=4))
     else:
         pol = cleanrl.Policy(models.Default(vec.driver_env))
-    data = clean_pufferl.create(make_config(per_gpu * world * (K + W) * 4, env={'c4': 'frames', 'c3': 'synthetic'}.get(args.workload, 'squared')),
+    data = clean_pufferl.create(make_config(per_gpu * world * (K + W + 8 + SUSTAINED_CAP) * 2, env={'c4': 'frames', 'c3': 'synthetic'}.get(args.workload, 'squared')),
                                 vec, pol)
 
     def barrier():
@@ -406,7 +407,7 @@ def main():
     # sampler with a seconds-scale period (the driver's rocm-smi poll) sees the device busy; iteration count agreed on rank 0
     sustained = None
     if args.sustained_seconds > 0:
-        n_sus = max(int(args.sustained_seconds / max(dt / K, 1e-6)) + 1, K)
+        n_sus = min(max(int(args.sustained_seconds / max(dt / K, 1e-6)) + 1, K), SUSTAINED_CAP)
         if world > 1:
             tn = torch.tensor([n_sus], dtype=torch.int64, device='cuda')
             dist.broadcast(tn, src=0)

@@ -25,6 +25,10 @@
 #include "sampler.hpp"
 #include "ppo_tile.hpp"
 
+#ifndef PFA_GRAD_PIPE
+#define PFA_GRAD_PIPE 1   // 0 = the round-2 instruction order (kept for A/B timing with tools/variant_bench.py)
+#endif
+
 namespace pfa {
 
 // (producer, consumer) wavefront pairs per workgroup.  Rows of up to 64 floats: 4 pairs = 8 waves, two per SIMD, two workgroups
@@ -233,6 +237,37 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             PFA_STAMP(j, 1);
 
             f32x4 h[kMT];
+#if PFA_GRAD_PIPE
+            // Software pipeline over the k-groups of 4 k-steps: the fragments of group k4 + 1 (8 ds_read_b128 of W1 + the X column
+            // quad) are issued BEFORE the 32 MFMAs of group k4 and land under them.  Left to itself the compiler sinks every
+            // ds_read next to its use and waits lgkmcnt(0) in front of each 4 MFMAs (round-2 ISA: the LDS latency exposed 26 times
+            // per tile); the sched_barriers pin the order.  Within a group the products run k-step-major: 8 independent accumulator
+            // chains instead of 4 dependent MFMAs on one chain.  KKU = ceil(obs_dim / 4) k-steps carry data; the rest is zero
+            // padding in X and in W1 and is not issued.
+            constexpr int NK4 = (ABL & 4) ? 0 : (KKU + 3) / 4;
+            f32x4 wq[2][kMT];
+            float xb[2][4];
+            auto load_group = [&](int k4, int b) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) xb[b][q] = xs[c * XS + 4 * (4 * k4 + q) + g];
+#pragma unroll
+                for (int m = 0; m < kMT; ++m) wq[b][m] = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + 4 * k4);
+            };
+            if (NK4 > 0) load_group(0, 0);
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) h[m] = *reinterpret_cast<const f32x4 *>(b1t + (m * 64 + lane) * 4);
+#pragma unroll
+            for (int k4 = 0; k4 < NK4; ++k4) {
+                if (k4 + 1 < NK4) load_group(k4 + 1, (k4 + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int m = 0; m < kMT; ++m)
+                        if (4 * k4 + q < KKU) h[m] = mfma16(wq[k4 & 1][m][q], xb[k4 & 1][q], h[m]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#else
 #pragma unroll
             for (int m = 0; m < kMT; ++m) h[m] = *reinterpret_cast<const f32x4 *>(b1t + (m * 64 + lane) * 4);
 #pragma unroll
@@ -249,6 +284,13 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                         if (4 * k4 + q < KKU) h[m] = mfma16(wq[q], xb[q], h[m]);
                 }
             }
+#endif
+#if PFA_GRAD_PIPE
+            f32x4 w4h[kMT];   // the heads' A fragments: issued here, they land under the ReLU's VALU stretch
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) w4h[m] = *reinterpret_cast<const f32x4 *>(w2t + (m * 64 + lane) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
@@ -256,6 +298,19 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                         // inline-asm v_max loses the MFMA->VALU hazard wait states; the integer form max(bits, 0) is exact and one
                         // instruction but shifts the block's schedule: 66.8 instead of 64.7 us per launch)
             f32x4 out;
+#if PFA_GRAD_PIPE
+            {
+                f32x4 o[4] = {f32x4{bo[0], bo[1], bo[2], bo[3]}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
+                              f32x4{0.f, 0.f, 0.f, 0.f}};  // four independent chains
+#pragma unroll
+                for (int m0 = 0; m0 < kMT; m0 += 4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) o[q] = mfma16(w4h[m0 + q][r], h[m0 + q][r], o[q]);
+                out = (o[0] + o[1]) + (o[2] + o[3]);  // out^T[o = 4g + r][row = c]
+            }
+#else
             {
                 f32x4 o[4] = {f32x4{bo[0], bo[1], bo[2], bo[3]}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
                               f32x4{0.f, 0.f, 0.f, 0.f}};  // four independent chains
@@ -271,6 +326,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 }
                 out = (o[0] + o[1]) + (o[2] + o[3]);  // out^T[o = 4g + r][row = c]
             }
+#endif
             if (out[0] == 12345.678f) PFA_STAMP(j, 7);   // (never true) pins the stamp behind the heads' result
             PFA_STAMP(j, 2);
             LossOut lo;
@@ -302,6 +358,23 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             __syncthreads();  // beta_j
             PFA_STAMP(j, 5);
             // ---- dW2v^T[u][o] += hidden^T . dout, both operands back from LDS in A/B fragment order -----------------------
+#if PFA_GRAD_PIPE
+            if (!(ABL & 2)) {
+                float dfrag[4];  // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c)
+                float hrow[kMT][4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dfrag[r] = dsP[(4 * g + r) * DS + c];
+#pragma unroll
+                for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hrow[m][r] = hsP[(4 * g + r) * HS + 16 * m + c];  // hidden[row=4g+r][u=16m+c]
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int m = 0; m < kMT; ++m) acc_dw2[m] = mfma16(hrow[m][r], dfrag[r], acc_dw2[m]);   // 8 independent chains
+            }
+#else
             if (!(ABL & 2)) {
                 float dfrag[4];  // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c)
 #pragma unroll
@@ -319,6 +392,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                         for (int q = 0; q < 4; ++q) acc_dw2[m0 + q] = mfma16(hrow[q][r], dfrag[r], acc_dw2[m0 + q]);
                 }
             }
+#endif
         }
         __syncthreads();  // alpha_J: matches the consumer's trailing barrier pair
         __syncthreads();  // beta_J
@@ -391,6 +465,40 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 for (int kt = 0; kt < KTM; ++kt) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
                 xc[r] = COL ? xs[(4 * g + r) * XS + 16 * KTM] : 0.0f;
             }
+#if PFA_GRAD_PIPE
+            // every LDS read of the tile is issued up front (dout, the X fragments above, the W2v fragments, the hidden tile for
+            // relu'), then three dense stretches: 32 MFMAs of dh (8 chains), the relu' / db1 / column VALU, 32 KTM MFMAs of dW1
+            f32x4 dh[kMT], wb[kMT];
+            float hrow[kMT][4];
+#pragma unroll
+            for (int m = 0; m < kMT; ++m) {
+                dh[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+                wb[m] = *reinterpret_cast<const f32x4 *>(w2bt + (m * 64 + lane) * 4);
+            }
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hrow[m][r] = hsP[(4 * g + r) * HS + 16 * m + c];  // hidden[row=4g+r][u=16m+c]
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < kMT; ++m) dh[m] = mfma16(dout[r], wb[m][r], dh[m]);
+#pragma unroll
+            for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dh[m][r] = hrow[m][r] > 0.0f ? dh[m][r] : 0.0f;  // relu'
+                    db1[m] += dh[m][r];
+                    if (COL) acc_col[m] = fmaf(xc[r], dh[m][r], acc_col[m]);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int m = 0; m < kMT; ++m)
+#pragma unroll
+                    for (int kt = 0; kt < KTM; ++kt) acc_dw1[kt][m] = mfma16(xa[kt][r], dh[m][r], acc_dw1[kt][m]);
+#else
 #pragma unroll
             for (int m0 = 0; m0 < kMT; m0 += 4) {  // four hidden tiles = four independent accumulator chains
                 f32x4 dh[4], wb[4];
@@ -421,6 +529,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
                         for (int kt = 0; kt < KTM; ++kt) acc_dw1[kt][m0 + q] = mfma16(xa[kt][r], dh[q][r], acc_dw1[kt][m0 + q]);
             }
+#endif
         };
         for (int j = 0; j < J; ++j) {
             PFA_STAMP(j, 0);
