@@ -589,7 +589,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 // f64 partial of sum(g^2) per block for the gradient-norm clip.  Block = 64 native slots x 4 slices of the
 // partial index; 16 independent loads in flight per thread.
 template <int DP>
-__global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, int nparts, int a, float *grads,
+__global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
                                                         double *norm_partials) {
     using NL = NativeLayout<DP>;
     __shared__ float sh[4][64];
@@ -625,6 +625,9 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, 
         if (q < NL::kDw2) {
             const int ln = q & 63, r = (q >> 6) & 3, m = (q >> 8) & (kMT - 1), kt = q >> 11;
             p = off.w1 + (16 * m + (ln & 15)) * DP + 16 * kt + 4 * (ln >> 4) + r;
+            // columns >= obs_dim are observation padding: their gradient is zero by definition (kernel A2 keeps the bias's 1.0 in the
+            // first of them, which would otherwise put db1 there)
+            if (16 * kt + 4 * (ln >> 4) + r >= obs_dim) s = 0.0f;
         } else if (q < NL::kDb1) {
             const int t = q - NL::kDw2, ln = t & 63, r = (t >> 6) & 3, m = t >> 8;
             const int o = ln & 15, u = 16 * m + 4 * (ln >> 4) + r;
@@ -805,6 +808,13 @@ static size_t partials_bytes(const pfa_mlp_dims *dims) {
 static double *norm_partials_of(void *workspace, const pfa_mlp_dims *dims) {  // after the gradient partials
     return (double *)((char *)workspace + partials_bytes(dims));
 }
+static size_t tail_bytes(const pfa_mlp_dims *dims, int nmb) {   // what follows the partials: adv-stat partials / norm pieces (shared)
+    const size_t native = native_count(dims->obs_stride);
+    const size_t advp = align_up((size_t)nmb * 64 * 2 * sizeof(double), 256);
+    const size_t normp = align_up(((native + 63) / 64) * sizeof(double), 256);
+    return advp > normp ? advp : normp;
+}
+
 
 static int grad_grid(int64_t mb_rows, int dp) {
     const int64_t tiles = mb_rows / 16;
@@ -819,10 +829,8 @@ using namespace pfa;
 extern "C" size_t pfa_ppo_workspace_bytes(const pfa_mlp_dims *dims, int64_t batch_rows, const pfa_ppo_hparams *hp) {
     if (!dims || !hp || hp->num_minibatches < 1) return 0;
     (void)batch_rows;
-    const size_t native = native_count(dims->obs_stride);
-    const size_t advp = align_up((size_t)hp->num_minibatches * kAdvChunks * 2 * sizeof(double), 256);
-    const size_t normp = align_up(((native + 63) / 64) * sizeof(double), 256);
-    return partials_bytes(dims) + (advp > normp ? advp : normp);
+    static_assert(kAdvChunks == 64, "tail_bytes assumes 64 chunks");
+    return partials_bytes(dims) + tail_bytes(dims, hp->num_minibatches) + 256;
 }
 
 extern "C" int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_ppo_hparams *hp, double *stats,
@@ -903,19 +911,19 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
 #undef PFA_LAUNCH_GRAD
 #undef PFA_LAUNCH_GRAD_K
     PFA_LAUNCH_CHECK();
-    ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
     double *normp = norm_partials_of(workspace, dims);
+    ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
     switch (dims->obs_stride) {
         case 16: hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3((NativeLayout<16>::kCount + 63) / 64), dim3(256), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
         case 32: hipLaunchKernelGGL(ppo_reduce_kernel<32>, dim3((NativeLayout<32>::kCount + 63) / 64), dim3(256), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
         case 96: hipLaunchKernelGGL(ppo_reduce_kernel<96>, dim3((NativeLayout<96>::kCount + 63) / 64), dim3(256), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
         case 128: hipLaunchKernelGGL(ppo_reduce_kernel<128>, dim3((NativeLayout<128>::kCount + 63) / 64), dim3(256), 0,
-                                     (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+                                     (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
         default: hipLaunchKernelGGL(ppo_reduce_kernel<64>, dim3((NativeLayout<64>::kCount + 63) / 64), dim3(256), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, grads, normp); break;
+                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
     }
     PFA_LAUNCH_CHECK();
     return 0;
