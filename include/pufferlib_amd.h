@@ -564,6 +564,44 @@ int pfa_cnn_heads_loss(const float *h, const pfa_experience *exp, int64_t batch_
 int pfa_cnn_gather_frames(const uint8_t *frames, int64_t frame_bytes, int64_t batch_rows, int32_t mb, const pfa_ppo_hparams *hp,
                           int64_t q0, int64_t rows, uint8_t *out, pfa_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Width-general policy path (csrc/general.hip; host side pufferlib_amd/general.py): pufferlib.models.Default with any
+ * hidden_size / observation width, LSTMWrapper with any (input_size, hidden_size) (models.py:24,65) and the recurrent
+ * NatureCNN of environments/atari/torch.py:4-6 run as sequences of pfa_igemm_rows / pfa_igemm_weights launches plus these
+ * row-wise kernels on the head outputs `out` [rows][ld] (columns < num_actions: the logits of all heads side by side, column
+ * num_actions: the value).  num_actions <= 63; heads: the nibble packing of pfa_mlp_dims.heads, 0 = one Discrete head (which may then use all 63).
+ *   pfa_heads_rows_sample  sample_logits with action=None (frameworks/cleanrl.py:25-47): actions (packed like pfa_mlp_dims.heads
+ *                          for MultiDiscrete), log-prob, entropy (nullable), value
+ *   pfa_heads_rows_eval    sample_logits with GIVEN actions (cleanrl.py:38-44): the training-mode policy(obs, action=...) of
+ *                          frameworks.cleanrl.Policy / RecurrentPolicy (cleanrl.py:60-66,87-93)
+ *   pfa_heads_rows_loss    PPO loss (clean_pufferl.py:202-238) of the chunk's rows and d loss / d out into dout [rows][ldd]
+ *                          (columns >= num_out untouched, num_actions < j < num_out zeroed); chunk row r is minibatch row q0 + r, or,
+ *                          with time_major_rows = R > 0, row t * R + k is minibatch row q0 + k * bptt_horizon + t;
+ *                          loss_pairs16 as in pfa_ppo_mlp_grad (accumulate != 0 adds chunks up)
+ *   pfa_lstm_cell_forward  element-wise part of one nn.LSTM step: gates [rows][4 hidden] (i, f, g, o pre-activations, replaced by
+ *                          the activated gates), c_prev -> c_out, h_out (row stride ldh) and optionally a second copy h_out2
+ *   pfa_lstm_cell_backward its back-propagation: dh = dh_a (+ dh_b), dc in/out (running cell gradient), dgates [rows][4 hidden]
+ * ------------------------------------------------------------------------------------------ */
+int pfa_heads_rows_sample(const float *out, int32_t ld, int64_t rows, int32_t num_actions, uint32_t heads, const float *noise,
+                          const pfa_noise_key *key, int64_t row_offset, int64_t *actions, float *logprob, float *entropy,
+                          float *value, pfa_stream_t stream);
+int pfa_heads_rows_eval(const float *out, int32_t ld, int64_t rows, int32_t num_actions, uint32_t heads, const int64_t *actions,
+                        float *logprob, float *entropy, float *value, pfa_stream_t stream);
+size_t pfa_heads_rows_loss_workspace_bytes(int64_t rows);
+int pfa_heads_rows_loss(const float *out, int32_t ld, const pfa_experience *exp, int64_t batch_rows, int32_t mb, int64_t q0,
+                        int64_t rows, int32_t time_major_rows, int32_t num_actions, uint32_t heads, const pfa_ppo_hparams *hp,
+                        const double *adv_stats, int64_t global_mb_rows, float *dout, int32_t ldd, int32_t num_out,
+                        float *loss_pairs16, int32_t accumulate, void *workspace, pfa_stream_t stream);
+int pfa_lstm_cell_forward(float *gates, const float *c_prev, float *c_out, float *h_out, int32_t ldh, float *h_out2, int32_t ldh2,
+                          int64_t rows, int32_t hidden, pfa_stream_t stream);
+int pfa_lstm_cell_backward(const float *dh_a, int32_t lda, const float *dh_b, int32_t ldb, float *dc, const float *gates_act,
+                           const float *c_prev, const float *c, float *dgates, int64_t rows, int32_t hidden, pfa_stream_t stream);
+/* Row copy between the two row orders of a chunk of `segments` x `steps` rows — segment-major (row k * steps + t) and time-major
+ * (row t * segments + k) — optionally masked by relu' of `act` (nullable; SRC order, row stride lda): dst = act > 0 ? src : 0.
+ * segments == 0: row for row.  cols a multiple of 4, strides multiples of 4, buffers 16-byte aligned. */
+int pfa_rows_perm(const float *src, int32_t lds_, float *dst, int32_t ldd, const float *act, int32_t lda, int64_t rows, int32_t cols,
+                  int32_t segments, int32_t steps, int32_t to_time_major, pfa_stream_t stream);
+
 /* One-shot all-reduce over peer-mapped device memory (csrc/p2p.hip) for the small buckets of the data-parallel update: every
  * rank writes its bucket into a slot of every peer's buffer over the xGMI mesh, raises a flag, waits for the peers' flags and
  * sums the slots in rank order (one hop instead of a ring's 2 (R-1); identical bits on every rank).  pfa_p2p_alloc creates

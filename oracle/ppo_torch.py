@@ -89,7 +89,8 @@ class Policy:
         """nn.LSTM(H, H, 1) on (TT, B, H) with gate order i,f,g,o (models.py:76,103-105)."""
         w_ih, w_hh = self.p('weight_ih_l0'), self.p('weight_hh_l0')
         b_ih, b_hh = self.p('bias_ih_l0'), self.p('bias_hh_l0')
-        TT, B, H = x.shape
+        TT, B, _ = x.shape
+        H = w_hh.shape[1]            # nn.LSTM(input_size, hidden_size): the state has hidden_size columns, x has input_size
         if state is None:
             h = torch.zeros(B, H)
             c = torch.zeros(B, H)
@@ -160,6 +161,35 @@ class ConvPolicy:
     def forward(self, obs, state=None):
         logits, value = self.decode(self.encode(obs))
         return logits, value, None
+
+
+class RecurrentConvPolicy(ConvPolicy):
+    """environments/atari/torch.py:4-6: ``Recurrent`` = pufferlib.models.LSTMWrapper(input_size=512, hidden_size=512) over the
+    NatureCNN ``Policy`` — encode_observations -> nn.LSTM -> decode_actions (models.py:84-111).  Parameters in the reference's
+    named_parameters order: the wrapped policy's first, then the LSTM's."""
+    recurrent = True
+    LSTM_NAMES = Policy.LSTM_NAMES
+
+    def __init__(self, weights, framestack=4):
+        self.names = list(ConvPolicy.NAMES) + list(self.LSTM_NAMES)
+        self.framestack = framestack
+        self.params = [torch.tensor(np.asarray(weights[n]), dtype=torch.float32, requires_grad=True) for n in self.names]
+
+    lstm = Policy.lstm
+
+    def forward(self, obs, state=None):
+        """obs (B, F*84*84) [one step] or (B, TT, F*84*84)."""
+        if obs.dim() == 2:
+            B, TT = obs.shape[0], 1
+        else:
+            B, TT = obs.shape[:2]
+        hidden = self.encode(obs.reshape(B * TT, -1).float())
+        H = hidden.shape[1]
+        hidden = hidden.reshape(B, TT, H).transpose(0, 1)
+        hidden, state = self.lstm(hidden, state)
+        hidden = hidden.transpose(0, 1).reshape(B * TT, -1)
+        logits, value = self.decode(hidden)
+        return logits, value, state
 
 
 def sample_logits(logits, action=None, noise=None):

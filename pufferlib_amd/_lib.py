@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip', 'igemm.hip', 'cnn_heads.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip', 'igemm.hip', 'cnn_heads.hip', 'general.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -223,6 +223,14 @@ _SIGNATURES = {
     'pfa_dist_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
     'pfa_dist_info': (C.c_int, [P]),
     'pfa_ppo_mlp_grad_mfma_per_tile': (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    'pfa_heads_rows_sample': (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, C.c_uint32, P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
+    'pfa_heads_rows_eval': (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, C.c_uint32, P, P, P, P, P]),
+    'pfa_heads_rows_loss_workspace_bytes': (C.c_size_t, [C.c_int64]),
+    'pfa_heads_rows_loss': (C.c_int, [P, C.c_int32, C.POINTER(Experience), C.c_int64, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                      C.c_uint32, C.POINTER(PpoHparams), P, C.c_int64, P, C.c_int32, C.c_int32, P, C.c_int32, P, P]),
+    'pfa_lstm_cell_forward': (C.c_int, [P, P, P, P, C.c_int32, P, C.c_int32, C.c_int64, C.c_int32, P]),
+    'pfa_lstm_cell_backward': (C.c_int, [P, C.c_int32, P, C.c_int32, P, P, P, P, P, C.c_int64, C.c_int32, P]),
+    'pfa_rows_perm': (C.c_int, [P, C.c_int32, P, C.c_int32, P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P]),
     'pfa_igemm_rows': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, C.c_int32, P]),
     'pfa_igemm_weights_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     'pfa_igemm_weights': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, P]),

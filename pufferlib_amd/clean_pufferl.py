@@ -275,8 +275,6 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     conv = find_cnn(policy) is not None
     if conv:
         space = vecenv.single_observation_space
-        if recurrent:
-            raise NotImplementedError('the convolutional policy (models.Convolutional) trains without an LSTM here')
         if not (host_mode or isinstance(vecenv, Frames)):
             raise NotImplementedError('models.Convolutional reads uint8 (framestack, 84, 84) frames: a host vecenv or vector.Frames')
         if np.dtype(space.dtype) != np.uint8 or tuple(space.shape[-2:]) != (84, 84):
@@ -321,12 +319,20 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     experience = Experience(config.batch_size, config.bptt_horizon, _cfg(config, 'minibatch_size', None),
                             obs_stride, total_agents, device, obs_bytes=fp.obs_dim if conv else None)
     optimizer = HipAdam(fp, lr=config.learning_rate, eps=1e-5)
-    lstm_engine = cnn_engine = None
-    if conv:
+    lstm_engine = cnn_engine = gen_engine = None
+    from . import general
+    if isinstance(fp, general.GeneralParams):
+        # a policy shape outside the fused kernels (wide Default, wide / conv LSTM): GEMM-path engine for rollout steps and updates
+        gen_engine = general.Engine(fp, experience, total_agents)
+        policy.gen_engine = gen_engine
+        policy._evaluator = None
+        if gen_engine.lstm_h is not None:
+            experience.lstm_h, experience.lstm_c = gen_engine.lstm_h, gen_engine.lstm_c
+    elif conv:
         cnn_engine = policy.cnn_engine
         cnn_engine.experience = experience
         cnn_engine._alloc(min(8192, max(experience.minibatch_size, total_agents)))
-    if recurrent:
+    if recurrent and gen_engine is None:
         from . import lstm as plstm
         lstm_engine = plstm.Engine(fp, experience, vecenv)
         experience.lstm_h, experience.lstm_c = lstm_engine.lstm_h, lstm_engine.lstm_c   # clean_pufferl.py:407-412
@@ -342,7 +348,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         experience=experience, profile=profile, losses=losses, wandb=wandb, global_step=0, epoch=0, stats={},
         msg=msg, last_log_time=0, utilization=utilization,
         # engine state
-        flat_params=fp, rank=rank, world_size=world, native_dp=native_dp, lstm_engine=lstm_engine, cnn_engine=cnn_engine,
+        flat_params=fp, rank=rank, world_size=world, native_dp=native_dp, lstm_engine=lstm_engine, cnn_engine=cnn_engine, gen_engine=gen_engine,
         env_offset=env_offset, host_bridge=host_bridge,
         workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
         grads=torch.zeros(fp.count + 16, dtype=torch.float32, device=device),   # gradient + 8 loss sums as (hi, lo) float pairs
@@ -381,6 +387,10 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
+    if data.gen_engine is not None:       # a policy shape outside the fused kernels: GEMM-path policy step + store + send per step
+        with profile.eval_forward:
+            _rollout_stepwise(data, noise, T, N)
+        return _finish_evaluate(data, N, T)
     if isinstance(vecenv, (Memory, Synthetic)) and data.lstm_engine is not None:   # recurrent policy: one persistent kernel
         with profile.env:
             if hasattr(vecenv, 'ensure_tape'):
@@ -434,6 +444,11 @@ def evaluate(data):
     return _finish_evaluate(data, N, T)
 
 
+def _frames_policy(data):
+    """True when observations are uint8 frames (models.Convolutional, with or without an LSTM on top): rows are moved as bytes."""
+    return data.cnn_engine is not None or (data.gen_engine is not None and data.gen_engine.net.kind == 'cnn')
+
+
 def _rollout_stepwise(data, noise, T, N):
     """clean_pufferl.evaluate's loop (clean_pufferl.py:84-124) for a device vecenv without a fused rollout kernel: per step
     policy forward + sample (one kernel, MLP or recurrent), Experience.store (one kernel), vecenv.device_send (one kernel)."""
@@ -453,7 +468,9 @@ def _rollout_stepwise(data, noise, T, N):
     for t in range(T):
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step + t)
         nz = None if noise is None else noise[t]
-        if data.cnn_engine is not None:
+        if data.gen_engine is not None:
+            data.gen_engine.policy_step(vecenv.obs_buf, N, nz, key, vecenv.env_offset, actions, logprob, None, value)
+        elif data.cnn_engine is not None:
             data.cnn_engine.policy_step(vecenv.obs_buf, N, nz, key, vecenv.env_offset, actions, logprob, None, value)
         elif eng is None:
             _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(vecenv.obs_buf), N, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(nz),
@@ -465,7 +482,7 @@ def _rollout_stepwise(data, noise, T, N):
                                               vecenv.env_offset, _lib.ptr(actions), _lib.ptr(logprob), None, _lib.ptr(value),
                                               stream), 'lstm_policy_step')
         # (frame rows are bytes: the copy moves them as obs_dim / 4 four-byte words)
-        _lib.check(L.pfa_store_step(C.byref(exp.c), t, N, fp.obs_dim // 4 if data.cnn_engine is not None else fp.obs_stride, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
+        _lib.check(L.pfa_store_step(C.byref(exp.c), t, N, fp.obs_dim // 4 if _frames_policy(data) else fp.obs_stride, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
                                     _lib.ptr(vecenv.terminals_u8), _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(value), stream),
                    'store_step')
         vecenv.device_send(actions)
@@ -571,7 +588,8 @@ def train(data):
     global_mb_rows = experience.minibatch_size * world
     loss_scale = 1.0 / (global_mb_rows * nmb)
     epochs_run = 0
-    eng = data.lstm_engine if data.lstm_engine is not None else data.cnn_engine   # multi-kernel updates: recurrent (lstm.py) / conv (cnn.py)
+    # multi-kernel updates: recurrent (lstm.py) / conv (cnn.py) / any other shape (general.py)
+    eng = data.gen_engine if data.gen_engine is not None else (data.lstm_engine if data.lstm_engine is not None else data.cnn_engine)
     if eng is not None:
         for epoch in range(config.update_epochs):
             eng.state = None                      # lstm_state = None (clean_pufferl.py:176)
@@ -723,6 +741,8 @@ def try_load_checkpoint(data):
             v.copy_(sd[k])
     if data.cnn_engine is not None:
         data.cnn_engine.version += 1          # the packed weight forms are stale
+    if data.gen_engine is not None:
+        data.gen_engine.net.version += 1
     data.optimizer.load_state_dict(resume['optimizer_state_dict'])
     data.global_step = resume['global_step']
     data.epoch = resume['update']

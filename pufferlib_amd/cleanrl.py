@@ -3,8 +3,13 @@
 ``policy(obs)`` (rollout mode, action=None) returns (actions, logprob, entropy, value) like the reference; the
 multinomial draw is argmax(softmax(logits)/q) with q ~ Exp(1) from either an explicit ``noise`` tensor (parity with
 torch.multinomial given its exponential draw) or the Philox stream keyed by ``seed`` (include/pufferlib_amd.h).
-``policy(obs, action=...)`` (training mode) is not offered as a standalone op: the fused update kernel owns that
-path (pufferlib_amd.clean_pufferl.train)."""
+``policy(obs, action=...)`` (training mode, cleanrl.py:60-66,87-93) returns the log-probability of the GIVEN actions, the entropy and
+the value through the GEMM path (pufferlib_amd.general.Evaluator) for every policy shape; no autograd graph is attached — the
+gradients of these quantities are computed by pufferlib_amd.clean_pufferl.train()'s kernels.
+
+Policy shapes outside the fused kernels' envelope (Default(hidden_size != 128), observation rows wider than 128 / 160 floats, more
+than 15 logits, LSTMWrapper sizes other than (128, 128), LSTMWrapper over the NatureCNN) adopt a general.GeneralParams buffer and
+run rollout and update through general.Engine."""
 import ctypes as C
 
 import torch
@@ -17,11 +22,61 @@ RECURRENT_STRIDES = KERNEL_STRIDES + (160,)  # the recurrent path also takes Min
 
 
 def obs_stride_for(obs_dim, recurrent=False):
+    """Row stride (floats) of a flat observation: the narrowest stride the fused kernels are built for, or — wider rows run in the
+    GEMM path (general.py) — the next multiple of 16."""
     for s in (RECURRENT_STRIDES if recurrent else KERNEL_STRIDES):
         if obs_dim <= s:
             return s
-    raise NotImplementedError(f'flat observation of {obs_dim} floats: the MLP kernels take rows of up to 128 floats, the '
-                              'recurrent path up to 160')
+    return (obs_dim + 15) // 16 * 16
+
+
+def needs_general(policy_module, recurrent):
+    """True when the policy's shape is outside what the fused kernels are instantiated for (see the module docstring)."""
+    from .models import HIDDEN, decoder_heads, find_lstm, find_mlp
+    lstm = find_lstm(policy_module)
+    if find_cnn(policy_module) is not None:
+        return lstm is not None
+    mlp = find_mlp(policy_module)
+    H, D = mlp.encoder.weight.shape
+    nvec = decoder_heads(mlp)
+    if H != HIDDEN or sum(nvec) > 15 or D > (RECURRENT_STRIDES if recurrent else KERNEL_STRIDES)[-1]:
+        return True
+    return lstm is not None and (lstm.input_size, lstm.hidden_size) != (HIDDEN, HIDDEN)
+
+
+def _adopt(self, obs_stride, device, recurrent):
+    """Shared by Policy / RecurrentPolicy: move the parameters into one flat device buffer (idempotent for the same stride/device)."""
+    if needs_general(self.policy, recurrent):
+        from . import general
+        if (self._flat is None or not isinstance(self._flat, general.GeneralParams) or self._flat.flat.device != torch.device(device)
+                or (self._flat.kind == 'mlp' and obs_stride and self._flat.obs_stride != obs_stride)):
+            self._flat = general.GeneralParams(self.policy, device, obs_stride or None)
+            self._evaluator = None
+        return self._flat
+    if (self._flat is None or self._flat.obs_stride != obs_stride or self._flat.flat.device != torch.device(device)):
+        self._flat = FlatParams(self.policy, obs_stride, device)
+        self._evaluator = None
+    return self._flat
+
+
+def _evaluator(self, device, recurrent):
+    """general.Evaluator over this policy's parameter buffer (built on first use; re-packs its operand copies on every call: the
+    fused update kernels change the parameters without telling it)."""
+    from . import general
+    if self._flat is None:
+        D = general.find_mlp(self.policy).encoder.weight.shape[1] if find_cnn(self.policy) is None else 0
+        self.adopt(obs_stride_for(int(D), recurrent) if D else 0, device)
+    if getattr(self, '_evaluator', None) is None:
+        if isinstance(self._flat, general.GeneralParams):
+            eng = getattr(self, 'gen_engine', None)
+            net = eng.net if eng is not None else general._net_for_general(self._flat)
+        elif isinstance(self._flat, ConvParams):
+            raise NotImplementedError('policy(obs, action=...) for the non-recurrent models.Convolutional: wrap it in LSTMWrapper or use train()')
+        else:
+            net = general.net_for_flat(self._flat)
+        self._evaluator = general.Evaluator(net)
+    self._evaluator.net.version += 1
+    return self._evaluator
 
 
 class Policy(torch.nn.Module):
@@ -40,10 +95,7 @@ class Policy(torch.nn.Module):
                 self._flat = ConvParams(self.policy, device)
                 self.cnn_engine = cnn.Engine(self._flat, chunk=256)       # grows on demand (Engine._alloc)
             return self._flat
-        if (self._flat is None or self._flat.obs_stride != obs_stride
-                or self._flat.flat.device != torch.device(device)):
-            self._flat = FlatParams(self.policy, obs_stride, device)
-        return self._flat
+        return _adopt(self, obs_stride, device, False)
 
     @property
     def flat_params(self):
@@ -55,6 +107,8 @@ class Policy(torch.nn.Module):
         state = dict(self.__dict__)
         state['_flat'] = None
         state.pop('cnn_engine', None)
+        state.pop('gen_engine', None)
+        state.pop('_evaluator', None)
         return state
 
     def get_value(self, x, state=None):
@@ -64,9 +118,6 @@ class Policy(torch.nn.Module):
         return self.forward(x, action=action, noise=noise)
 
     def forward(self, x, action=None, noise=None):
-        if action is not None:
-            raise NotImplementedError('training-mode forward lives in the fused PPO update kernel '
-                                      '(pufferlib_amd.clean_pufferl.train)')
         _lib.require_gpu()
         L = _lib.lib()
         if not x.is_cuda:
@@ -74,6 +125,19 @@ class Policy(torch.nn.Module):
         rows = x.shape[0]
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]
+        general_shape = needs_general(self.policy, False)
+        if action is not None or general_shape:
+            # given actions (cleanrl.py:60-66 with action=...): log-prob / entropy / value of THOSE actions; or a policy shape that
+            # runs in the GEMM path altogether
+            if find_cnn(self.policy) is not None and not general_shape:
+                raise NotImplementedError('policy(frames, action=...) for the non-recurrent models.Convolutional')
+            ev = _evaluator(self, x.device, False)
+            key = None
+            if action is None and noise is None:
+                key = _lib.NoiseKey(self.noise_seed, self.noise_step)
+                self.noise_step += 1
+            a, logprob, entropy, value, _ = ev.forward(x2, action=action, noise=noise, key=key)
+            return (action if action is not None else self._flat.unpack_actions(a)), logprob, entropy, value
         if find_cnn(self.policy) is not None:
             return self._forward_cnn(x2, rows, noise)
         stride = obs_stride_for(D)
@@ -149,25 +213,39 @@ class RecurrentPolicy(torch.nn.Module):
         raise ValueError('Policy must have a subnetwork named lstm or recurrent')
 
     def adopt(self, obs_stride, device):
-        if (self._flat is None or self._flat.obs_stride != obs_stride
-                or self._flat.flat.device != torch.device(device)):
-            self._flat = FlatParams(self.policy, obs_stride, device)
-        return self._flat
+        return _adopt(self, obs_stride, device, True)
 
     @property
     def flat_params(self):
         return self._flat
 
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state['_flat'] = None
+        state.pop('gen_engine', None)
+        state.pop('_evaluator', None)
+        return state
+
     def get_action_and_value(self, x, state=None, action=None, noise=None):
         return self.forward(x, state=state, action=action, noise=noise)
 
     def forward(self, x, state=None, action=None, noise=None):
-        if action is not None:
-            raise NotImplementedError('training-mode forward lives in pufferlib_amd.clean_pufferl.train (BPTT path)')
         from . import lstm as plstm
         _lib.require_gpu()
         if not x.is_cuda:
             x = x.cuda()
+        if action is not None or needs_general(self.policy, True):
+            # cleanrl.py:87-93: (B, obs...) or (B, TT, obs...) through encoder -> LSTM over TT steps -> heads, with the given actions
+            # scored (or, for a policy shape outside the fused kernels, sampled) — the GEMM path
+            ev = _evaluator(self, x.device, True)
+            obs_shape = getattr(self.policy, 'obs_shape', None)
+            key = None
+            if action is None and noise is None:
+                key = _lib.NoiseKey(self.noise_seed, self.noise_step)
+                self.noise_step += 1
+            a, logprob, entropy, value, new_state = ev.forward(x, action=action, state=state, noise=noise, key=key,
+                                                               obs_rank=len(obs_shape) if obs_shape is not None else None)
+            return (action if action is not None else self._flat.unpack_actions(a)), logprob, entropy, value, new_state
         rows = x.shape[0]
         x2 = x.reshape(rows, -1)
         D = x2.shape[1]

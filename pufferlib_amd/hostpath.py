@@ -126,7 +126,13 @@ def evaluate(data):
             actions = torch.empty(n, dtype=torch.int64, device=bridge.obs.device)
             logprob = torch.empty(n, device=bridge.obs.device)
             value = torch.empty(n, device=bridge.obs.device)
-            if data.cnn_engine is not None:                          # models.Convolutional on the staged uint8 frames
+            if data.gen_engine is not None:                          # a policy shape outside the fused kernels (general.py)
+                ids = None
+                if data.gen_engine.lstm_h is not None:               # state rows of these agents (clean_pufferl.py:100-105)
+                    bridge.ids64[:n].copy_(bridge.ids[:n])
+                    ids = bridge.ids64[:n]
+                data.gen_engine.policy_step(bridge.obs, n, noise, key, row0, actions, logprob, None, value, ids=ids)
+            elif data.cnn_engine is not None:                        # models.Convolutional on the staged uint8 frames
                 data.cnn_engine.policy_step(bridge.obs, n, noise, key, row0, actions, logprob, None, value)
             elif eng is None:
                 _lib.check(L.pfa_mlp_forward_sample(_lib.ptr(bridge.obs), n, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(noise),
@@ -148,7 +154,7 @@ def evaluate(data):
         with profile.eval_misc:
             # (frame rows are bytes: the copy moves them as obs_dim / 4 four-byte words)
             _lib.check(L.pfa_store_rows(C.byref(experience.c), n, bridge.total_agents,
-                                        fp.obs_dim // 4 if data.cnn_engine is not None else fp.obs_stride, _lib.ptr(bridge.obs),
+                                        fp.obs_dim // 4 if (data.cnn_engine is not None or (data.gen_engine is not None and data.gen_engine.net.kind == 'cnn')) else fp.obs_stride, _lib.ptr(bridge.obs),
                                         _lib.ptr(bridge.rew), _lib.ptr(bridge.done), _lib.ptr(actions), _lib.ptr(logprob),
                                         _lib.ptr(value), _lib.ptr(bridge.ids), _lib.ptr(bridge.mask), _lib.ptr(bridge.counters),
                                         _lib.ptr(bridge.stored_dropped), stream), 'store_rows')

@@ -25,8 +25,9 @@ class Default(nn.Module):
 
     def __init__(self, env, hidden_size=HIDDEN):
         super().__init__()
-        if hidden_size != HIDDEN:
-            raise ValueError(f'pufferlib_amd.models.Default supports hidden_size={HIDDEN} only')
+        if hidden_size < 16 or hidden_size % 16 != 0:     # 128 runs in the fused kernels, any other width in the GEMM path (general.py)
+            raise ValueError(f'pufferlib_amd.models.Default: hidden_size must be a multiple of 16 (got {hidden_size})')
+        self.hidden_size = int(hidden_size)
         self.obs_dim = int(np.prod(env.single_observation_space.shape))
         self.encoder = nn.Linear(self.obs_dim, hidden_size)
         self.is_multidiscrete = hasattr(env.single_action_space, 'nvec')
@@ -45,13 +46,17 @@ class Default(nn.Module):
 
 
 class LSTMWrapper(nn.Module):
-    """pufferlib.models.LSTMWrapper (models.py:64-111): policy.encode_observations -> nn.LSTM(128, 128, 1) ->
-    policy.decode_actions; LSTM weights orthogonal (gain 1), biases 0.  Parameter container like ``Default``."""
+    """pufferlib.models.LSTMWrapper (models.py:64-111): policy.encode_observations -> nn.LSTM(input_size, hidden_size, 1) ->
+    policy.decode_actions; LSTM weights orthogonal (gain 1), biases 0.  Parameter container like ``Default``.  (128, 128) over
+    ``Default`` runs in the fused recurrent kernels; any other sizes — and the NatureCNN underneath, environments/atari/torch.py:4-6 —
+    in the GEMM path (general.py).  As in the reference the heads of `policy` must read hidden_size features."""
 
     def __init__(self, env, policy, input_size=HIDDEN, hidden_size=HIDDEN, num_layers=1):
         super().__init__()
-        if (input_size, hidden_size, num_layers) != (HIDDEN, HIDDEN, 1):
-            raise ValueError(f'pufferlib_amd.models.LSTMWrapper supports nn.LSTM({HIDDEN}, {HIDDEN}, 1) only')
+        if num_layers != 1:
+            raise ValueError('pufferlib_amd.models.LSTMWrapper supports num_layers=1 (the reference default, models.py:65)')
+        if hidden_size % 16 != 0 or input_size % 16 != 0:
+            raise ValueError('pufferlib_amd.models.LSTMWrapper: input_size and hidden_size must be multiples of 16')
         self.obs_shape = env.single_observation_space.shape
         self.policy = policy
         self.input_size, self.hidden_size = input_size, hidden_size

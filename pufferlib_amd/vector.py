@@ -291,6 +291,14 @@ class Squared:
         self.sends += 1
         self.infos = self._collect_infos() if self.info_mode == 'sync' else []
 
+    def device_send(self, actions):
+        """send() for a device int64 tensor of actions, no protocol bookkeeping and no host sync (rollout loops of policies
+        without a fused rollout kernel); the caller has drawn the reset rounds (ensure_tape)."""
+        self._wait_tape()
+        _lib.check(self.L.pfa_squared_send(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(actions), *self._live(),
+                                           _lib.stream_handle()), 'send')
+        self.sends += 1
+
     def recv(self):
         recv_precheck(self)
         return (self.observations, self.rewards, self.terminals, self.truncations, self.infos, self.agent_ids,

@@ -44,12 +44,31 @@ def test_flat_params_layout_matches_native_offsets(recurrent):
 def test_obs_stride_selection():
     from pufferlib_amd import hostpath
     assert [hostpath.obs_stride_for(d) for d in (1, 16, 17, 49, 64, 65, 96, 97, 128)] == [16, 16, 32, 64, 64, 96, 96, 128, 128]
-    with pytest.raises(NotImplementedError):
-        hostpath.obs_stride_for(129)
+    # wider rows run in the GEMM path (general.py): the next multiple of 16
+    assert [hostpath.obs_stride_for(d) for d in (129, 300, 1024)] == [144, 304, 1024]
     # the recurrent path also takes MiniGrid-shaped 160-byte rows (BASELINE configs[2])
-    assert [hostpath.obs_stride_for(d, True) for d in (49, 128, 129, 155, 160)] == [64, 128, 160, 160, 160]
-    with pytest.raises(NotImplementedError):
-        hostpath.obs_stride_for(161, True)
+    assert [hostpath.obs_stride_for(d, True) for d in (49, 128, 129, 155, 160, 161)] == [64, 128, 160, 160, 160, 176]
+
+
+def test_which_policy_shapes_take_the_gemm_path():
+    """cleanrl.needs_general: the fused kernels cover Default(128) on rows of up to 128 (160 recurrent) floats with up to 15 logits
+    and LSTMWrapper(128, 128); every other shape of the reference's models goes through general.py."""
+    from pufferlib_amd import cleanrl, models, namespace, spaces
+
+    def env(obs, act):
+        return namespace(single_observation_space=spaces.Box(low=-1, high=1, shape=(obs,), dtype=np.float32), single_action_space=act)
+    d8 = spaces.Discrete(8)
+    assert not cleanrl.needs_general(models.Default(env(49, d8)), False)
+    assert cleanrl.needs_general(models.Default(env(49, d8), hidden_size=256), False)
+    assert cleanrl.needs_general(models.Default(env(300, d8)), False)
+    assert cleanrl.needs_general(models.Default(env(49, spaces.Discrete(40))), False)
+    assert not cleanrl.needs_general(models.LSTMWrapper(env(160, d8), models.Default(env(160, d8))), True)
+    assert cleanrl.needs_general(models.LSTMWrapper(env(49, d8), models.Default(env(49, d8), hidden_size=256), input_size=256, hidden_size=256), True)
+    frames = namespace(single_observation_space=spaces.Box(low=0, high=255, shape=(4, 84, 84), dtype=np.uint8), single_action_space=spaces.Discrete(4))
+    assert not cleanrl.needs_general(models.Convolutional(frames), False)
+    assert cleanrl.needs_general(models.LSTMWrapper(frames, models.Convolutional(frames), input_size=512, hidden_size=512), True)
+    with pytest.raises(ValueError):
+        models.Default(env(49, d8), hidden_size=100)
 
 
 def test_experience_shape_checks_raise_before_touching_the_gpu():
