@@ -348,7 +348,9 @@ def main():
     L = _lib.lib()
     K, W = args.steps, args.warmup
     per_gpu = NUM_ENVS * HORIZON
+    cnn_lstm = False
     if args.workload == 'c4':
+        cnn_lstm = args.policy == 'lstm'       # environments/atari/torch.py:4-6: LSTMWrapper(512, 512) over the NatureCNN (GEMM path, general.py)
         args.policy = 'cnn'
         vec = vector.make(vector.make_frames, env_kwargs=dict(framestack=4, num_actions=4, episode_length=100), num_envs=NUM_ENVS,
                           backend=vector.Frames)
@@ -361,6 +363,8 @@ def main():
                           backend=vector.Squared, obs_stride=64)
     if args.policy == 'lstm':
         pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
+    elif args.policy == 'cnn' and cnn_lstm:
+        pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Convolutional(vec.driver_env, framestack=4), input_size=512, hidden_size=512))
     elif args.policy == 'cnn':
         pol = cleanrl.Policy(models.Convolutional(vec.driver_env, framestack=4))
     else:
@@ -468,6 +472,9 @@ def main():
             # the rows-form kernel runs every forward and dX product of the step (launches of different shapes): algorithmic flop of
             # all of them over their summed duration.  Rollout: B forwards; update: EPOCHS x B x (forward + dX)
             step_flop = per_gpu * (CNN_FWD_FLOP + EPOCHS * (CNN_FWD_FLOP + CNN_DX_FLOP))
+            if cnn_lstm:   # + the LSTM's gate product [x | h] Wcat^T (1024 x 2048) forward, its transpose in the BPTT, and the heads' two
+                lstm_f = 2 * 1024 * 2048
+                step_flop += per_gpu * (lstm_f + 2 * 512 * 16 + EPOCHS * (2 * lstm_f + 2 * 2 * 512 * 16))
             achieved = step_flop * K / (total_ms * 1e-3) / 1e12 if launches else 0.0
             flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
         traffic, traffic_source = pmc_traffic(dominant)
@@ -478,7 +485,7 @@ def main():
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': (f'synthetic Atari-shaped frames (uint8 (4,84,84), 4 actions, 100-step episodes), {NUM_ENVS} envs/GPU x {HORIZON} steps, '
-                                    f'NatureCNN (models.Convolutional), {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[3]; env parity '
+                                    f'NatureCNN (models.Convolutional){" + LSTMWrapper(512, 512)" if cnn_lstm else ""}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[3]; env parity '
                                     'unpinned: third-party emulator' + (', sharded' if world > 1 else '') + ')')
                        if args.workload == 'c4' else
                        (f'synthetic MiniGrid-shaped rows (160 bytes as 160 f32, 7 actions, 100-step episodes), {NUM_ENVS} envs/GPU x '
@@ -539,7 +546,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)
-            if args.workload == 'c4':
+            if args.workload == 'c4' and not cnn_lstm:
                 out['cpu_baseline'] = cpu_baseline_c4()
             elif args.policy == 'mlp':          # the headline configuration; the recurrent side workloads carry none
                 out['cpu_baseline'] = cpu_baseline()
@@ -549,7 +556,9 @@ def main():
             del data, vec, pol
             torch.cuda.empty_cache()
             out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),
-                                      extra_workload(['--workload', 'c4', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0'])]
+                                      extra_workload(['--workload', 'c4', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0']),
+                                      # the recurrent NatureCNN of environments/atari/torch.py:4-6 (GEMM path, general.py)
+                                      extra_workload(['--workload', 'c4', '--policy', 'lstm', '--steps', '2', '--warmup', '1', '--sustained-seconds', '0'])]
         print(json.dumps(out), flush=True)
     if world > 1:
         from pufferlib_amd import dist as pdist

@@ -19,6 +19,7 @@ Fixtures written (all small, committed):
   stochastic.npz     pufferlib.vector.Serial over ocean make_stochastic (ocean.py:529-582): deterministic trajectories
   ppo_mlp.npz        clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with models.Default
   ppo_lstm.npz       same with models.LSTMWrapper (models.py:64-111)
+  ppo_mlp_h256.npz   same as ppo_mlp with models.Default(hidden_size=256) (models.py:24): a width outside the fused kernels (`make_golden.py wide`)
   ppo_mp.npz         same as ppo_mlp over the reference's own pufferlib.vector.Multiprocessing backend (vector.py:218-447) in
                      EnvPool mode (8 of 16 envs per recv): every recv() batch, the noise, the actions sent back, the sorted experience
   ppo_cnn.npz        same with models.Convolutional (models.py:113-157, NatureCNN) on a stub env with uint8 (4, 84, 84) frames;
@@ -314,7 +315,7 @@ def gen_nativize(rows_per_case=21):
     np.savez_compressed(os.path.join(HERE, 'nativize.npz'), **out)
 
 
-def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2, env='squared'):
+def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2, env='squared', hidden=128):
     import pufferlib
     import pufferlib.vector
     import pufferlib.models
@@ -344,9 +345,9 @@ def gen_ppo(tag, use_rnn, num_envs=16, horizon=32, iters=2, env='squared'):
     vec = pufferlib.vector.make(ocean.env_creator(env), num_envs=num_envs, backend=pufferlib.vector.Serial)
 
     torch.manual_seed(1)
-    policy = pufferlib.models.Default(vec.driver_env, hidden_size=128)
+    policy = pufferlib.models.Default(vec.driver_env, hidden_size=hidden)
     if use_rnn:
-        policy = pufferlib.models.LSTMWrapper(vec.driver_env, policy, input_size=128, hidden_size=128)
+        policy = pufferlib.models.LSTMWrapper(vec.driver_env, policy, input_size=hidden, hidden_size=hidden)
         policy = pufferlib.frameworks.cleanrl.RecurrentPolicy(policy)
     else:
         policy = pufferlib.frameworks.cleanrl.Policy(policy)
@@ -715,6 +716,9 @@ if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'mp':
         gen_ppo_mp()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'wide':     # pufferlib.models.Default(hidden_size=256): outside the fused kernels' width
+        gen_ppo('mlp_h256', use_rnn=False, hidden=256)
+        sys.exit(0)
     import clean_pufferl  # builds c_gae through pyximport exactly as the reference does (clean_pufferl.py:24-27)
     gen_gae(clean_pufferl.compute_gae)
     gen_squared('d3t1', 64, 3, 1, 1, 60)
@@ -731,5 +735,6 @@ if __name__ == '__main__':
     gen_ppo('mlp', use_rnn=False)
     gen_ppo('lstm', use_rnn=True)
     gen_ppo('spaces', use_rnn=False, env='spaces')
+    gen_ppo('mlp_h256', use_rnn=False, hidden=256)
     gen_ppo_mp()
     gen_ppo_cnn()

@@ -405,3 +405,45 @@ def test_recurrent_nature_cnn_rollout_and_update_vs_oracle():
     def name(k):
         return 'policy.recurrent.' + k if k in ppo_torch.Policy.LSTM_NAMES else 'policy.policy.' + k
     _check_update(data, pol, opol, tr, name)
+
+
+def test_hidden_256_replays_the_reference_golden(golden_dir):
+    """tests/golden/ppo_mlp_h256.npz: the unmodified reference's create / evaluate / train with models.Default(hidden_size=256) on
+    Serial(Squared) — its multinomial noise in, its actions bit for bit, experience, advantages, losses, weights and Adam moments out."""
+    from pufferlib_amd import clean_pufferl, cleanrl, general, models
+    from test_gpu_ppo import _config, _load_weights, _step_major
+    g = np.load(os.path.join(golden_dir, 'ppo_mlp_h256.npz'))
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    vec = _squared(n)
+    pol = cleanrl.Policy(models.Default(vec.driver_env, hidden_size=256))
+    _load_weights(pol, g, 'w0.')
+    data = clean_pufferl.create(_config(n, horizon, mbs, bptt, epochs, total, [float(x) for x in g['hparams']]), vec, pol)
+    assert isinstance(data.flat_params, general.GeneralParams)
+    exp = data.experience
+    for it in range(iters):
+        assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_used'])) < 1e-12
+        data.noise = torch.as_tensor(g[f'it{it}.noise'])
+        stats, _ = clean_pufferl.evaluate(data)
+        assert np.array_equal(_step_major(exp.actions, n, horizon), g[f'it{it}.actions'].astype(np.int32))
+        assert np.array_equal(_step_major(exp.obs, n, horizon)[:, :49], g[f'it{it}.obs'].astype(np.float32))
+        assert np.array_equal(_step_major(exp.rewards, n, horizon), g[f'it{it}.rewards'])
+        assert np.array_equal(_step_major(exp.dones, n, horizon), g[f'it{it}.dones'])
+        np.testing.assert_allclose(_step_major(exp.logprobs, n, horizon), g[f'it{it}.logprobs'], **TOL)
+        np.testing.assert_allclose(_step_major(exp.values, n, horizon), g[f'it{it}.values'], **TOL)
+        assert data.global_step == int(g[f'it{it}.global_step'])
+        np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']], g[f'it{it}.stats'], rtol=1e-9)
+        clean_pufferl.train(data)
+        for m in range(exp.num_minibatches):
+            idx = exp.minibatch_rows_index(m)
+            np.testing.assert_allclose(exp.advantages[idx].cpu().numpy(), g[f'it{it}.advantages'][m], **TOL)
+        L = data.losses
+        got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=1e-5, atol=1e-5)
+        sd = pol.state_dict()
+        m_, v_ = data.flat_params.split(data.optimizer.exp_avg), data.flat_params.split(data.optimizer.exp_avg_sq)
+        for k in sd:
+            np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'it{it}.w.{k}'], err_msg=k, **TOL)
+            short = k[len('policy.'):]
+            np.testing.assert_allclose(m_[short].cpu().numpy(), g[f'it{it}.m.{k}'], rtol=1e-4, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(v_[short].cpu().numpy(), g[f'it{it}.v.{k}'], rtol=1e-4, atol=1e-8, err_msg=k)
+        assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-12

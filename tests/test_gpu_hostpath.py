@@ -89,11 +89,12 @@ def test_store_rows_places_rows_by_env_and_counts_drops():
     assert stored == N * T and dropped == N - 1                       # the lagging env used the extra step, the others were dropped
 
 
-def test_create_rejects_wide_observations():
+def test_wide_observations_take_the_gemm_path():
+    """Rows beyond the fused kernels' 128 floats are not rejected any more: they get a stride of the next multiple of 16 and the
+    policy adopts a general.GeneralParams buffer (tests/test_gpu_general.py runs them end to end)."""
     from pufferlib_amd import hostpath
     assert hostpath.obs_stride_for(49) == 64 and hostpath.obs_stride_for(128) == 128
-    with pytest.raises(NotImplementedError):
-        hostpath.obs_stride_for(129)
+    assert hostpath.obs_stride_for(129) == 144 and hostpath.obs_stride_for(1000) == 1008
 
 
 def test_host_path_throughput_report(capsys):

@@ -363,7 +363,8 @@ def test_minigrid_shaped_160_byte_rows_vs_oracle_trainer():
         for k, arr in opol.state_arrays().items():
             key = ('policy.recurrent.' + k) if k.endswith('_l0') else ('policy.policy.' + k)
             np.testing.assert_allclose(sd[key].cpu().numpy(), arr, rtol=1e-5, atol=1e-5, err_msg=k)
-    # the MLP kernels stop at 128 floats per row: loud, not a fallback
-    with pytest.raises(NotImplementedError):
-        clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, hp, seed=3), HostByteRows(n),
-                             cleanrl.Policy(models.Default(vec.driver_env)))
+    # the fused MLP kernels stop at 128 floats per row: the same rows behind a non-recurrent Default take the GEMM path (general.py)
+    from pufferlib_amd import general
+    d2 = clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, hp, seed=3), HostByteRows(n),
+                              cleanrl.Policy(models.Default(vec.driver_env)))
+    assert isinstance(d2.flat_params, general.GeneralParams) and d2.gen_engine is not None and d2.flat_params.obs_stride == 160

@@ -178,4 +178,5 @@ def test_unsupported_combinations_fail_loudly():
     from test_gpu_ppo import _config
     hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
     with pytest.raises(NotImplementedError):
-        clean_pufferl.create(_config(16, 16, 128, 8, 1, 10 ** 5, hp), HostMultiHead(16, [9, 9]), _policy(HostMultiHead(16, [9, 9])))
+        # (two heads of 9 = 18 logits run in the GEMM path now; a head of more than 15 choices does not fit the 4-bit action packing)
+        clean_pufferl.create(_config(16, 16, 128, 8, 1, 10 ** 5, hp), HostMultiHead(16, [16, 2]), _policy(HostMultiHead(16, [16, 2])))

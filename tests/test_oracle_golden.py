@@ -117,7 +117,7 @@ def _replay(golden_dir, tag):
     return g, pol, tr, iters
 
 
-@pytest.mark.parametrize('tag', ['mlp', 'lstm'])
+@pytest.mark.parametrize('tag', ['mlp', 'lstm', 'mlp_h256'])     # mlp_h256: models.Default(hidden_size=256)
 def test_ppo_replay_matches_reference(golden_dir, tag):
     torch.set_num_threads(1)
     g, pol, tr, iters = _replay(golden_dir, tag)
