@@ -108,6 +108,9 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KT = DP / 16, KS = DP / 4, V = DP / 4, W1S = L::W1S;
     constexpr int NLD = (16 * V + 63) / 64;  // float4 loads per lane per tile
     constexpr int kGradPairs = grad_pairs(DP), kGradThreads = grad_threads(DP);
+    // the software-pipelined instruction order costs ~40 registers (double-buffered fragments, all eight dh / hidden-tile fragments
+    // live at once): taken where the instantiation stays inside its register budget without spilling (checked in the ISA)
+    constexpr bool kPipe = PFA_GRAD_PIPE && (DP <= 32 || (DP == 64 && KTM <= 3));
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
     const int pair = wv & (kGradPairs - 1);
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             PFA_STAMP(j, 1);
 
             f32x4 h[kMT];
-#if PFA_GRAD_PIPE
+            if constexpr (kPipe) {
             // Software pipeline over the k-groups of 4 k-steps: the fragments of group k4 + 1 (8 ds_read_b128 of W1 + the X column
             // quad) are issued BEFORE the 32 MFMAs of group k4 and land under them.  Left to itself the compiler sinks every
             // ds_read next to its use and waits lgkmcnt(0) in front of each 4 MFMAs (round-2 ISA: the LDS latency exposed 26 times
@@ -267,7 +270,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                         if (4 * k4 + q < KKU) h[m] = mfma16(wq[k4 & 1][m][q], xb[k4 & 1][q], h[m]);
                 __builtin_amdgcn_sched_barrier(0);
             }
-#else
+            } else {
 #pragma unroll
             for (int m = 0; m < kMT; ++m) h[m] = *reinterpret_cast<const f32x4 *>(b1t + (m * 64 + lane) * 4);
 #pragma unroll
@@ -284,13 +287,13 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                         if (4 * k4 + q < KKU) h[m] = mfma16(wq[q], xb[q], h[m]);
                 }
             }
-#endif
-#if PFA_GRAD_PIPE
+            }
             f32x4 w4h[kMT];   // the heads' A fragments: issued here, they land under the ReLU's VALU stretch
+            if constexpr (kPipe) {
 #pragma unroll
-            for (int m = 0; m < kMT; ++m) w4h[m] = *reinterpret_cast<const f32x4 *>(w2t + (m * 64 + lane) * 4);
-            __builtin_amdgcn_sched_barrier(0);
-#endif
+                for (int m = 0; m < kMT; ++m) w4h[m] = *reinterpret_cast<const f32x4 *>(w2t + (m * 64 + lane) * 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
@@ -298,8 +301,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                         // inline-asm v_max loses the MFMA->VALU hazard wait states; the integer form max(bits, 0) is exact and one
                         // instruction but shifts the block's schedule: 66.8 instead of 64.7 us per launch)
             f32x4 out;
-#if PFA_GRAD_PIPE
-            {
+            if constexpr (kPipe) {
                 f32x4 o[4] = {f32x4{bo[0], bo[1], bo[2], bo[3]}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
                               f32x4{0.f, 0.f, 0.f, 0.f}};  // four independent chains
 #pragma unroll
@@ -309,9 +311,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
                         for (int q = 0; q < 4; ++q) o[q] = mfma16(w4h[m0 + q][r], h[m0 + q][r], o[q]);
                 out = (o[0] + o[1]) + (o[2] + o[3]);  // out^T[o = 4g + r][row = c]
-            }
-#else
-            {
+            } else {
                 f32x4 o[4] = {f32x4{bo[0], bo[1], bo[2], bo[3]}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
                               f32x4{0.f, 0.f, 0.f, 0.f}};  // four independent chains
 #pragma unroll
@@ -326,7 +326,6 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 }
                 out = (o[0] + o[1]) + (o[2] + o[3]);  // out^T[o = 4g + r][row = c]
             }
-#endif
             if (out[0] == 12345.678f) PFA_STAMP(j, 7);   // (never true) pins the stamp behind the heads' result
             PFA_STAMP(j, 2);
             LossOut lo;
@@ -358,7 +357,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             __syncthreads();  // beta_j
             PFA_STAMP(j, 5);
             // ---- dW2v^T[u][o] += hidden^T . dout, both operands back from LDS in A/B fragment order -----------------------
-#if PFA_GRAD_PIPE
+            if constexpr (kPipe) {
             if (!(ABL & 2)) {
                 float dfrag[4];  // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c)
                 float hrow[kMT][4];
@@ -374,7 +373,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
                     for (int m = 0; m < kMT; ++m) acc_dw2[m] = mfma16(hrow[m][r], dfrag[r], acc_dw2[m]);   // 8 independent chains
             }
-#else
+            } else {
             if (!(ABL & 2)) {
                 float dfrag[4];  // B frags of dout[row][o] (k-slot g <-> row 4g+r, j = o = c)
 #pragma unroll
@@ -392,7 +391,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                         for (int q = 0; q < 4; ++q) acc_dw2[m0 + q] = mfma16(hrow[q][r], dfrag[r], acc_dw2[m0 + q]);
                 }
             }
-#endif
+            }
         }
         __syncthreads();  // alpha_J: matches the consumer's trailing barrier pair
         __syncthreads();  // beta_J
@@ -465,7 +464,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 for (int kt = 0; kt < KTM; ++kt) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
                 xc[r] = COL ? xs[(4 * g + r) * XS + 16 * KTM] : 0.0f;
             }
-#if PFA_GRAD_PIPE
+            if constexpr (kPipe) {
             // every LDS read of the tile is issued up front (dout, the X fragments above, the W2v fragments, the hidden tile for
             // relu'), then three dense stretches: 32 MFMAs of dh (8 chains), the relu' / db1 / column VALU, 32 KTM MFMAs of dW1
             f32x4 dh[kMT], wb[kMT];
@@ -498,7 +497,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 for (int m = 0; m < kMT; ++m)
 #pragma unroll
                     for (int kt = 0; kt < KTM; ++kt) acc_dw1[kt][m] = mfma16(xa[kt][r], dh[m][r], acc_dw1[kt][m]);
-#else
+            } else {
 #pragma unroll
             for (int m0 = 0; m0 < kMT; m0 += 4) {  // four hidden tiles = four independent accumulator chains
                 f32x4 dh[4], wb[4];
@@ -513,7 +512,19 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) dh[q] = mfma16(dout[r], wb[q][r], dh[q]);
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr (DP > 64) {
+                            // Wide rows: the 32 KT dW1 accumulators fill the whole accumulation-register half of the file (256 of 512);
+                            // left to the compiler these short-lived dh accumulators go there too and it spills dW1 tiles around them
+                            // (round-2 ISA: 64 spilled registers).  Pinned to architectural VGPRs instead.
+                            asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(dh[q]) : "v"(dout[r]), "v"(wb[q][r]));
+                        } else {
+                            dh[q] = mfma16(dout[r], wb[q][r], dh[q]);
+                        }
+                    }
+                if constexpr (DP > 64) {   // the inline form is invisible to the hazard recogniser: MFMA (8 passes) -> VALU read needs 11 wait states
+                    asm volatile("s_nop 7\n\ts_nop 3" ::: "memory");
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -529,7 +540,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
                         for (int kt = 0; kt < KTM; ++kt) acc_dw1[kt][m0 + q] = mfma16(xa[kt][r], dh[q][r], acc_dw1[kt][m0 + q]);
             }
-#endif
+            }
         };
         for (int j = 0; j < J; ++j) {
             PFA_STAMP(j, 0);

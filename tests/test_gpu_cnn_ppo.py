@@ -235,3 +235,48 @@ def test_update_in_several_chunks_equals_one_chunk():
         assert torch.equal(acts, out[0][0]) and torch.equal(vals, out[0][1])          # rollout forward: rows are independent
         np.testing.assert_allclose(losses, out[0][3], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(flat.cpu().numpy(), out[0][2].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_one_optimizer_step_over_an_8192_frame_chunk_vs_the_double_precision_oracle(capsys):
+    """The conv update END TO END at the chunk size the bench runs (cnn.Engine walks a 65 536-frame minibatch in 8192-frame chunks):
+    512 envs x 16 steps = one minibatch = one chunk, forward + PPO loss + backward through all four layers + clip + Adam, against
+    the oracle trainer in double precision on the same uint8 frames."""
+    import cnn_golden
+    from oracle import ppo_torch
+    from pufferlib_amd import clean_pufferl
+    n, horizon, bptt = 512, 16, 16
+    B = n * horizon
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    start = cnn_golden.start_weights(cnn_golden.container())
+    vec, pol, data = _trainer(n, horizon, B, bptt, 1, B * 10, hp, 3, start=start, episode_length=11)
+    assert data.cnn_engine.chunk == 8192
+    clean_pufferl.evaluate(data)
+    e = data.experience
+    sm = lambda x: x.view(n, horizon, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    try:
+        torch.set_default_dtype(torch.float64)
+        opol = ppo_torch.ConvPolicy(start, dtype=torch.float64)
+        tr = ppo_torch.Trainer(opol, cnn_golden.ReplayVec.blank(n), batch_size=B, minibatch_size=B, bptt_horizon=bptt, update_epochs=1,
+                               learning_rate=hp[0], gamma=hp[1], gae_lambda=hp[2], clip_coef=hp[3], vf_coef=hp[4], vf_clip_coef=hp[5],
+                               max_grad_norm=hp[6], ent_coef=hp[7], total_timesteps=B * 10, seed=3)
+        tr.obs = torch.as_tensor(sm(e.obs)).to(torch.float64)
+        tr.actions = sm(e.actions).astype(np.int64)
+        tr.logprobs, tr.rewards, tr.dones, tr.values = (sm(x).copy() for x in (e.logprobs, e.rewards, e.dones, e.values))
+        tr.global_step = data.global_step
+        Lo = tr.train()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    clean_pufferl.train(data)
+    L = data.losses
+    keys = ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac')
+    got, want = [getattr(L, k) for k in keys], [Lo[k] for k in keys]
+    np.testing.assert_allclose(got, want, **TOL)
+    sd = pol.state_dict()
+    worst = 0.0
+    for k, arr in opol.state_arrays().items():
+        mine = sd['policy.' + k].cpu().numpy()
+        worst = max(worst, float(np.abs(mine - arr).max()))
+        np.testing.assert_allclose(mine, arr, err_msg=k, **TOL)
+    with capsys.disabled():
+        print(f'\n[conv update, one 8192-frame chunk] max |loss err| {np.abs(np.array(got) - np.array(want)).max():.2e}, max |weight err| {worst:.2e}')

@@ -86,11 +86,11 @@ def _compare(pol, opol, data, Lo, recurrent, tr, what):
     return float(err.max()), worst
 
 
-@pytest.mark.parametrize('recurrent,epochs', [(False, 4), (True, 1)])
+@pytest.mark.parametrize('recurrent,epochs', [(False, 4), (True, 4)])
 def test_full_size_update_through_create_evaluate_train(recurrent, epochs, capsys):
     """BASELINE configs[1] (and configs[2]'s policy): 4096 envs x 128 steps, 4 minibatches of 131 072 rows, bptt 16.
-    MLP: all 4 epochs = the 16 optimizer steps one bench step runs.  LSTM: one epoch (4 steps, state carried across the
-    minibatches) — the oracle's BPTT over 524 288 rows on the host is what bounds the test time."""
+    Both policies: all 4 epochs = the 16 optimizer steps one bench step runs (LSTM: state carried across the minibatches of an
+    epoch, reset at every epoch)."""
     from pufferlib_amd import clean_pufferl
     from test_gpu_ppo import _config
     n, horizon, nmb, bptt = 4096, 128, 4, 16
