@@ -463,9 +463,14 @@ def _rollout_stepwise(data, noise, T, N):
     actions = torch.empty(N, dtype=torch.int64, device=dev)
     logprob = torch.empty(N, device=dev)
     value = torch.empty(N, device=dev)
+    # the reset rounds are drawn ahead in chunks the tape ring can hold (a whole rollout where it fits: one launch instead of one
+    # per resetting send; a long horizon on few envs — e.g. Spaces with batch_size / num_envs >= 512 — in several)
+    tape_chunk = T
     if hasattr(vecenv, 'ensure_tape'):
-        vecenv.ensure_tape(T)        # the whole rollout's reset rounds in one go instead of one launch per resetting send
+        tape_chunk = max(1, min(T, int(getattr(vecenv, 'max_sends_per_tape', T))))
     for t in range(T):
+        if hasattr(vecenv, 'ensure_tape') and t % tape_chunk == 0:
+            vecenv.ensure_tape(min(tape_chunk, T - t))
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step + t)
         nz = None if noise is None else noise[t]
         if data.gen_engine is not None:
@@ -650,6 +655,11 @@ def train(data):
         # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
         _lib.check(L.pfa_train_log_sums(C.byref(experience.c), B, experience.num_envs, _lib.ptr(data.loss_acc),
                                         _lib.ptr(data.log_sums), _lib.ptr(data.workspace), stream), 'train_log_sums')
+        if getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference':
+            # the reference's y_pred is the value buffer in STORAGE order = arrival order here (hostpath.evaluate kept it)
+            yp, ad = data.arrival_values.double(), experience.advantages.double()
+            yt = ad + yp
+            data.log_sums[6:10] = torch.stack([yt.sum(), (yt * yt).sum(), ad.sum(), (ad * ad).sum()])
         if data.native_dp:                                      # explained variance over the GLOBAL batch, like the (global) losses
             _lib.check(L.pfa_dist_all_reduce_f64(C.c_void_p(data.log_sums.data_ptr() + 6 * 8), 4, stream), 'ev all-reduce')
         elif world > 1:
@@ -682,7 +692,7 @@ def train(data):
                 data.wandb.log({
                     '0verview/SPS': profile.SPS, '0verview/agent_steps': data.global_step,
                     '0verview/epoch': data.epoch, '0verview/learning_rate': opt.param_groups[0]['lr'],
-                    **{f'environment/{k}': v for k, v in data.stats.items()},
+                    **{f'environment/{k}': v for k, v in readback.materialize(data.stats).items()},
                     **{f'losses/{k}': v for k, v in data.losses.items()},
                     **{f'performance/{k}': v for k, v in data.profile},
                 })

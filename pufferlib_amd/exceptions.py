@@ -33,13 +33,22 @@ class APIUsageError(RuntimeError):
         self.message = message
         RuntimeError.__init__(self, self.message)
 
+    def __reduce__(self):
+        # rebuilt through THIS class: the combined subclass _resolve may have produced is not importable by name, and an error
+        # that crosses a process boundary (multiprocessing / Ray workers, concurrent.futures) must not become a PicklingError
+        return (APIUsageError, (self.message,))
+
 
 class InvalidAgentError(ValueError):
     def __new__(cls, *args, **kwargs):
         return ValueError.__new__(_resolve(cls, 'InvalidAgentError') if cls is InvalidAgentError else cls, *args)
 
     def __init__(self, agent_id, agents):
+        self.agent_id, self.agents = agent_id, agents
         ValueError.__init__(self, f'Invalid agent/team ({agent_id}) specified. Valid values:\n{agents}')
+
+    def __reduce__(self):
+        return (InvalidAgentError, (self.agent_id, self.agents))
 
 
 class ExtensionError(RuntimeError):

@@ -92,6 +92,23 @@ class HostBridge:
         return out
 
 
+def utils_cfg(config, key, default):
+    return getattr(config, key, default) if not isinstance(config, dict) else config.get(key, default)
+
+
+def _arrival_buffers(data, experience, bridge):
+    """Arrival-order staging of one rollout for config.async_store = 'reference' (allocated once)."""
+    a = getattr(data, '_arrival', None)
+    if a is None:
+        B, dev = experience.batch_size, experience.obs.device
+        a = dict(obs=torch.zeros_like(experience.obs), rewards=torch.zeros(B, device=dev), dones=torch.zeros(B, device=dev),
+                 actions=torch.zeros(B, dtype=torch.int32, device=dev), logprobs=torch.zeros(B, device=dev), values=torch.zeros(B, device=dev),
+                 keys=torch.zeros(B, dtype=torch.int64, device=dev))
+        data._arrival = a
+    a['dropped'] = 0
+    return a
+
+
 def evaluate(data):
     """clean_pufferl.evaluate (clean_pufferl.py:76-154) for a host vecenv."""
     config, profile, experience, vecenv, policy = data.config, data.profile, data.experience, data.vecenv, data.policy
@@ -104,6 +121,15 @@ def evaluate(data):
     bridge.stored_dropped.zero_()
     recvs = 0
     stored = 0
+    # config.async_store = 'reference': Experience.store / sort_training_data exactly as the reference runs them on a pool whose
+    # agents report unevenly (clean_pufferl.py:436-464) — the first batch_size masked rows in ARRIVAL order, then one stable sort by
+    # (env_id, step); agents then own runs of different lengths in the flat batch, which GAE / the minibatch partition / the update
+    # kernels never look at (they walk flat rows).  Default 'balanced': every agent contributes exactly batch_size / num_agents
+    # rows, written straight to their sorted place, surplus rows of fast agents dropped (one kernel, no sort).
+    exact = utils_cfg(config, 'async_store', 'balanced') == 'reference'
+    if exact:
+        arrival = _arrival_buffers(data, experience, bridge)
+        arr_ptr = 0
     eng = data.lstm_engine
     # `while not experience.full` (clean_pufferl.py:84).  "Full" = every agent has its batch_size / num_agents rows: a genuinely
     # async pool (fast workers return more often, vector.py:382-390) keeps being stepped until the slow agents have caught up;
@@ -151,6 +177,34 @@ def evaluate(data):
                 eng.lstm_h[0].index_copy_(0, idx, h)
                 eng.lstm_c[0].index_copy_(0, idx, c)
             policy.noise_step += 1
+        if exact:
+            with profile.eval_misc:
+                m_host = bridge.mask_pin.numpy()[:n].astype(bool)
+                take = np.nonzero(m_host)[0][:experience.batch_size - arr_ptr]     # indices = where(mask)[:batch_size - ptr] (clean_pufferl.py:439-440)
+                k = len(take)
+                if k:
+                    idx = torch.as_tensor(take, dtype=torch.int64).to(bridge.obs.device, non_blocking=True)
+                    sl = slice(arr_ptr, arr_ptr + k)
+                    arrival['obs'][sl] = bridge.obs.index_select(0, idx)
+                    arrival['rewards'][sl] = bridge.rew.index_select(0, idx)
+                    arrival['dones'][sl] = bridge.done.index_select(0, idx).float()
+                    arrival['actions'][sl] = actions.index_select(0, idx).to(torch.int32)
+                    arrival['logprobs'][sl] = logprob.index_select(0, idx)
+                    arrival['values'][sl] = value.index_select(0, idx)
+                    arrival['keys'][sl] = (bridge.ids.index_select(0, idx).to(torch.int64) << 32) + recvs     # sort key (env_id, step)
+                arrival['dropped'] += int(m_host.sum()) - k
+                arr_ptr += k
+                actions_np = bridge.download_actions(actions, n, order, fp.nvec if fp.multidiscrete else None)
+                stored = arr_ptr
+                recvs += 1
+                if recvs > max_recvs:
+                    raise RuntimeError(f'host rollout: {stored} of {experience.batch_size} rows after {recvs} recv() calls')
+                for i in info:
+                    for kk, v in utils.unroll_nested_dict(i):
+                        infos[kk].append(v)
+            with profile.env:
+                vecenv.send(actions_np)
+            continue
         with profile.eval_misc:
             # (frame rows are bytes: the copy moves them as obs_dim / 4 four-byte words)
             _lib.check(L.pfa_store_rows(C.byref(experience.c), n, bridge.total_agents,
@@ -170,8 +224,16 @@ def evaluate(data):
         with profile.env:
             vecenv.send(actions_np)
 
+    if exact:
+        with profile.eval_misc:
+            # sort_training_data (clean_pufferl.py:452-464): one stable sort by (env_id, step), rows gathered into the trainer's buffers
+            perm = torch.argsort(arrival['keys'], stable=True)
+            for name in ('obs', 'rewards', 'dones', 'actions', 'logprobs', 'values'):
+                getattr(experience, name).copy_(arrival[name].index_select(0, perm))
+            data.arrival_values = arrival['values']                 # y_pred of the reference's explained-variance line is in storage order
+            data.sort_perm = perm
     with profile.eval_misc:
-        data.host_rows_dropped = int(bridge.stored_pin[1])          # surplus rows of already-complete agents (async pools)
+        data.host_rows_dropped = arrival['dropped'] if exact else int(bridge.stored_pin[1])   # surplus rows (async pools)
         data.noise = None
         experience.ptr = experience.batch_size
         experience.step = experience.horizon

@@ -61,7 +61,11 @@ class Pending:
 
 class LazyDict(dict):
     """A dict whose contents arrive with a ``Pending`` readback: every read or write first resolves it.  Behaves as a plain
-    dict afterwards (and compares, prints, copies and pickles as one)."""
+    dict afterwards (and compares, prints, copies and pickles as one).
+
+    Limitation (why lazy mode is opt-in, PFA_LAZY_READBACK=1): C code that reads a dict's storage directly — ``json.dumps``'s C
+    encoder, ``PyDict_*`` callers — bypasses the forcing wrappers and sees an unresolved instance as EMPTY.  Hand such consumers
+    ``materialize(d)`` (or ``dict(d)``, which forces).  clean_pufferl materialises before it logs to wandb / the dashboard."""
     __slots__ = ('_pending',)
 
     def __init__(self, pending=None):
@@ -82,6 +86,14 @@ class LazyDict(dict):
     def __reduce__(self):
         self._force()
         return (dict, (dict(dict.items(self)),))
+
+
+def materialize(d):
+    """A plain dict / namespace with the readback resolved: for consumers that bypass the lazy containers' python-level hooks."""
+    if isinstance(d, LazyDict):
+        d._force()
+        return dict(dict.items(d))
+    return d
 
 
 def _forcing(name):

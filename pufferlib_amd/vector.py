@@ -243,6 +243,11 @@ class Squared:
         """Number of reset rounds consumed by sends 1..upto_send (every env resets on sends k*episode_len)."""
         return upto_send // self.episode_len
 
+    @property
+    def max_sends_per_tape(self):
+        """Sends whose reset rounds one ensure_tape() call may draw ahead (half the ring: the other half may still be in use)."""
+        return max(1, (self.tape_rounds // 2) * self.episode_len)
+
     def ensure_tape(self, extra_sends):
         self._wait_tape()
         need = self._rounds_needed(self.sends + extra_sends)
@@ -629,6 +634,10 @@ class Memory(_DeviceVecEnv):
         """Reset rounds consumed by sends 1..upto_send: every env resets on sends k*horizon."""
         return upto_send // self.episode_len
 
+    @property
+    def max_sends_per_tape(self):
+        return max(1, (self.tape_rounds // 2) * self.episode_len)
+
     def ensure_tape(self, extra_sends):
         need = self._rounds_needed(self.sends + extra_sends)
         if need - self._rounds_needed(self.sends) > self.tape_rounds:
@@ -730,6 +739,10 @@ class Spaces(_DeviceVecEnv):
     def _rounds_needed(self, upto_send):
         """Tape rounds consumed by async_reset (round 0) and sends 1..upto_send (every second send is a reset row)."""
         return 1 + upto_send // 2
+
+    @property
+    def max_sends_per_tape(self):
+        return max(2, self.tape_rounds)          # a reset round every second send: half the ring
 
     def ensure_tape(self, extra_sends):
         need = self._rounds_needed(self.sends + extra_sends)

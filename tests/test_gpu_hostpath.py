@@ -199,6 +199,60 @@ def test_uneven_async_pool_fast_workers_return_more_often():
     assert torch.isfinite(data.flat_params.flat).all()
 
 
+def test_reference_exact_store_on_an_uneven_pool():
+    """config.async_store = 'reference' (VERDICT r2 item 10): Experience.store + sort_training_data as the reference runs them when
+    agents report unevenly (clean_pufferl.py:436-464) — the FIRST batch_size masked rows in arrival order, one stable sort by
+    (env_id, step), runs of different lengths per agent — restated here in numpy from the recorded recv()/send() stream."""
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from host_vecenv import HostSquaredPool
+    from oracle import c_oracle
+    from test_gpu_ppo import _config
+    n, workers, horizon = 32, 2, 8
+    B = n * horizon
+    inner = HostSquaredPool(n, workers, schedule=[0, 0, 1])
+    log = dict(recv=[], send=[])
+
+    class Recording:
+        def __getattr__(self, k):
+            return getattr(inner, k)
+
+        def recv(self):
+            out = inner.recv()
+            log['recv'].append(tuple(np.array(x).copy() if not isinstance(x, list) else x for x in out))
+            return out
+
+        def send(self, actions):
+            log['send'].append(np.array(actions).copy())
+            inner.send(actions)
+    vec = Recording()
+    pol = cleanrl.Policy(models.Default(inner.driver_env))
+    data = clean_pufferl.create(_config(n, horizon, B // 2, 4, 1, B * 8, HP, seed=4, async_store='reference'), vec, pol)
+    clean_pufferl.evaluate(data)
+    e = data.experience
+    # the reference's store + sort on the recorded stream
+    rows, ptr = [], 0
+    for step, ((o, r, d, t, info, env_id, mask), a) in enumerate(zip(log['recv'], log['send'])):
+        idx = np.nonzero(mask)[0][:B - ptr]
+        for i in idx:
+            rows.append((int(env_id[i]), step, o[i].reshape(-1), float(r[i]), float(d[i]), int(np.asarray(a).reshape(-1)[i])))
+        ptr += len(idx)
+    assert ptr == B and len(log['recv']) == len(log['send'])
+    order = sorted(range(B), key=lambda j: (rows[j][0], rows[j][1]))
+    per_agent = np.bincount([rows[j][0] for j in range(B)], minlength=n)
+    assert per_agent.min() < horizon < per_agent.max()                    # genuinely uneven: the fast group holds more rows than the slow one
+    want_obs = np.stack([rows[j][2] for j in order])
+    assert np.array_equal(e.obs[:, :49].cpu().numpy(), want_obs)
+    assert np.array_equal(e.rewards.cpu().numpy(), np.array([rows[j][3] for j in order], np.float32))
+    assert np.array_equal(e.dones.cpu().numpy(), np.array([rows[j][4] for j in order], np.float32))
+    assert np.array_equal(e.actions.cpu().numpy(), np.array([rows[j][5] for j in order], np.int32))
+    assert data.host_rows_dropped == sum(int(m.sum()) for (_, _, _, _, _, _, m) in log['recv']) - B
+    clean_pufferl.train(data)
+    # GAE is the reference's single scan over the sorted flat batch (clean_pufferl.py:163-169)
+    want = c_oracle.compute_gae(e.dones.cpu().numpy(), e.values.cpu().numpy(), e.rewards.cpu().numpy(), HP[1], HP[2])
+    np.testing.assert_allclose(e.advantages.cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    assert torch.isfinite(data.flat_params.flat).all() and np.isfinite(data.losses.explained_variance)
+
+
 class _ReplayPool:
     """A host vecenv that hands out, recv by recv, exactly what the REFERENCE's pufferlib.vector.Multiprocessing backend handed
     the reference trainer in tests/golden/ppo_mp.npz (EnvPool mode: 8 of 16 envs per recv, shared-memory worker processes), and

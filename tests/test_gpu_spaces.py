@@ -117,3 +117,20 @@ def test_train_loop_runs_on_device_spaces():
         clean_pufferl.train(data)
     assert data.global_step == 4 * n * horizon
     assert torch.isfinite(data.flat_params.flat).all() and not torch.equal(w0, data.flat_params.flat)
+
+
+def test_long_horizon_on_few_envs_draws_the_tape_in_chunks():
+    """batch_size / num_envs >= 512 on Spaces needs more reset rounds than the tape ring holds at once; the stepwise
+    rollout draws them in chunks (clean_pufferl._rollout_stepwise) instead of asking for the whole rollout up front."""
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from test_gpu_ppo import _config
+    n, horizon = 2, 1024
+    hp = [2.5e-4, 0.99, 0.95, 0.2, 0.5, 0.2, 0.5, 0.001]
+    vec = _make(n)
+    assert horizon // 2 >= vec.tape_rounds                      # the up-front request this used to make would be refused
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 8, 1, n * horizon * 4, hp, seed=5), vec, pol)
+    stats, _ = clean_pufferl.evaluate(data)
+    assert stats['episode_length'] == 1 and data.global_step == n * horizon
+    clean_pufferl.train(data)
+    assert torch.isfinite(data.flat_params.flat).all()

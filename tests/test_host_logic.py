@@ -337,3 +337,29 @@ def test_bench_self_spawn_builds_the_torchrun_command(monkeypatch):
     monkeypatch.setattr(torch.cuda, 'device_count', lambda: 0)
     with pytest.raises(SystemExit):
         bench.self_spawn(argparse.Namespace(gpus=2))
+
+
+def test_combined_exception_classes_survive_pickling(monkeypatch):
+    """ADVICE r2: with pufferlib.exceptions loaded our errors are instances of BOTH packages' classes (a synthesised subclass);
+    they must still cross a process boundary (multiprocessing / Ray / concurrent.futures pickle exceptions)."""
+    import pickle
+    import sys
+    import types
+    from pufferlib_amd import exceptions as ex
+    fake = types.ModuleType('pufferlib.exceptions')
+
+    class APIUsageError(RuntimeError):
+        pass
+
+    class InvalidAgentError(ValueError):
+        pass
+    fake.APIUsageError, fake.InvalidAgentError = APIUsageError, InvalidAgentError
+    monkeypatch.setitem(sys.modules, 'pufferlib.exceptions', fake)
+    e = ex.APIUsageError('Call reset before stepping')
+    assert isinstance(e, APIUsageError) and isinstance(e, ex.APIUsageError) and type(e) is not ex.APIUsageError
+    back = pickle.loads(pickle.dumps(e))
+    assert isinstance(back, ex.APIUsageError) and back.message == 'Call reset before stepping'
+    e2 = ex.InvalidAgentError(3, [1, 2])
+    assert isinstance(e2, InvalidAgentError)
+    back2 = pickle.loads(pickle.dumps(e2))
+    assert isinstance(back2, ex.InvalidAgentError) and str(back2) == str(e2)
