@@ -599,22 +599,28 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 // Fixed-order sum of the workgroup partials (native layout) + scatter into the flat gradient layout, plus one
 // f64 partial of sum(g^2) per block for the gradient-norm clip.  Block = 64 native slots x 4 slices of the
 // partial index; 16 independent loads in flight per thread.
+#ifndef PFA_REDUCE_SLICES
+#define PFA_REDUCE_SLICES 16   // slices of the partial index per slot (4 = the round-2 shape, for A/B timing)
+#endif
+constexpr int kRedSl = PFA_REDUCE_SLICES;
+// (16 slices: 163 workgroups x 16 waves, every thread's 16 loads in flight at once — the reduction is a latency chain over the
+// L2-resident partials, and 4 waves per workgroup left most SIMDs without a wave to hide it)
 template <int DP>
-__global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
-                                                        double *norm_partials) {
+__global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
+                                                                double *norm_partials) {
     using NL = NativeLayout<DP>;
-    __shared__ float sh[4][64];
-    __shared__ double shd[4][64];   // the loss-sum slots are carried in f64
+    __shared__ float sh[kRedSl][64];
+    __shared__ double shd[kRedSl][64];   // the loss-sum slots are carried in f64
     const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + ql;
     float acc = 0.0f;
     double dacc = 0.0;
     if (q < NL::kCount) {
-        for (int i0 = sl; i0 < nparts; i0 += 64) {
+        for (int i0 = sl; i0 < nparts; i0 += 16 * kRedSl) {
             float v[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                const int i = i0 + 4 * u;
+                const int i = i0 + kRedSl * u;
                 v[u] = i < nparts ? partials[(size_t)i * NL::kCount + q] : 0.0f;
             }
 #pragma unroll
@@ -632,7 +638,14 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, 
     float s = 0.0f;
     int p = -1;
     if (q < NL::kCount) {
-        s = (sh[0][ql] + sh[1][ql]) + (sh[2][ql] + sh[3][ql]);
+        float t[kRedSl];
+#pragma unroll
+        for (int w = 0; w < kRedSl; ++w) t[w] = sh[w][ql];
+#pragma unroll
+        for (int w = kRedSl / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int x = 0; x < w; ++x) t[x] += t[x + w];   // fixed tree: deterministic, whatever the slice count
+        s = t[0];
         if (q < NL::kDw2) {
             const int ln = q & 63, r = (q >> 6) & 3, m = (q >> 8) & (kMT - 1), kt = q >> 11;
             p = off.w1 + (16 * m + (ln & 15)) * DP + 16 * kt + 4 * (ln >> 4) + r;
@@ -652,7 +665,9 @@ __global__ void __launch_bounds__(256) ppo_reduce_kernel(const float *partials, 
             else if (o == a) p = off.bv;
         } else {
             // loss sums: summed over the partials in f64 and left as (hi, lo) float pairs behind the gradient
-            const double t = (shd[0][ql] + shd[1][ql]) + (shd[2][ql] + shd[3][ql]);
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kRedSl; ++w) t += shd[w][ql];
             const float hi = (float)t;
             grads[off.count + 2 * (q - NL::kStats)] = hi;
             grads[off.count + 2 * (q - NL::kStats) + 1] = (float)(t - (double)hi);
@@ -756,6 +771,15 @@ __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, 
                                                                 double *losses, double loss_scale, const double *norm_partials,
                                                                 int n_norm_partials) {
     __shared__ double sh[kAdamThreads / 64];
+    // this thread's element: loaded BEFORE the norm reduction, so the two memory latencies overlap instead of adding up
+    const long long i = (long long)blockIdx.x * kAdamThreads + threadIdx.x;
+    float g_i = 0.0f, m = 0.0f, v = 0.0f, p_i = 0.0f;
+    if (i < count) {
+        g_i = grads[i];
+        m = exp_avg[i];
+        v = exp_avg_sq[i];
+        p_i = params[i];
+    }
     double ss = 0.0;
     if (norm_partials) {  // sum(g^2) pieces left by ppo_reduce_kernel (single rank: no all-reduce in between)
         for (int i = threadIdx.x; i < n_norm_partials; i += kAdamThreads) ss += norm_partials[i];
@@ -786,14 +810,12 @@ __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, 
         clip = clip > 1.0f ? 1.0f : clip;
     }
     const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
-    const long long i = (long long)blockIdx.x * kAdamThreads + threadIdx.x;
     if (i < count) {
-        const float gi = grads[i] * grad_scale * clip;
-        float m = exp_avg[i], v = exp_avg_sq[i];
+        const float gi = g_i * grad_scale * clip;
         m = m + w1 * (gi - m);               // exp_avg.lerp_(grad, 1 - beta1)
         v = v * beta2 + w2 * gi * gi;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         const float denom = sqrtf(v) / bc2_sqrt + eps;
-        params[i] = params[i] + neg_step_size * m / denom;  // param.addcdiv_(exp_avg, denom, value=-step_size)
+        params[i] = p_i + neg_step_size * m / denom;  // param.addcdiv_(exp_avg, denom, value=-step_size)
         exp_avg[i] = m;
         exp_avg_sq[i] = v;
     }
@@ -925,15 +947,15 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     double *normp = norm_partials_of(workspace, dims);
     ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
     switch (dims->obs_stride) {
-        case 16: hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3((NativeLayout<16>::kCount + 63) / 64), dim3(256), 0,
+        case 16: hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3((NativeLayout<16>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
                                     (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        case 32: hipLaunchKernelGGL(ppo_reduce_kernel<32>, dim3((NativeLayout<32>::kCount + 63) / 64), dim3(256), 0,
+        case 32: hipLaunchKernelGGL(ppo_reduce_kernel<32>, dim3((NativeLayout<32>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
                                     (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        case 96: hipLaunchKernelGGL(ppo_reduce_kernel<96>, dim3((NativeLayout<96>::kCount + 63) / 64), dim3(256), 0,
+        case 96: hipLaunchKernelGGL(ppo_reduce_kernel<96>, dim3((NativeLayout<96>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
                                     (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        case 128: hipLaunchKernelGGL(ppo_reduce_kernel<128>, dim3((NativeLayout<128>::kCount + 63) / 64), dim3(256), 0,
+        case 128: hipLaunchKernelGGL(ppo_reduce_kernel<128>, dim3((NativeLayout<128>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
                                      (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        default: hipLaunchKernelGGL(ppo_reduce_kernel<64>, dim3((NativeLayout<64>::kCount + 63) / 64), dim3(256), 0,
+        default: hipLaunchKernelGGL(ppo_reduce_kernel<64>, dim3((NativeLayout<64>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
                                     (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
     }
     PFA_LAUNCH_CHECK();

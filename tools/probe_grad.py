@@ -19,7 +19,7 @@ def build():
     so = os.path.join(OUT, 'libprobe.so')
     src = os.path.join(REPO, 'pufferlib_amd', 'csrc')
     cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DPFA_PROBES',
-           '-x', 'hip', os.path.join(src, 'ppo_update.hip'), os.path.join(src, 'common.cpp'), os.path.join(src, 'dist.cpp'), '-ldl', '-o', so]
+           '-x', 'hip', os.path.join(src, 'ppo_update.hip'), os.path.join(src, 'common.cpp'), os.path.join(src, 'dist.cpp'), os.path.join(src, 'p2p.hip'), '-ldl', '-o', so]
     subprocess.check_call(cmd)
     return so
 
