@@ -63,14 +63,16 @@ struct GradLds {
 
 // "Native" layout of one workgroup partial: gradients in MFMA C-fragment order (conflict-free LDS reduction and
 // coalesced global traffic); ppo_reduce_kernel undoes the permutation once.
-template <int DP>
+template <int DP, int KTM = DP / 16, bool COL = false>
 struct NativeLayout {
-    static constexpr int KT = DP / 16;
-    static constexpr int kDw1 = 0;                          // ((kt*8+m)*4+r)*64 + lane -> W1[16m+c][16kt+4g+r]
-    static constexpr int kDw2 = kDw1 + KT * kMT * 4 * 64;   // ((m*4+r)*64 + lane)      -> W2v[o=c][16m+4g+r]
-    static constexpr int kDb1 = kDw2 + kMT * 4 * 64;        // u
-    static constexpr int kDb2 = kDb1 + kHidden;             // o (16)
-    static constexpr int kStats = kDb2 + kOut;              // 8
+    // only what the instantiation computes travels: KTM k-tiles of dW1 and, with COL, the one trailing column (the 7x7 grid's
+    // column 48) — the remaining k-tiles are observation padding, their gradient is zero and nobody writes or sums them
+    static constexpr int kDw1 = 0;                           // ((kt*8+m)*4+r)*64 + lane -> W1[16m+c][16kt+4g+r], kt < KTM
+    static constexpr int kCol = kDw1 + KTM * kMT * 4 * 64;   // u = 16m + c              -> W1[u][16 KTM]         (COL)
+    static constexpr int kDw2 = kCol + (COL ? kHidden : 0);  // ((m*4+r)*64 + lane)      -> W2v[o=c][16m+4g+r]
+    static constexpr int kDb1 = kDw2 + kMT * 4 * 64;         // u
+    static constexpr int kDb2 = kDb1 + kHidden;              // o (16)
+    static constexpr int kStats = kDb2 + kOut;               // 8
     static constexpr int kCount = kStats + kNumStats;
 };
 
@@ -104,8 +106,8 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, uint32_t heads,
                         pfa_ppo_hparams hp, const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
     using L = GradLds<DP>;
-    using NL = NativeLayout<DP>;
-    constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KT = DP / 16, KS = DP / 4, V = DP / 4, W1S = L::W1S;
+    using NL = NativeLayout<DP, KTM, COL>;
+    constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KS = DP / 4, V = DP / 4, W1S = L::W1S;
     constexpr int NLD = (16 * V + 63) / 64;  // float4 loads per lane per tile
     constexpr int kGradPairs = grad_pairs(DP), kGradThreads = grad_threads(DP);
     // the software-pipelined instruction order costs ~40 registers (double-buffered fragments, all eight dh / hidden-tile fragments
@@ -123,6 +125,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     const MlpOffsets off = mlp_offsets(DP, a);
 
     // Build the fragment tables.  All global loads of a thread are issued before the first LDS store so they pipeline.
+#ifndef PFA_DBG_SKIP_TABLES   // (timing experiments only, tools/variant_bench.py: what the table build costs per launch)
     {
         constexpr int N1 = kMT * 64 * KS / kGradThreads, N2 = kMT * 64 * 4 / kGradThreads;
         static_assert(kMT * 64 * KS % kGradThreads == 0 && kMT * 64 * 4 % kGradThreads == 0, "table sizes");
@@ -161,6 +164,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             w2bt[i] = tv[j];
         }
     }
+#endif
 
     const long long tiles = mb_rows / 16;
     const long long pair_global = (long long)blockIdx.x * kGradPairs + pair;
@@ -568,30 +572,32 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             if ((pair >> 1) == turn) {
                 const bool first = turn == 0;
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
+                for (int kt = 0; kt < KTM; ++kt)
 #pragma unroll
                     for (int m = 0; m < kMT; ++m)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int idx = NL::kDw1 + ((kt * kMT + m) * 4 + r) * 64 + lane;
-                            // k-tiles beyond KTM: the trailing column sits in the slot of (kt = KTM, r = 0, g = 0) -> W1[16m + c][16 KTM],
-                            // every other slot there is the (zero) gradient of observation padding
-                            float val = 0.0f;
-                            if (kt < KTM) val = acc_dw1[kt < KTM ? kt : 0][m][r];
-                            else if (COL && kt == KTM && r == 0 && g == 0) val = acc_col[m];
-                            red[idx] = (first ? 0.0f : red[idx]) + val;
+                            red[idx] = (first ? 0.0f : red[idx]) + acc_dw1[kt][m][r];
                         }
                 if (g == 0) {
 #pragma unroll
                     for (int m = 0; m < kMT; ++m) {
                         const int idx = NL::kDb1 + 16 * m + c;
                         red[idx] = (first ? 0.0f : red[idx]) + db1[m];
+                        if (COL) {   // the trailing column W1[16m + c][16 KTM]
+                            const int ic = NL::kCol + 16 * m + c;
+                            red[ic] = (first ? 0.0f : red[ic]) + acc_col[m];
+                        }
                     }
                 }
             }
             __syncthreads();
         }
     }
+#ifdef PFA_DBG_SKIP_STORE
+    if (blockIdx.x != 0xFFFF) return;
+#endif
     float *dst = partials + (size_t)blockIdx.x * NL::kCount;
     for (int i = threadIdx.x; i < NL::kCount; i += kGradThreads) dst[i] = lds[i] + lds[NL::kCount + i];
 }
@@ -605,10 +611,10 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 constexpr int kRedSl = PFA_REDUCE_SLICES;
 // (16 slices: 163 workgroups x 16 waves, every thread's 16 loads in flight at once — the reduction is a latency chain over the
 // L2-resident partials, and 4 waves per workgroup left most SIMDs without a wave to hide it)
-template <int DP>
+template <int DP, int KTM = DP / 16, bool COL = false>
 __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
                                                                 double *norm_partials) {
-    using NL = NativeLayout<DP>;
+    using NL = NativeLayout<DP, KTM, COL>;
     __shared__ float sh[kRedSl][64];
     __shared__ double shd[kRedSl][64];   // the loss-sum slots are carried in f64
     const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
@@ -633,8 +639,15 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *pa
     sh[sl][ql] = acc;
     shd[sl][ql] = dacc;
     __syncthreads();
-    if (sl != 0) return;
     const MlpOffsets off = mlp_offsets(DP, a);
+    if (sl == 1) {
+        // W1 columns no partial slot covers (k-tiles >= KTM past the COL column: observation padding): their gradient is zero by
+        // definition; written here so that the flat gradient is complete whatever the caller's buffer held
+        constexpr int kFirst = 16 * KTM + (COL ? 1 : 0), kPad = DP - kFirst, kDiv = kPad > 0 ? kPad : 1;
+        const int e = blockIdx.x * 64 + ql;
+        if (kPad > 0 && e < kHidden * kPad) grads[off.w1 + (e / kDiv) * DP + kFirst + e % kDiv] = 0.0f;
+    }
+    if (sl != 0) return;
     float s = 0.0f;
     int p = -1;
     if (q < NL::kCount) {
@@ -646,7 +659,10 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *pa
 #pragma unroll
             for (int x = 0; x < w; ++x) t[x] += t[x + w];   // fixed tree: deterministic, whatever the slice count
         s = t[0];
-        if (q < NL::kDw2) {
+        if (COL && q >= NL::kCol && q < NL::kDw2) {
+            p = off.w1 + (q - NL::kCol) * DP + 16 * KTM;
+            if (16 * KTM >= obs_dim) s = 0.0f;
+        } else if (q < NL::kCol) {
             const int ln = q & 63, r = (q >> 6) & 3, m = (q >> 8) & (kMT - 1), kt = q >> 11;
             p = off.w1 + (16 * m + (ln & 15)) * DP + 16 * kt + 4 * (ln >> 4) + r;
             // columns >= obs_dim are observation padding: their gradient is zero by definition (kernel A2 keeps the bias's 1.0 in the
@@ -834,6 +850,13 @@ static int check_update_args(const pfa_experience *ex, int64_t batch_rows, const
     return 0;
 }
 
+// the 7x7 grid behind one Discrete head on 64-float rows runs the instantiation with 3 dW1 k-tiles + the column-48 accumulator
+static bool grad_trimmed(const pfa_mlp_dims *dims) { return dims->obs_stride == 64 && !dims->heads && dims->obs_dim == 49; }
+static int norm_blocks(const pfa_mlp_dims *dims) {   // workgroups of the reduce launch = f64 pieces of sum(g^2) it leaves
+    const int count = grad_trimmed(dims) ? NativeLayout<64, 3, true>::kCount
+                                         : (dims->obs_stride / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats;
+    return (count + 63) / 64;
+}
 static size_t native_count(int dp) { return (size_t)(dp / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats; }
 static size_t partials_bytes(const pfa_mlp_dims *dims) {
     return align_up((size_t)256 * native_count(dims->obs_stride) * sizeof(float), 256);
@@ -908,7 +931,7 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
 #define PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, KTMV, COLV)                                                                    \
     {                                                                                                                      \
         constexpr size_t lds_bytes = (size_t)GradLds<DPV>::kFloats * sizeof(float);                                        \
-        static_assert((size_t)2 * NativeLayout<DPV>::kCount * sizeof(float) <= lds_bytes,                                   \
+        static_assert((size_t)2 * NativeLayout<DPV, KTMV, COLV>::kCount * sizeof(float) <= lds_bytes,                       \
                       "the two reduction buffers must fit in the tile/table area");                                       \
         static bool attr_set = false;                                                                                      \
         if (!attr_set) {                                                                                                   \
@@ -933,7 +956,7 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
             case 96: PFA_LAUNCH_GRAD(96) break;
             case 128: PFA_LAUNCH_GRAD(128) break;
             default:
-                if (!dims->heads && dims->obs_dim == 49) PFA_LAUNCH_GRAD_FULL(64, 13, false, 3, true)   // 7x7 grid: 13 of 16 forward k-steps, dW1 = 3 k-tiles + column 48
+                if (grad_trimmed(dims)) PFA_LAUNCH_GRAD_FULL(64, 13, false, 3, true)   // 7x7 grid: 13 of 16 forward k-steps, dW1 = 3 k-tiles + column 48
                 else if (!dims->heads && (dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)
                 else PFA_LAUNCH_GRAD(64)
                 break;
@@ -946,18 +969,20 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     PFA_LAUNCH_CHECK();
     double *normp = norm_partials_of(workspace, dims);
     ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
-    switch (dims->obs_stride) {
-        case 16: hipLaunchKernelGGL(ppo_reduce_kernel<16>, dim3((NativeLayout<16>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        case 32: hipLaunchKernelGGL(ppo_reduce_kernel<32>, dim3((NativeLayout<32>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        case 96: hipLaunchKernelGGL(ppo_reduce_kernel<96>, dim3((NativeLayout<96>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        case 128: hipLaunchKernelGGL(ppo_reduce_kernel<128>, dim3((NativeLayout<128>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
-                                     (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
-        default: hipLaunchKernelGGL(ppo_reduce_kernel<64>, dim3((NativeLayout<64>::kCount + 63) / 64), dim3(64 * kRedSl), 0,
-                                    (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp); break;
+#define PFA_LAUNCH_REDUCE(DPV, KTMV, COLV)                                                                                      \
+    hipLaunchKernelGGL((ppo_reduce_kernel<DPV, KTMV, COLV>), dim3((NativeLayout<DPV, KTMV, COLV>::kCount + 63) / 64),            \
+                       dim3(64 * kRedSl), 0, (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp)
+    switch (dims->obs_stride) {   // the same instantiation choice as the gradient launch above: the partial layout belongs to it
+        case 16: PFA_LAUNCH_REDUCE(16, 1, false); break;
+        case 32: PFA_LAUNCH_REDUCE(32, 2, false); break;
+        case 96: PFA_LAUNCH_REDUCE(96, 6, false); break;
+        case 128: PFA_LAUNCH_REDUCE(128, 8, false); break;
+        default:
+            if (grad_trimmed(dims)) PFA_LAUNCH_REDUCE(64, 3, true);
+            else PFA_LAUNCH_REDUCE(64, 4, false);
+            break;
     }
+#undef PFA_LAUNCH_REDUCE
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -1019,7 +1044,7 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
             } else if (int rc = pfa_adam_clip_step(params, grads, exp_avg, exp_avg_sq, count, lr, beta1, beta2, eps, opt_step,
                                                    max_grad_norm, 1.0f, grads + count, losses, loss_scale,
                                                    norm_partials_of(workspace, dims),
-                                                   (int)((native_count(dims->obs_stride) + 63) / 64), stream)) {
+                                                   norm_blocks(dims), stream)) {
                 return rc;
             }
         }
@@ -1043,9 +1068,9 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
     constexpr size_t lds_bytes = (size_t)GradLds<64>::kFloats * sizeof(float);
 #define PFA_PROBE_CASE(A)                                                                                              \
     case A:                                                                                                            \
-        PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A, 13>,                                \
+        PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A, 13, false, 3, true>,                                \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A, 13>), dim3(grid), dim3(grad_threads(64)), lds_bytes, (hipStream_t)stream, \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<64, A, 13, false, 3, true>), dim3(grid), dim3(grad_threads(64)), lds_bytes, (hipStream_t)stream, \
                            *exp, map, (long long)mbs, params, dims->num_actions, 0u, *hp, adv_stats, (double)mbs, partials); \
         break;
     switch (abl) {
