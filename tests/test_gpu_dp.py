@@ -30,6 +30,7 @@ def _free_port():
 
 
 CONV = 'conv'      # third policy kind next to recurrent = False / True: models.Convolutional on vector.Frames (4 envs x 8 steps per rank)
+WIDE = 'wide'      # fourth: models.Default(hidden_size=256) — the GEMM-path engine (general.py) under data parallelism
 
 
 def _sizes(recurrent):
@@ -46,8 +47,8 @@ def _loop(n_local, world, recurrent, inject=None):
         pol = cleanrl.Policy(models.Convolutional(vec.driver_env, framestack=4))
     else:
         vec = vector.make(vector.make_squared, num_envs=n_local, backend=vector.Squared)
-        base = models.Default(vec.driver_env)
-        pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base)) if recurrent else cleanrl.Policy(base)
+        base = models.Default(vec.driver_env, hidden_size=256 if recurrent == WIDE else 128)
+        pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base)) if recurrent is True else cleanrl.Policy(base)
     B = n_local * HORIZON
     data = clean_pufferl.create(_config(n_local, HORIZON, B // 2, bptt, 2, n_rank * 2 * HORIZON * 8, HP, seed=21,
                                         env='frames' if recurrent == CONV else 'squared'), vec, pol)
@@ -111,7 +112,7 @@ def _spawn(fn, args, world, timeout_s=240):
 
 
 @pytest.mark.parametrize('recurrent,transport', [(False, 'torch'), (True, 'torch'), (False, 'p2p'), (True, 'p2p'), (False, 'rccl-refused'),
-                                                 (CONV, 'torch'), (CONV, 'p2p')])
+                                                 (CONV, 'torch'), (CONV, 'p2p'), (WIDE, 'torch'), (WIDE, 'p2p')])
 def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent, transport):
     world = 2
     N_PER_RANK, HORIZON, _ = _sizes(recurrent)

@@ -447,3 +447,97 @@ def test_hidden_256_replays_the_reference_golden(golden_dir):
             np.testing.assert_allclose(m_[short].cpu().numpy(), g[f'it{it}.m.{k}'], rtol=1e-4, atol=1e-6, err_msg=k)
             np.testing.assert_allclose(v_[short].cpu().numpy(), g[f'it{it}.v.{k}'], rtol=1e-4, atol=1e-8, err_msg=k)
         assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-12
+
+
+def _general_run(kind, recurrent, order='natural', n=32, horizon=16, iters=2, H=256):
+    from pufferlib_amd import clean_pufferl, cleanrl, models, vector
+    from host_vecenv import HostSquared
+    from test_gpu_ppo import _config
+    torch.manual_seed(3)
+    vec = _squared(n) if kind == 'device' else HostSquared(n, order=order)
+    base = models.Default(vec.driver_env, hidden_size=H)
+    pol = (cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base, input_size=H, hidden_size=H)) if recurrent else cleanrl.Policy(base))
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 8, 2, n * horizon * 8, [2.5e-3] + HP[1:], seed=11), vec, pol)
+    out = []
+    for _ in range(iters):
+        clean_pufferl.evaluate(data)
+        e = data.experience
+        snap = [x.clone() for x in (e.obs, e.actions, e.logprobs, e.values, e.rewards, e.dones)]
+        clean_pufferl.train(data)
+        out.append((snap, data.flat_params.flat.clone(), data.global_step))
+    return out, data, pol
+
+
+@pytest.mark.parametrize('recurrent', [False, True])
+def test_general_path_host_vecenv_equals_device_vecenv(recurrent):
+    """The same wide policy behind the device Squared vecenv and behind a host vecenv handing out shuffled batches (the LSTM state
+    rows follow the env ids): identical experience and identical parameters after two iterations."""
+    dev, _, _ = _general_run('device', recurrent)
+    host, _, _ = _general_run('host', recurrent, order='shuffled')
+    for (sd, wd, gd), (sh, wh, gh) in zip(dev, host):
+        for x, y in zip(sd, sh):
+            assert torch.equal(x, y)
+        assert gd == gh and torch.equal(wd, wh)
+
+
+def test_general_policy_checkpoint_round_trip(tmp_path):
+    from pufferlib_amd import clean_pufferl
+    out, data, pol = _general_run('device', True, iters=1)
+    data.config.data_dir, data.config.exp_id = str(tmp_path), 'wide'
+    path = clean_pufferl.save_checkpoint(data)
+    want = {k: v.clone() for k, v in pol.state_dict().items()}
+    clean_pufferl.evaluate(data)
+    clean_pufferl.train(data)
+    after = data.flat_params.flat.clone()
+    assert any(not torch.equal(want[k], v) for k, v in pol.state_dict().items())
+    clean_pufferl.try_load_checkpoint(data)
+    for k, v in pol.state_dict().items():
+        assert torch.equal(want[k], v), k
+    # the packed operand copies follow the loaded weights: the next rollout is not the one the overwritten weights would give
+    loaded = torch.load(path, weights_only=False)
+    obs = torch.randn(5, 7, 7)
+    a0 = loaded(obs.cuda(), noise=torch.ones(5, 8))
+    a1 = pol(obs.cuda(), noise=torch.ones(5, 8))
+    for x, y in zip(a0[:4], a1[:4]):
+        assert torch.equal(x, y)
+    assert not torch.equal(after, data.flat_params.flat)
+
+
+def test_two_multidiscrete_heads_of_nine_run_end_to_end():
+    """18 logits in two heads: more than the fused kernels' 15, inside the 4-bit action packing — the GEMM path with per-head
+    log-softmax / sampling / entropy, against the oracle's list branch of sample_logits (cleanrl.py:31-44)."""
+    from host_vecenv import HostMultiHead
+    from pufferlib_amd import clean_pufferl, cleanrl, general, models
+    from test_gpu_ppo import _config
+    from oracle import ppo_torch
+    n, horizon, nmb, bptt = 16, 16, 2, 4
+    B = n * horizon
+    vec = HostMultiHead(n, [9, 9], obs_dim=20)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    _perturb(pol)
+    data = clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, HP, env='host'), vec, pol)
+    assert isinstance(data.flat_params, general.GeneralParams) and data.flat_params.nvec == [9, 9]
+    w0 = _weights(pol)
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    opol = ppo_torch.Policy(w0)
+
+    class _V:
+        num_envs = n
+        observations = np.zeros((n, 20), np.float32)
+
+        def async_reset(self, seed):
+            pass
+    tr = ppo_torch.Trainer(opol, _V(), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt, update_epochs=2, learning_rate=HP[0], gamma=HP[1],
+                           gae_lambda=HP[2], clip_coef=HP[3], vf_coef=HP[4], vf_clip_coef=HP[5], max_grad_norm=HP[6], ent_coef=HP[7],
+                           total_timesteps=B * 10, seed=1)
+    _inject(tr, exp, n, horizon, 20)
+    packed = tr.actions
+    tr.actions = np.stack([packed & 15, (packed >> 4) & 15], axis=1)       # the kernels' nibble packing -> [rows, heads]
+    assert tr.actions.max() < 9
+    with torch.no_grad():
+        logits, oval, _ = opol.forward(tr.obs)
+        _, olp, _ = ppo_torch.sample_logits(logits, action=torch.as_tensor(tr.actions))
+    np.testing.assert_allclose(tr.logprobs, olp.numpy(), **TOL)
+    tr.global_step = data.global_step
+    _check_update(data, pol, opol, tr, lambda k: 'policy.' + k)
