@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r01}
 EXTRA=${2:-}     # extra bench.py flags, e.g. "--policy lstm"
 PASSES=${3:-"sq1 sq2 fetch write grbm"}
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown $EXTRA"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-breakdown --no-extra --sustained-seconds 0 $EXTRA"
 run() { # name counters...
   local name=$1; shift
   rocprofv3 --pmc "$@" --output-format csv -d $ROOT/gpurun_out/pmc_${TAG}/$name -o $name -- $CMD > $ROOT/gpurun_out/pmc_${TAG}_$name.log 2>&1
