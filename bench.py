@@ -299,6 +299,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--policy', choices=['mlp', 'lstm'], default='mlp',
                     help="'lstm' = LSTMWrapper(128) on the same envs (BASELINE configs[2]'s policy; not the headline metric)")
+    ap.add_argument('--hidden', type=int, default=128,
+                    help="models.Default(hidden_size=...) on the squared workload: 128 = the fused kernels (headline); any other multiple of 16 runs "
+                         "the width-general GEMM path (pufferlib_amd/general.py) — a side workload, not the metric")
     ap.add_argument('--horizon', type=int, default=None, help='rollout steps per batch (default 128; 32 for c4)')
     ap.add_argument('--workload', choices=['squared', 'c3', 'c4'], default='squared',
                     help="'c3' = BASELINE configs[2] / SURVEY config C3: MiniGrid-shaped 160-byte rows, 7 actions, 100-step episodes from the "
@@ -361,7 +364,10 @@ def main():
     else:
         vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=D, num_targets=NT), num_envs=NUM_ENVS,
                           backend=vector.Squared, obs_stride=64)
-    if args.policy == 'lstm':
+    if args.workload == 'squared' and args.policy == 'mlp' and args.hidden != 128:
+        args.policy = 'wide'
+        pol = cleanrl.Policy(models.Default(vec.driver_env, hidden_size=args.hidden))
+    elif args.policy == 'lstm':
         pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Default(vec.driver_env)))
     elif args.policy == 'cnn' and cnn_lstm:
         pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, models.Convolutional(vec.driver_env, framestack=4), input_size=512, hidden_size=512))
@@ -381,13 +387,13 @@ def main():
         clean_pufferl.evaluate(data)
         clean_pufferl.train(data)
     # dominant kernel of the update: the fused fwd/loss/bwd kernel (MLP) or the BPTT kernel (LSTM)
-    dominant = {'mlp': 'ppo_mlp_grad', 'lstm': 'lstm_seq_bwd', 'cnn': 'igemm_rows'}[args.policy]
+    dominant = {'mlp': 'ppo_mlp_grad', 'lstm': 'lstm_seq_bwd', 'cnn': 'igemm_rows', 'wide': 'igemm_rows'}[args.policy]
     L.pfa_timing_select(dominant.encode())
     # The event pair around a launch serialises the queue (~7 us of dispatch bubble each: 16 bracketed launches per step cost
     # the headline 7 %, measured).  The dominant kernel's launches all have the same shape in the MLP / LSTM updates, so every
     # 5th one is bracketed (5 is coprime to the 16 launches of a step: every epoch x minibatch position gets sampled); the conv
     # update's launches differ in shape and are all bracketed.
-    event_stride = 1 if args.policy == 'cnn' else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '5'))
+    event_stride = 1 if args.policy in ('cnn', 'wide') else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '5'))
     L.pfa_timing_stride(event_stride)
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
@@ -450,7 +456,7 @@ def main():
     if rank == 0 and not args.no_breakdown:
         L.pfa_timing_enable(0)
         names = (('philox_exp_noise', 'rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
-                 else ('igemm_rows', 'igemm_weights', 'gae', 'adam_clip') if args.policy == 'cnn'
+                 else ('igemm_rows', 'igemm_weights', 'gae', 'adam_clip') if args.policy in ('cnn', 'wide')
                  else (('rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'), 'squared_tape', 'gae', 'lstm_seq_fwd',
                        'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
         for name in names:
@@ -477,10 +483,17 @@ def main():
                 step_flop += per_gpu * (lstm_f + 2 * 512 * 16 + EPOCHS * (2 * lstm_f + 2 * 2 * 512 * 16))
             achieved = step_flop * K / (total_ms * 1e-3) / 1e12 if launches else 0.0
             flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
+        if args.policy == 'wide':
+            # rows-form launches of the GEMM path: encoder + heads forward in the rollout and in every epoch, d feature = dout W2v per epoch
+            Hh, Kp_, NO_ = args.hidden, 64, 16
+            step_flop = per_gpu * ((2 * Kp_ * Hh + 2 * Hh * NO_) * (1 + EPOCHS) + EPOCHS * 2 * NO_ * Hh)
+            achieved = step_flop * K / (total_ms * 1e-3) / 1e12 if launches else 0.0
+            flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
         traffic, traffic_source = pmc_traffic(dominant)
         out = {
             'metric': (f'env steps/sec end-to-end PPO (rollout+GAE+update), {NUM_ENVS} envs'
-                       + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')),
+                       + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')
+                       + (f' [side workload: hidden {args.hidden}]' if args.policy == 'wide' else '')),
             'value': value, 'unit': 'env_steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
@@ -493,7 +506,7 @@ def main():
                                     'env parity unpinned: third-party simulator' + (', sharded' if world > 1 else '') + ')')
                        if args.workload == 'c3' else
                        f'squared d={D} nt={NT}, {NUM_ENVS} envs/GPU x {HORIZON} steps, obs 49->64 f32 rows, '
-                       f'{"MLP 128" if args.policy == "mlp" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[1]'
+                       f'{"MLP 128" if args.policy == "mlp" else f"MLP {args.hidden} (GEMM path, general.py)" if args.policy == "wide" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} ({"BASELINE configs[1]" if args.policy != "wide" else "the configs[1] env with a wider policy: side workload, not the metric"}'
                        + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
@@ -557,6 +570,8 @@ def main():
             torch.cuda.empty_cache()
             out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),
                                       extra_workload(['--workload', 'c4', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0']),
+                                      # a width outside the fused kernels on the headline env (GEMM path, general.py)
+                                      extra_workload(['--hidden', '256', '--steps', '5', '--warmup', '2', '--sustained-seconds', '0']),
                                       # the recurrent NatureCNN of environments/atari/torch.py:4-6 (GEMM path, general.py)
                                       extra_workload(['--workload', 'c4', '--policy', 'lstm', '--steps', '2', '--warmup', '1', '--sustained-seconds', '0'])]
         print(json.dumps(out), flush=True)
