@@ -301,9 +301,13 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
             for (int m = 0; m < kMT; ++m)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.0f);   // (canonicalise + max = 2 instructions.  Measured: an
-                        // inline-asm v_max loses the MFMA->VALU hazard wait states; the integer form max(bits, 0) is exact and one
-                        // instruction but shifts the block's schedule: 66.8 instead of 64.7 us per launch)
+                for (int r = 0; r < 4; ++r) {
+                    // ReLU.  fmaxf is two instructions (canonicalise + max); max(bits, 0) as integers is one and exact (negative floats
+                    // are negative integers; -0 -> +0).  In the round-2 instruction order it shifted the block's schedule for the worse
+                    // (66.8 vs 64.7 us); with the pipelined order it is 1 us per optimizer step faster (profiles/r03_grad_variants.txt)
+                    if constexpr (kPipe) h[m][r] = __int_as_float(max(__float_as_int(h[m][r]), 0));
+                    else h[m][r] = fmaxf(h[m][r], 0.0f);
+                }
             f32x4 out;
             if constexpr (kPipe) {
                 f32x4 o[4] = {f32x4{bo[0], bo[1], bo[2], bo[3]}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f},
