@@ -278,6 +278,25 @@ def pmc_traffic(kernel):
     return entry.get('hbm_bytes_per_launch'), f"{entry.get('source', 'profiles/pmc_summary.json')} [build {have}]"
 
 
+def pmc_mfma_utilisation(kernel, waves_per_simd=2):
+    """north_star's "MFMA utilisation" from the SQ counters of the same stamped summary: SQ_VALU_MFMA_BUSY_CYCLES over the SIMD
+    cycles of the launch (SQ_WAVE_CYCLES counts quad-cycles per wave; `waves_per_simd` waves share a SIMD).  Measured UNDER the
+    counters (the launch runs ~30 % longer then), so it is a floor of the undisturbed figure."""
+    pmc = os.path.join(REPO, 'profiles', 'pmc_summary.json')
+    try:
+        doc = json.load(open(pmc))
+        e = doc.get(kernel, {})
+        if doc.get('_build') != source_build_id() or e.get('carried_over'):
+            return None
+        busy, wave = e.get('sq_valu_mfma_busy_cycles'), e.get('sq_wave_cycles')
+        if not busy or not wave:
+            return None
+        return dict(sq_valu_mfma_busy_cycles=busy, simd_cycles=wave * 4.0 / waves_per_simd, frac=busy / (wave * 4.0 / waves_per_simd),
+                    sq_insts_mfma=e.get('sq_insts_mfma'), sq_insts_valu=e.get('sq_insts_valu'), launch_us_under_pmc=e.get('dur_us_under_pmc'))
+    except Exception:
+        return None
+
+
 def extra_workload(flags, timeout_s=600):
     """A short run of one of the side workloads (BASELINE configs[2] / configs[3]) as its own process; its JSON line, trimmed."""
     import subprocess
@@ -524,6 +543,7 @@ def main():
             # 32, dW2v 32, dh DHK x 8, dW1 KTM x 32): the padded SURVEY figure above is the contract's `frac`, this is the executed one
             mfma_tile = int(L.pfa_ppo_mlp_grad_mfma_per_tile(49, 64, 8))
             out['roofline']['mfma_per_tile'] = mfma_tile
+            out['roofline']['mfma_utilisation_pmc'] = pmc_mfma_utilisation('ppo_mlp_grad')
             out['roofline']['frac_executed'] = (mfma_tile * 2048 / 16 * rows_per_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
                                                 if launches else 0.0)
         # north_star asks for the HBM side next to the MFMA side: the rollout kernel is the path's HBM-facing kernel (it writes the
