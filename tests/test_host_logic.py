@@ -363,3 +363,45 @@ def test_combined_exception_classes_survive_pickling(monkeypatch):
     assert isinstance(e2, InvalidAgentError)
     back2 = pickle.loads(pickle.dumps(e2))
     assert isinstance(back2, ex.InvalidAgentError) and str(back2) == str(e2)
+
+
+def test_general_params_layout_and_packed_operands_on_cpu():
+    """general.GeneralParams / general.Net.pack need no GPU: the flat buffer holds every parameter in named_parameters() order with
+    torch shapes (module parameters are views of it), and the packed operand forms are what the GEMM launches multiply — the
+    encoder zero-padded to the row stride, the decoder rows of all heads + the value row stacked and padded to 16, [W_ih | W_hh]
+    side by side with b_ih + b_hh."""
+    from pufferlib_amd import general, models, namespace, spaces
+    env = namespace(single_observation_space=spaces.Box(low=-1, high=1, shape=(37,), dtype=np.float32),
+                    single_action_space=spaces.MultiDiscrete([3, 5, 2]))
+    torch.manual_seed(0)
+    base = models.Default(env, hidden_size=64)
+    wrap = models.LSTMWrapper(env, base, input_size=64, hidden_size=96)
+    # (the heads of `base` read 64 features, the LSTM emits 96: the reference would fail in decode_actions too — rebuild them)
+    base.decoder = torch.nn.ModuleList([torch.nn.Linear(96, n) for n in (3, 5, 2)])
+    base.value_head = torch.nn.Linear(96, 1)
+    before = {k: v.detach().clone() for k, v in wrap.state_dict().items()}
+    gp = general.GeneralParams(wrap, 'cpu')
+    assert gp.kind == 'mlp' and gp.nvec == [3, 5, 2] and gp.multidiscrete and gp.heads == 3 | (5 << 4) | (2 << 8)
+    assert gp.obs_dim == 37 and gp.obs_stride == 48 and gp.features == 64 and gp.head_in == 96
+    assert gp.names == [n for n, _ in wrap.named_parameters()] and gp.count == sum(p.numel() for p in wrap.parameters())
+    o = 0
+    for name, p in wrap.named_parameters():                      # contiguous, in order, values unchanged, module params alias the buffer
+        assert torch.equal(gp.flat[o:o + p.numel()].view(p.shape), before[name]) and p.data_ptr() == gp.flat[o:].data_ptr()
+        o += p.numel()
+    net = general._net_for_general(gp)
+    net.pack()
+    assert net.NO == 16 and net.FH == 96 and net.lstm == (64, 96)
+    assert torch.equal(net.w1p[:, :37], before['policy.encoder.weight']) and float(net.w1p[:, 37:].abs().sum()) == 0.0
+    want = torch.cat([before[f'policy.decoder.{h}.weight'] for h in range(3)] + [before['policy.value_head.weight']])
+    assert torch.equal(net.w2v[:11], want) and float(net.w2v[11:].abs().sum()) == 0.0 and torch.equal(net.w2vT, net.w2v.t())
+    assert torch.equal(net.b2v[:11], torch.cat([before[f'policy.decoder.{h}.bias'] for h in range(3)] + [before['policy.value_head.bias']]))
+    assert torch.equal(net.wcat, torch.cat([before['recurrent.weight_ih_l0'], before['recurrent.weight_hh_l0']], dim=1))
+    assert torch.equal(net.bcat, before['recurrent.bias_ih_l0'] + before['recurrent.bias_hh_l0'])
+    # an optimizer step through the flat buffer + a version bump re-packs
+    gp.flat.add_(1.0)
+    net.version += 1
+    net.pack()
+    assert torch.equal(net.w1p[:, :37], before['policy.encoder.weight'] + 1.0) and float(net.w1p[:, 37:].abs().sum()) == 0.0
+    assert gp.unpack_actions(torch.tensor([2 | (4 << 4) | (1 << 8)])).tolist() == [[2, 4, 1]]
+    with pytest.raises(NotImplementedError):
+        general.pack_heads([16, 2], True)
