@@ -101,7 +101,10 @@ struct LossOut {
 // MH: MultiDiscrete (cleanrl.py:31-44) — `heads` packs the head sizes, rs.action the per-head choices (pfa_mlp_dims.heads); the
 // log-softmax, the chosen log-probability and the entropy are taken per head and summed.  The single-head instantiation is the
 // code the headline workload runs, unchanged.
-template <bool MH, bool SWAP = false>
+// PERM (one Discrete head of at most 11 actions): the outputs sit in permuted rows of the out^T fragment — logical output o in
+// slot 4 (o / 3) + o % 3, i.e. lane group g holds outputs 3g .. 3g+2 in registers 0..2 and register 3 is padding everywhere — so
+// that dh = dout . W2v contracts over three k-steps instead of four and every per-logit loop below runs three times, not four.
+template <bool MH, bool SWAP = false, bool PERM = false>
 __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScalars &rs, int a, uint32_t heads, int g,
                                                  const pfa_ppo_hparams &hp, float adv_mean, float adv_rden, float inv_rows) {
     float nl[4], p[4], hent[4], ent = 0.0f, new_logprob = 0.0f, new_value = 0.0f;
@@ -161,23 +164,31 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
         new_value += __shfl_xor(new_value, 32, 64);
     } else {
     // log-softmax over the A logits of row c, spread over lane groups: reduce with xor 16 / 32
+    static_assert(!(MH && PERM), "the permuted layout is the single-head form");
+    constexpr int NR = PERM ? 3 : 4;
+    const int o0 = PERM ? 3 * g : 4 * g;     // logical output of register 0
+#pragma unroll
+    for (int r = NR; r < 4; ++r) {
+        nl[r] = p[r] = 0.0f;
+        chosen[r] = false;
+    }
     float lmax = -INFINITY;
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-        if (4 * g + r < a) lmax = fmaxf(lmax, out[r]);
+    for (int r = 0; r < NR; ++r)
+        if (o0 + r < a) lmax = fmaxf(lmax, out[r]);
     lmax = gmax<SWAP>(lmax);
     float ev[4], se = 0.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        ev[r] = 4 * g + r < a ? loss_exp(out[r] - lmax) : 0.0f;
+    for (int r = 0; r < NR; ++r) {
+        ev[r] = o0 + r < a ? loss_exp(out[r] - lmax) : 0.0f;
         se += ev[r];
     }
     se = gsum<SWAP>(se);
     const float lse = lmax + loss_log(se);
     const float inv_se = __builtin_amdgcn_rcpf(se);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
+    for (int r = 0; r < NR; ++r) {
+        const int o = o0 + r;
         nl[r] = out[r] - lse;
         p[r] = ev[r] * inv_se;  // softmax; the exponentials are shared with the log-sum-exp
         if (o < a) ent -= nl[r] * p[r];
@@ -230,7 +241,7 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
     LossOut lo_;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int o = 4 * g + r;
+        const int o = PERM ? (r < 3 ? 3 * g + r : 99) : 4 * g + r;
         float d = 0.0f;
         if (o < a) {
             // d new_logprob/d logit_o = [o==action] - p_o ; d entropy/d logit_o = -p_o (nl_o + H)

@@ -101,7 +101,11 @@ __device__ int g_trace_tiles = 0;
 // KTM / COL: dW1 = X^T dh is contracted on MFMA for the first KTM 16-column tiles of X only; COL adds ONE trailing column
 // (k = 16 KTM) as 32 VALU fmas per tile.  Columns beyond that are observation padding whose gradient is 0 by construction.
 // The 7x7 grid (49 = 3 x 16 + 1 columns) runs <KTM = 3, COL = true>: 32 MFMAs (1024 matrix-pipe cycles) less per tile.
-template <int DP, int ABL = 0, int KKU = DP / 4, bool MH = false, int KTM = DP / 16, bool COL = false>
+// PERM: the head outputs in permuted fragment rows (ppo_tile.hpp: ppo_loss_tile<.., PERM>): dh takes three k-steps, not four.
+__host__ __device__ constexpr int slot_output(bool perm, int slot) {   // fragment row `slot` -> logical output (>= 16: padding)
+    return !perm ? slot : ((slot & 3) == 3 ? 99 : 3 * (slot >> 2) + (slot & 3));
+}
+template <int DP, int ABL = 0, int KKU = DP / 4, bool MH = false, int KTM = DP / 16, bool COL = false, bool PERM = false>
 __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, uint32_t heads,
                         pfa_ppo_hparams hp, const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
@@ -113,6 +117,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     // the software-pipelined instruction order costs ~40 registers (double-buffered fragments, all eight dh / hidden-tile fragments
     // live at once): taken where the instantiation stays inside its register budget without spilling (checked in the ISA)
     constexpr bool kPipe = PFA_GRAD_PIPE && (DP <= 32 || (DP == 64 && KTM <= 3));
+    static_assert(!PERM || (kPipe && !MH), "the permuted head layout is wired into the pipelined single-head form");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
     const int pair = wv & (kGradPairs - 1);
@@ -137,8 +142,8 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             const int i = threadIdx.x + j * kGradThreads;
             const int r = i & 3, ln = (i >> 2) & 63, m = i >> 8, cc = ln & 15, gg = ln >> 4;
             tb[j] = params[off.b1 + 16 * m + 4 * gg + r];
-            tw[j] = w2v_at(params, off, a, cc, 16 * m + 4 * gg + r);    // A[i=o=cc][k-slot gg] for u = 16m+4gg+r
-            tv[j] = w2v_at(params, off, a, 4 * gg + r, 16 * m + cc);    // B[k-slot gg][j=u=16m+cc] for o = 4gg+r
+            tw[j] = w2v_at(params, off, a, slot_output(PERM, cc), 16 * m + 4 * gg + r);    // A[i=o=cc][k-slot gg] for u = 16m+4gg+r
+            tv[j] = w2v_at(params, off, a, slot_output(PERM, 4 * gg + r), 16 * m + cc);    // B[k-slot gg][j=u=16m+cc] for o = 4gg+r
         }
 #pragma unroll 1
         for (int j0 = 0; j0 < N1; j0 += CH) {
@@ -176,7 +181,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
         // ------------------------------------------------------------------------------------------ producer
         float bo[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bo[r] = b2v_at(params, off, a, 4 * g + r);
+        for (int r = 0; r < 4; ++r) bo[r] = b2v_at(params, off, a, slot_output(PERM, 4 * g + r));
         // advantage normalisation (clean_pufferl.py:211-213): unbiased std over the GLOBAL minibatch
         float adv_mean = 0.0f, adv_den = 1.0f;
         if (hp.norm_adv) {
@@ -341,7 +346,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 lo.dout = out * rs.weight;
                 lo.pg = lo.v_loss = lo.ent = lo.neg_logratio = lo.kl = lo.clipped = rs.adv;
             } else {
-                lo = ppo_loss_tile<MH, !MH>(out, rs, a, heads, g, hp, adv_mean, adv_rden, inv_rows);   // one head: permlane-swap reductions
+                lo = ppo_loss_tile<MH, !MH, PERM>(out, rs, a, heads, g, hp, adv_mean, adv_rden, inv_rows);   // one head: permlane-swap reductions
             }
             const f32x4 dout = lo.dout;
 #pragma unroll
@@ -488,7 +493,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 for (int r = 0; r < 4; ++r) hrow[m][r] = hsP[(4 * g + r) * HS + 16 * m + c];  // hidden[row=4g+r][u=16m+c]
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < (PERM ? 3 : 4); ++r)   // PERM: register 3 of every lane group is padding in dout and in W2v's fragments
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) dh[m] = mfma16(dout[r], wb[m][r], dh[m]);
 #pragma unroll
@@ -615,7 +620,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 constexpr int kRedSl = PFA_REDUCE_SLICES;
 // (16 slices: 163 workgroups x 16 waves, every thread's 16 loads in flight at once — the reduction is a latency chain over the
 // L2-resident partials, and 4 waves per workgroup left most SIMDs without a wave to hide it)
-template <int DP, int KTM = DP / 16, bool COL = false>
+template <int DP, int KTM = DP / 16, bool COL = false, bool PERM = false>
 __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
                                                                 double *norm_partials) {
     using NL = NativeLayout<DP, KTM, COL>;
@@ -674,13 +679,13 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *pa
             if (16 * kt + 4 * (ln >> 4) + r >= obs_dim) s = 0.0f;
         } else if (q < NL::kDb1) {
             const int t = q - NL::kDw2, ln = t & 63, r = (t >> 6) & 3, m = t >> 8;
-            const int o = ln & 15, u = 16 * m + 4 * (ln >> 4) + r;
+            const int o = slot_output(PERM, ln & 15), u = 16 * m + 4 * (ln >> 4) + r;
             if (o < a) p = off.w2 + o * kHidden + u;
             else if (o == a) p = off.wv + u;
         } else if (q < NL::kDb2) {
             p = off.b1 + (q - NL::kDb1);
         } else if (q < NL::kStats) {
-            const int o = q - NL::kDb2;
+            const int o = slot_output(PERM, q - NL::kDb2);
             if (o < a) p = off.b2 + o;
             else if (o == a) p = off.bv;
         } else {
@@ -856,6 +861,11 @@ static int check_update_args(const pfa_experience *ex, int64_t batch_rows, const
 
 // the 7x7 grid behind one Discrete head on 64-float rows runs the instantiation with 3 dW1 k-tiles + the column-48 accumulator
 static bool grad_trimmed(const pfa_mlp_dims *dims) { return dims->obs_stride == 64 && !dims->heads && dims->obs_dim == 49; }
+#ifndef PFA_GRAD_PERM
+#define PFA_GRAD_PERM 1   // 0 = head outputs in natural fragment rows everywhere (A/B timing)
+#endif
+// ... and, with at most 11 actions (12 outputs with the value), the permuted head rows: three k-steps of dh instead of four
+static bool grad_perm(const pfa_mlp_dims *dims) { return PFA_GRAD_PERM && dims->num_actions <= 11; }
 static int norm_blocks(const pfa_mlp_dims *dims) {   // workgroups of the reduce launch = f64 pieces of sum(g^2) it leaves
     const int count = grad_trimmed(dims) ? NativeLayout<64, 3, true>::kCount
                                          : (dims->obs_stride / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats;
@@ -932,18 +942,19 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
     const int grid = grad_grid(mbs, dims->obs_stride);
-#define PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, KTMV, COLV)                                                                    \
+#define PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, KTMV, COLV) PFA_LAUNCH_GRAD_PERM(DPV, KKUV, MHV, KTMV, COLV, false)
+#define PFA_LAUNCH_GRAD_PERM(DPV, KKUV, MHV, KTMV, COLV, PERMV)                                                             \
     {                                                                                                                      \
         constexpr size_t lds_bytes = (size_t)GradLds<DPV>::kFloats * sizeof(float);                                        \
         static_assert((size_t)2 * NativeLayout<DPV, KTMV, COLV>::kCount * sizeof(float) <= lds_bytes,                       \
                       "the two reduction buffers must fit in the tile/table area");                                       \
         static bool attr_set = false;                                                                                      \
         if (!attr_set) {                                                                                                   \
-            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV>,            \
+            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV, PERMV>,     \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
             attr_set = true;                                                                                               \
         }                                                                                                                  \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes, \
+        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV, PERMV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes, \
                            (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions, dims->heads, *hp,     \
                            adv_stats, (double)global_mb_rows, partials);                                                   \
     }
@@ -960,7 +971,8 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
             case 96: PFA_LAUNCH_GRAD(96) break;
             case 128: PFA_LAUNCH_GRAD(128) break;
             default:
-                if (grad_trimmed(dims)) PFA_LAUNCH_GRAD_FULL(64, 13, false, 3, true)   // 7x7 grid: 13 of 16 forward k-steps, dW1 = 3 k-tiles + column 48
+                if (grad_trimmed(dims) && grad_perm(dims)) PFA_LAUNCH_GRAD_PERM(64, 13, false, 3, true, true)   // + the permuted head rows (<= 11 actions)
+                else if (grad_trimmed(dims)) PFA_LAUNCH_GRAD_FULL(64, 13, false, 3, true)   // 7x7 grid: 13 of 16 forward k-steps, dW1 = 3 k-tiles + column 48
                 else if (!dims->heads && (dims->obs_dim + 3) / 4 == 13) PFA_LAUNCH_GRAD_K(64, 13)
                 else PFA_LAUNCH_GRAD(64)
                 break;
@@ -968,13 +980,15 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     }
 #undef PFA_LAUNCH_GRAD_KM
 #undef PFA_LAUNCH_GRAD_FULL
+#undef PFA_LAUNCH_GRAD_PERM
 #undef PFA_LAUNCH_GRAD
 #undef PFA_LAUNCH_GRAD_K
     PFA_LAUNCH_CHECK();
     double *normp = norm_partials_of(workspace, dims);
     ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
-#define PFA_LAUNCH_REDUCE(DPV, KTMV, COLV)                                                                                      \
-    hipLaunchKernelGGL((ppo_reduce_kernel<DPV, KTMV, COLV>), dim3((NativeLayout<DPV, KTMV, COLV>::kCount + 63) / 64),            \
+#define PFA_LAUNCH_REDUCE(DPV, KTMV, COLV) PFA_LAUNCH_REDUCE_P(DPV, KTMV, COLV, false)
+#define PFA_LAUNCH_REDUCE_P(DPV, KTMV, COLV, PERMV)                                                                             \
+    hipLaunchKernelGGL((ppo_reduce_kernel<DPV, KTMV, COLV, PERMV>), dim3((NativeLayout<DPV, KTMV, COLV>::kCount + 63) / 64),     \
                        dim3(64 * kRedSl), 0, (hipStream_t)stream, partials, grid, dims->num_actions, dims->obs_dim, grads, normp)
     switch (dims->obs_stride) {   // the same instantiation choice as the gradient launch above: the partial layout belongs to it
         case 16: PFA_LAUNCH_REDUCE(16, 1, false); break;
@@ -982,11 +996,13 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
         case 96: PFA_LAUNCH_REDUCE(96, 6, false); break;
         case 128: PFA_LAUNCH_REDUCE(128, 8, false); break;
         default:
-            if (grad_trimmed(dims)) PFA_LAUNCH_REDUCE(64, 3, true);
+            if (grad_trimmed(dims) && grad_perm(dims)) PFA_LAUNCH_REDUCE_P(64, 3, true, true);
+            else if (grad_trimmed(dims)) PFA_LAUNCH_REDUCE(64, 3, true);
             else PFA_LAUNCH_REDUCE(64, 4, false);
             break;
     }
 #undef PFA_LAUNCH_REDUCE
+#undef PFA_LAUNCH_REDUCE_P
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -999,7 +1015,8 @@ extern "C" int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_strid
     int kku = obs_stride / 4, ktm = obs_stride / 16;
     if (obs_stride == 64 && (obs_dim + 3) / 4 == 13) kku = 13;
     if (obs_stride == 64 && obs_dim == 49) ktm = 3;
-    return kku * kMT + 3 * 4 * kMT + ktm * 4 * kMT;
+    const bool perm = PFA_GRAD_PERM && obs_stride == 64 && obs_dim == 49 && num_actions <= 11;   // (one Discrete head assumed, as everywhere in this helper)
+    return kku * kMT + (perm ? 11 : 12) * kMT + ktm * 4 * kMT;
 }
 
 extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, int64_t count, float lr,
