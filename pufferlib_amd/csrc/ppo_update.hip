@@ -25,6 +25,9 @@
 #include "sampler.hpp"
 #include "ppo_tile.hpp"
 
+#ifndef PFA_GRAD_FCOL
+#define PFA_GRAD_FCOL 1   // 0 = the trailing column through a full MFMA k-step in the forward (A/B timing)
+#endif
 #ifndef PFA_GRAD_PIPE
 #define PFA_GRAD_PIPE 1   // 0 = the round-2 instruction order (kept for A/B timing with tools/variant_bench.py)
 #endif
@@ -117,6 +120,10 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     // the software-pipelined instruction order costs ~40 registers (double-buffered fragments, all eight dh / hidden-tile fragments
     // live at once): taken where the instantiation stays inside its register budget without spilling (checked in the ISA)
     constexpr bool kPipe = PFA_GRAD_PIPE && (DP <= 32 || (DP == 64 && KTM <= 3));
+    // FCOL: with COL the forward, too, runs the trailing observation column (k = 16 KTM, the 7x7 grid's column 48) as 32 VALU fmas on
+    // the accumulators instead of a whole k-step of 8 MFMAs that multiplies three padding columns with it: KKM k-steps on MFMA
+    constexpr bool FCOL = PFA_GRAD_FCOL && COL && kPipe && KKU > 4 * KTM;
+    constexpr int KKM = FCOL ? 4 * KTM : KKU;
     static_assert(!PERM || (kPipe && !MH), "the permuted head layout is wired into the pipelined single-head form");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
@@ -167,6 +174,21 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             b1t[i] = tb[j];
             w2t[i] = tw[j];
             w2bt[i] = tv[j];
+        }
+        if constexpr (FCOL) {   // W1[16m + 4g + r][16 KTM] in the C-fragment order of hidden^T, in the pad floats behind each lane's k-steps
+            static_assert(W1S - KS >= 4 && KS % 4 == 0, "the trailing-column fragment sits in the lane's pad floats");
+            float tc[N2];
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                const int i = threadIdx.x + j * kGradThreads;
+                const int r = i & 3, ln = (i >> 2) & 63, m = i >> 8, gg = ln >> 4;
+                tc[j] = params[off.w1 + (16 * m + 4 * gg + r) * DP + 16 * KTM];
+            }
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                const int i = threadIdx.x + j * kGradThreads;
+                w1t[(i >> 2) * W1S + KS + (i & 3)] = tc[j];
+            }
         }
     }
 #endif
@@ -256,7 +278,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             // per tile); the sched_barriers pin the order.  Within a group the products run k-step-major: 8 independent accumulator
             // chains instead of 4 dependent MFMAs on one chain.  KKU = ceil(obs_dim / 4) k-steps carry data; the rest is zero
             // padding in X and in W1 and is not issued.
-            constexpr int NK4 = (ABL & 4) ? 0 : (KKU + 3) / 4;
+            constexpr int NK4 = (ABL & 4) ? 0 : (KKM + 3) / 4;
             f32x4 wq[2][kMT];
             float xb[2][4];
             auto load_group = [&](int k4, int b) {
@@ -276,8 +298,17 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int m = 0; m < kMT; ++m)
-                        if (4 * k4 + q < KKU) h[m] = mfma16(wq[k4 & 1][m][q], xb[k4 & 1][q], h[m]);
+                        if (4 * k4 + q < KKM) h[m] = mfma16(wq[k4 & 1][m][q], xb[k4 & 1][q], h[m]);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (FCOL) {
+                const float xcol = xs[c * XS + 16 * KTM];     // X[row = c][16 KTM]
+#pragma unroll
+                for (int m = 0; m < kMT; ++m) {
+                    const f32x4 wc = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + KS);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[m][r] = fmaf(wc[r], xcol, h[m][r]);
+                }
             }
             } else {
 #pragma unroll
@@ -1015,6 +1046,7 @@ extern "C" int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_strid
     int kku = obs_stride / 4, ktm = obs_stride / 16;
     if (obs_stride == 64 && (obs_dim + 3) / 4 == 13) kku = 13;
     if (obs_stride == 64 && obs_dim == 49) ktm = 3;
+    if (PFA_GRAD_FCOL && obs_stride == 64 && obs_dim == 49) kku = 12;   // the forward's column 48 runs on the VALU (FCOL)
     const bool perm = PFA_GRAD_PERM && obs_stride == 64 && obs_dim == 49 && num_actions <= 11;   // (one Discrete head assumed, as everywhere in this helper)
     return kku * kMT + (perm ? 11 : 12) * kMT + ktm * 4 * kMT;
 }
