@@ -415,3 +415,58 @@ def test_deferred_readback_mode_gives_the_same_numbers(monkeypatch):
     assert repr(runs[0][0]) == repr(runs[1][0])          # (repr: an explained_variance of nan still compares equal)
     assert torch.equal(runs[0][1], runs[1][1])
     assert set(runs[0][0][-1][0]) == {'episode_return', 'episode_length', 'score'} and runs[0][0][-1][2]['value_loss'] > 0
+
+
+@pytest.mark.parametrize('num_actions', [3, 11, 12, 15])
+def test_49_float_rows_with_other_action_counts_vs_oracle(num_actions):
+    """The 7x7-grid instantiation of the gradient kernel (3 dW1 k-tiles + the column-48 accumulators) keeps the head outputs in
+    PERMUTED fragment rows for up to 11 actions (three outputs per lane group) and in natural rows above that: both against the
+    oracle trainer on a host vecenv with 49-float observations and 3 / 11 (permuted) and 12 / 15 (natural) actions."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from host_vecenv import HostMultiHead
+    from pufferlib_amd import clean_pufferl, cleanrl, models, spaces
+    from pufferlib_amd.models import FlatParams
+    from oracle import ppo_torch
+
+    class HostDiscrete(HostMultiHead):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.single_action_space = spaces.Discrete(self.nvec[0])
+    n, horizon, nmb, bptt = 32, 16, 2, 8
+    B = n * horizon
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    vec = HostDiscrete(n, [num_actions], obs_dim=49)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    data = clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, hp, env='host'), vec, pol)
+    assert isinstance(data.flat_params, FlatParams) and data.flat_params.obs_stride == 64       # the fused kernels, not the GEMM path
+    w0 = {k[len('policy.'):]: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    opol = ppo_torch.Policy(w0)
+
+    class _V:
+        num_envs = n
+        observations = np.zeros((n, 49), np.float32)
+
+        def async_reset(self, seed):
+            pass
+    tr = ppo_torch.Trainer(opol, _V(), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt, update_epochs=2, learning_rate=hp[0], gamma=hp[1],
+                           gae_lambda=hp[2], clip_coef=hp[3], vf_coef=hp[4], vf_clip_coef=hp[5], max_grad_norm=hp[6], ent_coef=hp[7],
+                           total_timesteps=B * 10, seed=1)
+    tr.obs = torch.as_tensor(_step_major(exp.obs, n, horizon)[:, :49].copy())
+    tr.actions = _step_major(exp.actions, n, horizon).astype(np.int64)
+    tr.logprobs, tr.rewards, tr.dones, tr.values = (_step_major(x, n, horizon).copy() for x in (exp.logprobs, exp.rewards, exp.dones, exp.values))
+    tr.global_step = data.global_step
+    Lo = tr.train()
+    clean_pufferl.train(data)
+    L = data.losses
+    np.testing.assert_allclose([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac],
+                               [Lo[k] for k in ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac')], **TOL)
+    sd = pol.state_dict()
+    for k, arr in opol.state_arrays().items():
+        np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=k, **TOL)
