@@ -5,6 +5,10 @@
 #pragma once
 #include <cmath>
 
+#ifndef PFA_LOSS_EXP_REPAIR_ALL
+#define PFA_LOSS_EXP_REPAIR_ALL 0   // 1 = the argument-repaired exponential for the softmax numerators too (A/B timing)
+#endif
+
 #include "common.hpp"
 #include "mlp_tile.hpp"
 
@@ -81,6 +85,17 @@ __device__ __forceinline__ float loss_exp(float x) {
     const float e = fmaf(x, kLl, fmaf(x, kL, -t));
     const float r = __builtin_amdgcn_exp2f(t);
     return fmaf(r, e * 0.693147182464599609375f, r);
+}
+// The softmax numerators exp(logit - max), x <= 0: without the repair — two instructions instead of six on the loss's dependent
+// chain.  The argument's rounding then shows as a relative error of |x| * 4e-8 in the result, i.e. < 1e-6 on probabilities that are
+// themselves < e^-20 and ~1e-8 on the ones that matter; measured on the bench shape: parameters after two updates move by 5e-8
+// against the repaired form, the launch gets 0.8 us shorter (profiles/r03_grad_variants.txt).  The ratio keeps the repaired form.
+__device__ __forceinline__ float loss_exp_softmax(float x) {
+#if PFA_LOSS_EXP_REPAIR_ALL
+    return loss_exp(x);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.44269502162933349609375f);
+#endif
 }
 __device__ __forceinline__ float loss_log(float x) {   // x in [1, 16] here (sum of exp(logit - max))
     const float l2 = __builtin_amdgcn_logf(x);           // v_log_f32 = log2
@@ -180,7 +195,7 @@ __device__ __forceinline__ LossOut ppo_loss_tile(const f32x4 &out, const RowScal
     float ev[4], se = 0.0f;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        ev[r] = o0 + r < a ? loss_exp(out[r] - lmax) : 0.0f;
+        ev[r] = o0 + r < a ? loss_exp_softmax(out[r] - lmax) : 0.0f;
         se += ev[r];
     }
     se = gsum<SWAP>(se);
