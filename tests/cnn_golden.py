@@ -13,9 +13,9 @@ def cnn_start_weight(name, shape, seed=4242):
     """Same as make_golden.cnn_start_weight: the golden run's start value of parameter `name`."""
     import zlib
     rs = np.random.RandomState(seed + zlib.crc32(name.encode()) % 100000)
-    if name.endswith('bias'):
+    if name.endswith('bias') or name.startswith('bias_'):          # (bias_ih_l0 / bias_hh_l0 of the recurrent variant)
         return (0.01 * rs.standard_normal(shape)).astype(np.float32)
-    gain = 0.01 if 'actor' in name else 1.0 if 'value_fn' in name else np.sqrt(2)
+    gain = 0.01 if 'actor' in name else 1.0 if ('value_fn' in name or name.startswith('weight_')) else np.sqrt(2)
     return (gain / np.sqrt(np.prod(shape[1:])) * rs.standard_normal(shape)).astype(np.float32)
 
 
@@ -37,6 +37,21 @@ def container(num_actions=4):
     from pufferlib_amd import models
     torch.manual_seed(1)
     return models.Convolutional(_Env(num_actions), framestack=4, flat_size=64 * 7 * 7)
+
+
+LSTM_SHAPES = {'weight_ih_l0': (2048, 512), 'weight_hh_l0': (2048, 512), 'bias_ih_l0': (2048,), 'bias_hh_l0': (2048,)}
+
+
+def recurrent_start_weights(net):
+    """Start values of the golden recurrent run (ppo_cnn_lstm.npz): the conv stack's as in ppo_cnn.npz + the LSTM(512, 512)'s."""
+    w = start_weights(net)
+    w.update({k: cnn_start_weight(k, sh) for k, sh in LSTM_SHAPES.items()})
+    return w
+
+
+def golden_key(name):
+    """Bare parameter name -> its key in ppo_cnn_lstm.npz (state_dict of cleanrl.RecurrentPolicy(LSTMWrapper(Convolutional)))."""
+    return ('policy.recurrent.' if name in LSTM_SHAPES else 'policy.policy.') + name
 
 
 def start_weights(net):

@@ -24,6 +24,8 @@ Fixtures written (all small, committed):
                      EnvPool mode (8 of 16 envs per recv): every recv() batch, the noise, the actions sent back, the sorted experience
   ppo_cnn.npz        same with models.Convolutional (models.py:113-157, NatureCNN) on a stub env with uint8 (4, 84, 84) frames;
                      frames are re-derivable from recorded frame numbers, big tensors recorded as digests (sum, |sum|, 64 samples)
+  ppo_cnn_lstm.npz   same as ppo_cnn with pufferlib.models.LSTMWrapper(input_size=512, hidden_size=512) on top and frameworks.cleanrl.RecurrentPolicy —
+                     the `Recurrent` policy of environments/atari/torch.py:4-6 (`make_golden.py cnn_lstm`)
   ppo_spaces.npz     same as ppo_mlp on ocean make_spaces: Dict observation emulated to 108-byte rows, Dict action emulated to
                      MultiDiscrete([2, 2]) -> models.Default's per-head decoders and sample_logits' list branch (cleanrl.py:25-47)
 """
@@ -561,9 +563,9 @@ def cnn_start_weight(name, shape, seed=4242):
     sqrt(2), actor 0.01, value_fn 1), N(0, 0.01^2) biases, from numpy's legacy generator keyed by the parameter name."""
     import zlib
     rs = np.random.RandomState(seed + zlib.crc32(name.encode()) % 100000)
-    if name.endswith('bias'):
+    if name.endswith('bias') or name.startswith('bias_'):          # (bias_ih_l0 / bias_hh_l0 of the recurrent variant)
         return (0.01 * rs.standard_normal(shape)).astype(np.float32)
-    gain = 0.01 if 'actor' in name else 1.0 if 'value_fn' in name else np.sqrt(2)
+    gain = 0.01 if 'actor' in name else 1.0 if ('value_fn' in name or name.startswith('weight_')) else np.sqrt(2)
     return (gain / np.sqrt(np.prod(shape[1:])) * rs.standard_normal(shape)).astype(np.float32)
 
 
@@ -574,7 +576,7 @@ def digest(a, samples=64):
     return np.concatenate([[f.sum(), np.abs(f).sum()], f[idx]])
 
 
-def gen_ppo_cnn(num_envs=4, horizon=16, iters=1):
+def gen_ppo_cnn(num_envs=4, horizon=16, iters=1, use_rnn=False):
     """clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) with pufferlib.models.Convolutional (models.py:113-157, the
     NatureCNN of BASELINE configs[3]) behind frameworks.cleanrl.Policy, on a stub env with Atari-shaped observations."""
     import gymnasium
@@ -637,14 +639,18 @@ def gen_ppo_cnn(num_envs=4, horizon=16, iters=1):
     vec = pufferlib.vector.make(make_env, num_envs=num_envs, backend=pufferlib.vector.Serial)
     torch.manual_seed(1)
     net = pufferlib.models.Convolutional(vec.driver_env, framestack=4, flat_size=64 * 7 * 7)
-    policy = pufferlib.frameworks.cleanrl.Policy(net)
+    if use_rnn:    # environments/atari/torch.py:4-6: Recurrent = LSTMWrapper(input_size=512, hidden_size=512) over the NatureCNN Policy
+        policy = pufferlib.frameworks.cleanrl.RecurrentPolicy(pufferlib.models.LSTMWrapper(vec.driver_env, net, input_size=512, hidden_size=512))
+    else:
+        policy = pufferlib.frameworks.cleanrl.Policy(net)
+    bare = lambda k: k.split('.', 2)[2] if use_rnn and k.startswith('policy.policy.') else k.split('.', 2)[2] if use_rnn else k[len('policy.'):]  # noqa: E731
     out = {}
     for k, v in policy.state_dict().items():
         out['init.' + k] = digest(v.detach().numpy())      # layer_init under torch.manual_seed(1) (QR: equal up to LAPACK rounding)
     # the run itself starts from weights any platform can rebuild bit for bit: numpy's legacy normal stream, layer_init's scales
     with torch.no_grad():
         for k, v in policy.state_dict().items():
-            v.copy_(torch.from_numpy(cnn_start_weight(k[len('policy.'):], tuple(v.shape))))   # keyed by the bare parameter name
+            v.copy_(torch.from_numpy(cnn_start_weight(bare(k), tuple(v.shape))))   # keyed by the bare parameter name
     for k, v in policy.state_dict().items():
         out['w0.' + k] = digest(v.detach().numpy())
     noise = []
@@ -689,6 +695,9 @@ def gen_ppo_cnn(num_envs=4, horizon=16, iters=1):
             out[f'it{it}.dones'] = exp.dones_np.copy()
             out[f'it{it}.values'] = exp.values_np.copy()
             out[f'it{it}.global_step'] = np.array(data.global_step, np.int64)
+            if use_rnn:
+                out[f'it{it}.lstm_h'] = exp.lstm_h.numpy().copy()
+                out[f'it{it}.lstm_c'] = exp.lstm_c.numpy().copy()
             lr_used = data.optimizer.param_groups[0]['lr']
             clean_pufferl.train(data)
             out[f'it{it}.lr_used'] = np.array(lr_used, np.float64)
@@ -705,13 +714,17 @@ def gen_ppo_cnn(num_envs=4, horizon=16, iters=1):
                               config.total_timesteps, iters], np.int64)
     out['hparams'] = np.array([config.learning_rate, config.gamma, config.gae_lambda, config.clip_coef, config.vf_coef,
                                config.vf_clip_coef, config.max_grad_norm, config.ent_coef], np.float64)
-    np.savez_compressed(os.path.join(HERE, 'ppo_cnn.npz'), **out)
-    print('ppo_cnn.npz', len(out), 'arrays; losses it0', out['it0.losses'])
+    fname = 'ppo_cnn_lstm.npz' if use_rnn else 'ppo_cnn.npz'
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname, len(out), 'arrays; losses it0', out['it0.losses'])
 
 
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'cnn':
         gen_ppo_cnn()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'cnn_lstm':   # the recurrent NatureCNN of environments/atari/torch.py:4-6
+        gen_ppo_cnn(use_rnn=True)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'mp':
         gen_ppo_mp()
@@ -738,3 +751,4 @@ if __name__ == '__main__':
     gen_ppo('mlp_h256', use_rnn=False, hidden=256)
     gen_ppo_mp()
     gen_ppo_cnn()
+    gen_ppo_cnn(use_rnn=True)

@@ -407,6 +407,60 @@ def test_recurrent_nature_cnn_rollout_and_update_vs_oracle():
     _check_update(data, pol, opol, tr, name)
 
 
+def test_recurrent_nature_cnn_replays_the_reference_golden(golden_dir):
+    """tests/golden/ppo_cnn_lstm.npz: the unmodified reference's cleanrl.RecurrentPolicy(LSTMWrapper(Convolutional, 512, 512))
+    (environments/atari/torch.py:4-6) through its create / evaluate / train on the frame stub. Rollout mode: policy(obs, state) on
+    its frames with its multinomial's exponential draws -> its actions bit for bit, log-probabilities, values, and the LSTM state it
+    ends the rollout with. Training mode: its experience through the update -> losses and every updated tensor."""
+    import cnn_golden
+    from pufferlib_amd import clean_pufferl, cleanrl, general, models, vector
+    from test_gpu_ppo import _config
+    g = np.load(os.path.join(golden_dir, 'ppo_cnn_lstm.npz'))
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    hp = [float(x) for x in g['hparams']]
+    B = n * horizon
+    vec = vector.make(vector.make_frames, num_envs=n, backend=vector.Frames)
+    conv = cnn_golden.container()
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, conv, input_size=512, hidden_size=512))
+    start = cnn_golden.recurrent_start_weights(conv)
+    with torch.no_grad():
+        for k, v in pol.state_dict().items():
+            bare = k.split('.', 2)[2]
+            assert cnn_golden.golden_key(bare) == k
+            v.copy_(torch.from_numpy(start[bare]))
+            assert np.array_equal(cnn_golden.digest(v.numpy()), g['w0.' + k]), k
+    data = clean_pufferl.create(_config(n, horizon, mbs, bptt, epochs, total, hp, seed=1, env='frames'), vec, pol)
+    assert isinstance(data.flat_params, general.GeneralParams) and data.gen_engine.net.kind == 'cnn' and data.gen_engine.net.lstm == (512, 512)
+    frame_ids, noise = g['it0.frame_ids'], g['it0.noise']
+    frames = np.stack([[cnn_golden.cnn_frame(frame_ids[t, e]) for e in range(n)] for t in range(horizon)])   # (T, N, 4, 84, 84)
+    dev = vec.device
+    state = None
+    for t in range(horizon):
+        a, lp, ent, val, state = pol(torch.as_tensor(frames[t]).to(dev), state, noise=torch.as_tensor(noise[t]))
+        assert np.array_equal(a.cpu().numpy().reshape(-1), g['it0.actions'][t * n:(t + 1) * n]), t
+        np.testing.assert_allclose(lp.cpu().numpy(), g['it0.logprobs'][t * n:(t + 1) * n], **TOL)
+        np.testing.assert_allclose(val.cpu().numpy().reshape(-1), g['it0.values'][t * n:(t + 1) * n], **TOL)
+    np.testing.assert_allclose(state[0].cpu().numpy(), g['it0.lstm_h'], **TOL)
+    np.testing.assert_allclose(state[1].cpu().numpy(), g['it0.lstm_c'], **TOL)
+    e = data.experience
+    em = lambda x: torch.as_tensor(np.ascontiguousarray(np.asarray(x).reshape(horizon, n, *np.asarray(x).shape[1:]).swapaxes(0, 1))  # noqa: E731
+                                   .reshape(B, *np.asarray(x).shape[1:])).to(dev)
+    e.obs.copy_(em(frames.reshape(B, -1)))
+    e.actions.copy_(em(g['it0.actions'].astype(np.int32)).view_as(e.actions))
+    for dst, key in ((e.logprobs, 'logprobs'), (e.values, 'values'), (e.rewards, 'rewards'), (e.dones, 'dones')):
+        dst.copy_(em(g['it0.' + key].astype(np.float32)))
+    e.ptr = B
+    data.global_step = int(g['it0.global_step'])
+    clean_pufferl.train(data)
+    L = data.losses
+    got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance]
+    np.testing.assert_allclose(got, g['it0.losses'], **TOL)
+    for k, v in pol.state_dict().items():
+        got, want = cnn_golden.digest(v.cpu().numpy()), g['it0.w.' + k]
+        np.testing.assert_allclose(got[2:], want[2:], err_msg=k, **TOL)                 # the sampled elements
+        np.testing.assert_allclose(got[:2], want[:2], rtol=0, atol=1e-5 * max(1.0, want[1]), err_msg=k + ' (sums)')
+
+
 def test_hidden_256_replays_the_reference_golden(golden_dir):
     """tests/golden/ppo_mlp_h256.npz: the unmodified reference's create / evaluate / train with models.Default(hidden_size=256) on
     Serial(Squared) — its multinomial noise in, its actions bit for bit, experience, advantages, losses, weights and Adam moments out."""

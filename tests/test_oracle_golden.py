@@ -182,6 +182,36 @@ def test_conv_ppo_replay_matches_reference(golden_dir):
         np.testing.assert_allclose(cnn_golden.digest(arr), g['it0.w.policy.' + name], rtol=1e-5, atol=1e-6, err_msg=name)
 
 
+def test_recurrent_conv_ppo_replay_matches_reference(golden_dir):
+    """oracle RecurrentConvPolicy + Trainer against the unmodified reference's run with LSTMWrapper(512, 512) over
+    models.Convolutional behind cleanrl.RecurrentPolicy (ppo_cnn_lstm.npz; environments/atari/torch.py:4-6): identical actions
+    given the recorded multinomial noise, log-probabilities / values / final LSTM state / losses / updated weights."""
+    import cnn_golden
+    torch.set_num_threads(1)
+    g = _load(golden_dir, 'ppo_cnn_lstm.npz')
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    lr, gamma, lam, clip, vf_coef, vf_clip, mgn, ent = (float(x) for x in g['hparams'])
+    w0 = cnn_golden.recurrent_start_weights(cnn_golden.container())
+    for k, v in w0.items():
+        assert np.array_equal(cnn_golden.digest(v), g['w0.' + cnn_golden.golden_key(k)]), k
+    pol = ppo_torch.RecurrentConvPolicy(w0)
+    tr = ppo_torch.Trainer(pol, cnn_golden.ReplayVec(g), batch_size=n * horizon, minibatch_size=mbs, bptt_horizon=bptt, update_epochs=epochs,
+                           learning_rate=lr, gamma=gamma, gae_lambda=lam, clip_coef=clip, vf_coef=vf_coef, vf_clip_coef=vf_clip,
+                           max_grad_norm=mgn, ent_coef=ent, total_timesteps=total, seed=1)
+    tr.evaluate(g['it0.noise'])
+    assert np.array_equal(tr.actions, g['it0.actions'].astype(np.int64)), 'actions differ'
+    np.testing.assert_allclose(tr.logprobs, g['it0.logprobs'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tr.values, g['it0.values'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tr.lstm_h.numpy(), g['it0.lstm_h'], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(tr.lstm_c.numpy(), g['it0.lstm_c'], rtol=1e-5, atol=1e-6)
+    L = tr.train()
+    np.testing.assert_allclose(tr.b_advantages.numpy(), g['it0.advantages'], rtol=1e-5, atol=1e-6)
+    got = [L['policy_loss'], L['value_loss'], L['entropy'], L['old_approx_kl'], L['approx_kl'], L['clipfrac'], L['explained_variance']]
+    np.testing.assert_allclose(got, g['it0.losses'], rtol=2e-5, atol=1e-7)
+    for name, arr in pol.state_arrays().items():
+        np.testing.assert_allclose(cnn_golden.digest(arr), g['it0.w.' + cnn_golden.golden_key(name)], rtol=1e-5, atol=1e-6, err_msg=name)
+
+
 def test_stochastic_oracle_replays_reference_trajectory(golden_dir):
     """ocean.Stochastic under Serial + GymnasiumPufferEnv + EpisodeStats (tests/golden/stochastic.npz from the unmodified
     reference): observations, f32 rewards, terminals, auto-reset rows and the episode infos, bit for bit."""
