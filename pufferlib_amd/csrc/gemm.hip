@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__rest
 }
 
 struct GemmTnPlan {
-    int cfg;  // 0: 128x128, 1: 128x64, 2: 16x128, 3: 128x32, 4: 128x16
+    int cfg;  // 0: 128x128, 1: 128x64, 2: 16x128, 3: 128x32, 4: 128x16, 5: 128x160
     int tm, tn, tiles, splits;
     long long k_per_split;
 };
@@ -171,6 +171,8 @@ static bool gemm_tn_plan(int mo, int no, long long K, GemmTnPlan &p) {
         p.cfg = 0, p.tm = 128, p.tn = 128;
     } else if (mo % 128 == 0 && no % 64 == 0) {
         p.cfg = 1, p.tm = 128, p.tn = 64;
+    } else if (mo % 128 == 0 && no % 160 == 0) {   // the encoder gradient of 160-float rows (configs[2]): one 32 x 160 strip per wave, 20 MFMAs
+        p.cfg = 5, p.tm = 128, p.tn = 160;          // per 12 fragment reads (the 128 x 32 tile it used before: 4 per 5, LDS-issue bound)
     } else if (mo % 128 == 0 && no % 32 == 0) {
         p.cfg = 3, p.tm = 128, p.tn = 32;
     } else if (mo % 128 == 0 && no % 16 == 0) {
@@ -222,6 +224,9 @@ extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int6
                            mo, no, (long long)k, p.k_per_split, partial);
     else if (p.cfg == 3)
         hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 1>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
+                           mo, no, (long long)k, p.k_per_split, partial);
+    else if (p.cfg == 5)
+        hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 1, 2, 10>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
                            mo, no, (long long)k, p.k_per_split, partial);
     else if (p.cfg == 4)
         hipLaunchKernelGGL((gemm_tn_partial_kernel<4, 1, 2, 1>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
