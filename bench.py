@@ -534,6 +534,10 @@ def main():
                                          if args.policy == 'mlp' else None),   # on the 49 real columns (32 000 FLOP/row)
                          'traffic': traffic, 'traffic_source': traffic_source, 'traffic_build': source_build_id(),
                          'avg_launch_ms': avg_ms, 'launches': launches, 'bracketed': f'every {event_stride}. launch of the timed region' if event_stride > 1 else 'every launch of the timed region',
+                         # ppo_mlp_grad's launch carries its own HIP events (hipExtLaunchKernelGGL start/stop: the dispatch's begin and end,
+                         # what rocprofv3's kernel trace reports); the other kernels are bracketed by events recorded on their stream
+                         'timing': ('HIP events attached to the dispatch (hip_ext.h start/stop)' if args.policy == 'mlp' and os.environ.get('PFA_TIMING_EXT', '1') != '0'
+                                    else 'HIP events recorded on the launch stream before / after the launch'),
                          'flop_per_launch': flop_row * rows_per_launch},
             'kernel_ms_per_step': breakdown,
             'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'per_rank': [round(x, 4) for x in rank_ms]},

@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -34,7 +35,7 @@ bool timing_enabled() { return g_timing != 0; }
 
 // Returns the stop event (to be recorded after the launch) or nullptr when timing is off.
 void *timing_begin(const char *name, hipStream_t stream) {
-    if (g_timing == 0 || (g_timing == 1 && g_selected != name)) return nullptr;
+    if (!name || g_timing == 0 || (g_timing == 1 && g_selected != name)) return nullptr;
     if (g_timing == 1 && g_stride > 1 && (g_seen++ % g_stride) != 0) return nullptr;
     TimedKernel &k = g_timed[name];
     if (k.used == k.pairs.size()) {
@@ -48,6 +49,31 @@ void *timing_begin(const char *name, hipStream_t stream) {
 }
 void timing_end(void *stop, hipStream_t stream) {
     if (stop) (void)hipEventRecord((hipEvent_t)stop, stream);
+}
+// An event pair for a launch that carries its own events (hipExtLaunchKernelGGL: the runtime stamps them with the dispatch's begin
+// and end, the same two timestamps rocprofv3's kernel trace reports) — nothing is recorded here.  false: timing is off for this
+// launch (or PFA_TIMING_EXT=0 asks for the stream-position bracket instead).
+bool timing_ext_mode() {
+    static const bool ext = [] {
+        const char *e = getenv("PFA_TIMING_EXT");
+        return !(e && e[0] == '0');
+    }();
+    return ext;
+}
+bool timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop) {
+    const bool ext = timing_ext_mode();
+    if (!ext || g_timing == 0 || (g_timing == 1 && g_selected != name)) return false;
+    if (g_timing == 1 && g_stride > 1 && (g_seen++ % g_stride) != 0) return false;
+    TimedKernel &k = g_timed[name];
+    if (k.used == k.pairs.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+        k.pairs.emplace_back(a, b);
+    }
+    auto &p = k.pairs[k.used++];
+    *start = p.first;
+    *stop = p.second;
+    return true;
 }
 }  // namespace pfa
 

@@ -20,6 +20,8 @@
 #include <cmath>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 #include "mlp_tile.hpp"
 #include "sampler.hpp"
@@ -985,9 +987,14 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                \
             attr_set = true;                                                                                               \
         }                                                                                                                  \
-        hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV, PERMV>), dim3(grid), dim3(grad_threads(DPV)), lds_bytes, \
-                           (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions, dims->heads, *hp,     \
-                           adv_stats, (double)global_mb_rows, partials);                                                   \
+        if (grad_timed)                                                                                                    \
+            hipExtLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV, PERMV>), dim3(grid), dim3(grad_threads(DPV)), \
+                                  lds_bytes, (hipStream_t)stream, grad_ev0, grad_ev1, 0, *exp, map, (long long)mbs, params,  \
+                                  dims->num_actions, dims->heads, *hp, adv_stats, (double)global_mb_rows, partials);      \
+        else                                                                                                               \
+            hipLaunchKernelGGL((ppo_mlp_grad_kernel<DPV, 0, KKUV, MHV, KTMV, COLV, PERMV>), dim3(grid), dim3(grad_threads(DPV)), \
+                               lds_bytes, (hipStream_t)stream, *exp, map, (long long)mbs, params, dims->num_actions,       \
+                               dims->heads, *hp, adv_stats, (double)global_mb_rows, partials);                             \
     }
 #define PFA_LAUNCH_GRAD_KM(DPV, KKUV, MHV) PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, DPV / 16, false)
 #define PFA_LAUNCH_GRAD_K(DPV, KKUV) PFA_LAUNCH_GRAD_KM(DPV, KKUV, false)
@@ -995,7 +1002,11 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     if (dims->heads) PFA_LAUNCH_GRAD_KM(DPV, DPV / 4, true)         \
     else PFA_LAUNCH_GRAD_KM(DPV, DPV / 4, false)
     {
-        ScopedKernelTimer timer("ppo_mlp_grad", (hipStream_t)stream);
+        // bench.py's roofline leg: the launch carries its own events (stamped with the dispatch's begin and end); with
+        // PFA_TIMING_EXT=0 the stream-position bracket of the other kernels is used instead (it adds the dispatch gap, ~2.4 us)
+        hipEvent_t grad_ev0 = nullptr, grad_ev1 = nullptr;
+        const bool grad_timed = timing_pair("ppo_mlp_grad", &grad_ev0, &grad_ev1);
+        ScopedKernelTimer timer(timing_ext_mode() ? nullptr : "ppo_mlp_grad", (hipStream_t)stream);
         switch (dims->obs_stride) {
             case 16: PFA_LAUNCH_GRAD(16) break;
             case 32: PFA_LAUNCH_GRAD(32) break;
