@@ -37,6 +37,23 @@ def test_size_helpers(L):
     assert L.pfa_gae_workspace_bytes(524288) == 256 * 16
 
 
+def test_weight_gradient_workspace_never_shrinks_with_more_rows(L):
+    """cnn.Engine / general.Engine size the dW workspace once for their largest chunk and reuse it for shorter ones: the launch plan
+    of csrc/igemm.hip (row splits x partial tiles) must therefore never need MORE room for FEWER rows — also where a small gradient
+    is split finer (>= 256 rows per split until ~1024 workgroups exist)."""
+    shapes = [(64, 256), (256, 16), (512, 16), (256, 32), (512, 64), (576, 64), (3136, 512), (160, 128), (48, 64), (1024, 512)]
+    for K, N in shapes:
+        prev = 0
+        for M in (1, 16, 255, 256, 257, 4096, 8192, 65536, 131072, 8192 * 49, 8192 * 81, 8192 * 400):
+            b = L.pfa_igemm_weights_workspace_bytes(M, K, N)
+            assert b >= prev > -1, (K, N, M, b, prev)
+            assert b >= K * N * 4, (K, N, M)
+            prev = b
+    assert L.pfa_igemm_weights_workspace_bytes(0, 64, 64) == 0 and L.pfa_igemm_weights_workspace_bytes(100, 64, 24) == 0
+    # gemm_tn (csrc/gemm.hip): the 160-float encoder gradient has its own strip
+    assert L.pfa_gemm_tn_workspace_bytes(128, 160, 131072) > 0 and L.pfa_gemm_tn_workspace_bytes(128, 24, 4096) == 0
+
+
 def test_no_cpu_fallback():
     """The product path must fail loudly without a GPU."""
     import torch
