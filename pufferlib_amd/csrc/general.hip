@@ -230,14 +230,16 @@ __global__ void __launch_bounds__(256) heads_rows_loss_kernel(const float *out, 
 }
 
 // loss_pairs16 (+)= the (hi, lo) float pairs of the chunk's six f64 sums, fixed summation order over the block partials
-__global__ void gen_stats_final_kernel(const double *partial, int nblocks, float *loss_pairs16, int accumulate) {   // one wave
+__global__ void __launch_bounds__(256) gen_stats_final_kernel(const double *partial, int nblocks, float *loss_pairs16, int accumulate) {
+    __shared__ double sh[32][8];      // 32 strided chains per statistic, combined in a fixed order
     const int i = threadIdx.x & 7, part = threadIdx.x >> 3;
     double s = 0.0;
-    for (int b = part; b < nblocks; b += 8) s += partial[(size_t)b * 8 + i];
-    s += __shfl_xor(s, 8, 64);
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    for (int b = part; b < nblocks; b += 32) s += partial[(size_t)b * 8 + i];
+    sh[part][i] = s;
+    __syncthreads();
     if (threadIdx.x >= 8) return;
+    s = 0.0;
+    for (int q = 0; q < 32; ++q) s += sh[q][i];
     if (accumulate) s += (double)loss_pairs16[2 * i] + (double)loss_pairs16[2 * i + 1];
     const float hi = (float)s;
     loss_pairs16[2 * i] = hi;
@@ -386,7 +388,7 @@ extern "C" int pfa_heads_rows_loss(const float *out, int32_t ld, const pfa_exper
                        (int)time_major_rows, *exp, HeadSpec{(int)num_actions, heads}, *hp, adv_stats, (double)global_mb_rows, dout, (int)ldd,
                        (int)num_out, (double *)workspace);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gen_stats_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double *)workspace, (int)grid, loss_pairs16,
+    hipLaunchKernelGGL(gen_stats_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)workspace, (int)grid, loss_pairs16,
                        (int)accumulate);
     PFA_LAUNCH_CHECK();
     return 0;

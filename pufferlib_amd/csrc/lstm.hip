@@ -32,14 +32,6 @@ __device__ __forceinline__ void stage_heads(const float *params, int dp, int a, 
     for (int i = threadIdx.x; i < kOut; i += blockDim.x) b2v[i] = b2v_at(params, off, a, i);
 }
 
-__device__ __forceinline__ float head_dot(const float *hrow, const float *w2v, const float *b2v, int lo) {
-    float acc = b2v[lo];
-    const float *w = w2v + lo * (kLstmH + 1);
-#pragma unroll 8
-    for (int u = 0; u < kLstmH; ++u) acc = fmaf(hrow[u], w[u], acc);  // k-ordered fma chain, like nn.Linear's fp32 dot
-    return acc;
-}
-
 // Experience.store of one rollout step (clean_pufferl.py:436-450) into the env-major buffers: row (e, t) at e*T + t.
 __global__ void __launch_bounds__(256) store_step_kernel(pfa_experience ex, int t, int num_envs, int dp, const float *obs,
                                                         const float *rewards, const uint8_t *terminals, const long long *actions,
@@ -132,21 +124,46 @@ __global__ void __launch_bounds__(256) gather_obs_tm_kernel(const float *obs, Ti
 }
 
 // decode_actions + PPO loss (clean_pufferl.py:202-238) on the hidden states of one minibatch (time-major rows) and the
-// gradients w.r.t. the 16 padded head outputs and w.r.t. h.  16 lanes per row.  stats_partial: [gridDim.x][8].
+// gradients w.r.t. the 16 padded head outputs and w.r.t. h.  One wavefront per 16-row tile, both small products on the matrix
+// cores (v_mfma_f32_16x16x4_f32), the head weights as MFMA B fragments in registers for the whole launch:
+//   out[row][o]  = h[row][:] . W2v[o][:] + b2v[o]        32 MFMAs (two accumulator chains); lane (c, g) then holds output o = c of
+//                                                        rows 4g .. 4g+3 — the 16 lanes of a DPP row are the 16 outputs of one row,
+//                                                        which is the shape the shared log-softmax / arg-max pieces (sampler.hpp) take
+//   dh[row][u]   = sum_o dout[row][o] W2v[o][u]          32 MFMAs (8 independent column tiles), dout handed from the accumulator
+//                                                        layout to the A-operand layout through a 1 KB wave-private LDS tile
+// (the first version ran both as per-lane fma loops over LDS: 75 us per 131 072-row minibatch, LDS-issue bound; now 51 us, of
+// which ~35 are the 142 MB of h / dh / dout at HBM rate.  Measured and not taken: dh through an LDS transpose for whole-row stores
+// (68 us), tiles of 16 time steps of one segment so that the five experience gathers of a tile share a cache line (55 us: the h
+// rows of a tile are then 4 MB apart).)
+// stats_partial: [gridDim.x][24].
 __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, long long rows, TimeMajorMap map,
                                                              pfa_experience ex, const float *params, int dp, int a,
                                                              uint32_t heads, pfa_ppo_hparams hp, const double *adv_stats,
                                                              double global_rows,
                                                              float *dout /* [rows][16] */, float *dh /* [rows][128] */,
                                                              float *stats_partial) {
-    __shared__ float w2v[kOut * (kLstmH + 1)];
+    constexpr int WS = kLstmH + 4;     // W2v row stride in LDS: 16-byte aligned rows, 16 rows x float4 = all 64 banks once
+    __shared__ __attribute__((aligned(16))) float w2v[kOut * WS];
     __shared__ float b2v[kOut];
-    __shared__ float hs[16][kLstmH];
+    __shared__ float dt[4][16][17];   // per wave: dout of its tile as [row][o]
     __shared__ float st[16][8];
     __shared__ float sd[16][16];
-    float dsum = 0.0f;  // this lane's column of sum_rows dout (the head bias gradient)
-    stage_heads(params, dp, a, w2v, b2v);
-    const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
+    {
+        const MlpOffsets off = mlp_offsets(dp, a);
+        for (int i = threadIdx.x; i < kOut * kLstmH; i += 256) {
+            const int o = i / kLstmH, u = i - o * kLstmH;
+            w2v[o * WS + u] = w2v_at(params, off, a, o, u);
+        }
+        if (threadIdx.x < kOut) b2v[threadIdx.x] = b2v_at(params, off, a, threadIdx.x);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int le = wv * 4 + g, lo = c;      // (le: one of the workgroup's 16 DPP rows; lo: the head output this lane owns)
+    // B fragments come from the LDS copy at their point of use (in registers they cost 64 VGPRs and half the occupancy that hides
+    // this kernel's gather latencies).  Heads: contraction index k = 16 j + 4 g + e (the A operand is read as float4
+    // h[row][16 j + 4 g ..]); dh: contraction index o = 4 kk + g, column tile n.
+    const float *wfp = w2v + c * WS + 4 * g, *wbp = w2v + g * WS + c;
+    const float bias = b2v[c];
     float adv_mean = 0.0f, adv_den = 1.0f;
     if (hp.norm_adv) {
         const double s1 = adv_stats[2 * map.mb], s2 = adv_stats[2 * map.mb + 1];
@@ -157,98 +174,125 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
         adv_den = (float)sqrt(var) + 1e-8f;
     }
     const float inv_rows = (float)(1.0 / global_rows);
+    const float lo_c = 1.0f - hp.clip_coef, hi_c = 1.0f + hp.clip_coef;
+    const bool is_logit = lo < a;
     float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dsum = 0.0f;  // this lane's column of sum_rows dout (the head bias gradient)
     const long long tiles = (rows + 15) / 16;
-    for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < 16 * kLstmH; i += 256) {
-            const long long r = tile * 16 + i / kLstmH;
-            hs[i / kLstmH][i % kLstmH] = r < rows ? h[r * kLstmH + i % kLstmH] : 0.0f;
-        }
-        __syncthreads();
-        const long long row = tile * 16 + le;
-        const bool ok = row < rows;
-        const long long fr = ok ? map.flat(row) : 0;
-        const float w = ok ? 1.0f : 0.0f;
-        const int action = ex.actions[fr];
-        const float old_logprob = ex.logprobs[fr], old_value = ex.values[fr], adv_raw = ex.advantages[fr], ret = ex.returns[fr];
-        const float mine = head_dot(hs[le], w2v, b2v, lo);
-        // log-softmax over the row's logits
-        bool is_logit = lo < a, chosen;
-        float nl, p, ent, hent, new_logprob;
-        if (heads == 0) {
-            const float mx = row16_max(is_logit ? mine : -INFINITY);
-            const float ev = is_logit ? expf(mine - mx) : 0.0f;
-            const float se = row16_sum(ev);
-            const float lse = mx + logf(se);
-            nl = mine - lse;
-            p = ev / se;
-            ent = hent = row16_sum(is_logit ? -nl * p : 0.0f);
-            chosen = lo == action;
-            new_logprob = row16_sum(chosen ? nl : 0.0f);
-        } else {  // MultiDiscrete: per-head softmax, sums over heads (sampler.hpp)
-            const Row16Eval ev = eval_row16_heads(mine, lo, a, heads, action);
-            nl = ev.nl, p = ev.p, hent = ev.head_entropy, ent = ev.entropy, chosen = ev.chosen, new_logprob = ev.logprob;
-        }
-        const float new_value = row16_sum(lo == a ? mine : 0.0f);
-        const float logratio = new_logprob - old_logprob;
-        const float ratio = expf(logratio);
-        const float adv = hp.norm_adv ? (adv_raw - adv_mean) / adv_den : adv_raw;
-        const float lo_c = 1.0f - hp.clip_coef, hi_c = 1.0f + hp.clip_coef;
-        const float pg1 = -adv * ratio, pg2 = -adv * fminf(fmaxf(ratio, lo_c), hi_c);
-        const bool inside = ratio >= lo_c && ratio <= hi_c;
-        float dpg;  // d pg / d ratio: torch.max tie rule + clamp pass-through (see csrc/ppo_update.hip)
-        if (pg1 > pg2) dpg = -adv;
-        else if (pg1 < pg2) dpg = inside ? -adv : 0.0f;
-        else dpg = inside ? -adv : -0.5f * adv;
-        const float scale = inv_rows * w;
-        const float g_lp = dpg * ratio * scale;
-        float v_loss, dv;
-        if (hp.clip_vloss) {
-            const float du = new_value - ret, vl_u = du * du;
-            const float delta = new_value - old_value;
-            const float vcl = old_value + fminf(fmaxf(delta, -hp.vf_clip_coef), hp.vf_clip_coef);
-            const float dc = vcl - ret, vl_c = dc * dc;
-            const bool vin = delta >= -hp.vf_clip_coef && delta <= hp.vf_clip_coef;
-            v_loss = 0.5f * fmaxf(vl_u, vl_c);
-            const float gu = 2.0f * du, gc = vin ? 2.0f * dc : 0.0f;
-            dv = 0.5f * (vl_u > vl_c ? gu : (vl_u < vl_c ? gc : 0.5f * (gu + gc)));
-        } else {
-            const float du = new_value - ret;
-            v_loss = 0.5f * du * du;
-            dv = du;
-        }
-        dv *= hp.vf_coef * scale;
-        float d = 0.0f;
-        if (is_logit) d = g_lp * ((chosen ? 1.0f : 0.0f) - p) + hp.ent_coef * scale * p * (nl + hent);
-        else if (lo == a) d = dv;
-        if (ok) {
-            dout[row * kOut + lo] = d;
-            dsum += d;
-        }
-        // d loss / d h[u] = sum_o d_o W2v[o][u]; lane lo owns u = lo, lo+16, ...
-        float dhv[kLstmH / 16];
+    for (long long tile = (long long)blockIdx.x * 4 + wv; tile < tiles; tile += (long long)gridDim.x * 4) {
+        const long long r0 = tile * 16;
+        auto rowq = [&](int i) -> long long { return r0 + i < rows ? r0 + i : -1; };     // row i of the tile, or -1 past the end
+        const long long arow = r0 + c < rows ? r0 + c : rows - 1;     // (rows past the end repeat the last one; nothing of them is kept)
+        float4 ha[8];
 #pragma unroll
-        for (int j = 0; j < kLstmH / 16; ++j) dhv[j] = 0.0f;
-        for (int o = 0; o <= a; ++o) {
-            const float d_o = __shfl(d, (lane_id() & 48) | o, 64);
+        for (int j = 0; j < 8; ++j) ha[j] = *reinterpret_cast<const float4 *>(h + arow * kLstmH + 16 * j + 4 * g);
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < kLstmH / 16; ++j) dhv[j] = fmaf(d_o, w2v[o * (kLstmH + 1) + lo + 16 * j], dhv[j]);
+        for (int j = 0; j < 8; j += 2) {
+            const float4 w0 = *reinterpret_cast<const float4 *>(wfp + 16 * j), w1 = *reinterpret_cast<const float4 *>(wfp + 16 * (j + 1));
+            o0 = mfma16(ha[j].x, w0.x, o0);
+            o1 = mfma16(ha[j + 1].x, w1.x, o1);
+            o0 = mfma16(ha[j].y, w0.y, o0);
+            o1 = mfma16(ha[j + 1].y, w1.y, o1);
+            o0 = mfma16(ha[j].z, w0.z, o0);
+            o1 = mfma16(ha[j + 1].z, w1.z, o1);
+            o0 = mfma16(ha[j].w, w0.w, o0);
+            o1 = mfma16(ha[j + 1].w, w1.w, o1);
         }
-        if (ok) {
 #pragma unroll
-            for (int j = 0; j < kLstmH / 16; ++j) dh[row * kLstmH + lo + 16 * j] = dhv[j];
+        for (int r = 0; r < 4; ++r) {
+            const long long row = rowq(4 * g + r);
+            const bool ok = row >= 0;
+            const long long fr = ok ? map.flat(row) : 0;
+            const float w = ok ? 1.0f : 0.0f;
+            const int action = ex.actions[fr];
+            const float old_logprob = ex.logprobs[fr], old_value = ex.values[fr], adv_raw = ex.advantages[fr], ret = ex.returns[fr];
+            const float mine = (o0[r] + o1[r]) + bias;
+            // log-softmax over the row's logits
+            bool chosen;
+            float nl, p, ent, hent, new_logprob;
+            if (heads == 0) {
+                const float mx = row16_max(is_logit ? mine : -INFINITY);
+                const float ev = is_logit ? expf(mine - mx) : 0.0f;
+                const float se = row16_sum(ev);
+                const float lse = mx + logf(se);
+                nl = mine - lse;
+                p = ev / se;
+                ent = hent = row16_sum(is_logit ? -nl * p : 0.0f);
+                chosen = lo == action;
+                new_logprob = row16_sum(chosen ? nl : 0.0f);
+            } else {  // MultiDiscrete: per-head softmax, sums over heads (sampler.hpp)
+                const Row16Eval ev = eval_row16_heads(mine, lo, a, heads, action);
+                nl = ev.nl, p = ev.p, hent = ev.head_entropy, ent = ev.entropy, chosen = ev.chosen, new_logprob = ev.logprob;
+            }
+            const float new_value = row16_sum(lo == a ? mine : 0.0f);
+            const float logratio = new_logprob - old_logprob;
+            const float ratio = expf(logratio);
+            const float adv = hp.norm_adv ? (adv_raw - adv_mean) / adv_den : adv_raw;
+            const float pg1 = -adv * ratio, pg2 = -adv * fminf(fmaxf(ratio, lo_c), hi_c);
+            const bool inside = ratio >= lo_c && ratio <= hi_c;
+            float dpg;  // d pg / d ratio: torch.max tie rule + clamp pass-through (see csrc/ppo_update.hip)
+            if (pg1 > pg2) dpg = -adv;
+            else if (pg1 < pg2) dpg = inside ? -adv : 0.0f;
+            else dpg = inside ? -adv : -0.5f * adv;
+            const float scale = inv_rows * w;
+            const float g_lp = dpg * ratio * scale;
+            float v_loss, dv;
+            if (hp.clip_vloss) {
+                const float du = new_value - ret, vl_u = du * du;
+                const float delta = new_value - old_value;
+                const float vcl = old_value + fminf(fmaxf(delta, -hp.vf_clip_coef), hp.vf_clip_coef);
+                const float dc = vcl - ret, vl_c = dc * dc;
+                const bool vin = delta >= -hp.vf_clip_coef && delta <= hp.vf_clip_coef;
+                v_loss = 0.5f * fmaxf(vl_u, vl_c);
+                const float gu = 2.0f * du, gc = vin ? 2.0f * dc : 0.0f;
+                dv = 0.5f * (vl_u > vl_c ? gu : (vl_u < vl_c ? gc : 0.5f * (gu + gc)));
+            } else {
+                const float du = new_value - ret;
+                v_loss = 0.5f * du * du;
+                dv = du;
+            }
+            dv *= hp.vf_coef * scale;
+            float d = 0.0f;
+            if (is_logit) d = g_lp * ((chosen ? 1.0f : 0.0f) - p) + hp.ent_coef * scale * p * (nl + hent);
+            else if (lo == a) d = dv;
+            if (ok) {
+                dout[row * kOut + lo] = d;
+                dsum += d;
+            }
+            dt[wv][4 * g + r][lo] = ok ? d : 0.0f;
+            if (lo == 0) {
+                acc[0] += fmaxf(pg1, pg2) * w;
+                acc[1] += v_loss * w;
+                acc[2] += ent * w;
+                acc[3] += -logratio * w;
+                acc[4] += ((ratio - 1.0f) - logratio) * w;
+                acc[5] += (fabsf(ratio - 1.0f) > hp.clip_coef ? 1.0f : 0.0f) * w;
+            }
         }
-        if (lo == 0) {
-            acc[0] += fmaxf(pg1, pg2) * w;
-            acc[1] += v_loss * w;
-            acc[2] += ent * w;
-            acc[3] += -logratio * w;
-            acc[4] += ((ratio - 1.0f) - logratio) * w;
-            acc[5] += (fabsf(ratio - 1.0f) > hp.clip_coef ? 1.0f : 0.0f) * w;
+        // d loss / d h = dout W2v: A operand lane (c, g) = dout[row c][o = 4 kk + g] from this wave's own LDS tile (a wave's LDS
+        // operations complete in order: no barrier between its writes above and these reads)
+        __builtin_amdgcn_wave_barrier();
+        float da[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) da[kk] = dt[wv][c][4 * kk + g];
+        f32x4 dacc[8];
+#pragma unroll
+        for (int n = 0; n < 8; ++n) dacc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int n = 0; n < 8; ++n) dacc[n] = mfma16(da[kk], wbp[4 * kk * WS + 16 * n], dacc[n]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long row = rowq(4 * g + r);
+            if (row >= 0) {
+#pragma unroll
+                for (int n = 0; n < 8; ++n) dh[row * kLstmH + 16 * n + c] = dacc[n][r];
+            }
         }
+        __builtin_amdgcn_wave_barrier();
     }
-    __syncthreads();
     if (lo == 0)
         for (int i = 0; i < 8; ++i) st[le][i] = i < 6 ? acc[i] : 0.0f;
     sd[le][lo] = dsum;
@@ -371,7 +415,7 @@ extern "C" int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, in
     PFA_REQUIRE(!hp->norm_adv || adv_stats, "lstm_heads_loss: norm_adv needs adv_stats");
     const long long mbs = batch_rows / hp->num_minibatches;
     TimeMajorMap map{mb, hp->num_minibatches, hp->bptt_horizon, mbs / hp->bptt_horizon};
-    const long long tiles = (mbs + 15) / 16;
+    const long long tiles = ((mbs + 15) / 16 + 3) / 4;        // workgroup = four 16-row tiles, one per wavefront
     const unsigned grid = (unsigned)(tiles < 1024 ? tiles : 1024);
     float *partial = (float *)workspace;
     hipLaunchKernelGGL(lstm_heads_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, h, mbs, map, *exp, params,
