@@ -1,6 +1,5 @@
 """ctypes bindings of oracle/puffer_oracle.c (CPU ORACLE — test infrastructure only)."""
 import ctypes as C
-import os
 
 import numpy as np
 

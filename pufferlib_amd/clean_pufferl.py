@@ -38,7 +38,7 @@ import torch
 from . import _lib, readback, utils
 from . import dist as pdist
 from .cleanrl import Policy, RecurrentPolicy
-from .models import FlatParams
+from .models import FlatParams  # noqa: F401  (re-exported: callers of create() type-check the trainer's parameter buffer against it)
 from .namespace import namespace
 from .vector import Bandit, Frames, Memory, Multiagent, Spaces, Squared, Stochastic, Synthetic
 

@@ -13,7 +13,6 @@ placed one after the other, each rounded up to ITS OWN alignment (pytorch.py:73-
 whole.  For the emulated dtypes the reference builds (``np.dtype(..., align=True)`` of leaf arrays) both agree unless a
 nested struct begins with a member of smaller alignment than its largest one.
 """
-import ctypes as C
 
 import numpy as np
 import torch
