@@ -193,6 +193,47 @@ def test_eight_ranks_on_one_gpu_run_the_full_slot_and_flag_logic(tmp_path):
     assert all(int(np.load(tmp_path / f'ok{q}.npy')[0]) == 1 for q in range(world))
 
 
+def _p2p_skew_worker(rank, world, port, out_dir, calls=300):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='20000')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pufferlib_amd import _lib, dist as pdist
+    assert pdist.init_p2p(1 << 16)
+    L = _lib.lib()
+    n = 9497                                            # the MLP policy's bucket
+    idx = torch.arange(n, device='cuda')
+    rs = np.random.RandomState(1000 + rank)             # every rank stalls at different calls, for different lengths
+    outs = []
+    for j in range(calls):
+        if rs.rand() < 0.3:
+            torch.cuda._sleep(int(rs.randint(1, 400)) * 10000)      # up to ~2 ms of GPU-side delay in front of this rank's push
+        x = (((idx + 31 * j) % 97) * (rank + 1)).float()
+        _lib.check(L.pfa_p2p_all_reduce_f32(_lib.ptr(x), n, _lib.stream_handle()), 'p2p all-reduce')
+        outs.append(x)                                  # no host synchronisation between calls: ranks run ahead of each other
+    torch.cuda.synchronize()
+    ok = L.pfa_p2p_status() == 0
+    scale = world * (world + 1) // 2
+    for j, x in enumerate(outs):
+        ok = ok and bool(torch.equal(x, (((idx + 31 * j) % 97) * scale).float()))
+    np.save(os.path.join(out_dir, f'ok{rank}.npy'), np.array([int(ok)]))
+    dist.barrier()
+    L.pfa_p2p_close()
+    dist.destroy_process_group()
+
+
+def test_back_to_back_peer_all_reduces_under_rank_skew(tmp_path):
+    """What training does to the peer path: hundreds of all-reduces enqueued back to back with no host synchronisation in between,
+    every rank stalling at different calls (GPU-side sleeps of up to ~2 ms in front of its push) — the two-phase slot reuse must hold
+    a fast rank back exactly when a slow peer has not read the previous round yet.  Integer-valued buckets: every result is known
+    exactly without a second collective."""
+    world = 4
+    _spawn(_p2p_skew_worker, (world, _free_port(), str(tmp_path)), world, timeout_s=300)
+    assert all(int(np.load(tmp_path / f'ok{q}.npy')[0]) == 1 for q in range(world))
+
+
 def _p2p_lost_peer_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
                       HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='700')
