@@ -116,7 +116,15 @@ int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
     const unsigned long long seq = ++g_p2p.seq;
     ++g_p2p.calls;
     const int phase = (int)(seq & 1);
-    long long chunks = (long long)((bytes + 16383) / 16384);   // >= 16 KB per workgroup
+    // Workgroups per call: a chunk is pushed to every peer by ONE workgroup, so the chunk size sets how many store streams run
+    // next to each other on the links.  4 KB (10 workgroups for the MLP policy's 38 KB bucket) unless PFA_P2P_CHUNK_BYTES says otherwise;
+    // at most kP2pChunks workgroups (a flag per source and chunk).
+    static const long long chunk_bytes = [] {
+        const char *e = std::getenv("PFA_P2P_CHUNK_BYTES");
+        const long long v = e ? std::atoll(e) : 0;
+        return v >= 256 ? v : 4096ll;
+    }();
+    long long chunks = (long long)((bytes + chunk_bytes - 1) / chunk_bytes);
     chunks = chunks < 1 ? 1 : (chunks > kP2pChunks ? kP2pChunks : chunks);
     ScopedKernelTimer timer("p2p_all_reduce", stream);
     if (f64)
