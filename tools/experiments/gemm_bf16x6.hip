@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int TM = 128, TN = 64, BK = 32, THREADS = 256;
 constexpr int ROWS = TM + TN;
 constexpr int RS = 80;                       // bytes per LDS row of a plane: 32 bf16 + 16 bytes of padding
-constexpr int PLANE = ROWS * RS;
+constexpr int PLANE = ROWS * RS;             // (the 128 x 64 tile; the in-loader kernel is also instantiated at 64 x 64)
 
 __device__ __forceinline__ uint32_t pk(float a, float b) {   // two floats -> two bf16 (round to nearest even), a in the low half
     f32x2 v = {a, b};
@@ -43,17 +43,19 @@ __device__ __forceinline__ void split4(const float4 &x, uint2 &h, uint2 &m, uint
     l.y = pk(r2 - lo_f(m.y), r3 - hi_f(m.y));
 }
 
+template <int MI>
 __global__ void __launch_bounds__(THREADS) gemm_bf16x6_kernel(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M,
                                                               int N, int K) {
+    constexpr int TM = 64 * MI, ROWS = TM + TN, PLANE = ROWS * RS;
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const int lr = tid >> 3, kq = (tid & 7) * 4;                 // loader: rows lr + 32 q, four consecutive k
     const float *ap = A + (size_t)(m0 + lr) * K + kq, *bp = B + (size_t)(n0 + lr) * K + kq;
-    float4 ra[4], rb[2];
+    float4 ra[2 * MI], rb[2];
     auto fetch = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const float4 *>(ap + (size_t)(32 * q) * K);
+        for (int q = 0; q < 2 * MI; ++q) ra[q] = *reinterpret_cast<const float4 *>(ap + (size_t)(32 * q) * K);
 #pragma unroll
         for (int q = 0; q < 2; ++q) rb[q] = *reinterpret_cast<const float4 *>(bp + (size_t)(32 * q) * K);
         ap += BK;
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(THREADS) gemm_bf16x6_kernel(const float *__res
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 2 * MI; ++q) {
             uint2 h, m, l;
             split4(ra[q], h, m, l);
             unsigned char *p = lds + (lr + 32 * q) * RS + kq * 2;
@@ -79,23 +81,23 @@ __global__ void __launch_bounds__(THREADS) gemm_bf16x6_kernel(const float *__res
             *reinterpret_cast<uint2 *>(p + 2 * PLANE) = l;
         }
     };
-    f32x4 acc[2][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned char *la = lds + (wv * 32 + c) * RS + g * 16, *lb = lds + (TM + c) * RS + g * 16;
+    const unsigned char *la = lds + (wv * 16 * MI + c) * RS + g * 16, *lb = lds + (TM + c) * RS + g * 16;
     const int slabs = K / BK;
     fetch();
     for (int s = 0; s < slabs; ++s) {
         stash();
         __syncthreads();
         if (s + 1 < slabs) fetch();          // the next slab's global loads fly under this slab's products
-        bf16x8 fa[3][2], fb[3][4];
+        bf16x8 fa[3][MI], fb[3][4];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fa[p][a] = *reinterpret_cast<const bf16x8 *>(la + p * PLANE + a * 16 * RS);
+            for (int a = 0; a < MI; ++a) fa[p][a] = *reinterpret_cast<const bf16x8 *>(la + p * PLANE + a * 16 * RS);
 #pragma unroll
             for (int b = 0; b < 4; ++b) fb[p][b] = *reinterpret_cast<const bf16x8 *>(lb + p * PLANE + b * 16 * RS);
         }
@@ -104,16 +106,16 @@ __global__ void __launch_bounds__(THREADS) gemm_bf16x6_kernel(const float *__res
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < MI; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[TA[t]][a], fb[TB[t]][b], acc[a][b], 0, 0, 0);
         __syncthreads();
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = m0 + wv * 32 + a * 16 + 4 * g + r;
+            const int m = m0 + wv * 16 * MI + a * 16 + 4 * g + r;
 #pragma unroll
             for (int b = 0; b < 4; ++b) C[(size_t)m * N + n0 + b * 16 + c] = acc[a][b][r];
         }
@@ -235,19 +237,27 @@ int main() {
     CK(hipMalloc(&dC, (size_t)M * N * 4));
     CK(hipMemcpy(dA, a.data(), a.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dB, b.data(), b.size() * 4, hipMemcpyHostToDevice));
-    const dim3 grid(M / TM, N / TN);
-    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(THREADS), 0, 0, dA, dB, dC, M, N, K);
+    const dim3 grid(M / TM, N / TN), grid1(M / 64, N / TN);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_bf16x6_kernel<2>, grid, dim3(THREADS), 0, 0, dA, dB, dC, M, N, K);
     CK(hipDeviceSynchronize());
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int reps = 20;
     CK(hipEventRecord(e0, 0));
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_bf16x6_kernel, grid, dim3(THREADS), 0, 0, dA, dB, dC, M, N, K);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_bf16x6_kernel<2>, grid, dim3(THREADS), 0, 0, dA, dB, dC, M, N, K);
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, e0, e1));
+    float ms1 = 0.f;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_bf16x6_kernel<1>, grid1, dim3(THREADS), 0, 0, dA, dB, dC, M, N, K);
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_bf16x6_kernel<1>, grid1, dim3(THREADS), 0, 0, dA, dB, dC, M, N, K);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms1, e0, e1));
+    printf("64 x 64 tiles (1024 workgroups): %.1f us per launch\n", ms1 * 1e3 / reps);
     const double us = ms * 1e3 / reps, flop = 2.0 * M * N * K;
     std::vector<float> cout_((size_t)M * N);
     CK(hipMemcpy(cout_.data(), dC, cout_.size() * 4, hipMemcpyDeviceToHost));
