@@ -322,6 +322,10 @@ def main():
                     help="models.Default(hidden_size=...) on the squared workload: 128 = the fused kernels (headline); any other multiple of 16 runs "
                          "the width-general GEMM path (pufferlib_amd/general.py) — a side workload, not the metric")
     ap.add_argument('--horizon', type=int, default=None, help='rollout steps per batch (default 128; 32 for c4)')
+    ap.add_argument('--products', choices=['fp32', 'bf16x6'], default='fp32',
+                    help="how csrc/igemm.hip's rows form multiplies (conv / GEMM-path workloads): 'fp32' = v_mfma_f32_16x16x4_f32 (default, what "
+                         "every number of the line is quoted on); 'bf16x6' = each fp32 operand as three bf16 pieces, six partial products per product "
+                         "on the bf16 matrix path with fp32 accumulation (as close to f64 as the fp32 chain, other bits) — a labelled side measurement")
     ap.add_argument('--workload', choices=['squared', 'c3', 'c4'], default='squared',
                     help="'c3' = BASELINE configs[2] / SURVEY config C3: MiniGrid-shaped 160-byte rows, 7 actions, 100-step episodes from the "
                          "device-side synthetic generator (the simulator is third-party: env parity unpinned), LSTM(128) policy, bptt 16; "
@@ -368,6 +372,7 @@ def main():
     if args.horizon:
         HORIZON = args.horizon
     L = _lib.lib()
+    _lib.check(L.pfa_igemm_set_products(1 if args.products == 'bf16x6' else 0), 'set_products')
     K, W = args.steps, args.warmup
     per_gpu = NUM_ENVS * HORIZON
     cnn_lstm = False
@@ -512,10 +517,14 @@ def main():
         out = {
             'metric': (f'env steps/sec end-to-end PPO (rollout+GAE+update), {NUM_ENVS} envs'
                        + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')
-                       + (f' [side workload: hidden {args.hidden}]' if args.policy == 'wide' else '')),
+                       + (f' [side workload: hidden {args.hidden}]' if args.policy == 'wide' else '')
+                       + (' [rows-form products as six bf16 partial products, fp32 accumulate]' if args.products == 'bf16x6' else '')),
             'value': value, 'unit': 'env_steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            # what the products are computed in: fp32 MFMA everywhere by default; with --products bf16x6 the rows form of csrc/igemm.hip
+            # multiplies three-piece bf16 splits of the fp32 operands (six partial products, fp32 accumulation)
+            'dtype': 'f32' if args.products == 'fp32' else 'f32 operands as 3 x bf16, 6 partial products, f32 accumulate (rows form); f32 elsewhere',
+            'data': 'synthetic',
             'config': {'workload': (f'synthetic Atari-shaped frames (uint8 (4,84,84), 4 actions, 100-step episodes), {NUM_ENVS} envs/GPU x {HORIZON} steps, '
                                     f'NatureCNN (models.Convolutional){" + LSTMWrapper(512, 512)" if cnn_lstm else ""}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[3]; env parity '
                                     'unpinned: third-party emulator' + (', sharded' if world > 1 else '') + ')')
@@ -529,6 +538,7 @@ def main():
                        + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
+                         'products': args.products,      # bf16x6: `achieved` still counts the fp32 product's algorithmic flop, `peak` stays the fp32-MFMA peak
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'frac_useful': (achieved * FLOP_PER_ROW_USEFUL / FLOP_PER_ROW_UPDATE / PEAK_FP32_MFMA_TFLOPS
                                          if args.policy == 'mlp' else None),   # on the 49 real columns (32 000 FLOP/row)
@@ -594,6 +604,8 @@ def main():
             torch.cuda.empty_cache()
             out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),
                                       extra_workload(['--workload', 'c4', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0']),
+                                      # the same with the rows-form products on the bf16 matrix path (six-term split, fp32 accumulate)
+                                      extra_workload(['--workload', 'c4', '--products', 'bf16x6', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0']),
                                       # a width outside the fused kernels on the headline env (GEMM path, general.py)
                                       extra_workload(['--hidden', '256', '--steps', '5', '--warmup', '2', '--sustained-seconds', '0']),
                                       # the recurrent NatureCNN of environments/atari/torch.py:4-6 (GEMM path, general.py)

@@ -543,6 +543,13 @@ typedef struct {
 } pfa_igemm_operand;
 int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, const float *B, int32_t ldb, int32_t N, float *C, int32_t ldc,
                    int32_t epilogue, const float *bias, const float *mask, int32_t ldmask, pfa_stream_t stream);
+/* How the rows form multiplies (process-wide; no reference counterpart — the reference's torch.nn.functional.conv2d / linear
+ * (models.py:126-135) leave it to the BLAS): 0 (default) = v_mfma_f32_16x16x4_f32, exact fp32 products in k order; 1 = every fp32
+ * operand split into three bf16 pieces and each product issued as its six partial products above 2^-24 on the bf16 matrix path with
+ * fp32 accumulation — as close to an f64 product as the fp32 chain, not the same bits.  Contractions that are not a multiple of 32
+ * and 16-column outputs keep form 0. */
+int pfa_igemm_set_products(int32_t mode);
+int pfa_igemm_get_products(void);
 size_t pfa_igemm_weights_workspace_bytes(int64_t M, int32_t K, int32_t N);
 int pfa_igemm_weights(const pfa_igemm_operand *a, int64_t M, int32_t K, const float *D, int32_t ldd, int32_t N, float *out,
                       int32_t perm, int32_t accumulate, float *bias_out, void *workspace, pfa_stream_t stream);

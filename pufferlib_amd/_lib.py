@@ -231,6 +231,8 @@ _SIGNATURES = {
     'pfa_lstm_cell_forward': (C.c_int, [P, P, P, P, C.c_int32, P, C.c_int32, C.c_int64, C.c_int32, P]),
     'pfa_lstm_cell_backward': (C.c_int, [P, C.c_int32, P, C.c_int32, P, P, P, P, P, C.c_int64, C.c_int32, P]),
     'pfa_rows_perm': (C.c_int, [P, C.c_int32, P, C.c_int32, P, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P]),
+    'pfa_igemm_set_products': (C.c_int, [C.c_int32]),
+    'pfa_igemm_get_products': (C.c_int, []),
     'pfa_igemm_rows': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, C.c_int32, P]),
     'pfa_igemm_weights_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     'pfa_igemm_weights': (C.c_int, [C.POINTER(IgemmOperand), C.c_int64, C.c_int32, P, C.c_int32, C.c_int32, P, C.c_int32, C.c_int32, P, P, P]),

@@ -307,6 +307,174 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, int M,
     }
 }
 
+// ------------------------------------------------------------------------------- rows form on the bf16 matrix path (opt-in)
+// The same contraction with every fp32 operand split into three bf16 pieces in the loader (a = hi + mid + lo, round to nearest each
+// time; 24 mantissa bits in all) and every 16 x 16 x 32 tile product issued as the six partial products above 2^-24 relative — lo.hi,
+// hi.lo, mid.mid, mid.hi, hi.mid, hi.hi, small terms first — on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6/16 of the fp32
+// MFMA's matrix time per product.  The uint8 first layer needs three (its A values are integers 0..255: one exact bf16 piece).
+// Measured against f64 the result is as close as the fp32 fma chain (tools/experiments/bf16_split_accuracy.py, gemm_bf16x6.hip);
+// it is NOT the bit pattern of the fp32 kernel, so it is off unless pfa_igemm_set_products(1) asks for it (bench.py --products
+// bf16x6, tests/test_gpu_cnn.py).  32-deep slabs, three bf16 planes [row][32 k] of 80-byte rows in LDS, single-buffered (46 KB for
+// the 128 x 64 tile: three workgroups per CU), the next slab's global loads in flight under the products.
+typedef __bf16 ig_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ig_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ig_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t ig_pk_bf16(float a, float b) {   // two floats -> two bf16 (v_cvt_pk_bf16_f32, nearest even), a low
+    ig_f32x2 v = {a, b};
+    ig_bf16x2 r = __builtin_convertvector(v, ig_bf16x2);
+    return *reinterpret_cast<uint32_t *>(&r);
+}
+__device__ __forceinline__ float ig_bf16_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float ig_bf16_hi(uint32_t p) { return __uint_as_float(p & 0xFFFF0000u); }
+__device__ __forceinline__ void ig_split4(const float4 &x, uint2 &h, uint2 &m, uint2 &l) {
+    h.x = ig_pk_bf16(x.x, x.y);
+    h.y = ig_pk_bf16(x.z, x.w);
+    const float r0 = x.x - ig_bf16_lo(h.x), r1 = x.y - ig_bf16_hi(h.x), r2 = x.z - ig_bf16_lo(h.y), r3 = x.w - ig_bf16_hi(h.y);
+    m.x = ig_pk_bf16(r0, r1);
+    m.y = ig_pk_bf16(r2, r3);
+    l.x = ig_pk_bf16(r0 - ig_bf16_lo(m.x), r1 - ig_bf16_hi(m.x));
+    l.y = ig_pk_bf16(r2 - ig_bf16_lo(m.y), r3 - ig_bf16_hi(m.y));
+}
+
+constexpr int kIgSplitBK = 32;
+constexpr int kIgSplitRS = 80;   // bytes per LDS row of a plane: 32 bf16 + 16 bytes of padding (b128 fragment reads hit all banks once)
+
+template <int MODE, int MI, int NI>
+__global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_split_kernel(IgA A, int M, int K, const float *__restrict__ B, int ldb, int N,
+                                                                        float *__restrict__ Cout, int ldc, int epi, const float *__restrict__ bias,
+                                                                        const float *__restrict__ mask, int ldmask) {
+    constexpr int TM = 64 * MI, TN = 16 * NI, RS = kIgSplitRS, PLANE = (TM + TN) * RS;
+    constexpr int RPP = 32, LA = TM / RPP, LB = TN / RPP;      // loader: 8 threads per slab row, 32 rows per pass
+    constexpr bool kAInt = MODE == kAIm2colU8;                // A = bytes as floats: exact in ONE bf16 piece
+    static_assert(TN % RPP == 0 && LB >= 1 && LB <= 2, "the split form takes 32- and 64-column tiles");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int per_xcd = gridDim.x >> 3;
+    const int tile_m = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int m0 = tile_m * TM, n0 = blockIdx.y * TN;
+    if (m0 >= M) return;
+    const int py = MODE == kACol2im ? (int)blockIdx.z / A.g.S : 0, px = MODE == kACol2im ? (int)blockIdx.z % A.g.S : 0;
+    B += (size_t)blockIdx.z * N * ldb;
+    const int lr = tid >> 3, kq = (tid & 7) * 4;              // loader role: slab rows lr + 32 q, k-quad kq
+    IgRow rows[LA];
+#pragma unroll
+    for (int q = 0; q < LA; ++q) {
+        const int m = m0 + lr + RPP * q;
+        rows[q] = ig_row<MODE>(A, m < M ? m : M - 1);
+    }
+    IgK kc = ig_k_init<MODE>(A, kq);
+    const float *bp = B + (size_t)(n0 + lr) * ldb + kq;
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int stages = K / kIgSplitBK;
+    float4 ra[LA], rb0, rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&]() {   // the slab the cursor points at, then advance
+#pragma unroll
+        for (int q = 0; q < LA; ++q) ra[q] = ig_load4<MODE>(A, rows[q], kc);
+        rb0 = *reinterpret_cast<const float4 *>(bp);
+        if (LB > 1) rb1 = *reinterpret_cast<const float4 *>(bp + (size_t)RPP * ldb);
+        ig_k_advance<MODE>(A, kc);
+        ig_k_advance<MODE>(A, kc);
+        bp += kIgSplitBK;
+    };
+    auto stash = [&]() {
+        uint2 h, m, l;
+#pragma unroll
+        for (int q = 0; q < LA; ++q) {
+            unsigned char *p = lds + (lr + RPP * q) * RS + kq * 2;
+            if (kAInt) {
+                *reinterpret_cast<uint2 *>(p) = make_uint2(ig_pk_bf16(ra[q].x, ra[q].y), ig_pk_bf16(ra[q].z, ra[q].w));
+            } else {
+                ig_split4(ra[q], h, m, l);
+                *reinterpret_cast<uint2 *>(p) = h;
+                *reinterpret_cast<uint2 *>(p + PLANE) = m;
+                *reinterpret_cast<uint2 *>(p + 2 * PLANE) = l;
+            }
+        }
+        unsigned char *pb = lds + (TM + lr) * RS + kq * 2;
+        ig_split4(rb0, h, m, l);
+        *reinterpret_cast<uint2 *>(pb) = h;
+        *reinterpret_cast<uint2 *>(pb + PLANE) = m;
+        *reinterpret_cast<uint2 *>(pb + 2 * PLANE) = l;
+        if (LB > 1) {
+            ig_split4(rb1, h, m, l);
+            *reinterpret_cast<uint2 *>(pb + RPP * RS) = h;
+            *reinterpret_cast<uint2 *>(pb + RPP * RS + PLANE) = m;
+            *reinterpret_cast<uint2 *>(pb + RPP * RS + 2 * PLANE) = l;
+        }
+    };
+    const unsigned char *la = lds + (wv * 16 * MI + c) * RS + g * 16, *lb = lds + (TM + c) * RS + g * 16;
+    auto multiply = [&]() {
+        ig_bf16x8 fa[kAInt ? 1 : 3][MI], fb[3][NI];
+#pragma unroll
+        for (int p = 0; p < (kAInt ? 1 : 3); ++p)
+#pragma unroll
+            for (int a = 0; a < MI; ++a) fa[p][a] = *reinterpret_cast<const ig_bf16x8 *>(la + p * PLANE + a * 16 * RS);
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int b = 0; b < NI; ++b) fb[p][b] = *reinterpret_cast<const ig_bf16x8 *>(lb + p * PLANE + b * 16 * RS);
+        // (piece of A, piece of B): 0 = hi, 1 = mid, 2 = lo; small terms first, consecutive MFMAs on different accumulators
+        constexpr int kTerms = kAInt ? 3 : 6;
+        constexpr int TA[6] = {kAInt ? 0 : 2, 0, kAInt ? 0 : 1, 1, 0, 0}, TB[6] = {kAInt ? 2 : 0, kAInt ? 1 : 2, kAInt ? 0 : 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < kTerms; ++t)
+#pragma unroll
+            for (int a = 0; a < MI; ++a)
+#pragma unroll
+                for (int b = 0; b < NI; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[TA[t]][a], fb[TB[t]][b], acc[a][b], 0, 0, 0);
+    };
+    if (stages > 0) fetch();
+    for (int s = 0; s < stages; ++s) {
+        stash();
+        __syncthreads();
+        if (s + 1 < stages) fetch();          // the next slab's global loads fly under this slab's products
+        multiply();
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < MI; ++a) {
+        int en = 0, eyy = 0, exx = 0;
+        if (MODE == kACol2im) {
+            const int m = m0 + wv * 16 * MI + a * 16 + 4 * g, hw = A.HP * A.WP;
+            en = m / hw;
+            const int rem = m - en * hw;
+            eyy = rem / A.WP;
+            exx = rem - eyy * A.WP;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + wv * 16 * MI + a * 16 + 4 * g + r;
+            size_t orow = (size_t)m;
+            if (MODE == kACol2im) {
+                orow = ((size_t)en * A.g.IH + (size_t)(eyy * A.g.S + py)) * A.g.IW + (size_t)(exx * A.g.S + px);
+                if (++exx == A.WP) {
+                    exx = 0;
+                    if (++eyy == A.HP) {
+                        eyy = 0;
+                        ++en;
+                    }
+                }
+            }
+            if (m >= M) continue;
+#pragma unroll
+            for (int b = 0; b < NI; ++b) {
+                const int n = n0 + b * 16 + c;
+                float v = acc[a][b][r];
+                if (epi == kEpiBias || epi == kEpiBiasRelu) v += bias[n];
+                if (epi == kEpiBiasRelu) v = fmaxf(v, 0.0f);
+                if (epi == kEpiMask) v = mask[orow * ldmask + n] > 0.0f ? v : 0.0f;
+                Cout[orow * ldc + n] = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- weight form
 // partial[split][k][n] = sum over the split's rows of A(m, k) D[m][n], and (k-tile 0 only) colpart[split][n] = sum of D[m][n];
 // grid = ((K / 128 rounded up) * (N / (16 NI)), splits).  Wave w owns k rows 32w .. 32w+31 of the 128 x (16 NI) tile.
@@ -577,6 +745,8 @@ static int ig_check_a(const pfa_igemm_operand *a, int64_t M, int K) {
                     "igemm: col2im needs OC %% 4 == 0, K == KH*KW*OC, and KH, KW, IH, IW multiples of the stride");
     return 0;
 }
+static int g_ig_products = 0;   // 0: exact fp32 MFMA products (default); 1: six-term bf16 split products in the rows form
+
 static IgA ig_make_a(const pfa_igemm_operand *a) {
     IgA r;
     r.mode = a->mode;
@@ -671,7 +841,26 @@ extern "C" int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, 
     // A dense product over few rows (one rollout step of the width-general policies: 4096 rows) fills the chip only with 64-row tiles.
     const int tn = N % 64 == 0 ? 64 : N % 32 == 0 ? 32 : 16;
     const bool few = A.mode == kADense && ((Mp + (tn == 16 ? 255 : 127)) / (tn == 16 ? 256 : 128)) * (N / tn) < 256;
-    if (few) {
+    if (g_ig_products == 1 && !few && tn >= 32 && Kp % kIgSplitBK == 0) {   // opt-in: the six-term bf16 form of the same products
+#define PFA_IG_SPLIT(MODE, NI)                                                                                                             \
+    hipLaunchKernelGGL((igemm_rows_split_kernel<MODE, 2, NI>), dim3((unsigned)(((Mp + 127) / 128 + 7) / 8 * 8), N / (16 * NI), phases),    \
+                       dim3(kIgThreads), 0, (hipStream_t)stream, A, (int)Mp, (int)Kp, B, (int)ldb, (int)N, C, (int)ldc, (int)epilogue,   \
+                       bias, mask, (int)ldmask)
+#define PFA_IG_SPLIT_MODE(NI)                                        \
+    switch (A.mode) {                                                \
+        case kADense: PFA_IG_SPLIT(kADense, NI); break;              \
+        case kAIm2colF32: PFA_IG_SPLIT(kAIm2colF32, NI); break;      \
+        case kAIm2colU8: PFA_IG_SPLIT(kAIm2colU8, NI); break;        \
+        default: PFA_IG_SPLIT(kACol2im, NI); break;                  \
+    }
+        if (tn == 64) {
+            PFA_IG_SPLIT_MODE(4)
+        } else {
+            PFA_IG_SPLIT_MODE(2)
+        }
+#undef PFA_IG_SPLIT_MODE
+#undef PFA_IG_SPLIT
+    } else if (few) {
         if (tn == 64) {
             PFA_IG_ROWS(kADense, 1, 4);
         } else if (tn == 32) {
@@ -691,6 +880,13 @@ extern "C" int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, 
     PFA_LAUNCH_CHECK();
     return 0;
 }
+
+extern "C" int pfa_igemm_set_products(int32_t mode) {
+    PFA_REQUIRE(mode == 0 || mode == 1, "igemm.set_products: 0 = fp32 MFMA (default), 1 = six bf16 partial products per fp32 product");
+    g_ig_products = mode;
+    return 0;
+}
+extern "C" int pfa_igemm_get_products(void) { return g_ig_products; }
 
 extern "C" size_t pfa_igemm_weights_workspace_bytes(int64_t M, int32_t K, int32_t N) {
     if (M < 1 || K < 4 || N < 16 || N % 16 != 0) return 0;

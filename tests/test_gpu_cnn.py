@@ -40,7 +40,7 @@ def _torch_forward(ref, frames_u8):
 
 
 @pytest.mark.parametrize('n', [3, 37])
-def test_every_layer_forward_and_backward_matches_torch(n):
+def test_every_layer_forward_and_backward_matches_torch(n, matrix_products):
     net, ref, cp, eng = _net()
     assert cp.count == 1686693 - 0 if cp.num_actions == 4 else True
     g = torch.Generator().manual_seed(1)
@@ -71,6 +71,64 @@ def test_every_layer_forward_and_backward_matches_torch(n):
     eng.forward(dev_frames, n)
     eng.backward(dev_frames, n, eng.dh, gv, True)
     np.testing.assert_allclose(gv['network.2.weight'].cpu().numpy(), 2 * ref['network.2.weight'].grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_split_products_on_the_same_operands_as_the_fp32_products():
+    """The opt-in product form (six bf16 partial products per fp32 product, fp32 accumulation) against the default one on IDENTICAL
+    operands — every rows-form product of the NatureCNN at a chunk large enough for the 128-row tiles (forward of the four layers,
+    dX of the three that have one) — and both against an f64 evaluation of the same contraction on sampled outputs."""
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    n = 192
+    net, ref, cp, eng = _net()
+    eng._alloc(n)
+    g = torch.Generator(device='cuda').manual_seed(2)
+    frames = torch.randint(0, 256, (n, 4 * 84 * 84), dtype=torch.uint8, device='cuda', generator=g)
+    eng.forward(frames, n)                                             # operands of every product, from the default form
+    dh = torch.randn(n, 512, device='cuda', generator=g)
+    d3in = torch.randn(n * 49, 64, device='cuda', generator=g)
+    d2in = torch.randn(n * 81, 64, device='cuda', generator=g)
+    c1, c2, c3, fc = eng.conv1, eng.conv2, eng.conv3, eng.fc
+    a1, a2, a3 = eng.a1[:n * 400].clone(), eng.a2[:n * 81].clone(), eng.a3[:n * 49].clone()
+    outs = dict(conv1=torch.empty_like(a1), conv2=torch.empty_like(a2), conv3=torch.empty_like(a3), fc=torch.empty(n, 512, device='cuda'),
+                fc_dx=torch.empty_like(a3), conv3_dx=torch.empty_like(a2), conv2_dx=torch.empty_like(a1))
+    products = [('conv1', lambda o: c1.forward(frames, n, o)), ('conv2', lambda o: c2.forward(a1, n, o)), ('conv3', lambda o: c3.forward(a2, n, o)),
+                ('fc', lambda o: fc.forward(a3, n, o)), ('fc_dx', lambda o: fc.backward_dx(dh, n, a3, o)),
+                ('conv3_dx', lambda o: c3.backward_dx(d3in, n, a2, o)), ('conv2_dx', lambda o: c2.backward_dx(d2in, n, a1, o))]
+    try:
+        for name, fn in products:
+            got = {}
+            for mode in (0, 1):
+                _lib.check(L.pfa_igemm_set_products(mode), 'set_products')
+                out = outs[name]
+                out.zero_()
+                fn(out)
+                got[mode] = out.clone()
+            scale = float(got[0].abs().max())
+            err = float((got[1] - got[0]).abs().max())
+            assert scale > 0 and err <= 1e-5 * scale, (name, err, scale)
+            if name.startswith('conv'):          # (192 dense rows are too few for the 128-row tiles: the Linear keeps the fp32 form here)
+                assert not torch.equal(got[0], got[1]), name          # the opt-in form really ran: its bits differ
+    finally:
+        _lib.check(L.pfa_igemm_set_products(0), 'set_products')
+    # the Linear forward (the longest contraction, K = 3136) against f64 at a row count where both forms run their 128-row tiles
+    rows = 4096
+    x = torch.relu(torch.randn(rows, 3136, device='cuda', generator=g))
+    out = torch.empty(rows, 512, device='cuda')
+    w, b = cp.views['network.7.weight'], cp.views['network.7.bias']
+    wp = fc.w_p                                                        # [512][3136], columns in the NHWC order the rows arrive in
+    exact = torch.relu(x.double().cpu() @ wp.double().cpu().t() + b.double().cpu())
+    seen = {}
+    for mode in (0, 1):
+        _lib.check(L.pfa_igemm_set_products(mode), 'set_products')
+        try:
+            fc.forward(x, rows, out)
+        finally:
+            _lib.check(L.pfa_igemm_set_products(0), 'set_products')
+        seen[mode] = out.clone()
+        err = float((out.double().cpu() - exact).abs().max() / exact.abs().max())
+        assert err < 5e-6, (mode, err)
+    assert not torch.equal(seen[0], seen[1])
 
 
 def test_heads_sample_and_loss_match_the_oracle():

@@ -80,7 +80,7 @@ def _trainer(n, horizon, mbs, bptt, epochs, total, hp, seed, start=None, host=Fa
     return vec, pol, data
 
 
-def test_reference_run_with_convolutional_policy(golden_dir):
+def test_reference_run_with_convolutional_policy(golden_dir, matrix_products):
     import cnn_golden
     from pufferlib_amd import clean_pufferl
     g = np.load(os.path.join(golden_dir, 'ppo_cnn.npz'))
@@ -237,7 +237,7 @@ def test_update_in_several_chunks_equals_one_chunk():
         np.testing.assert_allclose(flat.cpu().numpy(), out[0][2].cpu().numpy(), rtol=1e-5, atol=1e-6)
 
 
-def test_one_optimizer_step_over_an_8192_frame_chunk_vs_the_double_precision_oracle(capsys):
+def test_one_optimizer_step_over_an_8192_frame_chunk_vs_the_double_precision_oracle(capsys, matrix_products):
     """The conv update END TO END at the chunk size the bench runs (cnn.Engine walks a 65 536-frame minibatch in 8192-frame chunks):
     512 envs x 16 steps = one minibatch = one chunk, forward + PPO loss + backward through all four layers + clip + Adam, against
     the oracle trainer in double precision on the same uint8 frames."""

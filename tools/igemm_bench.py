@@ -1,7 +1,8 @@
 """Per-product timing of the NatureCNN's implicit-GEMM launches at one 8192-frame chunk (developer tool, not product code).
 
     python tools/igemm_bench.py build  name1:-DFLAG=1  name2:...     (here, no GPU: hipcc cross-compiles csrc/igemm.hip per variant)
-    python tools/igemm_bench.py run [frames]                         (on the GPU box; with no variants built: the product library)
+    python tools/igemm_bench.py run [frames]                         (on the GPU box; with no variants built: the product library's two
+                                                                      product forms, fp32 MFMA and the six-term bf16 split, side by side)
 
 Every product of cnn.Engine.forward / backward (conv1..3 and the Linear: forward, dX, dW) is launched through the C-ABI entry points
 the engine uses, timed with HIP events on the stream they run on (median of 5 after 2 warm-ups), and summarised by a checksum of its
@@ -40,12 +41,14 @@ def build(specs):
         print(so)
 
 
-def one(so, n):
+def one(so, n, products=0, dump=''):
+    import numpy as np
     import torch
     from pufferlib_amd import _lib
     if so:
         _lib.LIB_PATH = so
     from pufferlib_amd import cnn, models
+    _lib.check(_lib.lib().pfa_igemm_set_products(int(products)), 'set_products')
 
     class _Env:
         single_action_space = type('Discrete', (), {'n': 4})()
@@ -78,8 +81,9 @@ def one(so, n):
         ('conv1 dW', lambda: c1.backward_dw(frames, n, eng.d1, gv['network.0.weight'], gv['network.0.bias'], False, eng.ws), 2 * n * 400 * 32 * 256,
          lambda: gv['network.0.weight']),
     ]
-    res = {}
-    for name, fn, flop, out in products:
+    res, samples = {}, {}
+    product_list, products = products, None
+    for name, fn, flop, out in product_list:
         for _ in range(2):
             fn()
         times = []
@@ -93,15 +97,22 @@ def one(so, n):
         us = sorted(times)[2]
         o = out().double()
         res[name] = dict(us=round(us, 1), tflops=round(flop / us / 1e6, 1), sum=float(o.sum()), abs=float(o.abs().sum()))
+        samples[name] = out().reshape(-1)[:1 << 20].float().cpu().numpy()
+    if dump:
+        np.savez(dump, **{k.replace(' ', '_'): v for k, v in samples.items()})
     print(json.dumps(res))
 
 
 def run(n):
-    libs = sorted(glob.glob(os.path.join(OUT, 'libig_*.so'))) or ['']
+    import numpy as np
+    libs = sorted(glob.glob(os.path.join(OUT, 'libig_*.so')))
+    jobs = [(os.path.basename(so)[6:-3], so, 0) for so in libs] or [('fp32', '', 0), ('bf16x6', '', 1)]   # no variants built: the product's two forms
     table = {}
-    for so in libs:
-        name = os.path.basename(so)[6:-3] if so else 'product'
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), 'one', so, str(n)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    for name, so, prod in jobs:
+        dump = os.path.join(REPO, 'gpurun_out', f'igb_{name}.npz')
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), 'one', so, str(n), str(prod), dump], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=280)
         if r.returncode != 0:
             print(name, 'FAILED', r.stderr.decode()[-600:])
             continue
@@ -115,11 +126,17 @@ def run(n):
         row = f'{prod:16s}'
         for v in names:
             t = table[v][prod]
-            same = abs(t['sum'] - first[prod]['sum']) <= 1e-6 * max(1.0, first[prod]['abs'])
+            same = abs(t['sum'] - first[prod]['sum']) <= 1e-5 * max(1.0, first[prod]['abs'])
             row += f'{t["us"]:9.1f} us {t["tflops"]:6.1f} TF{"" if same else " !"}'
         print(row)
     tot = {v: sum(table[v][p]['us'] for p in first) for v in names}
     print(f'{"sum":16s}' + ''.join(f'{tot[v]:9.1f} us {"":9s}' for v in names))
+    if len(names) > 1:     # element-wise distance of every variant's outputs (first 2^20 elements) from the first variant's
+        base = np.load(os.path.join(REPO, 'gpurun_out', f'igb_{names[0]}.npz'))
+        for v in names[1:]:
+            other = np.load(os.path.join(REPO, 'gpurun_out', f'igb_{v}.npz'))
+            print(f'max |{v} - {names[0]}| / max |{names[0]}| per product: ' +
+                  ', '.join(f"{k.replace('_', ' ')} {np.abs(other[k] - base[k]).max() / max(np.abs(base[k]).max(), 1e-30):.1e}" for k in base.files))
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(REPO, 'gpurun_out', 'igemm_bench_last.json'), 'w') as f:
         json.dump(table, f, indent=1)
@@ -130,6 +147,6 @@ if __name__ == '__main__':
     if sys.argv[1] == 'build':
         build(sys.argv[2:])
     elif sys.argv[1] == 'one':
-        one(sys.argv[2], int(sys.argv[3]))
+        one(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 0, sys.argv[5] if len(sys.argv) > 5 else '')
     else:
         sys.exit(run(int(sys.argv[2]) if len(sys.argv) > 2 else 8192))
