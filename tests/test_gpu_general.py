@@ -249,7 +249,7 @@ def _check_update(data, pol, opol, tr, strip):
 
 
 @pytest.mark.parametrize('hidden,d', [(64, 3), (256, 3), (512, 5)])
-def test_wide_default_policy_rollout_and_update_vs_oracle(hidden, d):
+def test_wide_default_policy_rollout_and_update_vs_oracle(hidden, d, matrix_products):
     """Default(hidden_size != 128) on the device Squared vecenv: the GEMM-path engine behind create / evaluate / train."""
     from pufferlib_amd import clean_pufferl, cleanrl, general, models
     from test_gpu_ppo import _config
@@ -323,7 +323,7 @@ def test_wide_observations_and_many_logits_on_a_host_vecenv():
     _check_update(data, pol, opol, tr, lambda k: 'policy.' + k)
 
 
-def test_wide_lstm_policy_rollout_and_update_vs_oracle():
+def test_wide_lstm_policy_rollout_and_update_vs_oracle(matrix_products):
     """LSTMWrapper(256, 256) over Default(256): state carried through the rollout and across the minibatches of an epoch."""
     from pufferlib_amd import clean_pufferl, cleanrl, general, models
     from test_gpu_ppo import _config
@@ -358,7 +358,7 @@ def test_wide_lstm_policy_rollout_and_update_vs_oracle():
     _check_update(data, pol, opol, tr, name)
 
 
-def test_recurrent_nature_cnn_rollout_and_update_vs_oracle():
+def test_recurrent_nature_cnn_rollout_and_update_vs_oracle(matrix_products):
     """environments/atari/torch.py:4-6: LSTMWrapper(512, 512) over the NatureCNN on the device frame vecenv."""
     from pufferlib_amd import clean_pufferl, cleanrl, general, models, vector
     from test_gpu_ppo import _config
@@ -407,7 +407,7 @@ def test_recurrent_nature_cnn_rollout_and_update_vs_oracle():
     _check_update(data, pol, opol, tr, name)
 
 
-def test_recurrent_nature_cnn_replays_the_reference_golden(golden_dir):
+def test_recurrent_nature_cnn_replays_the_reference_golden(golden_dir, matrix_products):
     """tests/golden/ppo_cnn_lstm.npz: the unmodified reference's cleanrl.RecurrentPolicy(LSTMWrapper(Convolutional, 512, 512))
     (environments/atari/torch.py:4-6) through its create / evaluate / train on the frame stub. Rollout mode: policy(obs, state) on
     its frames with its multinomial's exponential draws -> its actions bit for bit, log-probabilities, values, and the LSTM state it
@@ -461,7 +461,7 @@ def test_recurrent_nature_cnn_replays_the_reference_golden(golden_dir):
         np.testing.assert_allclose(got[:2], want[:2], rtol=0, atol=1e-5 * max(1.0, want[1]), err_msg=k + ' (sums)')
 
 
-def test_hidden_256_replays_the_reference_golden(golden_dir):
+def test_hidden_256_replays_the_reference_golden(golden_dir, matrix_products):
     """tests/golden/ppo_mlp_h256.npz: the unmodified reference's create / evaluate / train with models.Default(hidden_size=256) on
     Serial(Squared) — its multinomial noise in, its actions bit for bit, experience, advantages, losses, weights and Adam moments out."""
     from pufferlib_amd import clean_pufferl, cleanrl, general, models
