@@ -405,3 +405,35 @@ def test_general_params_layout_and_packed_operands_on_cpu():
     assert gp.unpack_actions(torch.tensor([2 | (4 << 4) | (1 << 8)])).tolist() == [[2, 4, 1]]
     with pytest.raises(NotImplementedError):
         general.pack_heads([16, 2], True)
+
+
+def test_six_term_bf16_split_is_as_close_to_f64_as_the_fp32_chain():
+    """The arithmetic behind csrc/igemm.hip's opt-in product form, restated in numpy (tools/experiments/bf16_split_accuracy.py): an fp32
+    value is the sum of its three bf16 pieces to 2^-23 relative, the six partial products above 2^-24 reproduce a K-long fp32 dot
+    product about as well as an fp32 accumulation chain does, and the three-term form does not (which is why it is not offered)."""
+    import importlib.util
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('bf16_split_accuracy', os.path.join(repo, 'tools', 'experiments', 'bf16_split_accuracy.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    rs = np.random.RandomState(3)
+    x = (rs.standard_normal(4096) * np.exp(rs.uniform(-20, 20, 4096))).astype(np.float32)
+    hi, mid, lo = m.split3(x)
+    for piece in (hi, mid, lo):                        # every piece is a bf16 value: its low 16 bits are zero
+        assert not (piece.view(np.uint32) & 0xFFFF).any()
+    rebuilt = hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)
+    assert np.abs(rebuilt - x.astype(np.float64)).max() <= 2.0 ** -23 * np.abs(x).max() and np.all(np.abs(rebuilt - x) <= 2.0 ** -23 * np.abs(x))
+    for K in (64, 576, 3136):
+        a = np.maximum(rs.standard_normal((32, K)), 0).astype(np.float32)
+        b = (rs.standard_normal((K, 32)) * np.sqrt(2.0 / K)).astype(np.float32)
+        exact = a.astype(np.float64) @ b.astype(np.float64)
+        scale = np.abs(exact).max()
+        ah, am, al = m.split3(a)
+        bh, bm, bl = m.split3(b)
+        x3 = m.matmul_f32_chain(ah, bh, 32) + m.matmul_f32_chain(ah, bm, 32) + m.matmul_f32_chain(am, bh, 32)
+        x6 = x3 + m.matmul_f32_chain(ah, bl, 32) + m.matmul_f32_chain(al, bh, 32) + m.matmul_f32_chain(am, bm, 32)
+        chain = m.matmul_f32_chain(a, b)
+        e3, e6, ec = (np.abs(c.astype(np.float64) - exact).max() / scale for c in (x3, x6, chain))
+        assert e6 <= 2.0 * ec + 1e-7 and e6 < 1e-6, (K, e6, ec)
+        assert e3 > 4.0 * e6, (K, e3, e6)
