@@ -6,6 +6,8 @@
 // pair of every column and piece into one 32-bit LDS write.  Shape: the recurrent policy's dW_ih (csrc/gemm.hip, 512 x 128 output,
 // 131 072 rows, 128 row splits), whose fp32 kernel gemm_tn_partial<2,2,4,4> takes ~152 us per launch (113 TFLOP/s).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/experiments/gemm_tn_bf16x6.hip -o tools/experiments/_bin/gemm_tn_bf16x6
+// RESULT (MI355X): packing loader 234 us (slower than fp32); row-major planes + ds_read_b64_tr_b16 fragments (second kernel below)
+// 131 us = 131 TFLOP/s; both 4.5e-7 of the largest sum from an f64 evaluation.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -117,6 +119,106 @@ __global__ void __launch_bounds__(THREADS) gemm_tn_bf16x6_kernel(const float *__
             for (int r = 0; r < 4; ++r) out[(size_t)(k0 + wr * 64 + a * 16 + 4 * g + r) * N + n0 + wc * 64 + b * 16 + c] = acc[a][b][r];
 }
 
+// ---- variant: row-major bf16 planes in LDS ([32 rows][128 columns], the layout a plain loader writes with 8-byte stores) and the
+// transposition done by the LDS itself: ds_read_b64_tr_b16 (lane map: tools/experiments/ds_read_tr_map.hip) hands lane n of a 16-lane
+// group four consecutive ROWS of column n; two reads make one 16 x 16 x 32 fragment.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int RSB = TK * 2 + 8;             // bytes per LDS row: 128 bf16 + 8 bytes of padding
+constexpr int PLANEB = BM * RSB;
+
+__device__ __forceinline__ void split4(const float4 &x, uint2 &h, uint2 &m, uint2 &l) {
+    h.x = pk(x.x, x.y);
+    h.y = pk(x.z, x.w);
+    const float r0 = x.x - lo_f(h.x), r1 = x.y - hi_f(h.x), r2 = x.z - lo_f(h.y), r3 = x.w - hi_f(h.y);
+    m.x = pk(r0, r1);
+    m.y = pk(r2, r3);
+    l.x = pk(r0 - lo_f(m.x), r1 - hi_f(m.x));
+    l.y = pk(r2 - lo_f(m.y), r3 - hi_f(m.y));
+}
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char *p) {     // rows 8 g .. 8 g + 7 of this lane's column
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    union {
+        s16x4 h[2];
+        bf16x8 v;
+    } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)(p + 4 * RSB));
+    return u.v;
+}
+
+__global__ void __launch_bounds__(THREADS) gemm_tn_bf16x6_tr_kernel(const float *__restrict__ A, int lda, const float *__restrict__ D, int ldd, int K,
+                                                                    int N, long long rows_per_split, float *__restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 3 * PLANEB];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int wr = wv >> 1, wc = wv & 1;
+    const int tiles_n = N / TN;
+    const int k0 = (blockIdx.x / tiles_n) * TK, n0 = (blockIdx.x % tiles_n) * TN;
+    const long long m_lo = (long long)blockIdx.y * rows_per_split;
+    const int slabs = (int)(rows_per_split / BM);
+    const int col4 = tid & 31, rr = tid >> 5;                 // loader: rows rr + 8 q, columns 4 col4 .. + 3
+    const float *ap = A + (m_lo + rr) * lda + k0 + 4 * col4, *dp = D + (m_lo + rr) * ldd + n0 + 4 * col4;
+    float4 a0, a1, a2, a3, d0, d1, d2, d3;
+    auto fetch = [&]() {
+        a0 = *reinterpret_cast<const float4 *>(ap);
+        a1 = *reinterpret_cast<const float4 *>(ap + 8 * (size_t)lda);
+        a2 = *reinterpret_cast<const float4 *>(ap + 16 * (size_t)lda);
+        a3 = *reinterpret_cast<const float4 *>(ap + 24 * (size_t)lda);
+        d0 = *reinterpret_cast<const float4 *>(dp);
+        d1 = *reinterpret_cast<const float4 *>(dp + 8 * (size_t)ldd);
+        d2 = *reinterpret_cast<const float4 *>(dp + 16 * (size_t)ldd);
+        d3 = *reinterpret_cast<const float4 *>(dp + 24 * (size_t)ldd);
+        ap += (size_t)BM * lda;
+        dp += (size_t)BM * ldd;
+    };
+    auto put = [&](unsigned char *base, const float4 &x, int row) {
+        uint2 h, m, l;
+        split4(x, h, m, l);
+        unsigned char *q = base + row * RSB + col4 * 8;
+        *reinterpret_cast<uint2 *>(q) = h;
+        *reinterpret_cast<uint2 *>(q + PLANEB) = m;
+        *reinterpret_cast<uint2 *>(q + 2 * PLANEB) = l;
+    };
+    auto stash = [&]() {
+        put(lds, a0, rr), put(lds, a1, rr + 8), put(lds, a2, rr + 16), put(lds, a3, rr + 24);
+        put(lds + 3 * PLANEB, d0, rr), put(lds + 3 * PLANEB, d1, rr + 8), put(lds + 3 * PLANEB, d2, rr + 16), put(lds + 3 * PLANEB, d3, rr + 24);
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's address inside a 16-column fragment: row 8 g + (c >> 2), columns 4 (c & 3) .. + 3 (c = lane within the 16-lane group)
+    const unsigned char *la = lds + (8 * g + (c >> 2)) * RSB + (wr * 64 + 4 * (c & 3)) * 2;
+    const unsigned char *lb = lds + 3 * PLANEB + (8 * g + (c >> 2)) * RSB + (wc * 64 + 4 * (c & 3)) * 2;
+    fetch();
+    for (int s = 0; s < slabs; ++s) {
+        stash();
+        __syncthreads();
+        if (s + 1 < slabs) fetch();
+        constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) fa[a] = frag_tr(la + TA[t] * PLANEB + a * 32);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) fb[b] = frag_tr(lb + TB[t] * PLANEB + b * 32);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float *out = partial + (size_t)blockIdx.y * K * N;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(size_t)(k0 + wr * 64 + a * 16 + 4 * g + r) * N + n0 + wc * 64 + b * 16 + c] = acc[a][b][r];
+}
+
 #define CK(x)                                                                  \
     do {                                                                       \
         hipError_t e_ = (x);                                                   \
@@ -171,6 +273,29 @@ int main() {
         worst = fmax(worst, fabs(got - ref));
         scale = fmax(scale, fabs(ref));
     }
+    // ---- the transpose-read variant
+    float *dP2;
+    CK(hipMalloc(&dP2, (size_t)splits * K * N * 4));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(gemm_tn_bf16x6_tr_kernel, grid, dim3(THREADS), 0, 0, dA, K, dD, N, K, N, per, dP2);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm_tn_bf16x6_tr_kernel, grid, dim3(THREADS), 0, 0, dA, K, dD, N, K, N, per, dP2);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us2 = ms * 1e3 / reps;
+    std::vector<float> p2((size_t)splits * K * N);
+    CK(hipMemcpy(p2.data(), dP2, p2.size() * 4, hipMemcpyDeviceToHost));
+    double worst2 = 0.0;
+    for (int s = 0; s < 96; ++s) {
+        const int k = (int)((s * 2654435761u) % K), n = (int)((s * 40503u + 17) % N);
+        double ref = 0.0, got = 0.0;
+        for (long long m = 0; m < M; ++m) ref += (double)a[(size_t)m * K + k] * (double)d[(size_t)m * N + n];
+        for (int q = 0; q < splits; ++q) got += (double)p2[((size_t)q * K + k) * N + n];
+        worst2 = fmax(worst2, fabs(got - ref));
+    }
+    printf("row-major planes + ds_read_b64_tr_b16 fragments: %.1f us per launch = %.1f TFLOP/s; max |err| / max |exact|: %.2e\n", us2, flop / us2 / 1e6,
+           worst2 / scale);
     printf("gemm_tn_bf16x6  G[%d][%d] over %lld rows, %d splits: %.1f us per launch = %.1f TFLOP/s of the fp32 product it replaces (the product's fp32\n"
            "                kernel gemm_tn_partial<2,2,4,4>: ~152 us = 113 TFLOP/s); max |err| of 96 sampled sums / max |exact|: %.2e\n",
            K, N, M, splits, us, flop / us / 1e6, worst / scale);
