@@ -332,6 +332,7 @@ def main():
                          "not the headline metric; 'c4' = BASELINE configs[3] / SURVEY config C4: 8192 envs of uint8 (4,84,84) frames from the "
                          "device-side generator (Atari is a third-party emulator: env parity unpinned), NatureCNN policy; not the headline metric")
     ap.add_argument('--no-breakdown', action='store_true', help='skip the extra (untimed) per-kernel breakdown pass')
+    ap.add_argument('--no-transport-ab', action='store_true', help='N > 1: skip the extra K-step legs per transport (p2p fused / p2p launch / rccl)')
     ap.add_argument('--no-extra', action='store_true', help="skip the short configs[2] / configs[3] side runs appended to the N = 1 headline line")
     ap.add_argument('--sustained-seconds', type=float, default=3.0,
                     help='after the K timed steps: an extra leg of at least this many seconds of the same loop, reported as sustained_value (0 = skip)')
@@ -421,14 +422,28 @@ def main():
     L.pfa_timing_stride(event_stride)
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
+    def profile_snapshot():
+        # the reference's six section timers + the two wall timers (clean_pufferl.py:328-339), cumulative seconds
+        pr, tm = data.profile, getattr(data, '_timers', {})
+        snap = {k: getattr(pr, k).elapsed for k in ('env', 'eval_forward', 'eval_misc', 'train_forward', 'learn', 'train_misc')}
+        snap.update({k: tm[k].elapsed for k in ('evaluate', 'train') if k in tm})
+        return snap
+
     barrier()
+    prof0 = profile_snapshot()
     t0 = time.perf_counter()
     for _ in range(K):
         clean_pufferl.evaluate(data)
         clean_pufferl.train(data)
     barrier()
     dt = time.perf_counter() - t0
+    prof1 = profile_snapshot()
     L.pfa_timing_enable(0)
+    # clean_pufferl.Profile's breakdown over the timed region, ms per step.  The section timers bracket kernel ENQUEUES (the device
+    # runs asynchronously); eval_time / train_time are the wall timers of evaluate() / train(), each ending in one stream sync.
+    names_ = dict(evaluate='eval_time', env='env_time', eval_forward='eval_forward_time', eval_misc='eval_misc_time', train='train_time',
+                  train_forward='train_forward_time', learn='learn_time', train_misc='train_misc_time')
+    profile_ms = {names_[k]: round((prof1[k] - prof0.get(k, 0.0)) / K * 1e3, 4) for k in prof1}
     rank_ms = [dt / K * 1e3]
     if world > 1:
         t = torch.zeros(world, dtype=torch.float64, device='cuda')
@@ -479,13 +494,65 @@ def main():
         barrier()
     if rank == 0 and not args.no_breakdown:
         L.pfa_timing_enable(0)
-        names = (('philox_exp_noise', 'rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
+        names = (('philox_exp_noise', 'rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce_adam', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
                  else ('igemm_rows', 'igemm_weights', 'gae', 'adam_clip') if args.policy in ('cnn', 'wide')
                  else (('rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'), 'squared_tape', 'gae', 'lstm_seq_fwd',
                        'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
         for name in names:
             n, ms = kernel_ms(name)
             breakdown[name] = dict(launches_per_step=n // KB, ms_per_step=round(ms / KB, 4))
+
+    # Data parallel: the same K-step loop once per transport that is up, so that ONE run of `--gpus N` holds the A/B (every rank takes
+    # the same legs: what is up was agreed on by MIN all-reduce at create()).  p2p_fused = the optimizer step's exchange inside the
+    # reduce + Adam launch (the default, = the headline loop above); p2p_launch = the peer all-reduce as a launch of its own between
+    # ppo_reduce and adam_clip; rccl = ncclAllReduce on the native communicator.  Per-collective figures: HIP events around every
+    # instrumented launch in a short extra pass (they cost the queue a few us each, so they stay out of the timed loops).
+    transports = None
+    if world > 1 and args.policy == 'mlp' and data.native_dp and not args.no_transport_ab:
+        from pufferlib_amd import dist as pdist
+        info0 = pdist.transport_info()
+        legs = []
+        if info0['p2p']:
+            legs += [('p2p_fused', '1', 1), ('p2p_launch', '0', 1)]
+        if info0['rccl']:
+            legs += [('rccl', '0', 0)]
+        transports = {}
+        saved_env = os.environ.get('PFA_FUSED_DP')
+        for name, fused_dp, p2p_on in legs:
+            os.environ['PFA_FUSED_DP'] = fused_dp
+            L.pfa_p2p_enable(p2p_on)
+            for _ in range(2):
+                clean_pufferl.evaluate(data)
+                clean_pufferl.train(data)
+            barrier()
+            tl = time.perf_counter()
+            for _ in range(K):
+                clean_pufferl.evaluate(data)
+                clean_pufferl.train(data)
+            barrier()
+            dtl = torch.tensor([time.perf_counter() - tl], dtype=torch.float64, device='cuda')
+            dist.all_reduce(dtl, op=dist.ReduceOp.MAX)
+            KC = 3
+            L.pfa_timing_reset()
+            L.pfa_timing_enable(2)
+            for _ in range(KC):
+                clean_pufferl.evaluate(data)
+                clean_pufferl.train(data)
+            barrier()
+            L.pfa_timing_enable(0)
+            per_call = {}
+            for kn in ('ppo_reduce_adam', 'ppo_reduce', 'p2p_all_reduce', 'rccl_all_reduce', 'adam_clip'):
+                n_, ms_ = kernel_ms(kn)
+                if n_:
+                    per_call[kn] = dict(calls_per_step=n_ // KC, us_per_call=round(ms_ / n_ * 1e3, 2))
+            leg_dt = float(dtl.item())
+            transports[name] = dict(value=world * per_gpu * K / leg_dt, ms_per_step=leg_dt / K * 1e3, steps=K,
+                                    launches_per_optimizer_step=2 if name == 'p2p_fused' else 4, rank0_events=per_call)
+        L.pfa_p2p_enable(1)
+        if saved_env is None:
+            os.environ.pop('PFA_FUSED_DP', None)
+        else:
+            os.environ['PFA_FUSED_DP'] = saved_env
 
     import torch as _t
     assert bool(_t.isfinite(data.flat_params.flat).all()), 'non-finite weights after the timed loop'
@@ -550,6 +617,7 @@ def main():
                                     else 'HIP events recorded on the launch stream before / after the launch'),
                          'flop_per_launch': flop_row * rows_per_launch},
             'kernel_ms_per_step': breakdown,
+            'profile_ms_per_step': profile_ms,
             'rank_ms_per_step': {'min': min(rank_ms), 'max': max(rank_ms), 'per_rank': [round(x, 4) for x in rank_ms]},
         }
         if args.policy == 'mlp':
@@ -587,9 +655,15 @@ def main():
                                          'grad_bucket_bytes': bucket_bytes,
                                          'small_reductions': ('p2p' if info['p2p'] else 'rccl' if (data.native_dp and info['rccl']) else 'torch')},
                            'rccl_nranks': info['rccl_nranks'], 'p2p_selftest_passed': info['p2p_selftest'], 'p2p_status': info['p2p_status'],
-                           'allreduce_calls': {'p2p': info['p2p_calls'], 'rccl_native': info['rccl_calls']},
-                           'collectives_per_step': 'GAE halo + affine maps (2 tiny), advantage sums (1), gradient bucket per optimizer step '
-                                                   f'({EPOCHS * NMB}), stats/EV sums (2)'}
+                           'allreduce_calls': {'p2p': info['p2p_calls'], 'p2p_flag_in_data': info['p2p_ll_calls'], 'rccl_native': info['rccl_calls']},
+                           # what one step (evaluate + train) exchanges, and the budget >= 6x weak scaling at 8 ranks leaves for it:
+                           # t_N <= 8/6 t_1, i.e. everything data parallelism adds (exchanges, rank skew, waits) <= t_1 / 3 per step
+                           'collectives_per_step': {'gradient_exchanges': EPOCHS * NMB, 'small_all_reduces': 2,
+                                                    'what': f'{EPOCHS * NMB} optimizer-step exchanges of the {bucket_bytes}-byte bucket (inside the reduce + '
+                                                            'Adam launch on the fused peer path: 2 launches per optimizer step, else an all-reduce of its '
+                                                            'own: 4); 1 all-reduce of [episode-statistic sums | 6 GAE numbers per rank] at the end of '
+                                                            'evaluate(), 1 of [advantage sums | explained-variance sums] after GAE'},
+                           'transports': transports}
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)

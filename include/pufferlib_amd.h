@@ -57,6 +57,21 @@ int pfa_gae_shard_pass1(const float *dones, const float *values, const float *re
 int pfa_gae_shard_pass2(const float *dones, const float *values, const float *rewards, float *advantages,
                         float *returns, int64_t n, int has_next, float gamma, float gae_lambda,
                         const void *workspace, const double *carry_in, pfa_stream_t stream);
+/* Data-parallel GAE with ONE exchange (csrc/gae.hip): a shard's affine map is (interior) o (last element) and only the last
+ * element needs the next shard's first row, so every rank publishes six numbers it can compute from its own rows — interior map
+ * (C, D), values[n-1], first row (done, value, reward) — next to `n_extra` other f64 sums of the caller (episode statistics):
+ *   pfa_gae_shard_publish   out[0 .. n_extra) = extra, out[n_extra + 6 q + j] = the six numbers for q == rank, 0 elsewhere
+ *   (caller) ONE all-reduce(SUM) of out[n_extra + 6 world]
+ *   pfa_gae_shard_fold      gathered = out + n_extra: completes every later shard's map, folds them into carry_out[0], patches this
+ *                           shard's last block aggregate in `workspace`, writes the halo row at index n of dones / values / rewards
+ *   pfa_gae_shard_pass2     has_next = rank < world - 1, carry_in = carry_out.
+ * `workspace` (pfa_gae_workspace_bytes(n)) must not be touched between the three calls; the arrays hold n + 1 elements. */
+int pfa_gae_shard_publish(const float *dones, const float *values, const float *rewards, int64_t n, float gamma, float gae_lambda,
+                          void *workspace, const double *extra, int32_t n_extra, double *out, int32_t rank, int32_t world,
+                          pfa_stream_t stream);
+int pfa_gae_shard_fold(const double *gathered, int32_t rank, int32_t world, int64_t n, float gamma, float gae_lambda, void *workspace,
+                       float *dones, float *values, float *rewards, double *carry_out, pfa_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * Squared vecenv — replaces pufferlib.vector.Serial (vector.py:70-166) over
@@ -386,9 +401,14 @@ int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float 
 /* The whole minibatch loop of one clean_pufferl.train call on ONE rank (clean_pufferl.py:175-258 without the
  * target_kl early exit): update_epochs x num_minibatches x { pfa_ppo_mlp_grad, pfa_adam_clip_step } enqueued from
  * native code (no per-step host work).  opt_step = optimizer steps taken before this call; losses as above.
- * data_parallel != 0: every optimizer step all-reduces the flat bucket [gradient | 16 loss-sum floats] over the RCCL
- * communicator of pfa_dist_init on `stream` (gradients are pre-divided by the GLOBAL minibatch rows = local rows x
- * world size; adv_stats must already hold the all-reduced sums) and takes the clip norm after the reduce. */
+ * data_parallel != 0: every optimizer step sums the flat bucket [gradient | 16 loss-sum floats] over the ranks (gradients are
+ * pre-divided by the GLOBAL minibatch rows = local rows x world size; adv_stats must already hold the all-reduced sums) and takes
+ * the clip norm after the sum.  Transport: with the peer path open (pfa_p2p_open) the exchange runs inside the reduce + Adam
+ * launch itself (two launches per optimizer step, PFA_FUSED_DP=0 turns that off); otherwise one all-reduce per step through
+ * pfa_dist_all_reduce_f32 (peer path as a launch of its own, else the RCCL communicator of pfa_dist_init) on `stream`.
+ * Single rank: sum of the partials, clip norm and Adam are one launch as well (PFA_FUSED_ADAM=0: the two-kernel form of
+ * pfa_ppo_mlp_grad + pfa_adam_clip_step, bit-identical results).  The last 256 bytes of the workspace hold that launch's
+ * grid barrier; this call resets them. */
 int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                       const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                       float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
@@ -623,12 +643,31 @@ int pfa_p2p_close(void);
 int pfa_p2p_status(void);
 int pfa_p2p_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
 int pfa_p2p_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
+/* The flag-in-data form of the same exchange (csrc/p2p_ll.hpp): every float travels as one 8-byte {value, sequence number} store
+ * into the peers' memory and is summed, rank order, as soon as the local copies carry this call's number — no flag, no fence, no
+ * assumption about the order in which a peer's stores land.  This is what pfa_ppo_mlp_train runs INSIDE its reduce + Adam launch
+ * when data parallel (no all-reduce launch at all); the stand-alone entry serves the start-up self-test and the tests.  Up to
+ * cap_bytes / 4 + 2304 floats; collective (every rank must make the same sequence of calls).  pfa_p2p_ll_calls: exchanges so far
+ * (stand-alone + fused). */
+int pfa_p2p_ll_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
+int64_t pfa_p2p_ll_calls(void);
+/* Routing switch for A/B measurements (call it on every rank alike): on = 0 makes pfa_dist_all_reduce_* and pfa_ppo_mlp_train stop
+ * using the peer path — they fall to the RCCL communicator of pfa_dist_init — while the buffers stay mapped; on = 1 routes over it
+ * again.  Returns the previous setting. */
+int pfa_p2p_enable(int on);
 
 /* What train() logs (clean_pufferl.py:249-254,266-270) in one device buffer of 10 f64: out[0..5] = `losses` (the six
  * running means above), out[6..9] = sum y_true, sum y_true^2, sum adv, sum adv^2 with y_pred = values in storage
  * (step-major) order and y_true = advantages (env-major) + y_pred — the reference's explained-variance inputs. */
 int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, const double *losses,
                        double *out10, void *workspace, pfa_stream_t stream);
+
+/* The same in two halves, for the data-parallel update: the four explained-variance sums are known as soon as GAE has run, so
+ * they ride the all-reduce of the advantage sums (one exchange instead of two).  pfa_train_ev_sums: out4 = this rank's four sums;
+ * pfa_train_log_pack: out10 = { losses[0..5] (nullable: zeros), ev4[0..3] }. */
+int pfa_train_ev_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, double *out4, void *workspace,
+                      pfa_stream_t stream);
+int pfa_train_log_pack(const double *losses, const double *ev4, double *out10, pfa_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
 SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip', 'igemm.hip', 'cnn_heads.hip', 'general.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp',
+HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp', 'p2p_ll.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
@@ -133,6 +133,10 @@ _SIGNATURES = {
     'pfa_gae_f32': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_float, C.c_float, P, P]),
     'pfa_gae_shard_pass1': (C.c_int, [P, P, P, C.c_int64, C.c_int, C.c_float, C.c_float, P, P, P]),
     'pfa_gae_shard_pass2': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_int, C.c_float, C.c_float, P, P, P]),
+    'pfa_gae_shard_publish': (C.c_int, [P, P, P, C.c_int64, C.c_float, C.c_float, P, P, C.c_int32, P, C.c_int32, C.c_int32, P]),
+    'pfa_gae_shard_fold': (C.c_int, [P, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_float, P, P, P, P, P, P]),
+    'pfa_train_ev_sums': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, P, P]),
+    'pfa_train_log_pack': (C.c_int, [P, P, P, P]),
     'pfa_squared_state_bytes': (C.c_size_t, [C.POINTER(SquaredConfig)]),
     'pfa_squared_async_reset': (C.c_int, [P, C.POINTER(SquaredConfig), C.c_int64, P, P, P, P, P, P]),
     'pfa_squared_fill_tape': (C.c_int, [P, C.POINTER(SquaredConfig), C.c_int32, P]),
@@ -252,6 +256,9 @@ _SIGNATURES = {
     'pfa_p2p_status': (C.c_int, []),
     'pfa_p2p_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
     'pfa_p2p_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
+    'pfa_p2p_ll_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
+    'pfa_p2p_ll_calls': (C.c_int64, []),
+    'pfa_p2p_enable': (C.c_int, [C.c_int]),
     'pfa_train_log_sums': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, P, P, P]),
     'pfa_adam_clip_step': (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,
                                      C.c_float, C.c_float, P, P, C.c_double, P, C.c_int32, P]),

@@ -348,6 +348,7 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     dims = _lib.MlpDims(64, 64, 128, 4, 0) if conv else fp.dims
     ws_bytes = max(L.pfa_ppo_workspace_bytes(C.byref(dims), config.batch_size, C.byref(hp)),
                    L.pfa_gae_workspace_bytes(config.batch_size))
+    dp_sums = torch.zeros(2 * experience.num_minibatches + 4, dtype=torch.float64, device=device)
     data = namespace(
         config=config, vecenv=vecenv, policy=policy, uncompiled_policy=policy, optimizer=optimizer,
         experience=experience, profile=profile, losses=losses, wandb=wandb, global_step=0, epoch=0, stats={},
@@ -357,7 +358,12 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
         env_offset=env_offset, host_bridge=host_bridge,
         workspace=torch.zeros(ws_bytes, dtype=torch.uint8, device=device),
         grads=torch.zeros(fp.count + 16, dtype=torch.float32, device=device),   # gradient + 8 loss sums as (hi, lo) float pairs
-        adv_stats=torch.zeros(experience.num_minibatches, 2, dtype=torch.float64, device=device),
+        # [adv_stats (nmb x 2) | the four explained-variance sums]: one allocation, so that data parallel they are ONE all-reduce
+        dp_sums=dp_sums, adv_stats=dp_sums[:2 * experience.num_minibatches].view(experience.num_minibatches, 2),
+        # data parallel: the sharded GAE's block aggregates (kept from the publish at the end of evaluate() to train()), the
+        # exchange buffer [episode-statistic sums | world x 6 GAE numbers] and the carry-in
+        gae_ws=torch.zeros(max(int(L.pfa_gae_workspace_bytes(config.batch_size)), 16), dtype=torch.uint8, device=device) if world > 1 else None,
+        gae_carry=torch.zeros(1, dtype=torch.float64, device=device), _dp_eval=None, _gae_published=False,
         loss_acc=torch.zeros(8, dtype=torch.float64, device=device),
         log_sums=torch.zeros(10, dtype=torch.float64, device=device),
         noise=None,            # optional explicit Exp(1) tensor [T][N][A] for the next evaluate() (parity tests)
@@ -508,7 +514,13 @@ def _finish_evaluate(data, N, T):
         experience.step = T
         data.global_step += N * T * data.world_size      # sum(mask) per recv (clean_pufferl.py:90), all ranks
         st = vecenv.stats_with_flag(reset=True)         # 4 sums + the tape underrun flag
-        if data.native_dp:
+        if data.world_size > 1 and _early_gae() and getattr(experience, '_rdv', None) is not None:
+            # data parallel: the episode statistics and the six numbers per rank the sharded GAE needs (csrc/gae.hip: interior map,
+            # last value, first row — all from this rank's own rows, complete once the rollout is) ride ONE all-reduce; train()
+            # finishes the scan from them without another exchange.  (PFA_DP_EARLY_GAE=0 for callers that rewrite rewards / values /
+            # dones between evaluate() and train(): the GAE exchange then happens in train().)
+            st = _publish_gae(data, st)
+        elif data.native_dp:
             _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(st), st.numel(), _lib.stream_handle()), 'stats all-reduce')
         elif data.world_size > 1:
             dist, _, _ = _dist()
@@ -544,24 +556,48 @@ def _all_gather_small(dist, x, rank, world, native=False):
     return buf
 
 
-def _sharded_gae(data, dist, rank, world, stream):
-    """compute_gae over the GLOBAL rank-major flat batch (c_gae.pyx:11-32 crosses env boundaries, so it also crosses
-    shard boundaries): two tiny exchanges — the first rows (halo of the previous rank) and the shards' affine maps."""
+def _early_gae():
+    return os.environ.get('PFA_DP_EARLY_GAE', '1') != '0'
+
+
+def _publish_gae(data, extra=None):
+    """First half of the data-parallel GAE (csrc/gae.hip, one-exchange form): this rank's six numbers + `extra` (f64 sums that
+    ride along: the episode statistics) -> ONE all-reduce(SUM).  Returns the all-reduced `extra` (a view of the exchange buffer);
+    the gathered GAE numbers stay in data._dp_eval for _finish_gae."""
+    config, ex = data.config, data.experience
+    L, B, stream = _lib.lib(), ex.batch_size, _lib.stream_handle()
+    dist, rank, world = _dist()
+    n_extra = 0 if extra is None else extra.numel()
+    if data._dp_eval is None or data._dp_eval.numel() != n_extra + 6 * world:
+        data._dp_eval = torch.zeros(n_extra + 6 * world, dtype=torch.float64, device=ex.device)
+    buf = data._dp_eval
+    _lib.check(L.pfa_gae_shard_publish(_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards), B, float(config.gamma),
+                                       float(config.gae_lambda), _lib.ptr(data.gae_ws), _lib.ptr(extra), n_extra, _lib.ptr(buf),
+                                       rank, world, stream), 'gae publish')
+    if data.native_dp:
+        _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(buf), buf.numel(), stream), 'stats + gae all-reduce')
+    else:
+        dist.all_reduce(buf)
+    data._gae_published = True
+    return buf[:n_extra]
+
+
+def _finish_gae(data, rank, world, stream):
+    """compute_gae over the GLOBAL rank-major flat batch (c_gae.pyx:11-32 crosses env boundaries, so it also crosses shard
+    boundaries) from the numbers _publish_gae gathered: fold the later shards into the carry-in, then the local scan."""
     config, ex = data.config, data.experience
     L, B = _lib.lib(), ex.batch_size
+    if not data._gae_published:           # evaluate() did not publish (host vecenv path, PFA_DP_EARLY_GAE=0): exchange here
+        _publish_gae(data, None)
+    gathered = data._dp_eval[data._dp_eval.numel() - 6 * world:]
     has_next = int(rank < world - 1)
-    rows = _all_gather_small(dist, ex._rdv[:, 0].contiguous(), rank, world, data.native_dp)
-    if has_next:
-        ex._rdv[:, B] = rows[rank + 1]
-    smap = torch.empty(2, dtype=torch.float64, device=ex.device)
     args = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
-    _lib.check(L.pfa_gae_shard_pass1(*args, B, has_next, float(config.gamma), float(config.gae_lambda),
-                                     _lib.ptr(data.workspace), _lib.ptr(smap), stream), 'gae pass 1')
-    maps = _all_gather_small(dist, smap, rank, world, data.native_dp)
-    carry = pdist.gae_fold_later(maps, rank)
+    _lib.check(L.pfa_gae_shard_fold(_lib.ptr(gathered), rank, world, B, float(config.gamma), float(config.gae_lambda),
+                                    _lib.ptr(data.gae_ws), *args, _lib.ptr(data.gae_carry), stream), 'gae fold')
     _lib.check(L.pfa_gae_shard_pass2(*args, _lib.ptr(ex.advantages), _lib.ptr(ex.returns), B, has_next,
-                                     float(config.gamma), float(config.gae_lambda), _lib.ptr(data.workspace),
-                                     _lib.ptr(carry) if has_next else None, stream), 'gae pass 2')
+                                     float(config.gamma), float(config.gae_lambda), _lib.ptr(data.gae_ws),
+                                     _lib.ptr(data.gae_carry) if has_next else None, stream), 'gae pass 2')
+    data._gae_published = False
 
 
 @utils.profile
@@ -579,7 +615,7 @@ def train(data):
     with profile.train_misc:
         # compute_gae over the env-major batch (clean_pufferl.py:163-169) + returns (:482)
         if world > 1:
-            _sharded_gae(data, dist, rank, world, stream)
+            _finish_gae(data, rank, world, stream)
         else:
             _lib.check(L.pfa_gae_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
                                      _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
@@ -587,6 +623,19 @@ def train(data):
         if config.norm_adv:
             _lib.check(L.pfa_ppo_adv_stats(C.byref(experience.c), B, C.byref(hp), _lib.ptr(data.adv_stats),
                                            _lib.ptr(data.workspace), stream), 'adv_stats')
+        # data parallel: the four explained-variance sums only need advantages and values, so they ride the all-reduce of the
+        # advantage sums instead of one of their own at the end of train()
+        early_ev = world > 1 and not (getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference')
+        if early_ev:
+            _lib.check(L.pfa_train_ev_sums(C.byref(experience.c), B, experience.num_envs, C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb),
+                                           _lib.ptr(data.workspace), stream), 'train_ev_sums')
+            if not config.norm_adv:
+                data.adv_stats.zero_()
+            if data.native_dp:
+                _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(data.dp_sums), data.dp_sums.numel(), stream), 'adv + ev all-reduce')
+            else:
+                dist.all_reduce(data.dp_sums)
+        elif config.norm_adv:
             if data.native_dp:
                 _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(data.adv_stats), data.adv_stats.numel(), stream), 'adv all-reduce')
             elif world > 1:
@@ -658,19 +707,23 @@ def train(data):
 
         # losses + explained variance exactly as the reference logs them (clean_pufferl.py:249-254,266-270, App. A.8):
         # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
-        _lib.check(L.pfa_train_log_sums(C.byref(experience.c), B, experience.num_envs, _lib.ptr(data.loss_acc),
-                                        _lib.ptr(data.log_sums), _lib.ptr(data.workspace), stream), 'train_log_sums')
-        if getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference':
-            # the reference's y_pred is the value buffer in STORAGE order = arrival order here (hostpath.evaluate kept it)
-            yp, ad = data.arrival_values.double(), experience.advantages.double()
-            yt = ad + yp
-            data.log_sums[6:10] = torch.stack([yt.sum(), (yt * yt).sum(), ad.sum(), (ad * ad).sum()])
-        if data.native_dp:                                      # explained variance over the GLOBAL batch, like the (global) losses
-            _lib.check(L.pfa_dist_all_reduce_f64(C.c_void_p(data.log_sums.data_ptr() + 6 * 8), 4, stream), 'ev all-reduce')
-        elif world > 1:
-            ev_sums = data.log_sums[6:10].clone()
-            dist.all_reduce(ev_sums)
-            data.log_sums[6:10] = ev_sums
+        if early_ev:                                            # the sums were all-reduced with the advantage sums
+            _lib.check(L.pfa_train_log_pack(_lib.ptr(data.loss_acc), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(data.log_sums),
+                                            stream), 'train_log_pack')
+        else:
+            _lib.check(L.pfa_train_log_sums(C.byref(experience.c), B, experience.num_envs, _lib.ptr(data.loss_acc),
+                                            _lib.ptr(data.log_sums), _lib.ptr(data.workspace), stream), 'train_log_sums')
+            if getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference':
+                # the reference's y_pred is the value buffer in STORAGE order = arrival order here (hostpath.evaluate kept it)
+                yp, ad = data.arrival_values.double(), experience.advantages.double()
+                yt = ad + yp
+                data.log_sums[6:10] = torch.stack([yt.sum(), (yt * yt).sum(), ad.sum(), (ad * ad).sum()])
+            if data.native_dp:                                  # explained variance over the GLOBAL batch, like the (global) losses
+                _lib.check(L.pfa_dist_all_reduce_f64(C.c_void_p(data.log_sums.data_ptr() + 6 * 8), 4, stream), 'ev all-reduce')
+            elif world > 1:
+                ev_sums = data.log_sums[6:10].clone()
+                dist.all_reduce(ev_sums)
+                data.log_sums[6:10] = ev_sums
         # one D2H of 10 f64 (the one sync of train(); with PFA_LAZY_READBACK=1 data.losses fills in when it is first read)
         Bg = B * world
 

@@ -76,6 +76,7 @@ bool dist_ready() { return g_comm != nullptr || p2p_ready(); }
 int dist_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
     if (p2p_fits(count * (f64 ? 8 : 4))) return p2p_all_reduce(buf, count, f64, stream);
     PFA_REQUIRE(g_comm != nullptr, "dist: communicator not initialised");
+    ScopedKernelTimer timer("rccl_all_reduce", stream);   // (bench.py's per-collective figure: whatever RCCL enqueues for this call)
     PFA_CHECK_NCCL(g_api.AllReduce(buf, buf, count, f64 ? kNcclFloat64 : kNcclFloat32, kNcclSum, g_comm, stream));
     ++g_rccl_calls;
     return 0;

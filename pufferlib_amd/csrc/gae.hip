@@ -172,6 +172,69 @@ __global__ void gae_shard_aggregate_kernel(const Affine *agg, int nblocks, doubl
     }
 }
 
+
+// ---- data-parallel GAE with ONE exchange -------------------------------------------------------------------------------------
+// A shard's map is (interior) o (last element), and only the last element's map needs the next shard's first row.  So every rank
+// publishes six numbers that come from its OWN rows alone — the interior map (C, D) of elements 0 .. n-2, values[n-1], and its
+// first row (done, value, reward) — and after one all-gather of those every rank can finish all the shards' maps itself.
+// Publish: out[0 .. n_extra) = extra (the caller's other f64 sums, e.g. the episode statistics, so that they ride the same
+// all-reduce), out[n_extra + 6 q + j] = this rank's six numbers for q == rank and 0 elsewhere (all-gather as a sum).
+__global__ void gae_shard_publish_kernel(const Affine *agg, int nblocks, const float *dones, const float *values, const float *rewards,
+                                         long long n, const double *extra, int n_extra, double *out, int rank, int world) {
+    const int lane = lane_id();
+    const int per = (nblocks + 63) / 64;
+    Affine f = {1.0, 0.0};
+    for (int i = per - 1; i >= 0; --i) {
+        const int b = lane * per + i;
+        if (b < nblocks) f = compose(agg[b], f);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const Affine o = shfl_down_affine(f, off);
+        if (lane + off < 64) f = compose(f, o);
+    }
+    const double c = __shfl(f.c, 0, 64), d = __shfl(f.d, 0, 64);
+    for (int i = lane; i < n_extra; i += 64) out[i] = extra[i];
+    for (int i = lane; i < 6 * world; i += 64) {
+        double v = 0.0;
+        if (i / 6 == rank) {
+            const int j = i % 6;
+            v = j == 0 ? c : j == 1 ? d : j == 2 ? (double)values[n - 1] : j == 3 ? (double)dones[0] : j == 4 ? (double)values[0] : (double)rewards[0];
+        }
+        out[n_extra + i] = v;
+    }
+}
+
+// Fold (one thread): pub = the gathered [world][6].  Completes shard q's map with its last element (the reference's statement
+// order and rounding, c_gae.pyx:27-30, on the next shard's first row; the very last element of the batch is pinned to adv = 0),
+// folds the later shards into this rank's carry-in, patches the last block aggregate of THIS shard (pass 2's apply kernel composes
+// the aggregates of the later blocks) and drops the next shard's first row behind the shard's arrays as halo.
+__global__ void gae_shard_fold_kernel(const double *pub, int rank, int world, long long n, float gamma, float lam, Affine *agg, int nblocks,
+                                      float *dones, float *values, float *rewards, double *carry_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto last_map = [&](int q) -> Affine {
+        if (q == world - 1) return Affine{0.0, 0.0};
+        const float d1 = (float)pub[6 * (q + 1) + 3], v1 = (float)pub[6 * (q + 1) + 4], r1 = (float)pub[6 * (q + 1) + 5];
+        const float v0 = (float)pub[6 * q + 2];
+        const float nnt = __fsub_rn(1.0f, d1);
+        const float delta = __fsub_rn(__fadd_rn(r1, __fmul_rn(__fmul_rn(gamma, v1), nnt)), v0);
+        const float coef = __fmul_rn(__fmul_rn(gamma, lam), nnt);
+        return Affine{(double)coef, (double)delta};
+    };
+    double x = 0.0;
+    for (int q = world - 1; q > rank; --q) {
+        const Affine m = compose(Affine{pub[6 * q], pub[6 * q + 1]}, last_map(q));
+        x = m.c * x + m.d;
+    }
+    carry_out[0] = x;
+    agg[nblocks - 1] = compose(agg[nblocks - 1], last_map(rank));
+    if (rank < world - 1) {
+        dones[n] = (float)pub[6 * (rank + 1) + 3];
+        values[n] = (float)pub[6 * (rank + 1) + 4];
+        rewards[n] = (float)pub[6 * (rank + 1) + 5];
+    }
+}
+
 }  // namespace pfa
 
 using namespace pfa;
@@ -229,6 +292,39 @@ extern "C" int pfa_gae_shard_pass2(const float *dones, const float *values, cons
     hipLaunchKernelGGL(gae_apply_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
                        advantages, returns, (long long)n, gamma, gae_lambda, (const Affine *)workspace, (int)nb,
                        has_next ? carry_in : (const double *)nullptr, has_next ? 1 : 0);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// One-exchange form of the data-parallel scan (see gae_shard_publish_kernel): publish -> ONE all-reduce(SUM) of
+// out[n_extra + 6 world] by the caller -> fold -> pfa_gae_shard_pass2 (has_next = rank < world - 1, carry_in = carry_out).
+// The arrays hold n + 1 elements (the fold writes the halo row at index n); `workspace` must stay untouched between the three.
+extern "C" int pfa_gae_shard_publish(const float *dones, const float *values, const float *rewards, int64_t n, float gamma, float gae_lambda,
+                                     void *workspace, const double *extra, int32_t n_extra, double *out, int32_t rank, int32_t world,
+                                     pfa_stream_t stream) {
+    PFA_REQUIRE(n >= 1 && dones && values && rewards && workspace && out && world >= 1 && rank >= 0 && rank < world && n_extra >= 0 &&
+                    (n_extra == 0 || extra),
+                "gae_shard_publish: bad arguments");
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
+    Affine *agg = (Affine *)workspace;
+    // interior map: elements 0 .. n-2 (each reads its successor, element n-1 at most); the blocks are those of the n-element pass 2
+    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       (long long)(n - 1), gamma, gae_lambda, agg, 1);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gae_shard_publish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, agg, (int)nb, dones, values, rewards, (long long)n,
+                       extra, (int)n_extra, out, (int)rank, (int)world);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_gae_shard_fold(const double *gathered, int32_t rank, int32_t world, int64_t n, float gamma, float gae_lambda, void *workspace,
+                                  float *dones, float *values, float *rewards, double *carry_out, pfa_stream_t stream) {
+    PFA_REQUIRE(gathered && workspace && dones && values && rewards && carry_out && n >= 1 && world >= 1 && rank >= 0 && rank < world,
+                "gae_shard_fold: bad arguments");
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    hipLaunchKernelGGL(gae_shard_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, (int)rank, (int)world, (long long)n, gamma,
+                       gae_lambda, (Affine *)workspace, (int)nb, dones, values, rewards, carry_out);
     PFA_LAUNCH_CHECK();
     return 0;
 }

@@ -25,10 +25,10 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "p2p_ll.hpp"
 
 namespace pfa {
 
-constexpr int kP2pMaxRanks = 8;
 constexpr int kP2pChunks = 64;
 constexpr int kP2pThreads = 512;
 
@@ -45,12 +45,24 @@ struct P2pState {
     int *status = nullptr;         // host-pinned word (device-visible): set non-zero when a wait ran out
     long long timeout_ticks = 0;   // of the 100 MHz wall clock
     unsigned long long calls = 0;
+    // flag-in-data area (p2p_ll.hpp) behind the slots and flags: [2][world][ll_entries] uint64
+    size_t ll_offset = 0;
+    unsigned ll_entries = 0, ll_seq = 0;
+    unsigned long long ll_calls = 0;
 };
 static P2pState g_p2p;
 
 __host__ __device__ inline size_t p2p_slot_offset(size_t cap, int world, int phase, int src) { return ((size_t)phase * world + src) * cap; }
 __host__ __device__ inline size_t p2p_flags_offset(size_t cap, int world) { return (size_t)2 * world * cap; }
-static size_t p2p_total_bytes(size_t cap, int world) { return p2p_flags_offset(cap, world) + (size_t)2 * world * kP2pChunks * sizeof(unsigned long long) + 256; }
+static size_t p2p_ll_offset(size_t cap, int world) {
+    return align_up(p2p_flags_offset(cap, world) + (size_t)2 * world * kP2pChunks * sizeof(unsigned long long) + 256, 256);
+}
+// entries per (phase, source): every float of a bucket that fits a slot + the head room the gradient's fragment-order layout
+// needs over the flat one (ppo_update.hip NativeLayout: up to 2048 + 24 entries more than the flat vector)
+static unsigned p2p_ll_entries(size_t cap) { return (unsigned)(cap / 4 + 2304); }
+static size_t p2p_total_bytes(size_t cap, int world) {
+    return p2p_ll_offset(cap, world) + (size_t)2 * world * p2p_ll_entries(cap) * sizeof(unsigned long long) + 256;
+}
 
 template <typename T>
 __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers peers, int rank, int world, size_t cap, int phase,
@@ -102,11 +114,38 @@ __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers pe
     }
 }
 
+// The flag-in-data exchange as a launch of its own (self-test at start-up, unit tests; the update runs it inside
+// ppo_reduce_adam_kernel): one entry per float.
+__global__ void __launch_bounds__(256) p2p_ll_all_reduce_kernel(LlArgs d, float *buf, unsigned n) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float v = buf[i];
+    ll_push(d, i, v);
+    buf[i] = ll_wait_sum(d, i, v);
+}
+
+static bool g_p2p_enabled = true;   // pfa_p2p_enable: routing switch for A/B runs (the buffers stay mapped)
+bool p2p_ll_ready(size_t entries_needed) { return g_p2p_enabled && g_p2p.ready && g_p2p.world > 1 && entries_needed <= g_p2p.ll_entries; }
+LlArgs p2p_ll_next() {
+    LlArgs d{};
+    for (int q = 0; q < g_p2p.world; ++q) d.base[q] = reinterpret_cast<unsigned long long *>(g_p2p.peers.base[q] + g_p2p.ll_offset);
+    d.rank = g_p2p.rank;
+    d.world = g_p2p.world;
+    d.entries = g_p2p.ll_entries;
+    if (++g_p2p.ll_seq == 0) g_p2p.ll_seq = 2;   // 0 is the zeroed area's value; keep the phase parity going (2^32 calls away)
+    d.seq = g_p2p.ll_seq;
+    d.status = g_p2p.status;
+    d.timeout_ticks = g_p2p.timeout_ticks;
+    ++g_p2p.ll_calls;
+    return d;
+}
+unsigned long long p2p_ll_calls() { return g_p2p.ll_calls; }
+
 bool p2p_ready() { return g_p2p.ready; }
 unsigned long long p2p_calls() { return g_p2p.calls; }
 size_t p2p_capacity() { return g_p2p.ready ? g_p2p.cap_bytes : 0; }
 int p2p_world() { return g_p2p.world; }
-bool p2p_fits(size_t bytes) { return g_p2p.ready && bytes <= g_p2p.cap_bytes; }
+bool p2p_fits(size_t bytes) { return g_p2p_enabled && g_p2p.ready && bytes <= g_p2p.cap_bytes; }
 
 int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
     PFA_REQUIRE(g_p2p.ready, "p2p: not initialised");
@@ -158,6 +197,8 @@ extern "C" int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64
     g_p2p.local = (char *)p;
     g_p2p.cap_bytes = cap;
     g_p2p.world = world;
+    g_p2p.ll_offset = p2p_ll_offset(cap, world);
+    g_p2p.ll_entries = p2p_ll_entries(cap);
     void *st = nullptr;
     PFA_CHECK_HIP(hipHostMalloc(&st, 64, hipHostMallocMapped));
     *(volatile int *)st = 0;
@@ -187,6 +228,7 @@ extern "C" int pfa_p2p_open(const uint8_t *handles_host, int32_t rank, int32_t w
     }
     g_p2p.rank = rank;
     g_p2p.seq = 0;
+    g_p2p.ll_seq = 0;
     g_p2p.ready = true;
     return 0;
 }
@@ -213,4 +255,26 @@ extern "C" int pfa_p2p_all_reduce_f32(float *buf, int64_t count, pfa_stream_t st
 extern "C" int pfa_p2p_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream) {
     PFA_REQUIRE(buf && count >= 0, "p2p.all_reduce: bad arguments");
     return p2p_all_reduce(buf, (size_t)count, true, (hipStream_t)stream);
+}
+
+// The flag-in-data form (csrc/p2p_ll.hpp) as a stand-alone all-reduce of up to `slot capacity / 4 + 2304` floats: what the fused
+// optimizer-step kernel does per gradient entry, exposed for the start-up self-test and the unit tests.
+extern "C" int pfa_p2p_ll_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream) {
+    PFA_REQUIRE(buf && count >= 0, "p2p.ll_all_reduce: bad arguments");
+    PFA_REQUIRE(g_p2p.ready, "p2p: not initialised");
+    PFA_REQUIRE((size_t)count <= g_p2p.ll_entries, "p2p.ll_all_reduce: %lld floats exceed the %u entries of a slot", (long long)count, g_p2p.ll_entries);
+    if (count == 0 || g_p2p.world == 1) return 0;
+    const LlArgs d = p2p_ll_next();
+    ScopedKernelTimer timer("p2p_ll_all_reduce", (hipStream_t)stream);
+    hipLaunchKernelGGL(p2p_ll_all_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d, buf, (unsigned)count);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int64_t pfa_p2p_ll_calls(void) { return (int64_t)g_p2p.ll_calls; }
+// Routing switch (bench.py's per-transport A/B, all ranks alike): 0 = pfa_dist_all_reduce_* and the native train loop stop using
+// the peer path (they fall to the RCCL communicator) although it stays open; 1 = use it again.  Returns the previous setting.
+extern "C" int pfa_p2p_enable(int on) {
+    const int was = g_p2p_enabled ? 1 : 0;
+    g_p2p_enabled = on != 0;
+    return was;
 }

@@ -1,0 +1,77 @@
+// p2p_ll.hpp — flag-in-data exchange over peer-mapped memory: the device half of the data-parallel optimizer step that runs INSIDE
+// the kernel that reduces the gradient partials (ppo_update.hip: ppo_reduce_adam_kernel) instead of as a launch of its own
+// (no reference counterpart).
+//
+// Every value travels as ONE 8-byte store {float bits, sequence number}: a reader that sees the sequence number of this call
+// sees the value that was stored with it (an aligned 8-byte store is a single transaction on the fabric), so the protocol needs
+// neither a fence nor any ordering between different stores — nothing about how xGMI orders posted writes from different
+// workgroups is assumed.  Layout in every rank's buffer: [2 phases][R sources][entries] of uint64.  A call with sequence
+// number s uses phase s & 1; rank A can only start call s + 2 (same phase again) after it finished call s + 1, which needed
+// every peer's push of call s + 1, which those peers issued after they had finished reading call s — two phases suffice.
+// A wait is bounded in wall-clock time (100 MHz counter): when it runs out the status word is raised and the value comes back
+// NaN, so a lost peer poisons parameters and losses instead of hanging the GPU or handing back a partial sum.
+#pragma once
+#include "common.hpp"
+
+namespace pfa {
+
+constexpr int kP2pMaxRanks = 8;
+
+struct LlArgs {
+    unsigned long long *base[kP2pMaxRanks];   // every rank's LL area as mapped into THIS process (base[rank] = the local one)
+    int rank, world;
+    unsigned entries;                         // per (phase, source) slot
+    unsigned seq;                             // this call's sequence number (never 0: the area starts zeroed)
+    int *status;                              // host-pinned status word (shared with the flag-based path)
+    long long timeout_ticks;
+};
+
+__device__ __forceinline__ unsigned long long ll_pack(float v, unsigned seq) {
+    return ((unsigned long long)seq << 32) | (unsigned long long)__float_as_uint(v);
+}
+
+// Publish v as entry idx of this rank's slot on every peer.
+__device__ __forceinline__ void ll_push(const LlArgs &d, unsigned idx, float v) {
+    const size_t off = ((size_t)(d.seq & 1u) * d.world + d.rank) * d.entries + idx;
+    const unsigned long long w = ll_pack(v, d.seq);
+    for (int q = 0; q < d.world; ++q)
+        if (q != d.rank) __hip_atomic_store(d.base[q] + off, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Sum of entry idx over all ranks in rank order (this rank's own term from the register).  Identical bits on every rank.
+__device__ __forceinline__ float ll_wait_sum(const LlArgs &d, unsigned idx, float mine) {
+    float s = 0.0f;
+    bool lost = false;
+    for (int r = 0; r < d.world; ++r) {
+        float v = mine;
+        if (r != d.rank) {
+            const unsigned long long *p = d.base[d.rank] + ((size_t)(d.seq & 1u) * d.world + r) * d.entries + idx;
+            unsigned long long w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((unsigned)(w >> 32) != d.seq) {
+                const long long t0 = (long long)wall_clock64();
+                int spin = 0;
+                do {
+                    __builtin_amdgcn_s_sleep(1);
+                    w = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if ((++spin & 255) == 0 && (long long)wall_clock64() - t0 > d.timeout_ticks) {
+                        lost = true;
+                        break;
+                    }
+                } while ((unsigned)(w >> 32) != d.seq);
+            }
+            v = __uint_as_float((unsigned)w);
+        }
+        s = r == 0 ? v : s + v;
+    }
+    if (lost) {
+        __hip_atomic_store(d.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        s = __builtin_nanf("");
+    }
+    return s;
+}
+
+// csrc/p2p.hip
+bool p2p_ll_ready(size_t entries_needed);
+LlArgs p2p_ll_next();   // arguments of the next call: bumps the sequence number
+
+}  // namespace pfa

@@ -18,6 +18,7 @@
 //   dW1^T[k][u] += X[row][k]^T . dh[row][u]      A from the LDS X tile
 //   dW2v^T[u][o] += hidden[row][u]^T . dout[row][o]   A from the LDS hidden tile, B from the LDS dout tile
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 #include <hip/hip_ext.h>
@@ -26,6 +27,7 @@
 #include "mlp_tile.hpp"
 #include "sampler.hpp"
 #include "ppo_tile.hpp"
+#include "p2p_ll.hpp"
 
 #ifndef PFA_GRAD_FCOL
 #define PFA_GRAD_FCOL 1   // 0 = the trailing column through a full MFMA k-step in the forward (A/B timing)
@@ -738,6 +740,175 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *pa
     if (ql == 0) norm_partials[blockIdx.x] = sq;
 }
 
+constexpr int kAdamThreads = 256;   // adam_clip_kernel's workgroup: its norm summation order is the contract of both forms
+
+// ---- Kernels B + C as ONE launch: partial sums -> (data parallel: exchange with the peers) -> clip norm -> Adam ----------------
+// Each workgroup owns 64 entries of the fragment-order ("native") gradient layout from the sum of the partials to the parameter
+// update; the global clip norm needs every workgroup's sum of squares, so the launch carries one grid-wide barrier (all of its
+// <= 300 workgroups are co-resident on 256 CUs; waves that only helped summing the partials have exited by then, a waiting
+// workgroup is one wavefront).  What this saves over ppo_reduce_kernel + adam_clip_kernel: a launch (its ramp and the gap in
+// front of it, ~16 times per update), the round trip of the flat gradient through L2, and — data parallel — the all-reduce as a
+// launch of its own: the exchange is 8-byte {value, sequence} stores into the peers' memory and a spin on the local copy
+// (p2p_ll.hpp), placed between the partial sum and the norm.  Arithmetic and summation order are those of the two-kernel form
+// (single rank: bit-identical results; R ranks: every entry is the rank-order sum of the ranks' entries, identical on all of them).
+struct GridBarrier {        // sense-reversing: `count` returns to 0 after every use, `gen` only ever grows
+    unsigned count, gen;
+};
+struct AdamArgs {
+    float *params, *exp_avg, *exp_avg_sq;
+    float neg_step_size, bc2_sqrt, beta1, beta2, eps, max_grad_norm;
+    double *losses;
+    double loss_scale;
+};
+template <int DP, int KTM, bool COL, bool PERM, bool DIST>
+__global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
+                                                                     double *norm_partials, GridBarrier *bar, AdamArgs ad, LlArgs ll) {
+    using NL = NativeLayout<DP, KTM, COL>;
+    __shared__ float sh[kRedSl][64];
+    __shared__ double shd[kRedSl][64];   // the loss-sum slots are carried in f64
+    const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + ql;
+    float acc = 0.0f;
+    double dacc = 0.0;
+    if (q < NL::kCount) {
+        for (int i0 = sl; i0 < nparts; i0 += 16 * kRedSl) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int i = i0 + kRedSl * u;
+                v[u] = i < nparts ? partials[(size_t)i * NL::kCount + q] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                acc += v[u];
+                if (q >= NL::kStats) dacc += (double)v[u];
+            }
+        }
+    }
+    sh[sl][ql] = acc;
+    shd[sl][ql] = dacc;
+    // the barrier generation this launch starts from: read before anyone (this workgroup included) can have arrived
+    unsigned gen0 = 0;
+    if (threadIdx.x == 0) gen0 = __hip_atomic_load(&bar->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const MlpOffsets off = mlp_offsets(DP, a);
+    if (sl == 1) {   // observation-padding columns of W1 no partial slot covers: gradient zero by definition (see ppo_reduce_kernel)
+        constexpr int kFirst = 16 * KTM + (COL ? 1 : 0), kPad = DP - kFirst, kDiv = kPad > 0 ? kPad : 1;
+        const int e = blockIdx.x * 64 + ql;
+        if (kPad > 0 && e < kHidden * kPad) grads[off.w1 + (e / kDiv) * DP + kFirst + e % kDiv] = 0.0f;
+    }
+    if (sl != 0) return;
+    float s = 0.0f, hi = 0.0f, lo = 0.0f;
+    int p = -1;
+    const bool stat = q >= NL::kStats && q < NL::kCount;
+    if (q < NL::kCount) {
+        float t[kRedSl];
+#pragma unroll
+        for (int w = 0; w < kRedSl; ++w) t[w] = sh[w][ql];
+#pragma unroll
+        for (int w = kRedSl / 2; w > 0; w >>= 1)
+#pragma unroll
+            for (int x = 0; x < w; ++x) t[x] += t[x + w];
+        s = t[0];
+        if (COL && q >= NL::kCol && q < NL::kDw2) {
+            p = off.w1 + (q - NL::kCol) * DP + 16 * KTM;
+            if (16 * KTM >= obs_dim) s = 0.0f;
+        } else if (q < NL::kCol) {
+            const int ln = q & 63, r = (q >> 6) & 3, m = (q >> 8) & (kMT - 1), kt = q >> 11;
+            p = off.w1 + (16 * m + (ln & 15)) * DP + 16 * kt + 4 * (ln >> 4) + r;
+            if (16 * kt + 4 * (ln >> 4) + r >= obs_dim) s = 0.0f;
+        } else if (q < NL::kDb1) {
+            const int t2 = q - NL::kDw2, ln = t2 & 63, r = (t2 >> 6) & 3, m = t2 >> 8;
+            const int o = slot_output(PERM, ln & 15), u = 16 * m + 4 * (ln >> 4) + r;
+            if (o < a) p = off.w2 + o * kHidden + u;
+            else if (o == a) p = off.wv + u;
+        } else if (q < NL::kDb2) {
+            p = off.b1 + (q - NL::kDb1);
+        } else if (q < NL::kStats) {
+            const int o = slot_output(PERM, q - NL::kDb2);
+            if (o < a) p = off.b2 + o;
+            else if (o == a) p = off.bv;
+        } else {
+            double t2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < kRedSl; ++w) t2 += shd[w][ql];
+            hi = (float)t2;                       // the (hi, lo) float pair of the f64 sum, as the two-kernel form leaves it
+            lo = (float)(t2 - (double)hi);
+        }
+    }
+    // this entry's parameter and moments: in flight across the exchange and the barrier
+    float p_i = 0.0f, m_i = 0.0f, v_i = 0.0f;
+    if (p >= 0) {
+        p_i = ad.params[p];
+        m_i = ad.exp_avg[p];
+        v_i = ad.exp_avg_sq[p];
+    }
+    if constexpr (DIST) {   // one hop: my entry into every peer's memory, theirs out of mine, summed in rank order
+        if (p >= 0) ll_push(ll, (unsigned)q, s);
+        if (stat) {
+            ll_push(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats)), hi);
+            ll_push(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats) + 1), lo);
+        }
+        if (p >= 0) s = ll_wait_sum(ll, (unsigned)q, s);
+        if (stat) {
+            hi = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats)), hi);
+            lo = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats) + 1), lo);
+        }
+    }
+    if (p >= 0) grads[p] = s;
+    if (stat) {
+        grads[off.count + 2 * (q - NL::kStats)] = hi;
+        grads[off.count + 2 * (q - NL::kStats) + 1] = lo;
+    }
+    double sq = (p >= 0 && p < off.count) ? (double)s * (double)s : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    // ---- grid barrier: publish this workgroup's piece of sum(g^2), wait for everyone's ----
+    if (ql == 0) {
+        __hip_atomic_store(norm_partials + blockIdx.x, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned arrived = __hip_atomic_fetch_add(&bar->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(&bar->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(&bar->gen, gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            while (__hip_atomic_load(&bar->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the norm in adam_clip_kernel's order: 256 strided partial sums, a butterfly per 64, then the four in order
+    const int npart = (int)gridDim.x;
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < kAdamThreads / 64; ++w) {
+        double ss = 0.0;
+        for (int i = 64 * w + ql; i < npart; i += kAdamThreads)
+            ss += __hip_atomic_load(norm_partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        tot += ss;
+    }
+    const float total_norm = (float)sqrt(tot);
+    float clip = 1.0f;
+    if (ad.max_grad_norm > 0.0f) {
+        clip = ad.max_grad_norm / (total_norm + 1e-6f);
+        clip = clip > 1.0f ? 1.0f : clip;
+    }
+    if (p >= 0) {
+        const float w1 = 1.0f - ad.beta1, w2 = 1.0f - ad.beta2;
+        const float gi = s * 1.0f * clip;
+        m_i = m_i + w1 * (gi - m_i);
+        v_i = v_i * ad.beta2 + w2 * gi * gi;
+        const float denom = sqrtf(v_i) / ad.bc2_sqrt + ad.eps;
+        ad.params[p] = p_i + ad.neg_step_size * m_i / denom;
+        ad.exp_avg[p] = m_i;
+        ad.exp_avg_sq[p] = v_i;
+    }
+    if (stat && ad.losses && q - NL::kStats < 6) ad.losses[q - NL::kStats] += ((double)hi + (double)lo) * ad.loss_scale;
+}
+
 // Per-minibatch advantage sums (f64).  grid = (chunks, nmb); deterministic two-stage reduction.
 constexpr int kAdvChunks = 64;
 __global__ void __launch_bounds__(256) adv_stats_partial_kernel(const float *adv, RowMap base, long long mb_rows,
@@ -821,7 +992,6 @@ __global__ void ev_final_kernel(const double *partial, const double *losses, dou
 // clip_grad_norm_ + torch.optim.Adam (single-tensor path) on the flat parameter vector.
 // Every workgroup recomputes the global gradient norm from the (L2-resident, ~38 KB) gradient in the same fixed
 // order — deterministic and no grid-wide hand-off — then updates its own 256-element slice.
-constexpr int kAdamThreads = 256;
 __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, const float *grads, float *exp_avg,
                                                                 float *exp_avg_sq, long long count, float neg_step_size,
                                                                 float bc2_sqrt, float beta1, float beta2, float eps,
@@ -953,9 +1123,11 @@ extern "C" int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, 
     return 0;
 }
 
-extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
-                                const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
-                                int64_t global_mb_rows, float *grads, void *workspace, pfa_stream_t stream) {
+// Kernel A of one optimizer step: validates the arguments and launches the fused forward + loss + backward over minibatch `mb`;
+// leaves *grid_out workgroup partials in the workspace.
+static int launch_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
+                       const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
+                       int64_t global_mb_rows, float *grads, void *workspace, pfa_stream_t stream, int *grid_out) {
     if (int rc = check_update_args(exp, batch_rows, dims, hp)) return rc;
     PFA_REQUIRE(dims && dims->hidden == kHidden, "ppo.grad: hidden must be %d", kHidden);
     PFA_REQUIRE(dims->obs_stride == 16 || dims->obs_stride == 32 || dims->obs_stride == 64 || dims->obs_stride == 96 ||
@@ -1026,6 +1198,16 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
 #undef PFA_LAUNCH_GRAD
 #undef PFA_LAUNCH_GRAD_K
     PFA_LAUNCH_CHECK();
+    *grid_out = grid;
+    return 0;
+}
+
+extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const float *params,
+                                const pfa_mlp_dims *dims, const pfa_ppo_hparams *hp, const double *adv_stats,
+                                int64_t global_mb_rows, float *grads, void *workspace, pfa_stream_t stream) {
+    int grid = 0;
+    if (int rc = launch_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, global_mb_rows, grads, workspace, stream, &grid)) return rc;
+    float *partials = (float *)workspace;
     double *normp = norm_partials_of(workspace, dims);
     ScopedKernelTimer timer2("ppo_reduce", (hipStream_t)stream);
 #define PFA_LAUNCH_REDUCE(DPV, KTMV, COLV) PFA_LAUNCH_REDUCE_P(DPV, KTMV, COLV, false)
@@ -1081,6 +1263,50 @@ extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_
     return 0;
 }
 
+// Kernels B + C in one launch (ppo_reduce_adam_kernel); `ll` non-null: with the data-parallel exchange inside.
+static GridBarrier *grid_barrier_of(void *workspace, const pfa_mlp_dims *dims, int nmb) {   // the 256 spare bytes behind the tail
+    return (GridBarrier *)((char *)workspace + partials_bytes(dims) + tail_bytes(dims, nmb));
+}
+static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
+                              float lr, float beta1, float beta2, float eps, int64_t step, float max_grad_norm, double *losses,
+                              double loss_scale, void *workspace, const LlArgs *ll, hipStream_t stream) {
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    AdamArgs ad{params, exp_avg, exp_avg_sq, (float)(-(double)lr / bc1), (float)std::sqrt(bc2), beta1, beta2, eps, max_grad_norm, losses, loss_scale};
+    const float *partials = (const float *)workspace;
+    double *normp = norm_partials_of(workspace, dims);
+    GridBarrier *bar = grid_barrier_of(workspace, dims, nmb);
+    const LlArgs none{};
+    ScopedKernelTimer timer("ppo_reduce_adam", stream);
+#define PFA_LAUNCH_RA(DPV, KTMV, COLV, PERMV)                                                                                        \
+    {                                                                                                                               \
+        const dim3 g((NativeLayout<DPV, KTMV, COLV>::kCount + 63) / 64), b(64 * kRedSl);                                            \
+        if (ll) hipLaunchKernelGGL((ppo_reduce_adam_kernel<DPV, KTMV, COLV, PERMV, true>), g, b, 0, stream, partials, grid,          \
+                                   dims->num_actions, dims->obs_dim, grads, normp, bar, ad, *ll);                                   \
+        else hipLaunchKernelGGL((ppo_reduce_adam_kernel<DPV, KTMV, COLV, PERMV, false>), g, b, 0, stream, partials, grid,            \
+                                dims->num_actions, dims->obs_dim, grads, normp, bar, ad, none);                                     \
+    }
+    switch (dims->obs_stride) {   // the instantiation choice of the gradient launch: the partial layout belongs to it
+        case 16: PFA_LAUNCH_RA(16, 1, false, false) break;
+        case 32: PFA_LAUNCH_RA(32, 2, false, false) break;
+        case 96: PFA_LAUNCH_RA(96, 6, false, false) break;
+        case 128: PFA_LAUNCH_RA(128, 8, false, false) break;
+        default:
+            if (grad_trimmed(dims) && grad_perm(dims)) PFA_LAUNCH_RA(64, 3, true, true)
+            else if (grad_trimmed(dims)) PFA_LAUNCH_RA(64, 3, true, false)
+            else PFA_LAUNCH_RA(64, 4, false, false)
+            break;
+    }
+#undef PFA_LAUNCH_RA
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+static size_t ll_entries_needed(const pfa_mlp_dims *dims) { return native_count(dims->obs_stride) + kTailFloats; }
+static bool env_on(const char *name, bool dflt) {
+    const char *e = std::getenv(name);
+    return e ? e[0] != '0' : dflt;
+}
+
 extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                                  const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                                  float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
@@ -1094,8 +1320,27 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
     const int64_t global_mbs = mbs * world;
     const int64_t count = mlp_offsets(dims->obs_stride, dims->num_actions).count;
     const double loss_scale = 1.0 / ((double)global_mbs * hp->num_minibatches);
+    // PFA_FUSED_ADAM=0: the two-kernel form (sum of the partials, then clip + Adam) for A/B timing; data parallel, the exchange
+    // rides inside the fused launch when the peer path's flag-in-data area is open (PFA_FUSED_DP=0: all-reduce as its own step)
+    const bool fused = env_on("PFA_FUSED_ADAM", true);
+    const bool fused_dp = fused && data_parallel && world > 1 && env_on("PFA_FUSED_DP", true) && p2p_ll_ready(ll_entries_needed(dims));
+    const bool one_launch = fused && (!data_parallel || fused_dp);   // (a 1-rank communicator keeps exercising the all-reduce call)
+    if (one_launch)
+        PFA_CHECK_HIP(hipMemsetAsync(grid_barrier_of(workspace, dims, hp->num_minibatches), 0, sizeof(GridBarrier), (hipStream_t)stream));
     for (int e = 0; e < update_epochs; ++e)
         for (int mb = 0; mb < hp->num_minibatches; ++mb) {
+            if (one_launch) {
+                int grid = 0;
+                if (int rc = launch_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, global_mbs, grads, workspace, stream, &grid)) return rc;
+                ++opt_step;
+                LlArgs ll{};
+                if (fused_dp) ll = p2p_ll_next();
+                if (int rc = launch_reduce_adam(dims, hp->num_minibatches, grid, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
+                                                opt_step, max_grad_norm, losses, loss_scale, workspace, fused_dp ? &ll : nullptr,
+                                                (hipStream_t)stream))
+                    return rc;
+                continue;
+            }
             if (int rc = pfa_ppo_mlp_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, global_mbs, grads, workspace, stream))
                 return rc;
             ++opt_step;
@@ -1157,6 +1402,42 @@ extern "C" int pfa_train_log_sums(const pfa_experience *exp, int64_t batch_rows,
                        (long long)batch_rows, (int)num_envs, (int)(batch_rows / num_envs), partial);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(ev_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, losses, out10);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// The two halves of pfa_train_log_sums for the data-parallel update, where the four explained-variance sums are known as soon as
+// GAE has run and ride the all-reduce of the advantage sums instead of one of their own at the end:
+//   pfa_train_ev_sums    out4 = sum y_true, sum y_true^2, sum adv, sum adv^2 of this rank's batch
+//   pfa_train_log_pack   out10 = { losses[0..5], ev4[0..3] }  (ev4 = the all-reduced sums)
+__global__ void ev_final4_kernel(const double *partial, double *out4) {
+    const int q = threadIdx.x;
+    if (q < 4) {
+        double s = 0.0;
+        for (int b = 0; b < kEvBlocks; ++b) s += partial[b * 4 + q];
+        out4[q] = s;
+    }
+}
+__global__ void log_pack_kernel(const double *losses, const double *ev4, double *out10) {
+    const int q = threadIdx.x;
+    if (q < 6) out10[q] = losses ? losses[q] : 0.0;
+    else if (q < 10) out10[q] = ev4[q - 6];
+}
+extern "C" int pfa_train_ev_sums(const pfa_experience *exp, int64_t batch_rows, int32_t num_envs, double *out4, void *workspace,
+                                 pfa_stream_t stream) {
+    PFA_REQUIRE(exp && exp->advantages && exp->values && out4 && workspace, "train_ev_sums: null buffer");
+    PFA_REQUIRE(num_envs >= 1 && batch_rows % num_envs == 0, "train_ev_sums: batch must be whole rollout steps");
+    double *partial = (double *)workspace;
+    hipLaunchKernelGGL(ev_partial_kernel, dim3(kEvBlocks), dim3(256), 0, (hipStream_t)stream, exp->advantages, exp->values,
+                       (long long)batch_rows, (int)num_envs, (int)(batch_rows / num_envs), partial);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ev_final4_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, partial, out4);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pfa_train_log_pack(const double *losses, const double *ev4, double *out10, pfa_stream_t stream) {
+    PFA_REQUIRE(ev4 && out10, "train_log_pack: null buffer");
+    hipLaunchKernelGGL(log_pack_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, losses, ev4, out10);
     PFA_LAUNCH_CHECK();
     return 0;
 }

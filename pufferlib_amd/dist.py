@@ -91,6 +91,41 @@ def gae_fold_later(maps, rank):
     return x.reshape(1) if hasattr(x, 'reshape') else x
 
 
+def gae_publish_numbers(dones, values, rewards, gamma, lam):
+    """Host mirror (numpy f64) of what a rank publishes for the one-exchange data-parallel GAE (csrc/gae.hip
+    gae_shard_publish_kernel): the affine map (C, D) of its elements 0 .. n-2 — every one of them reads its successor inside the
+    shard — then values[n-1] and the shard's first row (done, value, reward).  Used by the CPU protocol test; the product runs the
+    device kernels."""
+    n = len(values)
+    C, D = 1.0, 0.0
+    for t in range(n - 2, -1, -1):
+        nnt = 1.0 - dones[t + 1]
+        coef, delta = gamma * lam * nnt, rewards[t + 1] + gamma * values[t + 1] * nnt - values[t]
+        C, D = coef * C, delta + coef * D          # compose(f_t, acc): f_t is applied last
+    return [C, D, float(values[n - 1]), float(dones[0]), float(values[0]), float(rewards[0])]
+
+
+def gae_fold_published(pub, rank, gamma, lam):
+    """Host mirror of gae_shard_fold_kernel: from the gathered [world][6] numbers, (carry-in of `rank`'s shard = the advantage of
+    the first element after it, the (coef, delta) of this shard's last element).  The last element of the last shard is pinned
+    to advantage 0 (the map x -> 0)."""
+    world = len(pub)
+
+    def last_map(q):
+        if q == world - 1:
+            return 0.0, 0.0
+        d1, v1, r1 = pub[q + 1][3], pub[q + 1][4], pub[q + 1][5]
+        nnt = 1.0 - d1
+        return gamma * lam * nnt, r1 + gamma * v1 * nnt - pub[q][2]
+
+    x = 0.0
+    for q in range(world - 1, rank, -1):
+        lc, ld = last_map(q)
+        c, d = pub[q][0] * lc, pub[q][0] * ld + pub[q][1]     # interior o last
+        x = c * x + d
+    return x, last_map(rank)
+
+
 _native = dict(ready=False, world=1, rccl=False, p2p=False, p2p_selftest=None)
 
 
@@ -142,6 +177,17 @@ def init_p2p(bucket_bytes):
         want = x.clone()
         d.all_reduce(want)
         if fn(x.data_ptr(), n, _lib.stream_handle()) != 0:
+            good = 0
+        torch.cuda.synchronize()
+        if good and (L.pfa_p2p_status() != 0 or not torch.equal(x, want)):
+            good = 0
+    # ... and the flag-in-data form (csrc/p2p_ll.hpp) the fused optimizer step uses, twice per phase
+    for j in range(4):
+        n = min(int(bucket_bytes) // 4 + 2304, 1 << 16)
+        x = (((torch.arange(n, device='cuda') + 7 * j) % 127) * (rank + 1)).float()
+        want = x.clone()
+        d.all_reduce(want)
+        if L.pfa_p2p_ll_all_reduce_f32(x.data_ptr(), n, _lib.stream_handle()) != 0:
             good = 0
         torch.cuda.synchronize()
         if good and (L.pfa_p2p_status() != 0 or not torch.equal(x, want)):
@@ -214,7 +260,7 @@ def transport_info():
     _lib.check(_lib.lib().pfa_dist_info(out), 'dist_info')
     return dict(native=bool(_native['ready']), rccl=bool(out[0]), rccl_nranks=int(out[1]), p2p=bool(out[2]), p2p_world=int(out[3]),
                 p2p_slot_bytes=int(out[4]), p2p_calls=int(out[5]), rccl_calls=int(out[6]), p2p_status=int(out[7]),
-                p2p_selftest=_native.get('p2p_selftest'))
+                p2p_selftest=_native.get('p2p_selftest'), p2p_ll_calls=int(_lib.lib().pfa_p2p_ll_calls()))
 
 
 def raise_if_peer_lost():

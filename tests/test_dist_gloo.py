@@ -203,3 +203,56 @@ def test_sharded_gae_protocol_equals_flat_scan(tmp_path):
     want = c_oracle.compute_gae(dn, v, r, 0.99, 0.95)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
     assert got[-1] == 0.0
+
+
+def _gae_one_exchange_worker(rank, world, port, out_dir):
+    """The one-exchange form clean_pufferl runs since round 4 (_publish_gae / _finish_gae over csrc/gae.hip's publish and fold
+    kernels; here their host mirrors in pufferlib_amd.dist): every rank publishes six numbers computed from its OWN rows —
+    interior map, last value, first row — next to other f64 sums (the episode statistics), ONE all-reduce(SUM) of the zero-padded
+    [extra | world x 6] buffer, fold, local scan."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, REPO)
+    from pufferlib_amd import dist as pdist
+    d, _, _ = pdist.init_from_env('gloo')
+    rng = np.random.RandomState(5)
+    n, gamma, lam = 600, 0.99, 0.95
+    dn = (rng.rand(n) < 0.1).astype(np.float64)
+    v, r = rng.randn(n), rng.randn(n)
+    m = n // world
+    lo = rank * m
+    extra = np.array([1.0 + rank, 10.0 * (rank + 1)])                 # e.g. episode-return sum and episode count
+    buf = torch.zeros(2 + 6 * world, dtype=torch.float64)
+    buf[:2] = torch.from_numpy(extra)
+    buf[2 + 6 * rank:2 + 6 * rank + 6] = torch.tensor(pdist.gae_publish_numbers(dn[lo:lo + m], v[lo:lo + m], r[lo:lo + m], gamma, lam),
+                                                      dtype=torch.float64)
+    d.all_reduce(buf)                                                 # the ONE exchange
+    pub = buf[2:].view(world, 6).numpy()
+    x, (lc, ld) = pdist.gae_fold_published(pub, rank, gamma, lam)
+    adv = np.zeros(m)
+    adv[m - 1] = lc * x + ld                                          # the shard's last element: pinned to 0 on the last shard
+    for t in range(m - 2, -1, -1):
+        nnt = 1.0 - dn[lo + t + 1]
+        adv[t] = r[lo + t + 1] + gamma * v[lo + t + 1] * nnt - v[lo + t] + gamma * lam * nnt * adv[t + 1]
+    np.save(os.path.join(out_dir, f'adv{rank}.npy'), adv)
+    np.save(os.path.join(out_dir, f'extra{rank}.npy'), buf[:2].numpy())
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_one_exchange_sharded_gae_equals_flat_scan(tmp_path):
+    world = 3
+    mp.spawn(_gae_one_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f'adv{q}.npy') for q in range(world)])
+    rng = np.random.RandomState(5)
+    n = 600
+    dn = (rng.rand(n) < 0.1).astype(np.float64)
+    v, r = rng.randn(n), rng.randn(n)
+    want, x = np.zeros(n), 0.0
+    for t in range(n - 2, -1, -1):                                    # c_gae.pyx:11-32 in f64 over the whole flat batch
+        nnt = 1.0 - dn[t + 1]
+        x = r[t + 1] + 0.99 * v[t + 1] * nnt - v[t] + 0.99 * 0.95 * nnt * x
+        want[t] = x
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
+    assert got[-1] == 0.0
+    for q in range(world):                                            # the sums that rode along are the global sums on every rank
+        assert np.array_equal(np.load(tmp_path / f'extra{q}.npy'), np.array([6.0, 60.0]))

@@ -76,6 +76,8 @@ TRANSPORTS = {
     # the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every collective of the update: IPC-mapped slots work between two
     # processes on one device exactly as between two devices
     'p2p': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p'),
+    # ... with the MLP policy's optimizer-step exchange as an all-reduce launch of its own instead of inside the reduce + Adam launch
+    'p2p-unfused': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p', PFA_FUSED_DP='0'),
     # the native RCCL communicator: two ranks on ONE device are refused by RCCL ("duplicate GPU"); the refusal must be clean
     # on both ranks (no hang, torch's own RCCL instance unharmed) and the run must continue on the fallback path
     'rccl-refused': dict(PFA_NATIVE_RCCL='1', PFA_ALLREDUCE='rccl'),
@@ -93,6 +95,8 @@ def _worker(rank, world, port, recurrent, out_dir, transport='torch'):
     res = _loop(_sizes(recurrent)[0], world, recurrent)
     from pufferlib_amd import dist as pdist
     res['native'] = np.array([int(pdist.native_ready()), int(pdist._native.get('p2p', False)), int(pdist._native.get('rccl', False))])
+    from pufferlib_amd import _lib
+    res['ll_calls'] = np.array([int(_lib.lib().pfa_p2p_ll_calls())])
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), **res)
     dist.barrier()
     pdist.finalize_native()
@@ -111,31 +115,57 @@ def _spawn(fn, args, world, timeout_s=240):
             raise AssertionError(f'ranks still running after {timeout_s} s')
 
 
+def _check_against_single_process(tmp_path, world, recurrent):
+    N_PER_RANK, HORIZON, _ = _sizes(recurrent)
+    r = [np.load(tmp_path / f'rank{q}.npz') for q in range(world)]
+    names = ('obs', 'actions', 'logprobs', 'values', 'rewards', 'dones')
+    inject = [{n: np.concatenate([r[q][f'{it}.{n}'] for q in range(world)]) for n in names} for it in range(ITERS)]
+    single = _loop(N_PER_RANK * world, 1, recurrent, inject=inject)
+    rows = N_PER_RANK * HORIZON
+    for it in range(ITERS):
+        for q in range(world):      # one flat GAE scan across the shard boundaries
+            np.testing.assert_allclose(r[q][f'{it}.advantages'], single[f'{it}.advantages'][q * rows:(q + 1) * rows],
+                                       rtol=1e-5, atol=2e-6)
+            assert np.array_equal(r[0][f'{it}.flat'], r[q][f'{it}.flat'])              # replicas stay bit-identical
+            assert np.array_equal(r[0][f'{it}.stats'], r[q][f'{it}.stats'], equal_nan=True)   # all-reduced episode stats
+            assert np.array_equal(r[0][f'{it}.losses'], r[q][f'{it}.losses'])
+        np.testing.assert_allclose(r[0][f'{it}.flat'], single[f'{it}.flat'], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(r[0][f'{it}.losses'], single[f'{it}.losses'], rtol=1e-5, atol=1e-5)
+        assert r[0][f'{it}.global_step'][0] == single[f'{it}.global_step'][0] == (it + 1) * world * rows
+    return r
+
+
+def test_eight_ranks_full_update_equals_single_process_run(tmp_path):
+    """BASELINE configs[4]'s rank count before it meets eight GPUs: eight processes share the one GPU, each owning 32 envs; every
+    optimizer step's exchange runs INSIDE the reduce + Adam launch (flag-in-data over the IPC-mapped peer buffers), the episode
+    statistics and the sharded GAE's numbers ride one all-reduce, the advantage and explained-variance sums another.  After every
+    evaluate -> train all eight ranks hold identical bits, equal (fp32 summation order) to ONE process training on the rank-major
+    concatenation of the eight shard rollouts, with advantages equal to the single flat scan."""
+    world = 8
+    _spawn(_worker, (world, _free_port(), False, str(tmp_path), 'p2p'), world, timeout_s=420)
+    r = _check_against_single_process(tmp_path, world, False)
+    for q in range(world):
+        assert tuple(int(x) for x in r[q]['native']) == (1, 1, 0)
+        assert int(r[q]['ll_calls'][0]) == 4 + ITERS * 2 * 2          # self-test + iterations x epochs x minibatches, nothing else
+    assert not np.array_equal(r[0]['0.obs'], r[7]['0.obs'])
+
+
 @pytest.mark.parametrize('recurrent,transport', [(False, 'torch'), (True, 'torch'), (False, 'p2p'), (True, 'p2p'), (False, 'rccl-refused'),
-                                                 (CONV, 'torch'), (CONV, 'p2p'), (WIDE, 'torch'), (WIDE, 'p2p')])
+                                                 (CONV, 'torch'), (CONV, 'p2p'), (WIDE, 'torch'), (WIDE, 'p2p'), (False, 'p2p-unfused')])
 def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent, transport):
     world = 2
     N_PER_RANK, HORIZON, _ = _sizes(recurrent)
     _spawn(_worker, (world, _free_port(), recurrent, str(tmp_path), transport), world)
     r = [np.load(tmp_path / f'rank{q}.npz') for q in range(world)]
     native = [tuple(int(x) for x in r[q]['native']) for q in range(world)]
-    want_native = {'torch': (0, 0, 0), 'p2p': (1, 1, 0), 'rccl-refused': (0, 0, 0)}[transport]
+    want_native = {'torch': (0, 0, 0), 'p2p': (1, 1, 0), 'p2p-unfused': (1, 1, 0), 'rccl-refused': (0, 0, 0)}[transport]
     if recurrent == CONV and transport == 'p2p':
         want_native = (0, 0, 0)          # the 6.7 MB bucket is over the peer path's 1 MiB cap: the run stays on torch.distributed
     assert native[0] == native[1] == want_native, native
-    names = ('obs', 'actions', 'logprobs', 'values', 'rewards', 'dones')
-    inject = [{n: np.concatenate([r[q][f'{it}.{n}'] for q in range(world)]) for n in names} for it in range(ITERS)]
-    single = _loop(N_PER_RANK * world, 1, recurrent, inject=inject)
-    rows = N_PER_RANK * HORIZON
-    for it in range(ITERS):
-        for q in range(world):      # one flat GAE scan across the shard boundary
-            np.testing.assert_allclose(r[q][f'{it}.advantages'], single[f'{it}.advantages'][q * rows:(q + 1) * rows],
-                                       rtol=1e-5, atol=2e-6)
-        assert np.array_equal(r[0][f'{it}.flat'], r[1][f'{it}.flat'])                  # replicas stay bit-identical
-        np.testing.assert_allclose(r[0][f'{it}.flat'], single[f'{it}.flat'], rtol=2e-5, atol=2e-6)
-        np.testing.assert_allclose(r[0][f'{it}.losses'], single[f'{it}.losses'], rtol=1e-5, atol=1e-5)
-        assert np.array_equal(r[0][f'{it}.stats'], r[1][f'{it}.stats'])                # all-reduced episode stats
-        assert r[0][f'{it}.global_step'][0] == single[f'{it}.global_step'][0] == (it + 1) * world * rows
+    # the fused MLP update exchanges inside its reduce + Adam launch: one flag-in-data exchange per optimizer step (+ 4 in the self-test)
+    steps = ITERS * 2 * 2 if (transport == 'p2p' and recurrent is False) else 0
+    assert int(r[0]['ll_calls'][0]) == int(r[1]['ll_calls'][0]) == (4 + steps if want_native[1] else 0)
+    _check_against_single_process(tmp_path, world, recurrent)
     # the shards really are different envs (seeds seed + r*N + i), not replicas of each other
     assert not np.array_equal(r[0]['0.obs'], r[1]['0.obs'])
 
@@ -167,6 +197,10 @@ def _p2p_worker(rank, world, port, out_dir, sizes=(1, 7, 9497, 9497, 153752, 262
             for q in range(1, world):
                 want = want + ref[q]
             ok = ok and bool(torch.equal(x, want))
+            if dtype == torch.float32 and n <= (1 << 18) + 2304:       # the flag-in-data form of the same exchange (csrc/p2p_ll.hpp)
+                y = mine.clone()
+                _lib.check(L.pfa_p2p_ll_all_reduce_f32(_lib.ptr(y), n, _lib.stream_handle()), 'p2p ll all-reduce')
+                ok = ok and bool(torch.equal(y, want))
     assert L.pfa_p2p_status() == 0
     info = pdist.transport_info()
     assert info['p2p'] and info['p2p_world'] == world and info['p2p_calls'] > 0 and info['p2p_selftest'] is True, info
@@ -211,7 +245,8 @@ def _p2p_skew_worker(rank, world, port, out_dir, calls=300):
         if rs.rand() < 0.3:
             torch.cuda._sleep(int(rs.randint(1, 400)) * 10000)      # up to ~2 ms of GPU-side delay in front of this rank's push
         x = (((idx + 31 * j) % 97) * (rank + 1)).float()
-        _lib.check(L.pfa_p2p_all_reduce_f32(_lib.ptr(x), n, _lib.stream_handle()), 'p2p all-reduce')
+        fn = L.pfa_p2p_ll_all_reduce_f32 if j % 3 == 2 else L.pfa_p2p_all_reduce_f32       # both forms, interleaved
+        _lib.check(fn(_lib.ptr(x), n, _lib.stream_handle()), 'p2p all-reduce')
         outs.append(x)                                  # no host synchronisation between calls: ranks run ahead of each other
     torch.cuda.synchronize()
     ok = L.pfa_p2p_status() == 0

@@ -107,3 +107,50 @@ def test_sharded_two_pass_equals_flat_scan(n, shards, p_done):
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
     assert np.abs(got - want).max() <= 8 * np.finfo(np.float32).eps * max(1.0, np.abs(want).max())
     assert got[-1] == 0.0
+
+
+@pytest.mark.parametrize('n,shards,p_done', [(524288, 8, 0.01), (12288, 3, 0.2), (4100, 2, 0.0), (4098, 2, 0.05), (7, 7, 0.3), (16, 8, 0.5)])
+def test_sharded_one_exchange_form_equals_flat_scan(n, shards, p_done):
+    """The form clean_pufferl runs data parallel since round 4: every shard publishes six numbers from its OWN rows
+    (pfa_gae_shard_publish, next to extra sums that ride along), the host sums the zero-padded buffers (the all-reduce), every
+    shard folds the gathered numbers (pfa_gae_shard_fold: later shards' maps completed with their last elements, halo row, patched
+    last block aggregate) and finishes with pfa_gae_shard_pass2.  4098 = a shard of 2049 rows: its last element sits alone in a
+    block of the n-element pass; 7 / 7 and 16 / 8: shards of one and two rows."""
+    import torch
+    from oracle import c_oracle
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(n % 977 + shards)
+    d = (rng.rand(n) < p_done).astype(np.float32)
+    v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    want = c_oracle.compute_gae(d, v, r, 0.99, 0.95)
+    m = n // shards
+    st = _lib.stream_handle()
+    bufs, total = [], torch.zeros(3 + 6 * shards, dtype=torch.float64, device='cuda')
+    for q in range(shards):
+        t = [torch.cat([torch.as_tensor(x[q * m:(q + 1) * m].copy()), torch.full((1,), float('nan'))]).cuda() for x in (d, v, r)]   # + the halo slot
+        ws = torch.zeros(max(16, L.pfa_gae_workspace_bytes(m)), dtype=torch.uint8, device='cuda')
+        extra = torch.tensor([1.0, 2.0 * q, -0.5], dtype=torch.float64, device='cuda')
+        out = torch.full((3 + 6 * shards,), float('nan'), dtype=torch.float64, device='cuda')
+        _lib.check(L.pfa_gae_shard_publish(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), m, 0.99, 0.95, _lib.ptr(ws), _lib.ptr(extra), 3,
+                                           _lib.ptr(out), q, shards, st), 'publish')
+        assert int((out[3:] != 0).sum()) <= 6 and bool(torch.isfinite(out).all())      # zero outside this rank's six numbers
+        total += out
+        bufs.append((t, ws))
+    assert total[:3].tolist() == [float(shards), float(shards * (shards - 1)), -0.5 * shards]
+    got = np.empty(n, np.float32)
+    for q, (t, ws) in enumerate(bufs):
+        has_next = int(q < shards - 1)
+        carry = torch.full((1,), float('nan'), dtype=torch.float64, device='cuda')
+        _lib.check(L.pfa_gae_shard_fold(_lib.ptr(total[3:]), q, shards, m, 0.99, 0.95, _lib.ptr(ws), _lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]),
+                                        _lib.ptr(carry), st), 'fold')
+        adv = torch.full((m,), float('nan'), device='cuda')
+        ret = torch.full((m,), float('nan'), device='cuda')
+        _lib.check(L.pfa_gae_shard_pass2(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.ptr(adv), _lib.ptr(ret), m,
+                                         has_next, 0.99, 0.95, _lib.ptr(ws), _lib.ptr(carry) if has_next else None, st), 'pass2')
+        got[q * m:(q + 1) * m] = adv.cpu().numpy()
+        if has_next:       # the fold left the next shard's first row behind this shard's arrays
+            assert [float(x[m]) for x in t] == [float(d[(q + 1) * m]), float(v[(q + 1) * m]), float(r[(q + 1) * m])]
+    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
+    assert np.abs(got - want).max() <= 8 * np.finfo(np.float32).eps * max(1.0, np.abs(want).max())
+    assert got[-1] == 0.0

@@ -247,6 +247,31 @@ def test_native_data_parallel_path_single_rank_equals_plain():
         np.testing.assert_allclose(l1[k], l0[k], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('n,horizon,nmb,nt', [(256, 64, 4, 1), (64, 32, 2, 2), (4096, 32, 4, 1)])
+def test_one_launch_reduce_and_adam_equals_the_two_kernel_form_bit_for_bit(monkeypatch, n, horizon, nmb, nt):
+    """pfa_ppo_mlp_train sums the workgroup partials, takes the clip norm and applies Adam in ONE launch (grid barrier inside,
+    csrc/ppo_update.hip ppo_reduce_adam_kernel); PFA_FUSED_ADAM=0 runs the two kernels pfa_ppo_mlp_grad + pfa_adam_clip_step are
+    made of.  Same arithmetic in the same order: parameters, moments, gradient bucket and losses must be identical bits, over
+    several updates (the barrier's generation word carries over between launches)."""
+    from pufferlib_amd import clean_pufferl
+    hp = [2.5e-3, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    runs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('PFA_FUSED_ADAM', fused)
+        torch.manual_seed(11)
+        vec, pol = _make(n, nt=nt)
+        data = clean_pufferl.create(_config(n, horizon, n * horizon // nmb, 16, 3, n * horizon * 8, hp, seed=9), vec, pol)
+        for _ in range(3):
+            clean_pufferl.evaluate(data)
+            clean_pufferl.train(data)
+        runs.append((data.flat_params.flat.clone(), data.optimizer.exp_avg.clone(), data.optimizer.exp_avg_sq.clone(), data.grads.clone(),
+                     dict(data.losses)))
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert torch.equal(a, b)
+    assert repr(runs[0][4]) == repr(runs[1][4])
+    assert torch.isfinite(runs[0][0]).all()
+
+
 @pytest.mark.parametrize('d,nt,n,horizon,nmb,bptt', [(1, 4, 40, 16, 2, 8), (2, 2, 96, 32, 4, 16), (3, 2, 24, 48, 1, 4), (4, 3, 72, 32, 2, 16),
                                                      (5, 2, 200, 32, 4, 8)])
 def test_other_grid_sizes_rollout_and_update_vs_oracle(d, nt, n, horizon, nmb, bptt):
