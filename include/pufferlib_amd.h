@@ -407,8 +407,9 @@ int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float 
  * launch itself (two launches per optimizer step, PFA_FUSED_DP=0 turns that off); otherwise one all-reduce per step through
  * pfa_dist_all_reduce_f32 (peer path as a launch of its own, else the RCCL communicator of pfa_dist_init) on `stream`.
  * Single rank: sum of the partials, clip norm and Adam are one launch as well (PFA_FUSED_ADAM=0: the two-kernel form of
- * pfa_ppo_mlp_grad + pfa_adam_clip_step, bit-identical results).  The last 256 bytes of the workspace hold that launch's
- * grid barrier; this call resets them. */
+ * pfa_ppo_mlp_grad + pfa_adam_clip_step, bit-identical results).  The one-launch form hands the pieces of the clip norm from
+ * workgroup to workgroup through the norm-piece area of the workspace ({value, launch generation} words); this call zeroes
+ * that area before its first launch. */
 int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                       const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                       float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,

@@ -55,6 +55,7 @@ __device__ __forceinline__ void gae_load(const float *dones, const float *values
 
 __device__ __forceinline__ Affine gae_thread_map(const GaeItems &it, long long s, long long n, float gamma, float lam,
                                                  bool pin_last) {
+#pragma clang fp contract(off)   // (hipcc's __fmul_rn / __fadd_rn wrappers contract into fmas — checked in the ISA — so: plain operators, contraction off)
     Affine f = {1.0, 0.0};
 #pragma unroll
     for (int i = kGaeItems - 1; i >= 0; --i) {
@@ -64,9 +65,9 @@ __device__ __forceinline__ Affine gae_thread_map(const GaeItems &it, long long s
             f = {0.0, 0.0};
             continue;
         }
-        const float nnt = __fsub_rn(1.0f, it.d[i + 1]);
-        const float delta = __fsub_rn(__fadd_rn(it.r[i + 1], __fmul_rn(__fmul_rn(gamma, it.v[i + 1]), nnt)), it.v[i]);
-        const float coef = __fmul_rn(__fmul_rn(gamma, lam), nnt);
+        const float nnt = 1.0f - it.d[i + 1];
+        const float delta = (it.r[i + 1] + (gamma * it.v[i + 1]) * nnt) - it.v[i];
+        const float coef = (gamma * lam) * nnt;
         f = compose({(double)coef, (double)delta}, f);
     }
     return f;
@@ -133,6 +134,8 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
     Affine mine = gae_thread_map(it, s, n, gamma, lam, halo == 0), after;
     block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
     float last = (float)(after.c * s_carry + after.d);  // adv at the first element after this thread's items
+    {
+#pragma clang fp contract(off)   // the reference's x86-64 build multiplies and adds separately
 #pragma unroll
     for (int i = kGaeItems - 1; i >= 0; --i) {
         const long long t = s + i;
@@ -140,13 +143,14 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
         if (t == n - 1 && halo == 0) {
             last = 0.0f;
         } else {  // the reference's statement order and rounding (c_gae.pyx:27-30)
-            // explicit round-to-nearest ops: no FMA contraction, like the reference's x86-64 build
-            const float nnt = __fsub_rn(1.0f, it.d[i + 1]);
-            const float delta = __fsub_rn(__fadd_rn(it.r[i + 1], __fmul_rn(__fmul_rn(gamma, it.v[i + 1]), nnt)), it.v[i]);
-            last = __fadd_rn(delta, __fmul_rn(__fmul_rn(__fmul_rn(gamma, lam), nnt), last));
+            // every product and sum rounded on its own (contraction is off in this block), like the reference's x86-64 build
+            const float nnt = 1.0f - it.d[i + 1];
+            const float delta = (it.r[i + 1] + (gamma * it.v[i + 1]) * nnt) - it.v[i];
+            last = delta + (((gamma * lam) * nnt) * last);
         }
         adv[t] = last;
         if (ret) ret[t] = last + it.v[i];
+    }
     }
 }
 
@@ -213,12 +217,13 @@ __global__ void gae_shard_fold_kernel(const double *pub, int rank, int world, lo
                                       float *dones, float *values, float *rewards, double *carry_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     auto last_map = [&](int q) -> Affine {
+#pragma clang fp contract(off)
         if (q == world - 1) return Affine{0.0, 0.0};
         const float d1 = (float)pub[6 * (q + 1) + 3], v1 = (float)pub[6 * (q + 1) + 4], r1 = (float)pub[6 * (q + 1) + 5];
         const float v0 = (float)pub[6 * q + 2];
-        const float nnt = __fsub_rn(1.0f, d1);
-        const float delta = __fsub_rn(__fadd_rn(r1, __fmul_rn(__fmul_rn(gamma, v1), nnt)), v0);
-        const float coef = __fmul_rn(__fmul_rn(gamma, lam), nnt);
+        const float nnt = 1.0f - d1;
+        const float delta = (r1 + (gamma * v1) * nnt) - v0;
+        const float coef = (gamma * lam) * nnt;
         return Affine{(double)coef, (double)delta};
     };
     double x = 0.0;

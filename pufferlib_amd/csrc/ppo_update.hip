@@ -740,6 +740,28 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_kernel(const float *pa
     if (ql == 0) norm_partials[blockIdx.x] = sq;
 }
 
+// torch.optim.Adam's single-tensor update of one element (clean_pufferl.py:240-244), shared by adam_clip_kernel and the one-launch
+// form.  Every operation is an explicitly rounded one: left to the compiler, `a * b + c` contracts into an fma in one kernel and not
+// in the other, and the two forms of the optimizer step are specified to give identical bits.  (hipcc's __fmul_rn / __fadd_rn
+// wrappers contract all the same — checked in the ISA — so: plain operators with the contraction switched off for the body.)
+__device__ __forceinline__ void adam_element(float &p, float &m, float &v, float g, float clip, float neg_step_size, float bc2_sqrt,
+                                             float beta1, float beta2, float eps) {
+#pragma clang fp contract(off)
+    const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+    const float gi = g * clip;
+    m = m + w1 * (gi - m);                                   // exp_avg.lerp_(grad, 1 - beta1)
+    v = (v * beta2) + ((w2 * gi) * gi);                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
+    const float denom = (__fsqrt_rn(v) / bc2_sqrt) + eps;
+    p = p + ((neg_step_size * m) / denom);                   // param.addcdiv_(exp_avg, denom, value=-step_size)
+}
+__device__ __forceinline__ float clip_factor(double sum_sq, float max_grad_norm) {   // clip_grad_norm_: min(1, max_norm / (norm + 1e-6))
+#pragma clang fp contract(off)
+    const float total_norm = (float)sqrt(sum_sq);
+    if (!(max_grad_norm > 0.0f)) return 1.0f;
+    const float clip = max_grad_norm / (total_norm + 1e-6f);
+    return clip > 1.0f ? 1.0f : clip;
+}
+
 constexpr int kAdamThreads = 256;   // adam_clip_kernel's workgroup: its norm summation order is the contract of both forms
 
 // ---- Kernels B + C as ONE launch: partial sums -> (data parallel: exchange with the peers) -> clip norm -> Adam ----------------
@@ -751,8 +773,13 @@ constexpr int kAdamThreads = 256;   // adam_clip_kernel's workgroup: its norm su
 // launch of its own: the exchange is 8-byte {value, sequence} stores into the peers' memory and a spin on the local copy
 // (p2p_ll.hpp), placed between the partial sum and the norm.  Arithmetic and summation order are those of the two-kernel form
 // (single rank: bit-identical results; R ranks: every entry is the rank-order sum of the ranks' entries, identical on all of them).
-struct GridBarrier {        // sense-reversing: `count` returns to 0 after every use, `gen` only ever grows
-    unsigned count, gen;
+// The grid-wide hand-off of the sum-of-squares pieces carries its own arrival signal: every workgroup publishes its f64 piece as
+// two 8-byte words {32 bits of the value, generation of this launch} and reads everybody's words until they show this launch's
+// generation — no counter, no fence (a release fence here writes back the whole L2, megabytes of the gradient kernel's partials
+// still dirty in it: measured, it made the one-launch form slower than the two kernels it replaces).
+struct GridWords {
+    unsigned long long *words;   // [workgroups][2], zeroed once per pfa_ppo_mlp_train call
+    unsigned gen;                // never 0, different for every launch of the process
 };
 struct AdamArgs {
     float *params, *exp_avg, *exp_avg_sq;
@@ -762,7 +789,7 @@ struct AdamArgs {
 };
 template <int DP, int KTM, bool COL, bool PERM, bool DIST>
 __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
-                                                                     double *norm_partials, GridBarrier *bar, AdamArgs ad, LlArgs ll) {
+                                                                     GridWords gw, AdamArgs ad, LlArgs ll) {
     using NL = NativeLayout<DP, KTM, COL>;
     __shared__ float sh[kRedSl][64];
     __shared__ double shd[kRedSl][64];   // the loss-sum slots are carried in f64
@@ -787,9 +814,6 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
     }
     sh[sl][ql] = acc;
     shd[sl][ql] = dacc;
-    // the barrier generation this launch starts from: read before anyone (this workgroup included) can have arrived
-    unsigned gen0 = 0;
-    if (threadIdx.x == 0) gen0 = __hip_atomic_load(&bar->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const MlpOffsets off = mlp_offsets(DP, a);
     if (sl == 1) {   // observation-padding columns of W1 no partial slot covers: gradient zero by definition (see ppo_reduce_kernel)
@@ -863,46 +887,36 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
     double sq = (p >= 0 && p < off.count) ? (double)s * (double)s : 0.0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
-    // ---- grid barrier: publish this workgroup's piece of sum(g^2), wait for everyone's ----
-    if (ql == 0) {
-        __hip_atomic_store(norm_partials + blockIdx.x, sq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned arrived = __hip_atomic_fetch_add(&bar->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == gridDim.x - 1) {
-            __hip_atomic_store(&bar->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __hip_atomic_store(&bar->gen, gen0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            while (__hip_atomic_load(&bar->gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen0) __builtin_amdgcn_s_sleep(1);
-        }
+    // ---- grid-wide hand-off: publish this workgroup's piece of sum(g^2), collect everyone's ----
+    if (ql < 2) {
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(sq);
+        const unsigned half = ql == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
+        __hip_atomic_store(gw.words + 2 * blockIdx.x + ql, ((unsigned long long)gw.gen << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // the norm in adam_clip_kernel's order: 256 strided partial sums, a butterfly per 64, then the four in order
     const int npart = (int)gridDim.x;
     double tot = 0.0;
 #pragma unroll
     for (int w = 0; w < kAdamThreads / 64; ++w) {
         double ss = 0.0;
-        for (int i = 64 * w + ql; i < npart; i += kAdamThreads)
-            ss += __hip_atomic_load(norm_partials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 64 * w + ql; i < npart; i += kAdamThreads) {
+            unsigned long long w0, w1;
+            while (true) {
+                w0 = __hip_atomic_load(gw.words + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                w1 = __hip_atomic_load(gw.words + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(w0 >> 32) == gw.gen && (unsigned)(w1 >> 32) == gw.gen) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            ss += __longlong_as_double((long long)(((w1 & 0xffffffffull) << 32) | (w0 & 0xffffffffull)));
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
         tot += ss;
     }
-    const float total_norm = (float)sqrt(tot);
-    float clip = 1.0f;
-    if (ad.max_grad_norm > 0.0f) {
-        clip = ad.max_grad_norm / (total_norm + 1e-6f);
-        clip = clip > 1.0f ? 1.0f : clip;
-    }
+    const float clip = clip_factor(tot, ad.max_grad_norm);
     if (p >= 0) {
-        const float w1 = 1.0f - ad.beta1, w2 = 1.0f - ad.beta2;
-        const float gi = s * 1.0f * clip;
-        m_i = m_i + w1 * (gi - m_i);
-        v_i = v_i * ad.beta2 + w2 * gi * gi;
-        const float denom = sqrtf(v_i) / ad.bc2_sqrt + ad.eps;
-        ad.params[p] = p_i + ad.neg_step_size * m_i / denom;
+        adam_element(p_i, m_i, v_i, s, clip, ad.neg_step_size, ad.bc2_sqrt, ad.beta1, ad.beta2, ad.eps);
+        ad.params[p] = p_i;
         ad.exp_avg[p] = m_i;
         ad.exp_avg_sq[p] = v_i;
     }
@@ -1031,19 +1045,10 @@ __global__ void __launch_bounds__(kAdamThreads) adam_clip_kernel(float *params, 
     double tot = 0.0;
 #pragma unroll
     for (int w = 0; w < kAdamThreads / 64; ++w) tot += sh[w];
-    const float total_norm = (float)sqrt(tot);
-    float clip = 1.0f;
-    if (max_grad_norm > 0.0f) {
-        clip = max_grad_norm / (total_norm + 1e-6f);
-        clip = clip > 1.0f ? 1.0f : clip;
-    }
-    const float w1 = 1.0f - beta1, w2 = 1.0f - beta2;
+    const float clip = clip_factor(tot, max_grad_norm);
     if (i < count) {
-        const float gi = g_i * grad_scale * clip;
-        m = m + w1 * (gi - m);               // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * beta2 + w2 * gi * gi;        // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-        const float denom = sqrtf(v) / bc2_sqrt + eps;
-        params[i] = p_i + neg_step_size * m / denom;  // param.addcdiv_(exp_avg, denom, value=-step_size)
+        adam_element(p_i, m, v, g_i * grad_scale, clip, neg_step_size, bc2_sqrt, beta1, beta2, eps);
+        params[i] = p_i;
         exp_avg[i] = m;
         exp_avg_sq[i] = v;
     }
@@ -1084,7 +1089,7 @@ static double *norm_partials_of(void *workspace, const pfa_mlp_dims *dims) {  //
 static size_t tail_bytes(const pfa_mlp_dims *dims, int nmb) {   // what follows the partials: adv-stat partials / norm pieces (shared)
     const size_t native = native_count(dims->obs_stride);
     const size_t advp = align_up((size_t)nmb * 64 * 2 * sizeof(double), 256);
-    const size_t normp = align_up(((native + 63) / 64) * sizeof(double), 256);
+    const size_t normp = align_up(((native + 63) / 64) * 2 * sizeof(double), 256);   // (the one-launch form: two 8-byte words per piece)
     return advp > normp ? advp : normp;
 }
 
@@ -1264,9 +1269,10 @@ extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_
 }
 
 // Kernels B + C in one launch (ppo_reduce_adam_kernel); `ll` non-null: with the data-parallel exchange inside.
-static GridBarrier *grid_barrier_of(void *workspace, const pfa_mlp_dims *dims, int nmb) {   // the 256 spare bytes behind the tail
-    return (GridBarrier *)((char *)workspace + partials_bytes(dims) + tail_bytes(dims, nmb));
+static unsigned long long *grid_words_of(void *workspace, const pfa_mlp_dims *dims) {   // the norm-piece area behind the partials
+    return (unsigned long long *)norm_partials_of(workspace, dims);
 }
+static size_t grid_words_bytes(const pfa_mlp_dims *dims) { return (size_t)norm_blocks(dims) * 2 * sizeof(unsigned long long); }
 static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
                               float lr, float beta1, float beta2, float eps, int64_t step, float max_grad_norm, double *losses,
                               double loss_scale, void *workspace, const LlArgs *ll, hipStream_t stream) {
@@ -1274,17 +1280,20 @@ static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
     AdamArgs ad{params, exp_avg, exp_avg_sq, (float)(-(double)lr / bc1), (float)std::sqrt(bc2), beta1, beta2, eps, max_grad_norm, losses, loss_scale};
     const float *partials = (const float *)workspace;
-    double *normp = norm_partials_of(workspace, dims);
-    GridBarrier *bar = grid_barrier_of(workspace, dims, nmb);
+    static unsigned long long launches = 0;
+    unsigned gen = (unsigned)(++launches);
+    if (gen == 0) gen = (unsigned)(++launches);
+    const GridWords gw{grid_words_of(workspace, dims), gen};
+    (void)nmb;
     const LlArgs none{};
     ScopedKernelTimer timer("ppo_reduce_adam", stream);
 #define PFA_LAUNCH_RA(DPV, KTMV, COLV, PERMV)                                                                                        \
     {                                                                                                                               \
         const dim3 g((NativeLayout<DPV, KTMV, COLV>::kCount + 63) / 64), b(64 * kRedSl);                                            \
         if (ll) hipLaunchKernelGGL((ppo_reduce_adam_kernel<DPV, KTMV, COLV, PERMV, true>), g, b, 0, stream, partials, grid,          \
-                                   dims->num_actions, dims->obs_dim, grads, normp, bar, ad, *ll);                                   \
+                                   dims->num_actions, dims->obs_dim, grads, gw, ad, *ll);                                   \
         else hipLaunchKernelGGL((ppo_reduce_adam_kernel<DPV, KTMV, COLV, PERMV, false>), g, b, 0, stream, partials, grid,            \
-                                dims->num_actions, dims->obs_dim, grads, normp, bar, ad, none);                                     \
+                                dims->num_actions, dims->obs_dim, grads, gw, ad, none);                                     \
     }
     switch (dims->obs_stride) {   // the instantiation choice of the gradient launch: the partial layout belongs to it
         case 16: PFA_LAUNCH_RA(16, 1, false, false) break;
@@ -1326,7 +1335,7 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
     const bool fused_dp = fused && data_parallel && world > 1 && env_on("PFA_FUSED_DP", true) && p2p_ll_ready(ll_entries_needed(dims));
     const bool one_launch = fused && (!data_parallel || fused_dp);   // (a 1-rank communicator keeps exercising the all-reduce call)
     if (one_launch)
-        PFA_CHECK_HIP(hipMemsetAsync(grid_barrier_of(workspace, dims, hp->num_minibatches), 0, sizeof(GridBarrier), (hipStream_t)stream));
+        PFA_CHECK_HIP(hipMemsetAsync(grid_words_of(workspace, dims), 0, grid_words_bytes(dims), (hipStream_t)stream));
     for (int e = 0; e < update_epochs; ++e)
         for (int mb = 0; mb < hp->num_minibatches; ++mb) {
             if (one_launch) {

@@ -266,8 +266,8 @@ def test_one_launch_reduce_and_adam_equals_the_two_kernel_form_bit_for_bit(monke
             clean_pufferl.train(data)
         runs.append((data.flat_params.flat.clone(), data.optimizer.exp_avg.clone(), data.optimizer.exp_avg_sq.clone(), data.grads.clone(),
                      dict(data.losses)))
-    for a, b in zip(runs[0][:4], runs[1][:4]):
-        assert torch.equal(a, b)
+    for name, a, b in zip(('parameters', 'exp_avg', 'exp_avg_sq', 'gradient bucket'), runs[0][:4], runs[1][:4]):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()), int((a != b).sum()))
     assert repr(runs[0][4]) == repr(runs[1][4])
     assert torch.isfinite(runs[0][0]).all()
 
