@@ -191,6 +191,28 @@ int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cfg, const fl
                             const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards,
                             uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 
+/* The same two kernels for a Default policy of another width — models.Default(env, hidden_size=H) (models.py:24-39) with H in
+ * {64, 128, 256, 512}, the widths the reference's environment policies use (classic_control 64, nethack / nmmo 256, atari 512) —
+ * reading the module's own tensors in torch's shapes through a view (no packed copy): encoder.weight [hidden][ldw1] (columns
+ * >= obs_dim read as 0), encoder.bias, decoder.weight [num_actions][hidden], decoder.bias, value_head.weight [hidden],
+ * value_head.bias.  One Discrete head of up to 15 actions; observation rows of obs_stride in {16, 32, 64} floats.  The policy
+ * forward of the protocol path (pfa_mlp_view_forward_sample) and the persistent rollout (pfa_rollout_mlp_view_squared) run the
+ * same tile code, so stepping through recv/send and the fused rollout give bit-identical numbers, as for the 128-wide policy.
+ * pfa_mlp_view_supported: 1 when the shape is one these kernels take (other shapes: the GEMM path of general.py). */
+typedef struct pfa_mlp_view {
+    const float *w1;
+    int32_t ldw1, obs_dim, obs_stride, hidden, num_actions, reserved;
+    const float *b1, *w2, *b2, *wv, *bv;
+} pfa_mlp_view;
+int pfa_mlp_view_supported(const pfa_mlp_view *view);
+int pfa_mlp_view_forward_sample(const float *obs, int64_t rows, const pfa_mlp_view *view, const float *noise,
+                                const pfa_noise_key *key, int64_t row_offset, int64_t *actions, float *logprob,
+                                float *entropy, float *value, pfa_stream_t stream);
+int pfa_rollout_mlp_view_squared(void *state, const pfa_squared_config *cfg, const pfa_mlp_view *view, const pfa_experience *exp,
+                                 const float *noise, const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards,
+                                 uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
+
+
 /* ------------------------------------------------------------------------------------------
  * Stochastic vecenv (a second ocean env family on device) — replaces pufferlib.vector.Serial
  * (vector.py:70-166) over ocean.environment.make_stochastic (ocean/environment.py:61-64; horizon 100) =

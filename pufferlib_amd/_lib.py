@@ -103,6 +103,12 @@ class MlpDims(C.Structure):
                 ('heads', C.c_uint32)]       # MultiDiscrete head sizes, 4 bits each (0 = one Discrete head)
 
 
+class MlpView(C.Structure):
+    _fields_ = [('w1', C.c_void_p), ('ldw1', C.c_int32), ('obs_dim', C.c_int32), ('obs_stride', C.c_int32), ('hidden', C.c_int32),
+                ('num_actions', C.c_int32), ('reserved', C.c_int32), ('b1', C.c_void_p), ('w2', C.c_void_p), ('b2', C.c_void_p),
+                ('wv', C.c_void_p), ('bv', C.c_void_p)]
+
+
 class NoiseKey(C.Structure):
     _fields_ = [('seed', C.c_uint64), ('step', C.c_uint64)]
 
@@ -151,6 +157,10 @@ _SIGNATURES = {
     'pfa_philox_exp_noise': (C.c_int, [P, C.c_int64, C.c_int64, C.c_int32, C.POINTER(NoiseKey), C.c_int64, P]),
     'pfa_rollout_mlp_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), C.POINTER(Experience),
                                           P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
+    'pfa_mlp_view_supported': (C.c_int, [C.POINTER(MlpView)]),
+    'pfa_mlp_view_forward_sample': (C.c_int, [P, C.c_int64, C.POINTER(MlpView), P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
+    'pfa_rollout_mlp_view_squared': (C.c_int, [P, C.POINTER(SquaredConfig), C.POINTER(MlpView), C.POINTER(Experience), P, C.POINTER(NoiseKey),
+                                               C.c_int64, P, P, P, P, P, P]),
     'pfa_stochastic_state_bytes': (C.c_size_t, [C.c_int32]),
     'pfa_stochastic_async_reset': (C.c_int, [P, C.c_int32, P, P, P, P, P, P]),
     'pfa_stochastic_send': (C.c_int, [P, C.c_int32, C.c_double, C.c_int32, P, P, P, P, P, P, P]),

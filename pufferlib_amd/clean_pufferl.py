@@ -398,7 +398,9 @@ def evaluate(data):
             noise = noise.to(device=vecenv.device, dtype=torch.float32).contiguous()
             assert tuple(noise.shape) == (T, N, fp.num_actions), noise.shape
         key = _lib.NoiseKey(policy.noise_seed, policy.noise_step)
-    if data.gen_engine is not None:       # a policy shape outside the fused kernels: GEMM-path policy step + store + send per step
+    wide_view = data.gen_engine.mlp_view if data.gen_engine is not None else None
+    if data.gen_engine is not None and not (wide_view is not None and type(vecenv) is Squared):
+        # a policy shape outside the fused kernels: policy step + store + send per step
         with profile.eval_forward:
             _rollout_stepwise(data, noise, T, N)
         return _finish_evaluate(data, N, T)
@@ -435,11 +437,18 @@ def evaluate(data):
                 noise = data._noise_buf
                 _lib.check(L.pfa_philox_exp_noise(_lib.ptr(noise), T, N, fp.num_actions, C.byref(key), vecenv.env_offset,
                                                   _lib.stream_handle()), 'philox_exp_noise')
-            _lib.check(L.pfa_rollout_mlp_squared(
-                _lib.ptr(vecenv.state), C.byref(vecenv.cfg), _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(experience.c),
-                _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
-                _lib.ptr(vecenv.terminals_u8), _lib.ptr(vecenv.truncations_u8), _lib.ptr(vecenv.masks_u8),
-                _lib.stream_handle()), 'rollout')
+            if wide_view is not None:     # Default(hidden 64 / 256 / 512): the same persistent kernel, W1 fragments of that width in registers
+                _lib.check(L.pfa_rollout_mlp_view_squared(
+                    _lib.ptr(vecenv.state), C.byref(vecenv.cfg), C.byref(wide_view), C.byref(experience.c),
+                    _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
+                    _lib.ptr(vecenv.terminals_u8), _lib.ptr(vecenv.truncations_u8), _lib.ptr(vecenv.masks_u8),
+                    _lib.stream_handle()), 'rollout')
+            else:
+                _lib.check(L.pfa_rollout_mlp_squared(
+                    _lib.ptr(vecenv.state), C.byref(vecenv.cfg), _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(experience.c),
+                    _lib.ptr(noise), C.byref(key), vecenv.env_offset, _lib.ptr(vecenv.obs_buf), _lib.ptr(vecenv.rewards),
+                    _lib.ptr(vecenv.terminals_u8), _lib.ptr(vecenv.truncations_u8), _lib.ptr(vecenv.masks_u8),
+                    _lib.stream_handle()), 'rollout')
     with profile.env:
         vecenv.sends += T
         # The tape does not depend on actions: draw the NEXT rollout's reset rounds on the side stream while THIS

@@ -131,6 +131,10 @@ class Policy(torch.nn.Module):
             # runs in the GEMM path altogether
             if find_cnn(self.policy) is not None and not general_shape:
                 raise NotImplementedError('policy(frames, action=...) for the non-recurrent models.Convolutional')
+            if action is None and find_cnn(self.policy) is None:
+                out = self._forward_tile(x2, rows, D, noise)     # Default(64 / 256 / 512): the tile code the fused rollout runs
+                if out is not None:
+                    return out
             ev = _evaluator(self, x.device, False)
             key = None
             if action is None and noise is None:
@@ -165,6 +169,40 @@ class Policy(torch.nn.Module):
         return fp.unpack_actions(actions), logprob, entropy, value.unsqueeze(1)
 
 
+def _forward_tile(self, x2, rows, D, noise):
+    """policy(obs) in rollout mode for a Default of one of the tile kernels' widths (general.tile_view): one launch of
+    pfa_mlp_view_forward_sample — the same code, bit for bit, as the persistent fused rollout.  None when the shape is not one of them."""
+    from . import general
+    fp = self._flat if self._flat is not None else self.adopt(obs_stride_for(D), x2.device)
+    view = general.tile_view(fp)
+    if view is None:
+        return None
+    if x2.shape[1] != fp.obs_dim:
+        raise ValueError(f'observation rows of {x2.shape[1]} values, the policy reads {fp.obs_dim}')
+    stride = fp.obs_stride
+    if x2.dtype == torch.float32 and x2.stride(1) == 1 and x2.stride(0) == stride and x2.data_ptr() % 16 == 0:
+        src = x2                             # e.g. the vecenv's live buffer, already padded
+    else:
+        src = torch.zeros(rows, stride, dtype=torch.float32, device=x2.device)
+        src[:, :D] = x2.float()
+    dev = x2.device
+    actions = torch.empty(rows, dtype=torch.int64, device=dev)
+    logprob = torch.empty(rows, dtype=torch.float32, device=dev)
+    entropy = torch.empty(rows, dtype=torch.float32, device=dev)
+    value = torch.empty(rows, dtype=torch.float32, device=dev)
+    key = _lib.NoiseKey(self.noise_seed, self.noise_step)
+    if noise is not None:
+        noise = noise.to(device=dev, dtype=torch.float32).contiguous()
+        assert noise.shape == (rows, fp.num_actions)
+    else:
+        self.noise_step += 1
+    _lib.check(_lib.lib().pfa_mlp_view_forward_sample(_lib.ptr(src), rows, C.byref(view), _lib.ptr(noise), C.byref(key), 0, _lib.ptr(actions),
+                                                      _lib.ptr(logprob), _lib.ptr(entropy), _lib.ptr(value), _lib.stream_handle()),
+               'mlp_view_forward_sample')
+    return actions, logprob, entropy, value.unsqueeze(1)
+
+
+
 def _forward_cnn(self, x2, rows, noise):
     """policy(frames) for models.Convolutional: uint8 (rows, framestack*84*84) -> (actions, logprob, entropy, value)."""
     cp = self.adopt(0, x2.device)
@@ -189,6 +227,7 @@ def _forward_cnn(self, x2, rows, noise):
 
 
 Policy._forward_cnn = _forward_cnn
+Policy._forward_tile = _forward_tile
 
 
 class RecurrentPolicy(torch.nn.Module):

@@ -32,23 +32,23 @@ __device__ int g_rtrace_t0 = 0, g_rtrace_steps = 0;
 // ---------------------------------------------------------------------------------------------
 // standalone forward + sample over `rows` observation rows
 // ---------------------------------------------------------------------------------------------
-template <int DP, int KS>
-__global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const float *obs, long long rows, const float *params,
+template <int DP, int KS, int MW = kMW>
+__global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const float *obs, long long rows, MlpView pv,
                                                                          int a, uint32_t heads, const float *noise,
                                                                          uint64_t seed, uint64_t step, long long row_offset,
                                                                          long long *actions, float *logprob, float *entropy,
                                                                          float *value) {
     __shared__ float xs[XTile<DP>::kFloats];
     __shared__ float part[kRollWaves][kOut * 16];
-    SliceFrags<DP, KS> w;
-    w.load(params, a);
+    SliceFrags<DP, KS, MW> w;
+    w.load(pv);
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
     const long long tiles = (rows + 15) / 16;
     for (long long tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         __syncthreads();
         stage_rows<DP>(obs, tile * 16, rows, xs);
         __syncthreads();
-        forward_slice<DP, KS>(w, xs, part);
+        forward_slice<DP, KS, MW>(w, xs, part);
         __syncthreads();
         const long long row = tile * 16 + le;
         const bool ok = row < rows;
@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
 //     step's scalar stores.  One explicit drain before the loop removes it; the two per-step barriers order LDS only
 //     (`lds_barrier`, common.hpp).
 // ---------------------------------------------------------------------------------------------
-template <int DP, int EPW, bool NT1, int KS>
-__global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(SquaredView v, const float *params, int a,
+template <int DP, int EPW, bool NT1, int KS, int MW = kMW>
+__global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(SquaredView v, MlpView pv, int a,
                                                                           pfa_experience ex, const float *noise,
                                                                           uint64_t seed, uint64_t step0, long long env_offset,
                                                                           float *live_obs, float *live_rew, uint8_t *live_term,
@@ -108,8 +108,8 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
     const bool owner = lo == 0 && env_ok;  // the thread that carries env `e`
     const int T = ex.horizon_T;
 
-    SliceFrags<DP, KS> w;
-    w.load(params, a);
+    SliceFrags<DP, KS, MW> w;
+    w.load(pv);
 
     // recv(): the live buffers are the current observation / reward / terminal of every env
     stage_rows<DP>(live_obs, (long long)blockIdx.x * EPW, v.n, xs, EPW);
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
         // Experience.store of the observation rows (clean_pufferl.py:443), env-major: row (e, t) at e*T + t
         unstage_rows<DP>(xs, ex.obs + (size_t)t * DP, (long long)blockIdx.x * EPW, v.n, (size_t)T * DP, EPW);
         PFA_RSTAMP(t, 1);
-        forward_slice<DP, KS>(w, xs, part);
+        forward_slice<DP, KS, MW>(w, xs, part);
         PFA_RSTAMP(t, 2);
         lds_barrier();
         PFA_RSTAMP(t, 3);
@@ -308,8 +308,8 @@ extern "C" int pfa_mlp_forward_sample(const float *obs, int64_t rows, const floa
     const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
     PFA_DISPATCH_DP(dims,
                     hipLaunchKernelGGL((mlp_forward_sample_kernel<DP, KS>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, obs,
-                                       (long long)rows, params, dims->num_actions, dims->heads, noise, seed, step, (long long)row_offset,
-                                       (long long *)actions, logprob, entropy, value));
+                                       (long long)rows, mlp_view_of_flat(params, DP, dims->num_actions), dims->num_actions, dims->heads, noise, seed,
+                                       step, (long long)row_offset, (long long *)actions, logprob, entropy, value));
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -353,13 +353,99 @@ extern "C" int pfa_rollout_mlp_squared(void *state, const pfa_squared_config *cf
     if (cfg->num_targets == 1) {
         PFA_DISPATCH_DP(dims,
                         hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, true, KS>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
-                                           v, params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
-                                           terminals, truncations, masks));
+                                           v, mlp_view_of_flat(params, DP, dims->num_actions), dims->num_actions, *exp, noise, seed, step,
+                                           (long long)env_offset, obs, rewards, terminals, truncations, masks));
     } else {
         PFA_DISPATCH_DP(dims,
                         hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, false, KS>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
-                                           v, params, dims->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards,
-                                           terminals, truncations, masks));
+                                           v, mlp_view_of_flat(params, DP, dims->num_actions), dims->num_actions, *exp, noise, seed, step,
+                                           (long long)env_offset, obs, rewards, terminals, truncations, masks));
+    }
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same two kernels for a Default policy of another width (models.py:24-39: hidden_size 64 / 256 / 512 — what
+// environments/classic_control, nethack / nmmo and atari's MLP heads use), reading the module's own tensors through a
+// pfa_mlp_view: hidden = 64 MW with MW hidden tiles per wave, W1 fragments in registers for the whole launch like the 128-wide
+// instantiation.  One Discrete head of up to 15 actions, observation rows of 16 / 32 / 64 floats.
+// ---------------------------------------------------------------------------------------------
+static int check_view(const pfa_mlp_view *p) {
+    PFA_REQUIRE(p != nullptr, "mlp view: null");
+    PFA_REQUIRE(p->w1 && p->b1 && p->w2 && p->b2 && p->wv && p->bv, "mlp view: null tensor");
+    PFA_REQUIRE(p->hidden == 64 || p->hidden == 128 || p->hidden == 256 || p->hidden == 512, "mlp view: hidden %d is not one of 64/128/256/512", p->hidden);
+    PFA_REQUIRE(p->obs_stride == 16 || p->obs_stride == 32 || p->obs_stride == 64, "mlp view: obs_stride %d is not one of 16/32/64", p->obs_stride);
+    PFA_REQUIRE(p->obs_dim >= 1 && p->obs_dim <= p->obs_stride && p->ldw1 >= p->obs_dim, "mlp view: obs_dim %d / ldw1 %d out of range", p->obs_dim, p->ldw1);
+    PFA_REQUIRE(p->num_actions >= 1 && p->num_actions <= 15, "mlp view: num_actions must be in 1..15 (got %d)", p->num_actions);
+    return 0;
+}
+extern "C" int pfa_mlp_view_supported(const pfa_mlp_view *p) { return check_view(p) == 0 ? 1 : 0; }
+static MlpView device_view(const pfa_mlp_view *p) {
+    return MlpView{p->w1, p->ldw1, p->obs_dim, p->b1, p->w2, p->b2, p->wv, p->bv, p->num_actions, p->hidden};
+}
+// (variadic: the launch expression is macro-expanded before it reaches the inner dispatch and then holds top-level commas)
+#define PFA_DISPATCH_VIEW_DP(view_, ...)                                                                 \
+    if ((view_)->obs_stride == 64 && (view_)->obs_dim > 48 && (view_)->obs_dim <= 52) {                  \
+        constexpr int DP = 64, KS = 13; __VA_ARGS__;                                                     \
+    } else switch ((view_)->obs_stride) {                                                                \
+        case 16: { constexpr int DP = 16, KS = 4; __VA_ARGS__; } break;                                   \
+        case 32: { constexpr int DP = 32, KS = 8; __VA_ARGS__; } break;                                   \
+        default: { constexpr int DP = 64, KS = 16; __VA_ARGS__; } break;                                  \
+    }
+#define PFA_DISPATCH_VIEW(view_, ...)                                                                    \
+    switch ((view_)->hidden) {                                                                           \
+        case 64: { constexpr int MW = 1; PFA_DISPATCH_VIEW_DP(view_, __VA_ARGS__) } break;                \
+        case 128: { constexpr int MW = 2; PFA_DISPATCH_VIEW_DP(view_, __VA_ARGS__) } break;               \
+        case 256: { constexpr int MW = 4; PFA_DISPATCH_VIEW_DP(view_, __VA_ARGS__) } break;               \
+        default: { constexpr int MW = 8; PFA_DISPATCH_VIEW_DP(view_, __VA_ARGS__) } break;                \
+    }
+
+extern "C" int pfa_mlp_view_forward_sample(const float *obs, int64_t rows, const pfa_mlp_view *view, const float *noise,
+                                           const pfa_noise_key *key, int64_t row_offset, int64_t *actions, float *logprob,
+                                           float *entropy, float *value, pfa_stream_t stream) {
+    if (int rc = check_view(view)) return rc;
+    PFA_REQUIRE(rows >= 0, "mlp.forward: negative rows");
+    if (rows == 0) return 0;
+    PFA_REQUIRE(obs && actions && logprob && value, "mlp.forward: null buffer");
+    PFA_REQUIRE(noise || key, "mlp.forward: need an explicit noise tensor or a Philox key");
+    const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
+    const int64_t tiles = (rows + 15) / 16;
+    const unsigned grid = (unsigned)(tiles < 4096 ? tiles : 4096);
+    const MlpView pv = device_view(view);
+    PFA_DISPATCH_VIEW(view,
+                      hipLaunchKernelGGL((mlp_forward_sample_kernel<DP, KS, MW>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream, obs,
+                                         (long long)rows, pv, view->num_actions, 0u, noise, seed, step, (long long)row_offset,
+                                         (long long *)actions, logprob, entropy, value));
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pfa_rollout_mlp_view_squared(void *state, const pfa_squared_config *cfg, const pfa_mlp_view *view, const pfa_experience *exp,
+                                            const float *noise, const pfa_noise_key *key, int64_t env_offset, float *obs, float *rewards,
+                                            uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream) {
+    if (int rc = check_view(view)) return rc;
+    PFA_REQUIRE(state && cfg && exp && obs && rewards && terminals && truncations && masks, "rollout: null buffer");
+    PFA_REQUIRE(cfg->obs_stride == view->obs_stride, "rollout: env obs_stride %d != policy obs_stride %d", cfg->obs_stride, view->obs_stride);
+    PFA_REQUIRE(exp->horizon_T >= 1, "rollout: horizon must be >= 1");
+    PFA_REQUIRE(exp->obs && exp->actions && exp->logprobs && exp->values && exp->rewards && exp->dones, "rollout: null experience buffer");
+    PFA_REQUIRE(noise || key, "rollout: need an explicit noise tensor or a Philox key");
+    PFA_REQUIRE(cfg->num_targets <= kMaxTargets, "rollout: too many targets");
+    SquaredView v = squared_view(state, *cfg);
+    const uint64_t seed = key ? key->seed : 0, step = key ? key->step : 0;
+    const MlpView pv = device_view(view);
+    ScopedKernelTimer timer("rollout_mlp_squared", (hipStream_t)stream);
+    const unsigned grid = (unsigned)((cfg->num_envs + 15) / 16);
+    if (cfg->num_targets == 1) {
+        PFA_DISPATCH_VIEW(view,
+                          hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, true, KS, MW>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
+                                             v, pv, view->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards, terminals,
+                                             truncations, masks));
+    } else {
+        PFA_DISPATCH_VIEW(view,
+                          hipLaunchKernelGGL((rollout_mlp_squared_kernel<DP, 16, false, KS, MW>), dim3(grid), dim3(kRollThreads), 0, (hipStream_t)stream,
+                                             v, pv, view->num_actions, *exp, noise, seed, step, (long long)env_offset, obs, rewards, terminals,
+                                             truncations, masks));
     }
     PFA_LAUNCH_CHECK();
     return 0;

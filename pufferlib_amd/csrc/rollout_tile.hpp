@@ -21,19 +21,40 @@ constexpr int kRollThreads = 256;
 constexpr int kRollWaves = 4;
 constexpr int kMW = kMT / kRollWaves;  // hidden tiles per wave
 
+// Where a Default policy's tensors live (models.py:24-39), so that the same tile code serves the kernel-layout buffer of the 128-wide
+// policy (W1 rows padded to the observation stride) and a module's own tensors in torch's shapes (any width; general.py).
+struct MlpView {
+    const float *w1;   // encoder.weight [hidden][ldw1], columns >= cols read as 0
+    int ldw1, cols;
+    const float *b1;   // encoder.bias [hidden]
+    const float *w2;   // decoder.weight [a][hidden]
+    const float *b2;   // decoder.bias [a]
+    const float *wv;   // value_head.weight [hidden]
+    const float *bv;   // value_head.bias [1]
+    int a, hidden;
+    __device__ __forceinline__ float w2v(int o, int u) const { return o < a ? w2[o * hidden + u] : (o == a ? wv[u] : 0.0f); }
+    __device__ __forceinline__ float b2v(int o) const { return o < a ? b2[o] : (o == a ? bv[0] : 0.0f); }
+};
+inline MlpView mlp_view_of_flat(const float *params, int dp, int a) {   // the flat layout of include/pufferlib_amd.h (hidden 128)
+    const MlpOffsets off = mlp_offsets(dp, a);
+    return MlpView{params + off.w1, dp, dp, params + off.b1, params + off.w2, params + off.b2, params + off.wv, params + off.bv, a, kHidden};
+}
+
 // KS = k-steps (4 observation columns each) the forward issues.  Default: the whole padded row.  A launch whose true feature
 // count fits fewer steps passes the smaller number: the dropped products are pad weight x pad observation = +0 added to the
 // accumulator (like the gradient kernel's KKU, ppo_update.hip), and every rollout-mode kernel of a policy takes the same KS,
 // so the protocol path and the fused path stay bit-identical.
-template <int DP, int KS = DP / 4>
+// MW = hidden tiles (16 units each) per wave: hidden = 64 MW, i.e. 64 / 128 / 256 / 512 for MW = 1 / 2 / 4 / 8.  The W1 fragments
+// of any of them fit the registers of a one-wave-per-SIMD workgroup (MW x KS <= 128 floats at a 64-float row).
+template <int DP, int KS = DP / 4, int MW = kMW>
 struct SliceFrags {
-    float w1f[kMW][KS], b1f[kMW][4], w2f[kMW][4], bo[4];
+    float w1f[MW][KS], b1f[MW][4], w2f[MW][4], bo[4];
     __device__ __forceinline__ void load(const float *params, int a) {
         const MlpOffsets off = mlp_offsets(DP, a);
         const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
 #pragma unroll
-        for (int i = 0; i < kMW; ++i) {
-            const int m = kMW * wv + i;
+        for (int i = 0; i < MW; ++i) {
+            const int m = MW * wv + i;
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk) w1f[i][kk] = params[off.w1 + (16 * m + c) * DP + 4 * kk + g];
 #pragma unroll
@@ -44,6 +65,22 @@ struct SliceFrags {
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) bo[r] = wv == 0 ? b2v_at(params, off, a, 4 * g + r) : 0.0f;
+    }
+    __device__ __forceinline__ void load(const MlpView &p) {   // the same fragments from wherever the tensors live
+        const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+            const int m = MW * wv + i;
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) w1f[i][kk] = 4 * kk + g < p.cols ? p.w1[(size_t)(16 * m + c) * p.ldw1 + 4 * kk + g] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                b1f[i][r] = p.b1[16 * m + 4 * g + r];
+                w2f[i][r] = p.w2v(c, 16 * m + 4 * g + r);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bo[r] = wv == 0 ? p.b2v(4 * g + r) : 0.0f;
     }
 };
 
@@ -78,24 +115,28 @@ __device__ __forceinline__ void unstage_rows(const float *xs, float *dst, long l
 }
 
 // This wave's slice of models.Default.forward (models.py:41-62) for the 16 rows in xs -> part[wave][o*16 + row].
-template <int DP, int KS = DP / 4>
-__device__ __forceinline__ void forward_slice(const SliceFrags<DP, KS> &w, const float *xs, float (*part)[kOut * 16]) {
+template <int DP, int KS = DP / 4, int MW = kMW>   // MW = 1 or even
+__device__ __forceinline__ void forward_slice(const SliceFrags<DP, KS, MW> &w, const float *xs, float (*part)[kOut * 16]) {
     constexpr int XS = XTile<DP>::XS;
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
-    f32x4 h[kMW];
+    f32x4 h[MW];
 #pragma unroll
-    for (int i = 0; i < kMW; ++i) h[i] = f32x4{w.b1f[i][0], w.b1f[i][1], w.b1f[i][2], w.b1f[i][3]};
+    for (int i = 0; i < MW; ++i) h[i] = f32x4{w.b1f[i][0], w.b1f[i][1], w.b1f[i][2], w.b1f[i][3]};
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
         const float b = xs[c * XS + 4 * kk + g];
 #pragma unroll
-        for (int i = 0; i < kMW; ++i) h[i] = mfma16(w.w1f[i][kk], b, h[i]);
+        for (int i = 0; i < MW; ++i) h[i] = mfma16(w.w1f[i][kk], b, h[i]);
     }
+    // the heads' contraction over this wave's 16 MW hidden units: two accumulator chains (even / odd tiles)
     f32x4 o0 = f32x4{w.bo[0], w.bo[1], w.bo[2], w.bo[3]}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        o0 = mfma16(w.w2f[0][r], fmaxf(h[0][r], 0.0f), o0);
-        o1 = mfma16(w.w2f[1][r], fmaxf(h[1][r], 0.0f), o1);
+    for (int i = 0; i < MW; i += 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o0 = mfma16(w.w2f[i][r], fmaxf(h[i][r], 0.0f), o0);
+            if constexpr (MW >= 2) o1 = mfma16(w.w2f[i + 1][r], fmaxf(h[i + 1][r], 0.0f), o1);
+        }
     }
     const f32x4 po = o0 + o1;  // partial out^T[o = 4g + r][row = c]
 #pragma unroll

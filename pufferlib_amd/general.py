@@ -381,6 +381,29 @@ class Evaluator:
             net.encode(src[lo:lo + m], m, out[lo:lo + m], ldo)
 
 
+def tile_view(gp):
+    """pfa_mlp_view of a plain Default(hidden 64 / 128 / 256 / 512, one Discrete head of <= 15 actions, rows of <= 64 floats): the
+    rollout-mode forward of such a policy runs the register-resident tile kernels of csrc/rollout.hip — the standalone forward for
+    the protocol path (policy(obs), Engine.policy_step) and the persistent fused rollout on vector.Squared — straight from the
+    module's tensors (their addresses never change: every parameter is a view of the flat buffer).  None for any other shape: the
+    GEMM path.  PFA_WIDE_TILE=0 turns it off (A/B timing)."""
+    import os
+    if getattr(gp, '_tile_view', False) is not False:
+        return gp._tile_view
+    view = None
+    if (isinstance(gp, GeneralParams) and gp.kind == 'mlp' and gp.lstm is None and not gp.multidiscrete and gp.obs_stride in (16, 32, 64)
+            and gp.num_actions <= 15 and os.environ.get('PFA_WIDE_TILE', '1') != '0'):
+        m, v = gp.mlp, gp.views
+        t = {k: v[gp.name_of(p)] for k, p in (('w1', m.encoder.weight), ('b1', m.encoder.bias), ('w2', m.decoder.weight), ('b2', m.decoder.bias),
+                                              ('wv', m.value_head.weight), ('bv', m.value_head.bias))}
+        cand = _lib.MlpView(t['w1'].data_ptr(), int(gp.obs_dim), int(gp.obs_dim), int(gp.obs_stride), int(gp.features), int(gp.num_actions), 0,
+                            t['b1'].data_ptr(), t['w2'].data_ptr(), t['b2'].data_ptr(), t['wv'].data_ptr(), t['bv'].data_ptr())
+        if _lib.lib().pfa_mlp_view_supported(C.byref(cand)):
+            view = cand
+    gp._tile_view = view
+    return view
+
+
 class Engine:
     """Rollout step and PPO update of a general policy for one (experience, vecenv) pair; interface of lstm.Engine / cnn.Engine
     as clean_pufferl drives them: policy_step, update, clip_adam, state."""
@@ -396,6 +419,7 @@ class Engine:
         self.lstm_h = self.lstm_c = None
         self._step_rows = 0
         self._upd = None
+        self.mlp_view = tile_view(gp)
         if num_agents:
             self.reset_state(num_agents)
 
@@ -427,9 +451,14 @@ class Engine:
         """policy(obs) in rollout mode for the n rows of `obs` ([n][obs_stride] f32, or uint8 frames): encoder -> (one LSTM step on the
         state rows `ids`, default 0..n-1, updated in place) -> heads -> sample_logits."""
         net = self.net
+        L = _lib.lib()
+        if self.mlp_view is not None:       # a Default of one of the tile kernels' widths: the code the fused rollout runs, one launch
+            _lib.check(L.pfa_mlp_view_forward_sample(_lib.ptr(obs), n, C.byref(self.mlp_view), _lib.ptr(noise), C.byref(key), row_offset,
+                                                     _lib.ptr(actions), _lib.ptr(logprob), _lib.ptr(entropy), _lib.ptr(value),
+                                                     _lib.stream_handle()), 'mlp_view_forward_sample')
+            return
         net.pack()
         self._alloc_step(n)
-        L = _lib.lib()
         if net.lstm:
             I, Hl = net.lstm
             xh = self.s_xh[:n]

@@ -595,3 +595,61 @@ def test_two_multidiscrete_heads_of_nine_run_end_to_end():
     np.testing.assert_allclose(tr.logprobs, olp.numpy(), **TOL)
     tr.global_step = data.global_step
     _check_update(data, pol, opol, tr, lambda k: 'policy.' + k)
+
+
+@pytest.mark.parametrize('hidden,nt', [(64, 1), (256, 1), (512, 1), (256, 2)])
+def test_wide_fused_rollout_equals_stepwise_protocol_bit_for_bit(hidden, nt, monkeypatch):
+    """Default(hidden 64 / 256 / 512) on vector.Squared: evaluate()'s ONE persistent kernel (csrc/rollout.hip templated on the hidden
+    tiles per wave, W1 fragments of that width in registers) == T x {recv, policy(obs), store, send} through the public protocol,
+    bit for bit — policy(obs) runs the same tile code as a launch of its own (pfa_mlp_view_forward_sample).  And the GEMM path the
+    same policy took before (PFA_WIDE_TILE=0: igemm rows + head kernels per step) agrees within the fp32 tolerance."""
+    from pufferlib_amd import clean_pufferl, cleanrl, general, models, vector
+    from test_gpu_ppo import _config, _t
+    n, horizon = 48, 20          # not a multiple of 16 envs: the masked tail tile
+    def make():
+        vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=3, num_targets=nt), num_envs=n, backend=vector.Squared)
+        torch.manual_seed(7)
+        return vec, cleanrl.Policy(models.Default(vec.driver_env, hidden_size=hidden))
+    vec, pol = make()
+    _perturb(pol)
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 2, 4, 1, n * horizon * 4, HP, seed=5), vec, pol)
+    assert data.gen_engine is not None and data.gen_engine.mlp_view is not None
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+
+    vec2, pol2 = make()
+    pol2.load_state_dict(pol.state_dict())
+    pol2.noise_seed = 5
+    vec2.async_reset(5)
+    obs_l, act_l, lp_l, val_l, rew_l, done_l = [], [], [], [], [], []
+    for t in range(horizon):
+        o, r, d, tr_, info, ids, mask = vec2.recv()
+        a, lp, ent, val = pol2(o)
+        obs_l.append(o.reshape(n, -1).clone()); rew_l.append(r.clone()); done_l.append(d.clone().float())
+        act_l.append(a.clone()); lp_l.append(lp.clone()); val_l.append(val.flatten().clone())
+        vec2.send(a)
+    assert general.tile_view(pol2.flat_params) is not None
+    assert torch.equal(_t(exp.obs, n, horizon)[:, :49], torch.cat(obs_l))
+    assert torch.equal(_t(exp.actions, n, horizon).long(), torch.cat(act_l))
+    assert torch.equal(_t(exp.logprobs, n, horizon), torch.cat(lp_l))
+    assert torch.equal(_t(exp.values, n, horizon), torch.cat(val_l))
+    assert torch.equal(_t(exp.rewards, n, horizon), torch.cat(rew_l))
+    assert torch.equal(_t(exp.dones, n, horizon), torch.cat(done_l))
+    assert torch.equal(vec.observations, vec2.observations)
+    assert torch.equal(vec.rewards, vec2.rewards) and torch.equal(vec.terminals, vec2.terminals)
+
+    # the GEMM path on the recorded observations, under the noise the fused rollout drew
+    monkeypatch.setenv('PFA_WIDE_TILE', '0')
+    vec3, pol3 = make()
+    pol3.load_state_dict(pol.state_dict())
+    obs_all = torch.cat(obs_l).cuda()
+    import ctypes as C
+    from pufferlib_amd import _lib
+    noise = torch.empty(n * horizon, 8, device='cuda')
+    key, L = _lib.NoiseKey(5, 0), _lib.lib()
+    _lib.check(L.pfa_philox_exp_noise(_lib.ptr(noise), horizon, n, 8, C.byref(key), 0, _lib.stream_handle()), 'noise')
+    a3, lp3, _, val3 = pol3(obs_all.view(n * horizon, 7, 7), noise=noise)
+    assert general.tile_view(pol3.flat_params) is None
+    np.testing.assert_allclose(lp3.cpu().numpy(), torch.cat(lp_l).cpu().numpy(), **TOL)
+    np.testing.assert_allclose(val3.flatten().cpu().numpy(), torch.cat(val_l).cpu().numpy(), **TOL)
+    assert float((a3 != torch.cat(act_l)).float().mean()) < 0.01          # (near-ties of p/q may flip between the two summation orders)
