@@ -178,6 +178,61 @@ def cpu_baseline_c4(n=32, horizon=16):
                        f'{EPOCHS} epochs) after 1 warm-up; torch-fp32 NatureCNN on {cores} threads')
 
 
+def cpu_baseline_c3(n=256, horizon=128):
+    """The oracle port of the recurrent path (torch-fp32 Default(128) + nn.LSTM(128, 128) restatement + the restated trainer with
+    its bptt segments) on a bounded sample of the c3 workload's shape — BASELINE.md section 3's "C3-policy": `n` envs x `horizon`
+    steps of 160-float rows (numpy generator, 100-step episodes), 7 actions, 4 minibatches x 4 epochs, bptt 16."""
+    import numpy as np
+    import torch
+    from oracle import ppo_torch
+    cores_avail = os.cpu_count() or 1
+    cores = min(cores_avail, 16)
+    torch.set_num_threads(cores)
+    B = n * horizon
+    rs = np.random.RandomState(0)
+
+    class RowVec:
+        num_envs = n
+        observations = np.zeros((n, 160), np.float32)
+        tick = np.zeros(n, np.int64)
+
+        def async_reset(self, seed):
+            pass
+
+        def recv(self):
+            self.observations[:] = rs.randint(0, 11, self.observations.shape).astype(np.float32)
+            self.tick += 1
+            done = self.tick % 100 == 0
+            return (self.observations, rs.randint(0, 2, n).astype(np.float32), done, np.zeros(n, bool), [], np.arange(n), np.ones(n, bool))
+
+        def send(self, actions):
+            pass
+
+    shapes = {'encoder.weight': (128, 160), 'encoder.bias': (128,), 'decoder.weight': (7, 128), 'decoder.bias': (7,), 'value_head.weight': (1, 128),
+              'value_head.bias': (1,), 'weight_ih_l0': (512, 128), 'weight_hh_l0': (512, 128), 'bias_ih_l0': (512,), 'bias_hh_l0': (512,)}
+    w = {k: (rs.standard_normal(sh) * (0.01 if len(sh) == 1 else 1.0 / np.sqrt(sh[-1]))).astype(np.float32) for k, sh in shapes.items()}
+    tr = ppo_torch.Trainer(ppo_torch.Policy(w, recurrent=True), RowVec(), batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT, update_epochs=EPOCHS,
+                           learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, vf_coef=0.5, vf_clip_coef=0.1, max_grad_norm=0.5,
+                           ent_coef=0.01, total_timesteps=B * 1000, seed=1)
+
+    def one():
+        tr.evaluate(rs.exponential(size=(horizon, n, 7)).astype('float32'))
+        tr.train()
+
+    one()
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        one()
+        iters += 1
+        if time.perf_counter() - t0 > 15.0 or iters >= 20:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=iters * B / dt, unit='env_steps/s', cores=cores, cores_available=cores_avail, cpu_model=_cpu_model(), kind='port',
+                sample=f'{iters} evaluate+train iteration(s) of {n} envs x {horizon} steps of 160-float rows (batch {B}, {NMB} minibatches x '
+                       f'{EPOCHS} epochs, bptt {BPTT}) after 1 warm-up; numpy row generator, torch-fp32 MLP 128 + LSTM 128 on {cores} threads')
+
+
 def self_check(data, pol):
     """One more (untimed) evaluate + train, the train replayed by the torch-fp32 oracle trainer on the device rollout's
     experience at the FULL bench size (one epoch = 4 optimizer steps over all 524 288 rows, to bound the host time): losses and
@@ -300,12 +355,13 @@ def pmc_mfma_utilisation(kernel, waves_per_simd=2):
 def extra_workload(flags, timeout_s=600):
     """A short run of one of the side workloads (BASELINE configs[2] / configs[3]) as its own process; its JSON line, trimmed."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), '--no-cpu-baseline', '--no-breakdown', '--no-extra'] + flags
+    cmd = [sys.executable, os.path.abspath(__file__), '--no-breakdown', '--no-extra'] + flags
     try:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
         line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][-1]
         d = json.loads(line)
-        return {k: d[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline') if k in d}
+        return {k: d[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline',
+                                  'profile_ms_per_step') if k in d}
     except Exception as e:  # a side workload never takes the headline line down with it
         return dict(flags=flags, error=f'{type(e).__name__}: {e}')
 
@@ -609,7 +665,8 @@ def main():
                          'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'frac_useful': (achieved * FLOP_PER_ROW_USEFUL / FLOP_PER_ROW_UPDATE / PEAK_FP32_MFMA_TFLOPS
                                          if args.policy == 'mlp' else None),   # on the 49 real columns (32 000 FLOP/row)
-                         'traffic': traffic, 'traffic_source': traffic_source, 'traffic_build': source_build_id(),
+                         'traffic': traffic, 'traffic_source': traffic_source if traffic is not None else None,
+                         'traffic_note': None if traffic is not None else traffic_source, 'traffic_build': source_build_id(),
                          'avg_launch_ms': avg_ms, 'launches': launches, 'bracketed': f'every {event_stride}. launch of the timed region' if event_stride > 1 else 'every launch of the timed region',
                          # ppo_mlp_grad's launch carries its own HIP events (hipExtLaunchKernelGGL start/stop: the dispatch's begin and end,
                          # what rocprofv3's kernel trace reports); the other kernels are bracketed by events recorded on their stream
@@ -669,21 +726,24 @@ def main():
                 out['self_check'] = self_check(data, pol)
             if args.workload == 'c4' and not cnn_lstm:
                 out['cpu_baseline'] = cpu_baseline_c4()
-            elif args.policy == 'mlp':          # the headline configuration; the recurrent side workloads carry none
+            elif args.workload == 'c3':
+                out['cpu_baseline'] = cpu_baseline_c3()
+            elif args.policy == 'mlp':          # the headline configuration
                 out['cpu_baseline'] = cpu_baseline()
         if world == 1 and args.workload == 'squared' and args.policy == 'mlp' and not args.no_extra:
             # BASELINE configs[2] / configs[3] as short side runs (own processes, after everything of the headline is measured):
             # not the metric, but driver-run instead of builder-run numbers for the recurrent and the conv path
             del data, vec, pol
             torch.cuda.empty_cache()
-            out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),
-                                      extra_workload(['--workload', 'c4', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0']),
+            nb = ['--no-cpu-baseline']
+            out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),      # + its cpu_baseline
+                                      extra_workload(['--workload', 'c4', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0'] + nb),
                                       # the same with the rows-form products on the bf16 matrix path (six-term split, fp32 accumulate)
-                                      extra_workload(['--workload', 'c4', '--products', 'bf16x6', '--steps', '3', '--warmup', '1', '--sustained-seconds', '0']),
-                                      # a width outside the fused kernels on the headline env (GEMM path, general.py)
-                                      extra_workload(['--hidden', '256', '--steps', '5', '--warmup', '2', '--sustained-seconds', '0']),
+                                      extra_workload(['--workload', 'c4', '--products', 'bf16x6', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0'] + nb),
+                                      # widths outside the 128-wide fused kernels on the headline env (tile-kernel rollout + GEMM-path update)
+                                      extra_workload(['--hidden', '256', '--steps', '5', '--warmup', '2', '--sustained-seconds', '0'] + nb),
                                       # the recurrent NatureCNN of environments/atari/torch.py:4-6 (GEMM path, general.py)
-                                      extra_workload(['--workload', 'c4', '--policy', 'lstm', '--steps', '2', '--warmup', '1', '--sustained-seconds', '0'])]
+                                      extra_workload(['--workload', 'c4', '--policy', 'lstm', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0'] + nb)]
         print(json.dumps(out), flush=True)
     if world > 1:
         from pufferlib_amd import dist as pdist
