@@ -32,6 +32,13 @@
 #ifndef PFA_GRAD_FCOL
 #define PFA_GRAD_FCOL 1   // 0 = the trailing column through a full MFMA k-step in the forward (A/B timing)
 #endif
+#ifndef PFA_GRAD_GLDS
+// 1 = the next X tile by direct-to-LDS loads (global_load_lds_dwordx4, swizzled chunk layout, third tile slot) instead of the
+// 16-register prefetch + 8 ds_writes.  Built and measured in round 4 (profiles/r04_grad_variants.txt): identical bits, 54.75 vs
+// 54.73 us per launch — the register allocation is set by the consumer branch (dW1 accumulators), so the producer's freed
+// prefetch registers change neither the occupancy nor the three loop-invariant dwords that spill.  Kept as a variant, off.
+#define PFA_GRAD_GLDS 0
+#endif
 #ifndef PFA_GRAD_PIPE
 #define PFA_GRAD_PIPE 1   // 0 = the round-2 instruction order (kept for A/B timing with tools/variant_bench.py)
 #endif
@@ -52,20 +59,40 @@ constexpr int grad_waves_per_simd(int dp) { return dp <= 64 ? 2 : 1; }
 // Shared by all waves: lane-major MFMA fragment tables, every fragment read one conflict-free ds_read_b128:
 //   w1t[m][lane][KS(+4)] A frags of the forward GEMM: W1[16m + c][4kk + g]
 //   b1t[m][lane][4] accumulator init   w2t[m][lane][4] A frags of the heads   w2bt[m][lane][4] B frags of dh = dout.W2v
-template <int DP>
+// GL (64-float rows in the pipelined form): the X tiles are filled by direct-to-LDS loads (global_load_lds_dwordx4: the data never
+// passes through registers).  Such a load writes wave-uniform base + lane x 16 B, so the tile is stored as 16-byte chunks in the
+// order the lanes issue them, and which (row, column quad) a lane fetches is chosen so that both fragment reads stay free of bank
+// conflicts: chunk (row, kk) — columns 4 kk .. 4 kk + 3 of a row — sits in 1 KB block kk / 4 at position
+//   16 (kk & 3) + (row & 12) + ((row + kk) & 3)
+// (the forward's B fragment reads 16 rows x one kk per instruction, the consumer's A fragment 4 rows x 4 kk: either way the 64
+// lanes hit 64 different banks; the padded [row][DP + 2] tile of the register-staged form has 2-way conflicts on the second).
+// A third slot: the load of X(j+1) is issued at the top of tile j, while the consumer still reads X(j-1).
+constexpr bool grad_glds(int dp, int ktm) { return PFA_GRAD_GLDS && PFA_GRAD_PIPE && dp == 64 && ktm <= 3; }
+template <int DP, bool GL = false>
 struct GradLds {
     static constexpr int XS = XTile<DP>::XS;
     static constexpr int KS = DP / 4;
     static constexpr int W1S = KS + 4;        // lane stride of w1t (16 B aligned, spreads 16 lanes over all banks)
     static constexpr int HS = kHidden + 4;    // row stride of the hidden tile (16 B aligned rows, conflict-free reads)
     static constexpr int DS = 20;             // dout tile row stride
-    static constexpr int kXT = 0;                        // + slot * 16 * XS        X tiles (ring of 2)
-    static constexpr int kHT = 2 * 16 * XS;              // hidden tile [row][u] (post-relu) of the published tile
+    static constexpr int kXSlot = GL ? 16 * DP : 16 * XS;   // floats per X tile
+    static constexpr int kXSlots = GL ? 3 : 2;
+    static constexpr int kXT = 0;                        // + slot * kXSlot          X tiles (ring)
+    static constexpr int kHT = kXSlots * kXSlot;         // hidden tile [row][u] (post-relu) of the published tile
     static constexpr int kDT = kHT + 16 * HS;            // dout tile [row][o] of the published tile
     static constexpr int kPairFloats = kDT + 16 * DS;
     static constexpr int kW1Floats = kMT * 64 * W1S;
     static constexpr int kTabFloats = kMT * 64 * 4;
     static constexpr int kFloats = grad_pairs(DP) * kPairFloats + kW1Floats + 3 * kTabFloats;
+    // float index of X[row][col] inside a tile
+    __device__ static __forceinline__ int xi(int row, int col) {
+        if constexpr (GL) {
+            const int kk = col >> 2;
+            return (kk >> 2) * 256 + (((kk & 3) << 4) + (row & 12) + ((row + kk) & 3)) * 4 + (col & 3);
+        } else {
+            return row * XS + col;
+        }
+    }
 };
 
 // "Native" layout of one workgroup partial: gradients in MFMA C-fragment order (conflict-free LDS reduction and
@@ -116,7 +143,8 @@ template <int DP, int ABL = 0, int KKU = DP / 4, bool MH = false, int KTM = DP /
 __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     ppo_mlp_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, const float *params, int a, uint32_t heads,
                         pfa_ppo_hparams hp, const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
-    using L = GradLds<DP>;
+    constexpr bool kGlds = grad_glds(DP, KTM);
+    using L = GradLds<DP, kGlds>;
     using NL = NativeLayout<DP, KTM, COL>;
     constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KS = DP / 4, V = DP / 4, W1S = L::W1S;
     constexpr int NLD = (16 * V + 63) / 64;  // float4 loads per lane per tile
@@ -230,9 +258,9 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
 #pragma unroll
         for (int i = 0; i < 6; ++i) stats[i] = 0.0f;
 
-        float4 xpre[NLD];  // register prefetch of the next tile's X rows and per-row scalars: issued a whole tile ahead
+        float4 xpre[kGlds ? 1 : NLD];  // register prefetch of the next tile's X rows (GL: none, the rows go straight to LDS)
         RowScalars rspre;
-        auto prefetch = [&](long long tile) {
+        auto prefetch = [&](long long tile, float *xdst) {   // xdst: the LDS slot of `tile` (GL)
             const bool ok = tile < tiles;
             const unsigned first = ok ? map.tile_first((unsigned)tile) : 0u;
             rspre = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -240,6 +268,20 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 const unsigned fr = map.tile_row((unsigned)tile, first, c, aligned);
                 rspre = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
             }
+            if constexpr (kGlds) {
+                // lane l of block b fetches chunk (row, kk = 4b + (l >> 4)) with row = (l & 12) + ((l - (l >> 4)) & 3): position l of the block
+                const int kl = lane >> 4, row = (lane & 12) + ((lane - kl) & 3);
+                if (ok) {
+                    const unsigned frow = map.tile_row((unsigned)tile, first, row, aligned);
+                    const float *src = ex.obs + (size_t)frow * DP + 4 * kl;
+#pragma unroll
+                    for (int b = 0; b < DP / 16; ++b)
+                        __builtin_amdgcn_global_load_lds(src + 16 * b, (__attribute__((address_space(3))) void *)(xdst + 256 * b), 16, 0, 0);
+                } else {   // a pair's padding tile: zeros (its rows carry weight 0, but whatever the slot held must not reach the loss)
+#pragma unroll
+                    for (int b = 0; b < DP / 16; ++b) *reinterpret_cast<float4 *>(xdst + 256 * b + 4 * lane) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < NLD; ++j) {
                 const int idx = lane + 64 * j;
@@ -250,15 +292,17 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                     xpre[j] = *reinterpret_cast<const float4 *>(ex.obs + (size_t)row * DP + 4 * c4);
                 }
             }
+            }
         };
-        prefetch(pair_global);
-        __syncthreads();  // fragment tables ready
+        prefetch(pair_global, pl + L::kXT);
+        __syncthreads();  // fragment tables ready (GL: and X(0) landed — a workgroup barrier drains the direct-to-LDS loads)
 
         float *hsP = pl + L::kHT, *dsP = pl + L::kDT;
         for (int j = 0; j < J; ++j) {
-            float *xs = pl + L::kXT + (j & 1) * 16 * XS;
+            float *xs = pl + L::kXT + (j % L::kXSlots) * L::kXSlot;
             PFA_STAMP(j, 0);
             // ---- stage X(j), forward, heads, loss (registers + this tile's X slot only) ------------------------------
+            if constexpr (!kGlds) {
 #pragma unroll
             for (int q = 0; q < NLD; ++q) {
                 const int idx = lane + 64 * q;
@@ -269,8 +313,10 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                     d[1] = make_float2(xpre[q].z, xpre[q].w);
                 }
             }
+            }
             const RowScalars rs = rspre;
-            prefetch(pair_global + (long long)(j + 1) * pair_count);  // lands during this tile's ~10k cycles
+            // lands during this tile's ~10k cycles (GL: in the slot X(j-2) used; the barrier pair of this tile drains it)
+            prefetch(pair_global + (long long)(j + 1) * pair_count, pl + L::kXT + ((j + 1) % L::kXSlots) * L::kXSlot);
             wave_lds_fence();
             PFA_STAMP(j, 1);
 
@@ -287,7 +333,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             float xb[2][4];
             auto load_group = [&](int k4, int b) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) xb[b][q] = xs[c * XS + 4 * (4 * k4 + q) + g];
+                for (int q = 0; q < 4; ++q) xb[b][q] = xs[L::xi(c, 4 * (4 * k4 + q) + g)];
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) wq[b][m] = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + 4 * k4);
             };
@@ -306,7 +352,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (FCOL) {
-                const float xcol = xs[c * XS + 16 * KTM];     // X[row = c][16 KTM]
+                const float xcol = xs[L::xi(c, 16 * KTM)];     // X[row = c][16 KTM]
 #pragma unroll
                 for (int m = 0; m < kMT; ++m) {
                     const f32x4 wc = *reinterpret_cast<const f32x4 *>(w1t + (m * 64 + lane) * W1S + KS);
@@ -503,14 +549,14 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
         auto backward_tile = [&](int jj) {
             const long long tile = pair_global + (long long)jj * pair_count;
             if ((ABL & 2) || tile >= tiles) return;
-            const float *xs = pl + L::kXT + (jj & 1) * 16 * XS;
+            const float *xs = pl + L::kXT + (jj % L::kXSlots) * L::kXSlot;
             const f32x4 dout = *reinterpret_cast<const f32x4 *>(dsP + c * DS + 4 * g);
             float xa[KTM][4], xc[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                for (int kt = 0; kt < KTM; ++kt) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
-                xc[r] = COL ? xs[(4 * g + r) * XS + 16 * KTM] : 0.0f;
+                for (int kt = 0; kt < KTM; ++kt) xa[kt][r] = xs[L::xi(4 * g + r, 16 * kt + c)];
+                xc[r] = COL ? xs[L::xi(4 * g + r, 16 * KTM)] : 0.0f;
             }
             if constexpr (kPipe) {
             // every LDS read of the tile is issued up front (dout, the X fragments above, the W2v fragments, the hidden tile for
@@ -1155,7 +1201,7 @@ static int launch_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb
 #define PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, KTMV, COLV) PFA_LAUNCH_GRAD_PERM(DPV, KKUV, MHV, KTMV, COLV, false)
 #define PFA_LAUNCH_GRAD_PERM(DPV, KKUV, MHV, KTMV, COLV, PERMV)                                                             \
     {                                                                                                                      \
-        constexpr size_t lds_bytes = (size_t)GradLds<DPV>::kFloats * sizeof(float);                                        \
+        constexpr size_t lds_bytes = (size_t)GradLds<DPV, grad_glds(DPV, KTMV)>::kFloats * sizeof(float);                       \
         static_assert((size_t)2 * NativeLayout<DPV, KTMV, COLV>::kCount * sizeof(float) <= lds_bytes,                       \
                       "the two reduction buffers must fit in the tile/table area");                                       \
         static bool attr_set = false;                                                                                      \
@@ -1383,7 +1429,7 @@ extern "C" int pfa_probe_grad(const pfa_experience *exp, int64_t batch_rows, int
     const int grid = grad_grid(mbs, 64);
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
-    constexpr size_t lds_bytes = (size_t)GradLds<64>::kFloats * sizeof(float);
+    constexpr size_t lds_bytes = (size_t)GradLds<64, grad_glds(64, 3)>::kFloats * sizeof(float);
 #define PFA_PROBE_CASE(A)                                                                                              \
     case A:                                                                                                            \
         PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_kernel<64, A, 13, false, 3, true>,                                \
