@@ -345,7 +345,8 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     L = _lib.lib()
     hp = _make_hparams(config, experience)
     # (the conv engine owns its gradient workspaces; the shared one then only serves adv_stats / GAE / log sums: any MLP shape sizes it)
-    dims = _lib.MlpDims(64, 64, 128, 4, 0) if conv else fp.dims
+    # (likewise the GEMM-path engine: a wide flat observation would otherwise reserve 256 fused-kernel partials of 128 x obs_stride floats)
+    dims = _lib.MlpDims(64, 64, 128, 4, 0) if (conv or gen_engine is not None) else fp.dims
     ws_bytes = max(L.pfa_ppo_workspace_bytes(C.byref(dims), config.batch_size, C.byref(hp)),
                    L.pfa_gae_workspace_bytes(config.batch_size))
     dp_sums = torch.zeros(2 * experience.num_minibatches + 4, dtype=torch.float64, device=device)

@@ -31,7 +31,15 @@ def obs_stride_for(obs_dim, recurrent=False):
 
 
 def needs_general(policy_module, recurrent):
-    """True when the policy's shape is outside what the fused kernels are instantiated for (see the module docstring)."""
+    """True when the policy's shape is outside what the fused kernels are instantiated for (see the module docstring).  A module's
+    shape does not change: the answer is cached on it (forward() asks on every call)."""
+    cache = policy_module.__dict__.setdefault('_pfa_needs_general', {})
+    if recurrent not in cache:
+        cache[recurrent] = _needs_general(policy_module, recurrent)
+    return cache[recurrent]
+
+
+def _needs_general(policy_module, recurrent):
     from .models import HIDDEN, decoder_heads, find_lstm, find_mlp
     lstm = find_lstm(policy_module)
     if find_cnn(policy_module) is not None:
@@ -42,6 +50,15 @@ def needs_general(policy_module, recurrent):
     if H != HIDDEN or sum(nvec) > 15 or D > (RECURRENT_STRIDES if recurrent else KERNEL_STRIDES)[-1]:
         return True
     return lstm is not None and (lstm.input_size, lstm.hidden_size) != (HIDDEN, HIDDEN)
+
+
+def _weights_changed(module, _incompatible_keys=None):
+    """load_state_dict post hook of Policy / RecurrentPolicy: the parameters were overwritten in place, so every packed operand copy
+    (GEMM-path Net, conv engine) is stale — the same version bump the optimizer step and the checkpoint loader make."""
+    for obj in (getattr(getattr(module, 'gen_engine', None), 'net', None), getattr(getattr(module, '_evaluator', None), 'net', None),
+                getattr(module, 'cnn_engine', None)):
+        if obj is not None and hasattr(obj, 'version'):
+            obj.version += 1
 
 
 def _adopt(self, obs_stride, device, recurrent):
@@ -75,7 +92,12 @@ def _evaluator(self, device, recurrent):
         else:
             net = general.net_for_flat(self._flat)
         self._evaluator = general.Evaluator(net)
-    self._evaluator.net.version += 1
+    eng = getattr(self, 'gen_engine', None)
+    if not (isinstance(self._flat, general.GeneralParams) and eng is not None and self._evaluator.net is eng.net):
+        # the fused 128-wide update kernels change the kernel-layout buffer behind this evaluator's back: re-pack its operand copies on
+        # every call (so does a policy used on its own, whose tensors anybody may write).  A trainer's GEMM-path Net is told when its
+        # weights change: the optimizer step (Engine.clip_adam), the checkpoint loader and load_state_dict (post hook) bump its version.
+        self._evaluator.net.version += 1
     return self._evaluator
 
 
@@ -86,6 +108,7 @@ class Policy(torch.nn.Module):
         self.noise_seed = int(seed)
         self.noise_step = 0
         self._flat = None
+        self.register_load_state_dict_post_hook(_weights_changed)
 
     def adopt(self, obs_stride, device):
         """Move the parameters into one flat device buffer (idempotent for the same stride/device)."""
@@ -242,6 +265,7 @@ class RecurrentPolicy(torch.nn.Module):
         self.noise_seed = int(seed)
         self.noise_step = 0
         self._flat = None
+        self.register_load_state_dict_post_hook(_weights_changed)
 
     @property
     def lstm(self):

@@ -358,12 +358,19 @@ class Evaluator:
             packed = actions
         else:
             a = action.to(dev)
+            # given actions must name a choice of their head: the reference's gather (cleanrl.py:38-44) raises on anything else, and the
+            # kernels' nibble packing would let a choice >= 16 spill into the neighbouring heads (one host round trip: not the rollout path)
             if net.heads:                                            # (rows, heads) choices -> the kernels' nibble packing
                 a = a.reshape(rows, -1).to(torch.int64)
+                sizes = torch.tensor([(net.heads >> (4 * h)) & 15 for h in range(a.shape[1])], device=dev, dtype=torch.int64)
+                if sizes.numel() != a.shape[1] or int(sizes.min()) == 0 or bool(((a < 0) | (a >= sizes)).any()):
+                    raise IndexError(f'action out of range for MultiDiscrete heads {sizes.tolist()}')
                 shifts = torch.arange(0, 4 * a.shape[1], 4, device=dev, dtype=torch.int64)
                 packed = (a << shifts).sum(dim=1)
             else:
                 packed = a.reshape(rows).to(torch.int64)
+                if rows and bool(((packed < 0) | (packed >= net.A)).any()):
+                    raise IndexError(f'action out of range for Discrete({net.A})')
             packed = packed.contiguous()
             _lib.check(L.pfa_heads_rows_eval(_lib.ptr(out), NO, rows, net.A, net.heads, _lib.ptr(packed), _lib.ptr(logprob), _lib.ptr(entropy),
                                              _lib.ptr(value), _lib.stream_handle()), 'heads_rows_eval')
