@@ -468,13 +468,15 @@ def main():
         clean_pufferl.evaluate(data)
         clean_pufferl.train(data)
     # dominant kernel of the update: the fused fwd/loss/bwd kernel (MLP) or the BPTT kernel (LSTM)
-    dominant = {'mlp': 'ppo_mlp_grad', 'lstm': 'lstm_seq_bwd', 'cnn': 'igemm_rows', 'wide': 'igemm_rows'}[args.policy]
+    # (a wide Default on rows of <= 64 floats trains through the fused kernel of csrc/ppo_wide.hip; other wide shapes through the GEMM path)
+    wide_fused = args.policy == 'wide' and getattr(data.gen_engine, 'wide_ws', None) is not None
+    dominant = {'mlp': 'ppo_mlp_grad', 'lstm': 'lstm_seq_bwd', 'cnn': 'igemm_rows', 'wide': 'ppo_wide_grad' if wide_fused else 'igemm_rows'}[args.policy]
     L.pfa_timing_select(dominant.encode())
     # The event pair around a launch serialises the queue (~7 us of dispatch bubble each: 16 bracketed launches per step cost
     # the headline 7 %, measured).  The dominant kernel's launches all have the same shape in the MLP / LSTM updates, so every
     # 5th one is bracketed (5 is coprime to the 16 launches of a step: every epoch x minibatch position gets sampled); the conv
     # update's launches differ in shape and are all bracketed.
-    event_stride = 1 if args.policy in ('cnn', 'wide') else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '5'))
+    event_stride = 1 if (args.policy in ('cnn', 'wide') and not wide_fused) else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '5'))
     L.pfa_timing_stride(event_stride)
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
@@ -551,6 +553,7 @@ def main():
     if rank == 0 and not args.no_breakdown:
         L.pfa_timing_enable(0)
         names = (('philox_exp_noise', 'rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_mlp_grad', 'ppo_reduce_adam', 'ppo_reduce', 'adam_clip') if args.policy == 'mlp'
+                 else ('philox_exp_noise', 'rollout_mlp_squared', 'squared_tape', 'gae', 'ppo_wide_grad', 'ppo_wide_reduce', 'adam_clip') if wide_fused
                  else ('igemm_rows', 'igemm_weights', 'gae', 'adam_clip') if args.policy in ('cnn', 'wide')
                  else (('rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'), 'squared_tape', 'gae', 'lstm_seq_fwd',
                        'lstm_seq_bwd', 'gemm_tn', 'adam_clip'))
@@ -630,13 +633,18 @@ def main():
                 step_flop += per_gpu * (lstm_f + 2 * 512 * 16 + EPOCHS * (2 * lstm_f + 2 * 2 * 512 * 16))
             achieved = step_flop * K / (total_ms * 1e-3) / 1e12 if launches else 0.0
             flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
-        if args.policy == 'wide':
+        if wide_fused:
+            # SURVEY 8d's per-row figure at another width: forward 2 (64 H + 9 H), backward 2 (9 H + 9 H + 64 H) = 310 H (39 680 at H = 128)
+            flop_row = 310 * args.hidden
+            achieved = flop_row * rows_per_launch / (avg_ms * 1e-3) / 1e12 if launches else 0.0
+        elif args.policy == 'wide':
             # rows-form launches of the GEMM path: encoder + heads forward in the rollout and in every epoch, d feature = dout W2v per epoch
             Hh, Kp_, NO_ = args.hidden, 64, 16
             step_flop = per_gpu * ((2 * Kp_ * Hh + 2 * Hh * NO_) * (1 + EPOCHS) + EPOCHS * 2 * NO_ * Hh)
             achieved = step_flop * K / (total_ms * 1e-3) / 1e12 if launches else 0.0
             flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
         traffic, traffic_source = pmc_traffic(dominant)
+        wide_how = 'fused kernels of csrc/ppo_wide.hip + tile-kernel rollout' if wide_fused else 'GEMM path, general.py'
         out = {
             'metric': (f'env steps/sec end-to-end PPO (rollout+GAE+update), {NUM_ENVS} envs'
                        + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')
@@ -657,7 +665,7 @@ def main():
                                     'env parity unpinned: third-party simulator' + (', sharded' if world > 1 else '') + ')')
                        if args.workload == 'c3' else
                        f'squared d={D} nt={NT}, {NUM_ENVS} envs/GPU x {HORIZON} steps, obs 49->64 f32 rows, '
-                       f'{"MLP 128" if args.policy == "mlp" else f"MLP {args.hidden} (GEMM path, general.py)" if args.policy == "wide" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} ({"BASELINE configs[1]" if args.policy != "wide" else "the configs[1] env with a wider policy: side workload, not the metric"}'
+                       f'{"MLP 128" if args.policy == "mlp" else f"MLP {args.hidden} ({wide_how})" if args.policy == "wide" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} ({"BASELINE configs[1]" if args.policy != "wide" else "the configs[1] env with a wider policy: side workload, not the metric"}'
                        + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
             'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,

@@ -213,6 +213,7 @@ int pfa_rollout_mlp_view_squared(void *state, const pfa_squared_config *cfg, con
                                  uint8_t *terminals, uint8_t *truncations, uint8_t *masks, pfa_stream_t stream);
 
 
+
 /* ------------------------------------------------------------------------------------------
  * Stochastic vecenv (a second ocean env family on device) — replaces pufferlib.vector.Serial
  * (vector.py:70-166) over ocean.environment.make_stochastic (ocean/environment.py:61-64; horizon 100) =
@@ -437,6 +438,19 @@ int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *para
                       float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
                       float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
                       int32_t data_parallel, pfa_stream_t stream);
+
+/* The minibatch step of clean_pufferl.train (clean_pufferl.py:175-244 up to loss.backward()) for a pfa_mlp_view policy (declared with the rollout kernels above) with hidden in
+ * {64, 256, 512} (csrc/ppo_wide.hip: the hidden dimension split over the four wavefronts of a workgroup, every wave's slice of the
+ * weights and of every gradient in its registers for the whole launch): forward + sample_logits with the stored actions + PPO loss
+ * + backward over minibatch `mb` — the counterpart of pfa_ppo_mlp_grad for the 128-wide kernel-layout policy.  `grads` names the
+ * same six tensors inside the gradient buffer (torch shapes: what loss.backward() leaves in .grad, already divided by
+ * global_mb_rows), tail16 receives the loss sums as in pfa_ppo_mlp_grad.  workspace: pfa_ppo_wide_workspace_bytes(params).
+ * Clip + Adam: pfa_adam_clip_step on the flat buffer.  pfa_ppo_wide_supported: 1 when the shape is one this kernel takes. */
+int pfa_ppo_wide_supported(const pfa_mlp_view *view);
+size_t pfa_ppo_wide_workspace_bytes(const pfa_mlp_view *view);
+int pfa_ppo_wide_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, const pfa_mlp_view *params, const pfa_mlp_view *grads,
+                      float *tail16, const pfa_ppo_hparams *hp, const double *adv_stats, int64_t global_mb_rows, void *workspace,
+                      pfa_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Recurrent policy — pufferlib.models.LSTMWrapper (models.py:64-111): Default encoder -> nn.LSTM(128,128,1) ->

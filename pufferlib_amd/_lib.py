@@ -16,7 +16,7 @@ REPO = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
-SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip', 'igemm.hip', 'cnn_heads.hip', 'general.hip']
+SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip', 'igemm.hip', 'cnn_heads.hip', 'general.hip', 'ppo_wide.hip']
 HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp', 'p2p_ll.hpp',
            os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
@@ -158,6 +158,10 @@ _SIGNATURES = {
     'pfa_rollout_mlp_squared': (C.c_int, [P, C.POINTER(SquaredConfig), P, C.POINTER(MlpDims), C.POINTER(Experience),
                                           P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
     'pfa_mlp_view_supported': (C.c_int, [C.POINTER(MlpView)]),
+    'pfa_ppo_wide_supported': (C.c_int, [C.POINTER(MlpView)]),
+    'pfa_ppo_wide_workspace_bytes': (C.c_size_t, [C.POINTER(MlpView)]),
+    'pfa_ppo_wide_grad': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, C.POINTER(MlpView), C.POINTER(MlpView), P, C.POINTER(PpoHparams), P,
+                                    C.c_int64, P, P]),
     'pfa_mlp_view_forward_sample': (C.c_int, [P, C.c_int64, C.POINTER(MlpView), P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
     'pfa_rollout_mlp_view_squared': (C.c_int, [P, C.POINTER(SquaredConfig), C.POINTER(MlpView), C.POINTER(Experience), P, C.POINTER(NoiseKey),
                                                C.c_int64, P, P, P, P, P, P]),

@@ -427,6 +427,12 @@ class Engine:
         self._step_rows = 0
         self._upd = None
         self.mlp_view = tile_view(gp)
+        # ... and the fused forward + loss + backward kernel of csrc/ppo_wide.hip for the widths it is built for (64 / 256 / 512)
+        import os
+        self.wide_ws = self._wide_gview = None
+        if (self.mlp_view is not None and os.environ.get('PFA_WIDE_FUSED', '1') != '0'
+                and _lib.lib().pfa_ppo_wide_supported(C.byref(self.mlp_view))):
+            self.wide_ws = torch.empty(int(_lib.lib().pfa_ppo_wide_workspace_bytes(C.byref(self.mlp_view))), dtype=torch.uint8, device=self.dev)
         if num_agents:
             self.reset_state(num_agents)
 
@@ -559,6 +565,11 @@ class Engine:
         net, gp, exp = self.net, self.gp, self.experience
         L = _lib.lib()
         stream = _lib.stream_handle()
+        if self.wide_ws is not None:          # Default(64 / 256 / 512): one fused launch + the fixed-order sum of its partials
+            _lib.check(L.pfa_ppo_wide_grad(C.byref(exp.c), B, mb, C.byref(self.mlp_view), C.byref(self._grad_view(grads)),
+                                           C.c_void_p(grads.data_ptr() + 4 * gp.count), C.byref(hp), _lib.ptr(adv_stats), global_mb_rows,
+                                           _lib.ptr(self.wide_ws), stream), 'ppo_wide_grad')
+            return
         net.pack()
         M, Th = exp.minibatch_size, exp.bptt_horizon
         R = M // Th
@@ -657,6 +668,16 @@ class Engine:
                 gv[nm['w_hh']].copy_(u['gcat'][:, I:])
                 gv[nm['b_ih']].copy_(u['gbcat'])
                 gv[nm['b_hh']].copy_(u['gbcat'])
+
+    def _grad_view(self, grads):
+        """The six tensors of the policy inside the gradient buffer `grads` (GeneralParams layout: named_parameters() order, torch
+        shapes): the parameter view's pointers moved by the distance between the two buffers."""
+        if self._wide_gview is None or self._wide_gview[0] != grads.data_ptr():
+            v, shift = self.mlp_view, grads.data_ptr() - self.gp.flat.data_ptr()
+            gv = _lib.MlpView(v.w1 + shift, v.ldw1, v.obs_dim, v.obs_stride, v.hidden, v.num_actions, 0, v.b1 + shift, v.w2 + shift, v.b2 + shift,
+                              v.wv + shift, v.bv + shift)
+            self._wide_gview = (grads.data_ptr(), gv)
+        return self._wide_gview[1]
 
     def clip_adam(self, grads, opt, max_grad_norm, loss_acc, loss_scale):
         """clip_grad_norm_ + optimizer.step() (clean_pufferl.py:240-244) on the flat buffer; the packed operand forms go stale."""

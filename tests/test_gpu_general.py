@@ -248,9 +248,11 @@ def _check_update(data, pol, opol, tr, strip):
         np.testing.assert_allclose(sd[strip(k)].cpu().numpy(), arr, err_msg=k, **TOL)
 
 
-@pytest.mark.parametrize('hidden,d', [(64, 3), (256, 3), (512, 5)])
+@pytest.mark.parametrize('hidden,d', [(64, 3), (256, 3), (512, 3), (512, 5), (256, 1), (64, 2)])
 def test_wide_default_policy_rollout_and_update_vs_oracle(hidden, d, matrix_products):
-    """Default(hidden_size != 128) on the device Squared vecenv: the GEMM-path engine behind create / evaluate / train."""
+    """Default(hidden_size != 128) on the device Squared vecenv behind create / evaluate / train: rows of up to 64 floats (d <= 3: 9 / 25 / 49
+    columns) run the tile-kernel rollout and the fused gradient kernel of csrc/ppo_wide.hip (hidden split over the four waves), d = 5 (121
+    columns, 128-float rows) the GEMM-path engine."""
     from pufferlib_amd import clean_pufferl, cleanrl, general, models
     from test_gpu_ppo import _config
     from oracle import c_oracle, ppo_torch
