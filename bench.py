@@ -38,6 +38,7 @@ D, NT = 3, 1             # obs 7x7 = 49 floats, padded to a 64-float row (256 B)
 FLOP_PER_ROW_UPDATE = 39680          # fwd 18 688 + bwd 20 992 per row per epoch (the 64-float padded row)
 FLOP_PER_ROW_USEFUL = 2 * (49 * 128 + 128 * 9) + 2 * 49 * 128 + 2 * 2 * 128 * 9   # the same on the 49 real columns: 32 000
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 2:1-sparsity headline figure is not a roof)
 # NatureCNN (workload c4; SURVEY 8d: ~18.7 MFLOP per forward sample), products of the rows-form kernel per frame:
 #   forward  conv1 2*400*256*32 + conv2 2*81*512*64 + conv3 2*49*576*64 + fc 2*3136*512          = 18 685 952
 #   dX       fc 2*3136*512 + conv3 (= its forward) + conv2 (= its forward); conv1 needs none      = 12 132 352
@@ -645,6 +646,7 @@ def main():
             flop_row, rows_per_launch = step_flop * K / max(launches, 1), 1
         traffic, traffic_source = pmc_traffic(dominant)
         wide_how = 'fused kernels of csrc/ppo_wide.hip + tile-kernel rollout' if wide_fused else 'GEMM path, general.py'
+        roof_peak = PEAK_FP32_MFMA_TFLOPS if args.products == 'fp32' else PEAK_BF16_MFMA_TFLOPS / 6.0
         out = {
             'metric': (f'env steps/sec end-to-end PPO (rollout+GAE+update), {NUM_ENVS} envs'
                        + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')
@@ -668,9 +670,14 @@ def main():
                        f'{"MLP 128" if args.policy == "mlp" else f"MLP {args.hidden} ({wide_how})" if args.policy == "wide" else "MLP 128 + LSTM 128 (bptt 16)"}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} ({"BASELINE configs[1]" if args.policy != "wide" else "the configs[1] env with a wider policy: side workload, not the metric"}'
                        + (', sharded as configs[4]' if world > 1 else '') + ')',
                        'global_batch': world * per_gpu, 'parallelism': f'dp{world}'},
-            'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                         'products': args.products,      # bf16x6: `achieved` still counts the fp32 product's algorithmic flop, `peak` stays the fp32-MFMA peak
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS,
+            # bf16x6: `achieved` counts the fp32 products' algorithmic flop; every one of them is six partial products on the bf16 matrix
+            # pipe, so the roof it runs against is that pipe's dense peak / 6 (2.5 PFLOP/s / 6 = 416.7 TFLOP/s of fp32-equivalent products)
+            'roofline': {'bound': 'mfma', 'kernel': dominant, 'achieved': achieved, 'peak': roof_peak,
+                         'peak_is': ('fp32 MFMA dense peak (v_mfma_f32_16x16x4_f32)' if args.products == 'fp32' else
+                                     'bf16 MFMA dense peak 2500 TFLOP/s / 6 partial products per fp32 product'),
+                         'products': args.products,
+                         'unit': 'TFLOP/s', 'frac': achieved / roof_peak,
+                         'frac_of_fp32_peak': achieved / PEAK_FP32_MFMA_TFLOPS,
                          'frac_useful': (achieved * FLOP_PER_ROW_USEFUL / FLOP_PER_ROW_UPDATE / PEAK_FP32_MFMA_TFLOPS
                                          if args.policy == 'mlp' else None),   # on the 49 real columns (32 000 FLOP/row)
                          'traffic': traffic, 'traffic_source': traffic_source if traffic is not None else None,
