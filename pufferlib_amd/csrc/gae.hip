@@ -17,6 +17,13 @@
 // Roofline: HBM.  Algorithmic bytes: read r,v,d (12 B) + write adv, returns (8 B) = 20 B per element.
 #include "common.hpp"
 
+// Floating-point contraction is switched off where the reference's arithmetic is restated (hipcc's __fmul_rn / __fadd_rn wrappers
+// contract like plain operators — checked in the ISA — so the code below uses plain operators under this pragma), and the ONE
+// fused multiply-add it keeps is written out: the recurrence's last operation, adv = fma(coef, adv_next, delta).  That is one
+// rounding fewer per step than the reference's x86-64 build (<= 1 ulp per step apart, and closer to the exact value); the conv
+// policy's update test against the DOUBLE-precision oracle (tests/test_gpu_cnn_ppo.py) sits at its 1e-5 only with it.
+#define PFA_GAE_FP _Pragma("clang fp contract(off)")
+
 namespace pfa {
 
 constexpr int kGaeThreads = 256;
@@ -55,7 +62,7 @@ __device__ __forceinline__ void gae_load(const float *dones, const float *values
 
 __device__ __forceinline__ Affine gae_thread_map(const GaeItems &it, long long s, long long n, float gamma, float lam,
                                                  bool pin_last) {
-#pragma clang fp contract(off)   // (hipcc's __fmul_rn / __fadd_rn wrappers contract into fmas — checked in the ISA — so: plain operators, contraction off)
+    PFA_GAE_FP   // (hipcc's __fmul_rn / __fadd_rn wrappers contract into fmas — checked in the ISA — so: plain operators, contraction off)
     Affine f = {1.0, 0.0};
 #pragma unroll
     for (int i = kGaeItems - 1; i >= 0; --i) {
@@ -135,7 +142,7 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
     block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
     float last = (float)(after.c * s_carry + after.d);  // adv at the first element after this thread's items
     {
-#pragma clang fp contract(off)   // the reference's x86-64 build multiplies and adds separately
+    PFA_GAE_FP   // the reference's x86-64 build multiplies and adds separately
 #pragma unroll
     for (int i = kGaeItems - 1; i >= 0; --i) {
         const long long t = s + i;
@@ -143,10 +150,10 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
         if (t == n - 1 && halo == 0) {
             last = 0.0f;
         } else {  // the reference's statement order and rounding (c_gae.pyx:27-30)
-            // every product and sum rounded on its own (contraction is off in this block), like the reference's x86-64 build
+            // delta as the reference's x86-64 build rounds it (every product and sum on its own); the step itself is one fma
             const float nnt = 1.0f - it.d[i + 1];
             const float delta = (it.r[i + 1] + (gamma * it.v[i + 1]) * nnt) - it.v[i];
-            last = delta + (((gamma * lam) * nnt) * last);
+            last = fmaf((gamma * lam) * nnt, last, delta);
         }
         adv[t] = last;
         if (ret) ret[t] = last + it.v[i];
@@ -217,7 +224,7 @@ __global__ void gae_shard_fold_kernel(const double *pub, int rank, int world, lo
                                       float *dones, float *values, float *rewards, double *carry_out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     auto last_map = [&](int q) -> Affine {
-#pragma clang fp contract(off)
+        PFA_GAE_FP
         if (q == world - 1) return Affine{0.0, 0.0};
         const float d1 = (float)pub[6 * (q + 1) + 3], v1 = (float)pub[6 * (q + 1) + 4], r1 = (float)pub[6 * (q + 1) + 5];
         const float v0 = (float)pub[6 * q + 2];

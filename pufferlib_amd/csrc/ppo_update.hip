@@ -797,7 +797,7 @@ __device__ __forceinline__ void adam_element(float &p, float &m, float &v, float
     const float gi = g * clip;
     m = m + w1 * (gi - m);                                   // exp_avg.lerp_(grad, 1 - beta1)
     v = (v * beta2) + ((w2 * gi) * gi);                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
-    const float denom = (__fsqrt_rn(v) / bc2_sqrt) + eps;
+    const float denom = (sqrtf(v) / bc2_sqrt) + eps;
     p = p + ((neg_step_size * m) / denom);                   // param.addcdiv_(exp_avg, denom, value=-step_size)
 }
 __device__ __forceinline__ float clip_factor(double sum_sq, float max_grad_norm) {   // clip_grad_norm_: min(1, max_norm / (norm + 1e-6))

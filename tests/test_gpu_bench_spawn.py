@@ -35,6 +35,11 @@ def test_plain_python_invocation_spawns_its_ranks():
     assert dist['transport']['grad_bucket'] in ('p2p', 'torch') and dist['p2p_status'] in (0, -1)
     if dist['transport']['grad_bucket'] == 'p2p':
         assert dist['p2p_selftest_passed'] is True and dist['allreduce_calls']['p2p'] > 0
+        # the optimizer steps' exchanges ran inside the reduce + Adam launch (flag-in-data), and the per-transport A/B is in the line
+        assert dist['allreduce_calls']['p2p_flag_in_data'] > 0
+        assert set(dist['transports']) >= {'p2p_fused', 'p2p_launch'} and all(t['value'] > 0 for t in dist['transports'].values())
+        assert dist['transports']['p2p_fused']['launches_per_optimizer_step'] == 2
+    assert dist['collectives_per_step']['gradient_exchanges'] == 16 and dist['collectives_per_step']['small_all_reduces'] == 2
     assert len(d['rank_ms_per_step']['per_rank']) == 2 and d['rank_ms_per_step']['max'] >= d['rank_ms_per_step']['min'] > 0
 
 
@@ -43,4 +48,7 @@ def test_single_gpu_line_is_unchanged_in_shape():
     assert d['n_gpus'] == 1 and 'dist' not in d
     assert d['roofline']['kernel'] == 'ppo_mlp_grad' and 0 < d['roofline']['frac'] < 1 and d['roofline']['frac_executed'] < d['roofline']['frac']
     assert d['roofline_hbm']['bound'] == 'hbm' and 0 < d['roofline_hbm']['frac'] < 1
-    assert d['roofline']['traffic_build'] and d['roofline']['traffic_source']
+    # traffic is quoted only from a PMC summary stamped with this build: either it is there with its source, or it is null with the reason
+    r = d['roofline']
+    assert r['traffic_build'] and ((r['traffic'] is not None and r['traffic_source']) or (r['traffic'] is None and r['traffic_source'] is None and r['traffic_note']))
+    assert set(d['profile_ms_per_step']) >= {'eval_time', 'env_time', 'eval_forward_time', 'eval_misc_time', 'train_time', 'train_forward_time', 'learn_time', 'train_misc_time'}
