@@ -23,12 +23,12 @@ def _step_major(x, n, t):
     return x.view(n, t, *x.shape[1:]).transpose(0, 1).reshape(n * t, *x.shape[1:]).cpu().numpy()
 
 
-def _build(n, recurrent, seed_w, d=3, nt=1, perturb=0.05):
+def _build(n, recurrent, seed_w, d=3, nt=1, perturb=0.05, hidden=128):
     from pufferlib_amd import cleanrl, models, vector
     vec = vector.make(vector.make_squared, env_kwargs=dict(distance_to_target=d, num_targets=nt), num_envs=n,
                       backend=vector.Squared)
     torch.manual_seed(seed_w)
-    base = models.Default(vec.driver_env)
+    base = models.Default(vec.driver_env, hidden_size=hidden)
     pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base)) if recurrent else cleanrl.Policy(base)
     with torch.no_grad():
         for p in pol.parameters():
@@ -86,16 +86,17 @@ def _compare(pol, opol, data, Lo, recurrent, tr, what):
     return float(err.max()), worst
 
 
-@pytest.mark.parametrize('recurrent,epochs', [(False, 4), (True, 4)])
-def test_full_size_update_through_create_evaluate_train(recurrent, epochs, capsys):
+@pytest.mark.parametrize('recurrent,epochs,hidden', [(False, 4, 128), (True, 4, 128), (False, 4, 256), (False, 2, 512), (False, 4, 64)])
+def test_full_size_update_through_create_evaluate_train(recurrent, epochs, hidden, capsys):
     """BASELINE configs[1] (and configs[2]'s policy): 4096 envs x 128 steps, 4 minibatches of 131 072 rows, bptt 16.
     Both policies: all 4 epochs = the 16 optimizer steps one bench step runs (LSTM: state carried across the minibatches of an
-    epoch, reset at every epoch)."""
+    epoch, reset at every epoch).  hidden 64 / 256 / 512: the same configuration with Default(hidden_size=...) — the width-templated
+    persistent rollout and the fused gradient kernel of csrc/ppo_wide.hip (what `bench.py --hidden H` times)."""
     from pufferlib_amd import clean_pufferl
     from test_gpu_ppo import _config
     n, horizon, nmb, bptt = 4096, 128, 4, 16
     B = n * horizon
-    vec, pol = _build(n, recurrent, seed_w=11)
+    vec, pol = _build(n, recurrent, seed_w=11, hidden=hidden)
     cfg = _config(n, horizon, B // nmb, bptt, epochs, B * 10, HP)
     data = clean_pufferl.create(cfg, vec, pol)
     opol = _oracle_policy(pol, recurrent)
@@ -104,19 +105,21 @@ def test_full_size_update_through_create_evaluate_train(recurrent, epochs, capsy
     torch.set_num_threads(min(16, torch.get_num_threads()))
     Lo = tr.train()
     clean_pufferl.train(data)
-    if not recurrent:       # the configuration under test is the specialised one bench.py runs
+    if hidden != 128:
+        assert data.gen_engine is not None and data.gen_engine.mlp_view is not None and data.gen_engine.wide_ws is not None
+    elif not recurrent:       # the configuration under test is the specialised one bench.py runs
         assert data.flat_params.obs_dim == 49 and data.flat_params.obs_stride == 64 and data.experience.minibatch_size == 131072
     loss_err, w_err = _compare(pol, opol, data, Lo, recurrent, tr, 'full size')
     np.testing.assert_allclose(data.losses.explained_variance, Lo['explained_variance'], rtol=1e-4, atol=1e-5)
     with capsys.disabled():
-        print(f'\n[parity full-size {"lstm" if recurrent else "mlp"}] max |loss err| {loss_err:.2e}, max |weight err| {w_err:.2e}')
+        print(f'\n[parity full-size {"lstm" if recurrent else "mlp"} hidden {hidden}] max |loss err| {loss_err:.2e}, max |weight err| {w_err:.2e}')
 
 
 FLAGS = [dict(norm_adv=False), dict(clip_vloss=False), dict(norm_adv=False, clip_vloss=False), dict(anneal_lr=False),
          dict(target_kl=1e-7), dict(target_kl=10.0)]
 
 
-@pytest.mark.parametrize('recurrent', [False, True])
+@pytest.mark.parametrize('recurrent', [False, True, 'wide256'])
 @pytest.mark.parametrize('flags', FLAGS, ids=lambda f: ','.join(f'{k}={v}' for k, v in f.items()))
 def test_update_branches_vs_oracle_trainer(recurrent, flags):
     """clean_pufferl.py:211-213 (norm_adv), :222-235 (clip_vloss), :256-258 (target_kl break after an epoch), :261-264
@@ -126,9 +129,12 @@ def test_update_branches_vs_oracle_trainer(recurrent, flags):
     n, horizon, nmb, bptt, epochs = 128, 32, 2, 8, 3
     hp = [1e-3, 0.97, 0.9, 0.2, 0.5, 0.2, 0.5, 0.02]
     B = n * horizon
-    vec, pol = _build(n, recurrent, seed_w=5)
+    wide = recurrent == 'wide256'         # Default(hidden_size=256): the same branches through csrc/ppo_wide.hip
+    recurrent = recurrent is True
+    vec, pol = _build(n, recurrent, seed_w=5, hidden=256 if wide else 128)
     cfg = _config(n, horizon, B // nmb, bptt, epochs, B * 6, hp, **flags)
     data = clean_pufferl.create(cfg, vec, pol)
+    assert (data.gen_engine is not None and data.gen_engine.wide_ws is not None) == wide
     opol = _oracle_policy(pol, recurrent)
     tr = None
     for it in range(2):
