@@ -660,6 +660,7 @@ def train(data):
     # multi-kernel updates: recurrent (lstm.py) / conv (cnn.py) / any other shape (general.py)
     eng = data.gen_engine if data.gen_engine is not None else (data.lstm_engine if data.lstm_engine is not None else data.cnn_engine)
     if eng is not None:
+        eng.update_id = getattr(eng, 'update_id', 0) + 1     # a new batch of experience: per-update caches of the engine are stale
         for epoch in range(config.update_epochs):
             eng.state = None                      # lstm_state = None (clean_pufferl.py:176)
             for mb in range(nmb):

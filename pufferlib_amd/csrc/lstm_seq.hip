@@ -158,6 +158,10 @@ struct SeqBwdLds {
     float dg[kSeqRT][kDGTile];
 };
 
+// FULL: the minibatch is a whole number of 32-row tiles (every BASELINE shape) — no row guards, so every load and store of the loop is
+// unconditional and the compiler can COUNT the stores a wait skips (`vmcnt(n)`); with guards it cannot, and each wait for the prefetched
+// inputs became a full `vmcnt(0)` that also waits for the 16 dG stores issued just before (tools/isa_vmcnt_scan.py).
+template <bool FULL>
 __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float *__restrict__ gates_act, const float *__restrict__ Cs,
                                                                    const float *__restrict__ xe, const float *__restrict__ dh_heads,
                                                                    long long R, int Th, const float4 *__restrict__ wpack_bwd,
@@ -186,7 +190,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
     auto fetch = [&](int k, int tt) {  // load #k (0 .. 2*kIn-1) of step tt
         const int rt = k / kIn, j = k % kIn;
         const long long row = first + 16 * rt + c;
-        if (row >= R) {
+        if (!FULL && row >= R) {
             in[rt][j] = make_float4(0.f, 0.f, 0.f, 0.f);
             return;
         }
@@ -201,7 +205,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
     auto fetch_x = [&](int k, int tt) {  // load #k (0..3) of xe at step tt
         const int rt = k >> 1, sub = k & 1;
         const long long row = first + 16 * rt + c;
-        xv[rt][sub] = row < R ? *reinterpret_cast<const float4 *>(xe + ((size_t)tt * R + row) * kLH + 16 * sub + uoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[rt][sub] = (FULL || row < R) ? *reinterpret_cast<const float4 *>(xe + ((size_t)tt * R + row) * kLH + 16 * sub + uoff) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
 #pragma unroll
     for (int k = 0; k < kSeqRT * kIn; ++k) fetch(k, Th - 1);
@@ -210,7 +214,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             const long long row = first + 16 * rt + c;
-            ccur[rt][sub] = row < R ? *reinterpret_cast<const float4 *>(Cs + ((size_t)Th * R + row) * kLH + 16 * sub + uoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            ccur[rt][sub] = (FULL || row < R) ? *reinterpret_cast<const float4 *>(Cs + ((size_t)Th * R + row) * kLH + 16 * sub + uoff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 
     for (int t = Th - 1; t >= 0; --t) {
@@ -221,7 +225,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
 #pragma unroll
         for (int rt = 0; rt < kSeqRT; ++rt) {
             const long long row = first + 16 * rt + c;
-            const bool ok = row < R;
+            const bool ok = FULL || row < R;
             float4 *dgo = reinterpret_cast<float4 *>(dG + ((size_t)t * R + (ok ? row : 0)) * kLG + uoff);
             float *dgl = L.dg[rt] + c * kDGS + uoff;
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_bwd_kernel(const float 
 #pragma unroll
         for (int rt = 0; rt < kSeqRT; ++rt) {
             const long long row = first + 16 * rt + c;
-            const bool ok = row < R;
+            const bool ok = FULL || row < R;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
                 dhrec[rt][sub] = acc[rt][2 + sub];
@@ -397,8 +401,12 @@ extern "C" int pfa_lstm_seq_backward(const float *gates_act, const float *cs, co
     const unsigned grid = (unsigned)((rows + kSeqRows - 1) / kSeqRows);
     hipStream_t st = (hipStream_t)stream;
     ScopedKernelTimer timer("lstm_seq_bwd", st);
-    hipLaunchKernelGGL(lstm_seq_bwd_kernel, dim3(grid), dim3(kLstmThreads), 0, st, gates_act, cs, xe, dh_heads, (long long)rows,
-                       (int)steps, (const float4 *)wpack_bwd, dgates, dxe, (float *)workspace);
+    if (rows % kSeqRows == 0)
+        hipLaunchKernelGGL(lstm_seq_bwd_kernel<true>, dim3(grid), dim3(kLstmThreads), 0, st, gates_act, cs, xe, dh_heads, (long long)rows,
+                           (int)steps, (const float4 *)wpack_bwd, dgates, dxe, (float *)workspace);
+    else
+        hipLaunchKernelGGL(lstm_seq_bwd_kernel<false>, dim3(grid), dim3(kLstmThreads), 0, st, gates_act, cs, xe, dh_heads, (long long)rows,
+                           (int)steps, (const float4 *)wpack_bwd, dgates, dxe, (float *)workspace);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(lstm_bias_final_kernel, dim3(kBiasCols / 64), dim3(256), 0, st, (const float *)workspace, (int)grid,
                        gate_bias_grad, enc_bias_grad);

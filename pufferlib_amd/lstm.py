@@ -63,7 +63,16 @@ class Engine:
         self.M, self.Th, self.R = M, Th, M // Th
         R = self.R
         DP = fp.obs_stride
-        self.obs_tm = torch.empty(M, DP, device=dev)
+        # the minibatches' observation rows in time-major order: the rows do not change between the epochs of an update, so each
+        # minibatch is gathered once per update (epoch 0) and kept — one buffer per minibatch, up to PFA_LSTM_OBS_CACHE_MB (default
+        # 2048) in total, else one buffer re-gathered every time as before
+        import os
+        nmb = experience.num_minibatches
+        keep = nmb * M * DP * 4 <= int(os.environ.get('PFA_LSTM_OBS_CACHE_MB', '2048')) << 20
+        self.obs_tm_all = [torch.empty(M, DP, device=dev) for _ in range(nmb if keep else 1)]
+        self.obs_tm = self.obs_tm_all[0]
+        self._gathered = set()              # (update id, minibatch) pairs present in obs_tm_all
+        self.update_id = 0                  # set by clean_pufferl.train(): one id per train() call
         self.xe = torch.empty(M, H, device=dev)
         self.gates = torch.empty(Th, R, 4 * H, device=dev)
         self.Cs = torch.zeros(Th + 1, R, H, device=dev)
@@ -131,8 +140,13 @@ class Engine:
         fp, exp = self.fp, self.exp
         M, Th, R = self.M, self.Th, self.R
         # ---- forward -----------------------------------------------------------------------------------------------
-        _lib.check(L.pfa_gather_obs_time_major(C.byref(exp.c), B, mb, C.byref(hp), fp.obs_stride, _lib.ptr(self.obs_tm), stream),
-                   'gather_obs')
+        keep = len(self.obs_tm_all) > 1
+        self.obs_tm = self.obs_tm_all[mb if keep else 0]
+        if not keep or self.update_id == 0 or (self.update_id, mb) not in self._gathered:     # (id 0: update() driven without train())
+            _lib.check(L.pfa_gather_obs_time_major(C.byref(exp.c), B, mb, C.byref(hp), fp.obs_stride, _lib.ptr(self.obs_tm), stream),
+                       'gather_obs')
+            if keep:
+                self._gathered = {k for k in self._gathered if k[0] == self.update_id} | {(self.update_id, mb)}
         if mb == 0 or self.state is None:      # lstm_state = None at the start of every epoch (clean_pufferl.py:176)
             self.Hs[0].zero_()
             self.Cs[0].zero_()
