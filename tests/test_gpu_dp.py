@@ -78,6 +78,9 @@ TRANSPORTS = {
     'p2p': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p'),
     # ... with the MLP policy's optimizer-step exchange as an all-reduce launch of its own instead of inside the reduce + Adam launch
     'p2p-unfused': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p', PFA_FUSED_DP='0'),
+    # ... with the sharded GAE's exchange in train() instead of riding the statistics all-reduce at the end of evaluate() (what a
+    # host vecenv's evaluate, which does not publish, and callers that rewrite the experience between the two calls get)
+    'p2p-late-gae': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p', PFA_DP_EARLY_GAE='0'),
     # the native RCCL communicator: two ranks on ONE device are refused by RCCL ("duplicate GPU"); the refusal must be clean
     # on both ranks (no hang, torch's own RCCL instance unharmed) and the run must continue on the fallback path
     'rccl-refused': dict(PFA_NATIVE_RCCL='1', PFA_ALLREDUCE='rccl'),
@@ -151,19 +154,19 @@ def test_eight_ranks_full_update_equals_single_process_run(tmp_path):
 
 
 @pytest.mark.parametrize('recurrent,transport', [(False, 'torch'), (True, 'torch'), (False, 'p2p'), (True, 'p2p'), (False, 'rccl-refused'),
-                                                 (CONV, 'torch'), (CONV, 'p2p'), (WIDE, 'torch'), (WIDE, 'p2p'), (False, 'p2p-unfused')])
+                                                 (CONV, 'torch'), (CONV, 'p2p'), (WIDE, 'torch'), (WIDE, 'p2p'), (False, 'p2p-unfused'), (False, 'p2p-late-gae'), (True, 'p2p-late-gae')])
 def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent, transport):
     world = 2
     N_PER_RANK, HORIZON, _ = _sizes(recurrent)
     _spawn(_worker, (world, _free_port(), recurrent, str(tmp_path), transport), world)
     r = [np.load(tmp_path / f'rank{q}.npz') for q in range(world)]
     native = [tuple(int(x) for x in r[q]['native']) for q in range(world)]
-    want_native = {'torch': (0, 0, 0), 'p2p': (1, 1, 0), 'p2p-unfused': (1, 1, 0), 'rccl-refused': (0, 0, 0)}[transport]
+    want_native = {'torch': (0, 0, 0), 'p2p': (1, 1, 0), 'p2p-unfused': (1, 1, 0), 'p2p-late-gae': (1, 1, 0), 'rccl-refused': (0, 0, 0)}[transport]
     if recurrent == CONV and transport == 'p2p':
         want_native = (0, 0, 0)          # the 6.7 MB bucket is over the peer path's 1 MiB cap: the run stays on torch.distributed
     assert native[0] == native[1] == want_native, native
     # the fused MLP update exchanges inside its reduce + Adam launch: one flag-in-data exchange per optimizer step (+ 4 in the self-test)
-    steps = ITERS * 2 * 2 if (transport == 'p2p' and recurrent is False) else 0
+    steps = ITERS * 2 * 2 if (transport in ('p2p', 'p2p-late-gae') and recurrent is False) else 0
     assert int(r[0]['ll_calls'][0]) == int(r[1]['ll_calls'][0]) == (4 + steps if want_native[1] else 0)
     _check_against_single_process(tmp_path, world, recurrent)
     # the shards really are different envs (seeds seed + r*N + i), not replicas of each other
