@@ -752,7 +752,7 @@ def main():
             torch.cuda.empty_cache()
             nb = ['--no-cpu-baseline']
             out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),      # + its cpu_baseline
-                                      extra_workload(['--workload', 'c4', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0'] + nb),
+                                      extra_workload(['--workload', 'c4', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0']),                # + its cpu_baseline
                                       # the same with the rows-form products on the bf16 matrix path (six-term split, fp32 accumulate)
                                       extra_workload(['--workload', 'c4', '--products', 'bf16x6', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0'] + nb),
                                       # widths outside the 128-wide fused kernels on the headline env (tile-kernel rollout + GEMM-path update)

@@ -38,9 +38,15 @@ SMI=$!
 ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench_mlp.json 2> gpurun_out/${TAG}_bench_mlp.err ) 2> gpurun_out/${TAG}_bench_wall.txt; echo "bench rc=$?"
 kill $SMI 2>/dev/null
 timeout 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-extra --no-cpu-baseline > gpurun_out/${TAG}_bench_g2_shared_device.json 2> gpurun_out/${TAG}_bench_g2.err; echo "g2 rc=$?"
+timeout 900 python3 bench.py --gpus 8 --steps 5 --warmup 2 --no-extra --no-cpu-baseline --no-breakdown --sustained-seconds 0 > gpurun_out/${TAG}_bench_g8_shared_device.json 2> gpurun_out/${TAG}_bench_g8.err; echo "g8 rc=$?"
 python - "$TAG" <<'PY'
 import json, sys
 tag = sys.argv[1]
+try:
+    g8 = json.loads(open(f'gpurun_out/{tag}_bench_g8_shared_device.json').read().strip().splitlines()[-1])
+    print('g8 (ranks share the one device: functional, not scaling)', round(g8['value'] / 1e6, 1), 'M', g8['dist']['p2p_selftest_passed'], g8['dist']['allreduce_calls'], json.dumps(g8['dist']['transports']))
+except Exception as e:
+    print('g8 failed', e)
 d = json.loads(open(f'gpurun_out/{tag}_bench_mlp.json').read().strip().splitlines()[-1])
 print(round(d['value'] / 1e6, 1), 'M steps/s', round(d['ms_per_step'], 4), 'ms; sustained', round(d.get('sustained_value', 0) / 1e6, 1))
 print({k: d['roofline'][k] for k in ('frac', 'frac_executed', 'frac_useful', 'avg_launch_ms', 'traffic', 'traffic_source')})
