@@ -63,3 +63,54 @@ def test_no_cpu_fallback():
         pytest.skip('GPU present')
     with pytest.raises(ExtensionError):
         vector.make(vector.make_squared, num_envs=4)
+
+
+def _kernel_metadata(obj):
+    """{kernel symbol: (vgpr_spill_count, private_segment_fixed_size)} of the gfx950 code object inside a hipcc object file."""
+    import re
+    import subprocess
+    import tempfile
+    llvm = '/opt/rocm/lib/llvm/bin'
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, 'fat.bin'), os.path.join(d, 'dev.co')
+        subprocess.check_call(['objcopy', '-O', 'binary', '--only-section=.hip_fatbin', obj, fat])
+        subprocess.check_call([llvm + '/clang-offload-bundler', '--unbundle', '--type=o', '--input=' + fat,
+                               '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', '--output=' + co])
+        notes = subprocess.check_output([llvm + '/llvm-readelf', '--notes', co]).decode()
+    out = {}
+    for blk in notes.split('  - .agpr_count:')[1:]:
+        name = re.search(r'\.name:\s+(\S+)', blk)
+        if name:
+            out[name.group(1)] = tuple(int(re.search(r'\.' + k + r':\s+(\d+)', blk).group(1)) for k in ('vgpr_spill_count', 'private_segment_fixed_size'))
+    return out
+
+
+def test_no_kernel_spills_registers_except_the_known_gradient_instantiations():
+    """Register budget of every kernel in the library, read from the code objects' metadata (what `hipcc -S` prints as
+    vgpr_spill_count / private_segment_fixed_size).  Nothing spills except four instantiations of the 128-wide fused gradient kernel,
+    which sit on the 256-register line of their two-waves-per-SIMD budget: a handful of loop-invariant dwords (DESIGN 3.4 — freeing the
+    producer's prefetch registers does not change it, the allocation is set by the consumer branch).  Two seeding / tape kernels keep a
+    small per-thread array in scratch by design (no spill).  A change that makes any hot kernel spill shows up here, without a GPU."""
+    import shutil
+    from pufferlib_amd import _lib
+    if not (shutil.which('objcopy') and os.path.exists('/opt/rocm/lib/llvm/bin/clang-offload-bundler')):
+        pytest.skip('binutils / ROCm LLVM tools not available')
+    _lib.build()
+    spills, scratch_only, kernels = {}, {}, 0
+    for src in _lib.SOURCES:
+        if not src.endswith('.hip'):
+            continue
+        for name, (spill, scratch) in _kernel_metadata(os.path.join(_lib.LIB_DIR, os.path.splitext(src)[0] + '.o')).items():
+            kernels += 1
+            if spill:
+                spills[name] = spill
+            elif scratch:
+                scratch_only[name] = scratch
+    assert kernels > 250
+    assert all('ppo_mlp_grad_kernel' in k for k in spills), spills
+    assert len(spills) <= 4 and max(spills.values(), default=0) <= 6, spills
+    assert all(any(t in k for t in ('squared_seed_kernel', 'spaces_tape_kernel')) for k in scratch_only), scratch_only
+    # the round-4 kernels in particular: the width-templated rollout (up to 324 registers), the hidden-split gradient kernel (up to 498),
+    # the one-launch reduce + Adam
+    for frag in ('rollout_mlp_squared_kernel', 'ppo_wide_grad_kernel', 'ppo_reduce_adam_kernel', 'mlp_forward_sample_kernel', 'lstm_seq_bwd_kernel'):
+        assert not any(frag in k for k in spills)
