@@ -29,7 +29,30 @@
 
 namespace pfa {
 
-constexpr int kWideThreads = 256;
+#ifndef PFA_WIDE_OCC
+#define PFA_WIDE_OCC 1   // 0 = one workgroup per CU for every width (the first form of this kernel; A/B timing with tools/wide_variant_bench.py)
+#endif
+// Workgroups per CU.  A workgroup is one wave per SIMD, all four on the same tile behind two barriers per tile: nothing of its own
+// covers a wave's LDS round trips, barrier waits and the (VALU-only) loss.  Where the register budget allows, a second (third,
+// fourth) workgroup on the CU does: MS = 1 fits four (<= 128 registers), MS = 2 / 4 two (<= 256; at MS = 4 with the heads' A
+// fragments in LDS instead of registers and two hidden tiles per backward pass instead of four); MS = 8 needs the whole file.
+// (KKU = k-steps of the forward: MS KKU W1 fragments + 4 MS KTM dW1 accumulators set the budget; 64 full columns at MS = 4 do not fit twice.)
+__host__ __device__ constexpr int wide_wgs_per_cu(int ms, int kku) { return !PFA_WIDE_OCC ? 1 : ms == 1 ? 4 : (ms <= 4 && ms * kku <= 52) ? 2 : 1; }
+#ifndef PFA_WIDE_8W
+#define PFA_WIDE_8W 1    // 0 = hidden 512 as four waves of MS = 8 (the first form; A/B timing)
+#endif
+#ifndef PFA_WIDE_DEDUP
+#define PFA_WIDE_DEDUP 1 // 0 = in the eight-wave form every wave computes the loss for itself (A/B timing)
+#endif
+// Waves per workgroup (NW) and hidden tiles per wave (MS = hidden / (16 NW)).  Hidden 512 at four waves needs the whole register file
+// (MS = 8: 459-498 registers), so nothing covers its latencies either; as EIGHT waves of MS = 4 — two per SIMD, <= 256 registers each,
+// the same budget as hidden 256 with two workgroups per CU — each SIMD has a second wave to issue from.  The two waves of a SIMD would
+// both spend the loss's VALU time (MFMA and VALU do not overlap on a SIMD: DESIGN.md 3.4), so only waves 0-3 compute it and hand
+// d loss / d out to their SIMD partner (wave w + 4) through LDS behind a third barrier (DEDUP).
+__host__ __device__ constexpr int wide_waves(int hidden, int kku) { return PFA_WIDE_8W && hidden == 512 && 4 * kku <= 52 ? 8 : 4; }
+__host__ __device__ constexpr int wide_waves_per_simd(int ms, int kku, int nw) { return nw == 8 ? 2 : wide_wgs_per_cu(ms, kku); }
+__host__ __device__ constexpr bool wide_heads_in_lds(int ms, int kku, int nw) { return ms == 4 && wide_waves_per_simd(ms, kku, nw) > 1; }
+__host__ __device__ constexpr bool wide_small_pass(int ms, int kku, int nw) { return wide_waves_per_simd(ms, kku, nw) > 1; }
 
 // One workgroup partial (floats), fragment order.  MT = H / 16 hidden tiles, KTM 16-column tiles of dW1 on MFMA (+ COL: the
 // one trailing column 16 KTM, for rows of 16 KTM + 1 real columns like the 7x7 grid's 49).
@@ -53,46 +76,55 @@ __host__ __device__ inline WideLayout wide_layout(int hidden, int ktm, bool col)
 
 // LDS map (floats): two X tiles, the four partial out^T tiles, one hidden-slice patch and one dout patch per wave, the W2v
 // B-fragment table and the encoder bias.
-template <int DP, int MS>
+template <int DP, int MS, int KKU, int NW = 4>
 struct WideLds {
     static constexpr int XS = XTile<DP>::XS, HSW = 16 * MS + 4, DSW = 20;
     static constexpr int kXs = 0;                          // [2][16 * XS]
-    static constexpr int kPart = kXs + 2 * 16 * XS;        // [4][16 * 16]
-    static constexpr int kHs = kPart + 4 * kOut * 16;      // [4][16 * HSW]
-    static constexpr int kDs = kHs + 4 * 16 * HSW;         // [4][16 * DSW]
-    static constexpr int kWb = kDs + 4 * 16 * DSW;         // [4 MS][64][4]
-    static constexpr int kB1 = kWb + 4 * MS * 256;         // [64 MS]
-    static constexpr int kFloats = kB1 + 64 * MS;
+    static constexpr int kPart = kXs + 2 * 16 * XS;        // [NW][16 * 16]
+    static constexpr int kHs = kPart + NW * kOut * 16;     // [NW][16 * HSW]
+    static constexpr int kDs = kHs + NW * 16 * HSW;        // [NW][16 * DSW]
+    static constexpr int kWb = kDs + NW * 16 * DSW;        // [NW MS][64][4]
+    static constexpr int kB1 = kWb + NW * MS * 256;        // [16 NW MS]
+    static constexpr int kWa = kB1 + 16 * NW * MS;         // [NW MS][64][4]: the heads' A fragments (wide_heads_in_lds)
+    static constexpr int kFloats = kWa + (wide_heads_in_lds(MS, KKU, NW) ? NW * MS * 256 : 0);
 };
 
-template <int DP, int KKU, int KTM, bool COL, int MS>
-__global__ void __launch_bounds__(kWideThreads) ppo_wide_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, MlpView pv, pfa_ppo_hparams hp,
+template <int DP, int KKU, int KTM, bool COL, int MS, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo_wide_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, MlpView pv, pfa_ppo_hparams hp,
                                                                     const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
-    using LD = WideLds<DP, MS>;
-    constexpr int XS = LD::XS, V = DP / 4, HSW = LD::HSW, DSW = LD::DSW, MT = 4 * MS;
+    using LD = WideLds<DP, MS, KKU, NW>;
+    constexpr int XS = LD::XS, V = DP / 4, HSW = LD::HSW, DSW = LD::DSW, MT = NW * MS;
+    constexpr bool DEDUP = PFA_WIDE_DEDUP && NW == 8;
+    constexpr bool LATE_PREFETCH = NW == 8;
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *part = lds + LD::kPart;             // [4][16 * 16] partial out^T per wave
+    float *part = lds + LD::kPart;             // [NW][16 * 16] partial out^T per wave
     const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
     const int a = pv.a;
-    float *hs = lds + LD::kHs + wv * 16 * HSW, *ds = lds + LD::kDs + wv * 16 * DSW;
+    // (eight-wave form with DEDUP: wave w + 4 reads the dout patch its SIMD partner w wrote)
+    float *hs = lds + LD::kHs + wv * 16 * HSW, *ds = lds + LD::kDs + ((PFA_WIDE_DEDUP && NW == 8) ? (wv & 3) : wv) * 16 * DSW;
     float *wbt = lds + LD::kWb, *b1s = lds + LD::kB1;
+    constexpr bool W2L = wide_heads_in_lds(MS, KKU, NW);
+    float *wat = lds + LD::kWa;
 
     // ---- this wave's slice of the policy, as MFMA fragments, for the whole launch: W1 and the heads' A fragments in registers, the
     // B fragments of dh = dout . W2v and the encoder bias in LDS (written and read by this wave only) ------------------------------
     float w1f[MS][KKU];
-    f32x4 w2f[MS];
+    f32x4 w2f[W2L ? 1 : MS];
     float bo[4];
 #pragma unroll
     for (int i = 0; i < MS; ++i) {
         const int m = MS * wv + i;
 #pragma unroll
         for (int kk = 0; kk < KKU; ++kk) w1f[i][kk] = 4 * kk + g < pv.cols ? pv.w1[(size_t)(16 * m + c) * pv.ldw1 + 4 * kk + g] : 0.0f;
-        f32x4 wb;
+        f32x4 wb, wa;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            w2f[i][r] = pv.w2v(c, 16 * m + 4 * g + r);        // A[i = o = c][k-slot g] of the heads, u = 16m + 4g + r
+            wa[r] = pv.w2v(c, 16 * m + 4 * g + r);            // A[i = o = c][k-slot g] of the heads, u = 16m + 4g + r
             wb[r] = pv.w2v(4 * g + r, 16 * m + c);            // B[k-slot g][j = u = 16m + c] of dh = dout . W2v, o = 4g + r
         }
+        if constexpr (W2L) *reinterpret_cast<f32x4 *>(wat + (m * 64 + lane) * 4) = wa;
+        else w2f[i] = wa;
         *reinterpret_cast<f32x4 *>(wbt + (m * 64 + lane) * 4) = wb;
         if (lane < 16) b1s[16 * m + lane] = pv.b1[16 * m + lane];
     }
@@ -160,7 +192,7 @@ __global__ void __launch_bounds__(kWideThreads) ppo_wide_grad_kernel(pfa_experie
             d[1] = make_float2(xpre.z, xpre.w);
         }
         const RowScalars rs = rspre;
-        prefetch((long long)blockIdx.x + (long long)(j + 1) * gridDim.x);
+        if constexpr (!LATE_PREFETCH) prefetch((long long)blockIdx.x + (long long)(j + 1) * gridDim.x);
         __syncthreads();   // X(j) visible; every wave is done with tile j-1 (its partials and the other X slot)
 
         // ---- forward slice ---------------------------------------------------------------------------------------------------
@@ -178,6 +210,18 @@ __global__ void __launch_bounds__(kWideThreads) ppo_wide_grad_kernel(pfa_experie
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[i][r] = fmaxf(h[i][r], 0.0f);
         f32x4 o0 = f32x4{0.f, 0.f, 0.f, 0.f}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (W2L) {
+            f32x4 wa[MS];   // issued ahead of the ReLU's VALU stretch above would be better still; the other workgroup covers the wait
+#pragma unroll
+            for (int i = 0; i < MS; ++i) wa[i] = *reinterpret_cast<const f32x4 *>(wat + ((MS * wv + i) * 64 + lane) * 4);
+#pragma unroll
+            for (int i = 0; i < MS; i += 2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o0 = mfma16(wa[i][r], h[i][r], o0);
+                    o1 = mfma16(wa[i + 1][r], h[i + 1][r], o1);
+                }
+        } else {
 #pragma unroll
         for (int i = 0; i < MS; i += 2)
 #pragma unroll
@@ -185,6 +229,7 @@ __global__ void __launch_bounds__(kWideThreads) ppo_wide_grad_kernel(pfa_experie
                 o0 = mfma16(w2f[i][r], h[i][r], o0);
                 if constexpr (MS >= 2) o1 = mfma16(w2f[i + 1][r], h[i + 1][r], o1);
             }
+        }
         {
             const f32x4 po = o0 + o1;   // partial out^T[o = 4g + r][row = c] over this wave's hidden units
 #pragma unroll
@@ -196,28 +241,42 @@ __global__ void __launch_bounds__(kWideThreads) ppo_wide_grad_kernel(pfa_experie
         __syncthreads();   // the four partials of out^T
 
         // ---- out^T, loss, d loss / d out (every wave for itself) --------------------------------------------------------------
-        f32x4 out;
+        f32x4 dout;
+        if (!DEDUP || wv < 4) {
+            f32x4 out;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = (4 * g + r) * 16 + c;
-            out[r] = bo[r] + ((part[q] + part[kOut * 16 + q]) + (part[2 * kOut * 16 + q] + part[3 * kOut * 16 + q]));
-        }
-        const LossOut lo = ppo_loss_tile<false, true, false>(out, rs, a, 0u, g, hp, adv_mean, adv_rden, inv_rows);
-        const f32x4 dout = lo.dout;
-        if (wv == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) db2[r] += dout[r];
-            if (g == 0) {
-                stats[0] += lo.pg;
-                stats[1] += lo.v_loss;
-                stats[2] += lo.ent;
-                stats[3] += lo.neg_logratio;
-                stats[4] += lo.kl;
-                stats[5] += lo.clipped;
+            for (int r = 0; r < 4; ++r) {
+                const int q = (4 * g + r) * 16 + c;
+                float sum = (part[q] + part[kOut * 16 + q]) + (part[2 * kOut * 16 + q] + part[3 * kOut * 16 + q]);
+                if constexpr (NW == 8)
+                    sum += (part[4 * kOut * 16 + q] + part[5 * kOut * 16 + q]) + (part[6 * kOut * 16 + q] + part[7 * kOut * 16 + q]);
+                out[r] = bo[r] + sum;
             }
+            const LossOut lo = ppo_loss_tile<false, true, false>(out, rs, a, 0u, g, hp, adv_mean, adv_rden, inv_rows);
+            dout = lo.dout;
+            if (wv == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) db2[r] += dout[r];
+                if (g == 0) {
+                    stats[0] += lo.pg;
+                    stats[1] += lo.v_loss;
+                    stats[2] += lo.ent;
+                    stats[3] += lo.neg_logratio;
+                    stats[4] += lo.kl;
+                    stats[5] += lo.clipped;
+                }
+            }
+            *reinterpret_cast<f32x4 *>(ds + c * DSW + 4 * g) = dout;   // dout[row = c][o = 4g .. 4g+3]
         }
-        *reinterpret_cast<f32x4 *>(ds + c * DSW + 4 * g) = dout;   // dout[row = c][o = 4g .. 4g+3]
-        wave_lds_fence();
+        // (two waves per SIMD: the next tile's rows and scalars are fetched from here, behind the loss, so that they and this tile's
+        // scalars are never live together — the ~2500 cycles of the backward's MFMAs cover the fetch)
+        if constexpr (LATE_PREFETCH) prefetch((long long)blockIdx.x + (long long)(j + 1) * gridDim.x);
+        if constexpr (DEDUP) {
+            __syncthreads();   // d loss / d out of waves 0-3 -> their SIMD partners
+            if (wv >= 4) dout = *reinterpret_cast<const f32x4 *>(ds + c * DSW + 4 * g);
+        } else {
+            wave_lds_fence();
+        }
 
         // ---- backward slice ---------------------------------------------------------------------------------------------------
         float dfrag[4], xa[KTM][4], xc[4];
@@ -228,7 +287,8 @@ __global__ void __launch_bounds__(kWideThreads) ppo_wide_grad_kernel(pfa_experie
             for (int kt = 0; kt < KTM; ++kt) xa[kt][r] = xs[(4 * g + r) * XS + 16 * kt + c];
             xc[r] = COL ? xs[(4 * g + r) * XS + 16 * KTM] : 0.0f;
         }
-        constexpr int CH = MS < 4 ? MS : 4;     // hidden tiles per pass: bounds the registers of the short-lived fragments
+        // hidden tiles per pass: bounds the registers of the short-lived fragments (two where a second workgroup shares the register file)
+        constexpr int CH = wide_small_pass(MS, KKU, NW) ? (MS < 2 ? MS : 2) : (MS < 4 ? MS : 4);
 #pragma unroll
         for (int i0 = 0; i0 < MS; i0 += CH) {
             float hrow[CH][4];
@@ -383,9 +443,13 @@ static int wide_shape(const pfa_mlp_view *p, int *ktm, bool *col, int *kku) {
     *kku = grid49 ? 13 : p->obs_stride / 4;
     return 0;
 }
-static int wide_grid(int64_t mb_rows) {
-    const int64_t tiles = mb_rows / 16;
-    return (int)(tiles < 256 ? (tiles < 1 ? 1 : tiles) : 256);
+static int wide_slots(int hidden, int kku) {   // workgroups the chip holds at once
+    const int nw = wide_waves(hidden, kku);
+    return 256 * (nw == 8 ? 1 : wide_wgs_per_cu(hidden / 64, kku));
+}
+static int wide_grid(int64_t mb_rows, int hidden, int kku) {   // one workgroup per resident slot, fewer when the minibatch is small
+    const int64_t tiles = mb_rows / 16, slots = wide_slots(hidden, kku);
+    return (int)(tiles < slots ? (tiles < 1 ? 1 : tiles) : slots);
 }
 
 }  // namespace pfa
@@ -396,7 +460,7 @@ extern "C" size_t pfa_ppo_wide_workspace_bytes(const pfa_mlp_view *view) {
     int ktm, kku;
     bool col;
     if (wide_shape(view, &ktm, &col, &kku)) return 0;
-    return align_up((size_t)256 * wide_layout(view->hidden, ktm, col).kCount * sizeof(float), 256);
+    return align_up((size_t)wide_slots(view->hidden, kku) * wide_layout(view->hidden, ktm, col).kCount * sizeof(float), 256);
 }
 
 extern "C" int pfa_ppo_wide_supported(const pfa_mlp_view *view) {
@@ -423,30 +487,31 @@ extern "C" int pfa_ppo_wide_grad(const pfa_experience *exp, int64_t batch_rows, 
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     const MlpView pv{params->w1, params->ldw1, params->obs_dim, params->b1, params->w2, params->b2, params->wv, params->bv, params->num_actions, params->hidden};
     float *partials = (float *)workspace;
-    const int grid = wide_grid(mbs);
+    const int grid = wide_grid(mbs, params->hidden, kku);
     {
         ScopedKernelTimer timer("ppo_wide_grad", (hipStream_t)stream);
-#define PFA_WIDE_LAUNCH(DPV, KKUV, KTMV, COLV, MSV)                                                                                       \
+#define PFA_WIDE_LAUNCH(DPV, KKUV, KTMV, COLV, HV)                                                                                        \
     {                                                                                                                                    \
-        constexpr size_t lds_bytes = (size_t)WideLds<DPV, MSV>::kFloats * sizeof(float);                                                  \
+        constexpr int NWV = wide_waves(HV, KKUV), MSV = HV / (16 * NWV);                                                                 \
+        constexpr size_t lds_bytes = (size_t)WideLds<DPV, MSV, KKUV, NWV>::kFloats * sizeof(float);                                      \
         static bool attr_set = false;                                                                                                    \
         if (!attr_set) {                                                                                                                 \
-            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_wide_grad_kernel<DPV, KKUV, KTMV, COLV, MSV>,                             \
+            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_wide_grad_kernel<DPV, KKUV, KTMV, COLV, MSV, NWV>,                        \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                              \
             attr_set = true;                                                                                                             \
         }                                                                                                                                \
-        hipLaunchKernelGGL((ppo_wide_grad_kernel<DPV, KKUV, KTMV, COLV, MSV>), dim3(grid), dim3(kWideThreads), lds_bytes, (hipStream_t)stream, \
-                           *exp, map, (long long)mbs, pv, *hp, adv_stats, (double)global_mb_rows, partials);                             \
+        hipLaunchKernelGGL((ppo_wide_grad_kernel<DPV, KKUV, KTMV, COLV, MSV, NWV>), dim3(grid), dim3(64 * NWV), lds_bytes,                \
+                           (hipStream_t)stream, *exp, map, (long long)mbs, pv, *hp, adv_stats, (double)global_mb_rows, partials);        \
     }
-#define PFA_WIDE_DP(MSV)                                                                \
-    if (col) PFA_WIDE_LAUNCH(64, 13, 3, true, MSV)                                      \
-    else if (params->obs_stride == 64) PFA_WIDE_LAUNCH(64, 16, 4, false, MSV)           \
-    else if (params->obs_stride == 32) PFA_WIDE_LAUNCH(32, 8, 2, false, MSV)            \
-    else PFA_WIDE_LAUNCH(16, 4, 1, false, MSV)
+#define PFA_WIDE_DP(HV)                                                                \
+    if (col) PFA_WIDE_LAUNCH(64, 13, 3, true, HV)                                      \
+    else if (params->obs_stride == 64) PFA_WIDE_LAUNCH(64, 16, 4, false, HV)           \
+    else if (params->obs_stride == 32) PFA_WIDE_LAUNCH(32, 8, 2, false, HV)            \
+    else PFA_WIDE_LAUNCH(16, 4, 1, false, HV)
         switch (params->hidden) {
-            case 64: PFA_WIDE_DP(1) break;
-            case 256: PFA_WIDE_DP(4) break;
-            default: PFA_WIDE_DP(8) break;
+            case 64: PFA_WIDE_DP(64) break;
+            case 256: PFA_WIDE_DP(256) break;
+            default: PFA_WIDE_DP(512) break;
         }
 #undef PFA_WIDE_DP
 #undef PFA_WIDE_LAUNCH
