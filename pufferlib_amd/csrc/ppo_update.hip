@@ -110,6 +110,10 @@ struct NativeLayout {
     static constexpr int kCount = kStats + kNumStats;
 };
 
+}  // namespace pfa
+#include "ppo_bf16.hpp"   // the same step on the bf16 matrix path (opt-in product form); needs NativeLayout
+namespace pfa {
+
 #ifdef PFA_PROBES
 // tools/probe_grad.py --trace: s_memtime stamps of workgroup 0 (lane 0 of every wave), [wave][tile][8]
 __device__ unsigned long long *g_trace = nullptr;
@@ -1120,14 +1124,17 @@ static bool grad_trimmed(const pfa_mlp_dims *dims) { return dims->obs_stride == 
 #endif
 // ... and, with at most 11 actions (12 outputs with the value), the permuted head rows: three k-steps of dh instead of four
 static bool grad_perm(const pfa_mlp_dims *dims) { return PFA_GRAD_PERM && dims->num_actions <= 11; }
+// the opt-in product form (pfa_igemm_set_products(1): every fp32 product as six bf16 partial products, fp32 accumulate) covers the
+// headline shape: the 7x7 grid on 64-float rows behind one Discrete head, minibatches of whole 32-row tiles
+static bool grad_bf16(const pfa_mlp_dims *dims, int64_t mbs) { return pfa_igemm_get_products() == 1 && grad_trimmed(dims) && mbs >= 32 && mbs % 32 == 0; }
 static int norm_blocks(const pfa_mlp_dims *dims) {   // workgroups of the reduce launch = f64 pieces of sum(g^2) it leaves
     const int count = grad_trimmed(dims) ? NativeLayout<64, 3, true>::kCount
                                          : (dims->obs_stride / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats;
     return (count + 63) / 64;
 }
 static size_t native_count(int dp) { return (size_t)(dp / 16) * kMT * 4 * 64 + kMT * 4 * 64 + kHidden + kOut + kNumStats; }
-static size_t partials_bytes(const pfa_mlp_dims *dims) {
-    return align_up((size_t)256 * native_count(dims->obs_stride) * sizeof(float), 256);
+static size_t partials_bytes(const pfa_mlp_dims *dims) {   // (the opt-in bf16 form runs two workgroups per CU: kBfMaxGrid partials)
+    return align_up((size_t)(dims->obs_stride == 64 ? kBfMaxGrid : 256) * native_count(dims->obs_stride) * sizeof(float), 256);
 }
 static double *norm_partials_of(void *workspace, const pfa_mlp_dims *dims) {  // after the gradient partials
     return (double *)((char *)workspace + partials_bytes(dims));
@@ -1197,6 +1204,35 @@ static int launch_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb
     PFA_REQUIRE(global_mb_rows >= mbs, "ppo.grad: global_mb_rows < local minibatch rows");
     RowMap map{mb, hp->num_minibatches, hp->bptt_horizon};
     float *partials = (float *)workspace;
+    if (grad_bf16(dims, mbs)) {   // opt-in product form (pfa_igemm_set_products(1)): the same step on the bf16 matrix path, csrc/ppo_bf16.hpp
+        const int64_t tiles32 = mbs / 32;
+        const int grid = (int)(tiles32 < kBfMaxGrid ? tiles32 : kBfMaxGrid);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        const bool timed = timing_pair("ppo_mlp_grad", &ev0, &ev1);
+        ScopedKernelTimer timer(timing_ext_mode() ? nullptr : "ppo_mlp_grad", (hipStream_t)stream);
+#define PFA_LAUNCH_GRAD_BF16(PERMV)                                                                                                       \
+    {                                                                                                                                    \
+        static bool attr_set = false;                                                                                                    \
+        if (!attr_set) {                                                                                                                 \
+            PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_mlp_grad_bf16_kernel<PERMV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                              (int)BfLds::kBytes));                                                                      \
+            attr_set = true;                                                                                                             \
+        }                                                                                                                                \
+        if (timed)                                                                                                                       \
+            hipExtLaunchKernelGGL((ppo_mlp_grad_bf16_kernel<PERMV>), dim3(grid), dim3(kBfThreads), BfLds::kBytes, (hipStream_t)stream,    \
+                                  ev0, ev1, 0, *exp, map, (long long)mbs, params, dims->num_actions, *hp, adv_stats,                     \
+                                  (double)global_mb_rows, partials);                                                                     \
+        else                                                                                                                             \
+            hipLaunchKernelGGL((ppo_mlp_grad_bf16_kernel<PERMV>), dim3(grid), dim3(kBfThreads), BfLds::kBytes, (hipStream_t)stream, *exp, \
+                               map, (long long)mbs, params, dims->num_actions, *hp, adv_stats, (double)global_mb_rows, partials);        \
+    }
+        if (grad_perm(dims)) PFA_LAUNCH_GRAD_BF16(true)
+        else PFA_LAUNCH_GRAD_BF16(false)
+#undef PFA_LAUNCH_GRAD_BF16
+        PFA_LAUNCH_CHECK();
+        *grid_out = grid;
+        return 0;
+    }
     const int grid = grad_grid(mbs, dims->obs_stride);
 #define PFA_LAUNCH_GRAD_FULL(DPV, KKUV, MHV, KTMV, COLV) PFA_LAUNCH_GRAD_PERM(DPV, KKUV, MHV, KTMV, COLV, false)
 #define PFA_LAUNCH_GRAD_PERM(DPV, KKUV, MHV, KTMV, COLV, PERMV)                                                             \
@@ -1415,6 +1451,13 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
     return 0;
 }
 
+#ifdef PFA_BF16_TRACE
+extern "C" int pfa_probe_bf16_trace(unsigned long long *buf, int tiles) {   // tools/bf16_trace.py (probe builds only)
+    PFA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bf_trace), &buf, sizeof(buf)));
+    PFA_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_bf_trace_tiles), &tiles, sizeof(tiles)));
+    return 0;
+}
+#endif
 #ifdef PFA_PROBES
 // Probe-only entry (tools/probe_grad.py): same launch as pfa_ppo_mlp_grad for obs_stride 64 with an ablation mask.
 extern "C" int pfa_probe_set_trace(unsigned long long *buf, int tiles) {
