@@ -172,14 +172,13 @@ __global__ void __launch_bounds__(kBfThreads, 2)
     const float inv_rows = (float)(1.0 / global_rows), adv_rden = 1.0f / adv_den;
 
     f32x4 acc_dw1[4][2], acc_dw2[2];   // [k-tile][i]: dW1^T[16kt + 4g + r][32wv + 16i + c];  [i]: dW2v^T[32wv + 16i + 4g + r][slot c]
-    float db1[2][4], db2[4], stats[6];
+    float db1[2], db2[4], stats[6];   // db1[i]: unit 32wv + 16i + c, summed over the rows this lane group saw
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) acc_dw1[kt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc_dw2[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) db1[i][r] = 0.0f;
+        db1[i] = 0.0f;
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) db2[r] = 0.0f;
@@ -189,43 +188,34 @@ __global__ void __launch_bounds__(kBfThreads, 2)
     const long long tiles = mb_rows / 32;   // 32-row tiles = pairs of the 16-row tiles RowMap speaks of
     const int J = (int)((tiles + gridDim.x - 1) / gridDim.x);   // the same for every workgroup: everybody runs the same barriers
     const bool aligned = (map.horizon & 15) == 0;
-    const int my_half = wv & 1;   // the 16-row half whose loss this wave computes when it is its turn
+    const int my_half = wv & 1;   // the 16-row half whose loss this wave computes when it is its pair's turn
+    const int pairid = wv >> 1;   // waves (0, 1) / (2, 3): the pair with pairid == (j & 1) computes the loss of tile j, the other pair
+                                  // stages X(j + 1) meanwhile (two workgroup barriers per tile; the loss is a latency chain, the
+                                  // staging is what the other pair would otherwise wait behind)
+    const int st = threadIdx.x & 127;
+    auto tile_of = [&](int j) { return (long long)blockIdx.x + (long long)j * gridDim.x; };
 
-    // register prefetch of the next tile: two float4 of X per thread (row = idx >> 4, column quad = idx & 15, idx = tid + 256 q: the
-    // rows of one q lie in one 16-row half for a whole wave) + the per-row scalars of this wave's half
-    float4 xpre[2];
-    RowScalars rspre;
-    auto prefetch = [&](long long tile) {
-        const bool ok = tile < tiles;
-        rspre = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // a pair stages a whole tile: four float4 of X per thread (idx = st + 128 q: row = idx >> 4, column quad = idx & 15; the rows of
+    // one q lie in one 16-row half)
+    float4 xpre[4];
+    auto load_x = [&](long long tile) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) xpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) {
-            {
-                const unsigned t16 = 2u * (unsigned)tile + (unsigned)my_half;
-                const unsigned first = map.tile_first(t16);
-                const unsigned fr = map.tile_row(t16, first, c, aligned);
-                rspre = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
-            }
+        for (int q = 0; q < 4; ++q) xpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile < tiles) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int idx = threadIdx.x + kBfThreads * q, r = (idx >> 4) & 15, c4 = idx & 15;
-                const unsigned t16 = 2u * (unsigned)tile + (unsigned)q;
+            for (int q = 0; q < 4; ++q) {
+                const int idx = st + 128 * q, r = (idx >> 4) & 15, c4 = idx & 15;
+                const unsigned t16 = 2u * (unsigned)tile + (unsigned)(q >> 1);
                 const unsigned first = map.tile_first(t16);
                 const unsigned row = map.tile_row(t16, first, r, aligned);
                 xpre[q] = *reinterpret_cast<const float4 *>(ex.obs + (size_t)row * DP + 4 * c4);
             }
         }
     };
-    prefetch(blockIdx.x);
-
-    for (int j = 0; j < J; ++j) {
-        unsigned char *xs = smem + L::kX + (j & 1) * L::kXSlot;
-        BF_STAMP(0);
-        // ---- stage X(j): split into the three planes, 8 bytes (four bf16) per piece and thread ----------------------------------
+    auto store_x = [&](unsigned char *xs) {   // split into the three planes, 8 bytes (four bf16) per piece
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int idx = threadIdx.x + kBfThreads * q, row = idx >> 4, c4 = idx & 15;
+        for (int q = 0; q < 4; ++q) {
+            const int idx = st + 128 * q, row = idx >> 4, c4 = idx & 15;
             uint2 h, m, l;
             bf_split2(xpre[q].x, xpre[q].y, h.x, m.x, l.x);
             bf_split2(xpre[q].z, xpre[q].w, h.y, m.y, l.y);
@@ -234,11 +224,31 @@ __global__ void __launch_bounds__(kBfThreads, 2)
             *reinterpret_cast<uint2 *>(d + L::kXPlane) = m;
             *reinterpret_cast<uint2 *>(d + 2 * L::kXPlane) = l;
         }
-        const RowScalars rs = rspre;
-        prefetch((long long)blockIdx.x + (long long)(j + 1) * gridDim.x);
+    };
+    RowScalars rspre;   // the per-row scalars of this wave's half of its pair's next loss tile
+    auto load_rs = [&](long long tile) {
+        rspre = RowScalars{0, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tile < tiles) {
+            const unsigned t16 = 2u * (unsigned)tile + (unsigned)my_half;
+            const unsigned first = map.tile_first(t16);
+            const unsigned fr = map.tile_row(t16, first, c, aligned);
+            rspre = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
+        }
+    };
+    // prologue: pair 0 stages X(0); both pairs fetch the scalars of their first loss tile (tiles 0 and 1)
+    load_rs(tile_of(pairid));
+    if (pairid == 0) {
+        load_x(tile_of(0));
+        store_x(smem + L::kX);
+    }
+    __syncthreads();   // X(0) and the zeroed dout planes
+
+    for (int j = 0; j < J; ++j) {
+        unsigned char *xs = smem + L::kX + (j & 1) * L::kXSlot;
+        const bool loss_wave = pairid == (j & 1);
+        BF_STAMP(0);
+        if (!loss_wave) load_x(tile_of(j + 1));   // in flight over the forward; staged behind barrier B
         BF_STAMP(1);
-        __syncthreads();   // A: X(j) visible; every wave is done with tile j - 1 (partials, dout planes, the other X slot)
-        BF_STAMP(2);
 
         // ---- forward slice: hidden^T[32wv + 16i + 4g + r][row 16nt + c] ----------------------------------------------------------
         f32x4 h[2][2];   // [nt][i]
@@ -267,7 +277,9 @@ __global__ void __launch_bounds__(kBfThreads, 2)
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[nt][i][r] = fmaxf(h[nt][i][r], 0.0f);   // ReLU (models.py:52)
+#ifdef PFA_BF16_TRACE
         if (h[0][0][0] == 12345.678f) BF_STAMP(15);   // (never true) pins the stamp behind the forward's result
+#endif
         BF_STAMP(3);
         // ---- this slice's part of the heads; hidden pieces into the wave's patch [row][unit] for the transposed reads below --------
 #pragma unroll
@@ -289,12 +301,13 @@ __global__ void __launch_bounds__(kBfThreads, 2)
                         make_uint2(hp3.p[p].w[2 * i], hp3.p[p].w[2 * i + 1]);
         }
         BF_STAMP(4);
-        __syncthreads();   // B: the four partials of out^T
+        __syncthreads();   // B: the four partials of out^T; every wave is done with tile j - 1 (dout planes, the other X slot)
         BF_STAMP(5);
 
-        // ---- loss of one 16-row half per wave, two waves per tile (the pair alternates from tile to tile) ---------------------------
-        if ((wv >> 1) == (j & 1)) {
+        if (loss_wave) {
+            // ---- loss of one 16-row half per wave of the pair --------------------------------------------------------------------
             const int nt = my_half;
+            const RowScalars rs = rspre;
             f32x4 out;
             {
                 const f32x4 p0 = *reinterpret_cast<const f32x4 *>(part + ((0 * 2 + nt) * 64 + lane) * 4);
@@ -322,16 +335,24 @@ __global__ void __launch_bounds__(kBfThreads, 2)
             *reinterpret_cast<uint2 *>(d) = dh_;
             *reinterpret_cast<uint2 *>(d + L::kDPlane) = dm_;
             *reinterpret_cast<uint2 *>(d + 2 * L::kDPlane) = dl_;
+            load_rs(tile_of(j + 2));
+        } else {
+            // ---- ... while the other pair stages X(j + 1) into the slot tile j - 1 has left ---------------------------------------
+            store_x(smem + L::kX + ((j + 1) & 1) * L::kXSlot);
         }
+#ifdef PFA_BF16_TRACE
         if (db2[0] == 12345.678f) BF_STAMP(15);
+#endif
         BF_STAMP(6);
-        __syncthreads();   // C: d loss / d out of both halves
+        __syncthreads();   // C: d loss / d out of both halves, X(j + 1)
         BF_STAMP(7);
 
         // ---- backward slice -----------------------------------------------------------------------------------------------------
-        // dW2v^T[u][slot] += sum over the 32 rows of hidden[row][u] dout[row][slot]: both operands by transposed reads
+        // dW2v^T[u][slot] += sum over the 32 rows of hidden[row][u] dout[row][slot]: both operands by transposed reads (element e of a
+        // fragment = row 8g + e)
+        BfFrag ha[2][3];
         {
-            BfFrag db_[3], ha[2][3];
+            BfFrag db_[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 bf_tr8(dpl + p * L::kDPlane, L::DRS, 0, 0, c, g, db_[p]);
@@ -343,66 +364,60 @@ __global__ void __launch_bounds__(kBfThreads, 2)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc_dw2[i] = bf_mfma(ha[i][kBfTA[t]], db_[kBfTB[t]], acc_dw2[i]);
         }
-        // dh^T[u][row] = sum over the slots of W2v[slot][u] dout[row][slot]; relu' from the forward's own C fragments; db1
-        f32x4 dh[2][2];
+        // dh[row][u] = sum over the slots of dout[row][slot] W2v[slot][u], NOT transposed: with the rows of the A operand permuted
+        // (lane c = 4g' + r' of M tile mt <-> row 8g' + 4mt + r'), lane (c, g) of the C fragments holds dh[row 8g + 4mt + r][unit c] —
+        // after relu' and the split that IS the B fragment (k = row 8g + e, n = unit) of the weight gradient below: no transpose.
+        f32x4 dh[2][2];   // [mt][i]
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            BfFrag dB[3];   // B[k = slot 8g + e][n = row 16nt + c]; slots 16 .. 31 are the zero half
+        for (int mt = 0; mt < 2; ++mt) {
+            BfFrag dA[3];   // A[m = row pi(mt, c)][k = slot 8g + e]; slots 16 .. 31 are the zero half
 #pragma unroll
-            for (int p = 0; p < 3; ++p) dB[p].v = *reinterpret_cast<const bf16x8 *>(dpl + p * L::kDPlane + (16 * nt + c) * L::DRS + 16 * g);
+            for (int p = 0; p < 3; ++p)
+                dA[p].v = *reinterpret_cast<const bf16x8 *>(dpl + p * L::kDPlane + (8 * (c >> 2) + 4 * mt + (c & 3)) * L::DRS + 16 * g);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) dh[nt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 2; ++i) dh[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int i = 0; i < 2; ++i) dh[nt][i] = bf_mfma(wT[i].p[kBfTA[t]], dB[kBfTB[t]], dh[nt][i]);
+                for (int i = 0; i < 2; ++i) dh[mt][i] = bf_mfma(dA[kBfTA[t]], wT[i].p[kBfTB[t]], dh[mt][i]);
         }
+#ifdef PFA_BF16_TRACE
         if (dh[0][0][0] == 12345.678f || acc_dw2[0][0] == 12345.678f) BF_STAMP(15);
+#endif
         BF_STAMP(8);
-        wave_lds_fence();   // this wave's transposed reads of the hidden pieces are issued before the patch is overwritten (LDS is in order)
+        // relu' from the hi piece of hidden the dW2v fragment already holds (element 4mt + r of ha[i] = row 8g + 4mt + r, unit 16i + c:
+        // hidden >= 0, so "piece != 0" is "hidden > 0"); db1; the three pieces of dh as B fragments
+        BfFrag3 dhb[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+        for (int i = 0; i < 2; ++i) {
             float t8[8];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = h[nt][i][r] > 0.0f ? dh[nt][i][r] : 0.0f;   // relu'
-                    db1[i][r] += v;
-                    t8[4 * i + r] = v;
-                }
-            BfFrag3 d3;
-            bf_split8(t8, d3);
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    *reinterpret_cast<uint2 *>(patch + p * L::kHPlane + (16 * nt + c) * L::HRS + (16 * i + 4 * g) * 2) =
-                        make_uint2(d3.p[p].w[2 * i], d3.p[p].w[2 * i + 1]);
+            for (int e = 0; e < 8; ++e) {
+                const uint32_t w = ha[i][0].w[e >> 1];
+                const bool on = (e & 1) ? (w >> 16) != 0u : (w & 0xFFFFu) != 0u;
+                const float v = on ? dh[e >> 2][i][e & 3] : 0.0f;
+                db1[i] += v;
+                t8[e] = v;
+            }
+            bf_split8(t8, dhb[i]);
         }
-        wave_lds_fence();
         BF_STAMP(9);
         // dW1^T[k][u] += sum over the 32 rows of X[row][k] dh[row][u]
-        {
-            BfFrag dhb[2][3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+        for (int kt = 0; kt < 4; ++kt) {
+            BfFrag xa[3];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) bf_tr8(patch + p * L::kHPlane, L::HRS, 0, 16 * i, c, g, dhb[i][p]);
+            for (int p = 0; p < 3; ++p) bf_tr8(xs + p * L::kXPlane, L::XRS, 0, 16 * kt, c, g, xa[p]);
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-                BfFrag xa[3];
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) bf_tr8(xs + p * L::kXPlane, L::XRS, 0, 16 * kt, c, g, xa[p]);
-#pragma unroll
-                for (int t = 0; t < 6; ++t)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) acc_dw1[kt][i] = bf_mfma(xa[kBfTA[t]], dhb[i][kBfTB[t]], acc_dw1[kt][i]);
-            }
+                for (int i = 0; i < 2; ++i) acc_dw1[kt][i] = bf_mfma(xa[kBfTA[t]], dhb[i].p[kBfTB[t]], acc_dw1[kt][i]);
         }
+#ifdef PFA_BF16_TRACE
         if (acc_dw1[0][0][0] == 12345.678f) BF_STAMP(15);
+#endif
         BF_STAMP(10);
-        wave_lds_fence();   // ... and the reads of the dh pieces before the next tile's hidden pieces land in the patch
+        wave_lds_fence();   // this wave's transposed reads of the hidden pieces are issued before the next tile's land in the patch
     }
 
     // ---- this workgroup's partial: every wave its own slices, in the fragment order of NativeLayout<64, 3, true> --------------------
@@ -417,12 +432,11 @@ __global__ void __launch_bounds__(kBfThreads, 2)
         if (g == 0) dst[NL::kCol + 16 * m + c] = acc_dw1[3][i][0];   // column 48 = row (g = 0, r = 0) of k-tile 3
 #pragma unroll
         for (int r = 0; r < 4; ++r) dst[NL::kDw2 + (m * 4 + r) * 64 + lane] = acc_dw2[i][r];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float b = db1[i][r];
-#pragma unroll
-            for (int s = 1; s < 16; s <<= 1) b += __shfl_xor(b, s, 64);
-            if (c == 0) dst[NL::kDb1 + 16 * m + 4 * g + r] = b;
+        {
+            float b = db1[i];
+            b += __shfl_xor(b, 16, 64);
+            b += __shfl_xor(b, 32, 64);
+            if (g == 0) dst[NL::kDb1 + 16 * m + c] = b;
         }
     }
     float *red = reinterpret_cast<float *>(smem + L::kRed) + wv * 32;
