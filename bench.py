@@ -362,7 +362,7 @@ def extra_workload(flags, timeout_s=600):
         line = [ln for ln in r.stdout.decode().splitlines() if ln.startswith('{')][-1]
         d = json.loads(line)
         return {k: d[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'dtype', 'config', 'roofline', 'cpu_baseline',
-                                  'profile_ms_per_step') if k in d}
+                                  'profile_ms_per_step', 'self_check', 'kernel_ms_per_step') if k in d}
     except Exception as e:  # a side workload never takes the headline line down with it
         return dict(flags=flags, error=f'{type(e).__name__}: {e}')
 
@@ -373,6 +373,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--self-check', action='store_true', help='run the oracle self-check of the headline workload even with --no-cpu-baseline')
     ap.add_argument('--policy', choices=['mlp', 'lstm'], default='mlp',
                     help="'lstm' = LSTMWrapper(128) on the same envs (BASELINE configs[2]'s policy; not the headline metric)")
     ap.add_argument('--hidden', type=int, default=128,
@@ -651,12 +652,17 @@ def main():
             'metric': (f'env steps/sec end-to-end PPO (rollout+GAE+update), {NUM_ENVS} envs'
                        + {'c3': ' [configs[2] workload]', 'c4': ' [configs[3] workload]'}.get(args.workload, '')
                        + (f' [side workload: hidden {args.hidden}]' if args.policy == 'wide' else '')
-                       + (' [rows-form products as six bf16 partial products, fp32 accumulate]' if args.products == 'bf16x6' else '')),
+                       + (' [fused gradient step as six bf16 partial products per fp32 product, fp32 accumulate: opt-in product form, not the metric]'
+                          if args.products == 'bf16x6' and args.policy == 'mlp' and args.workload == 'squared' else
+                          ' [rows-form products as six bf16 partial products, fp32 accumulate]' if args.products == 'bf16x6' else '')),
             'value': value, 'unit': 'env_steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': dt / K * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             # what the products are computed in: fp32 MFMA everywhere by default; with --products bf16x6 the rows form of csrc/igemm.hip
             # multiplies three-piece bf16 splits of the fp32 operands (six partial products, fp32 accumulation)
-            'dtype': 'f32' if args.products == 'fp32' else 'f32 operands as 3 x bf16, 6 partial products, f32 accumulate (rows form); f32 elsewhere',
+            'dtype': ('f32' if args.products == 'fp32' else
+                      'f32 operands as 3 x bf16, 6 partial products, f32 accumulate (fused gradient step, csrc/ppo_bf16.hpp); f32 elsewhere'
+                      if args.policy == 'mlp' and args.workload == 'squared' else
+                      'f32 operands as 3 x bf16, 6 partial products, f32 accumulate (rows form); f32 elsewhere'),
             'data': 'synthetic',
             'config': {'workload': (f'synthetic Atari-shaped frames (uint8 (4,84,84), 4 actions, 100-step episodes), {NUM_ENVS} envs/GPU x {HORIZON} steps, '
                                     f'NatureCNN (models.Convolutional){" + LSTMWrapper(512, 512)" if cnn_lstm else ""}, {NMB} minibatches x {EPOCHS} epochs, bptt {BPTT} (BASELINE configs[3]; env parity '
@@ -695,11 +701,24 @@ def main():
         if args.policy == 'mlp':
             # the MFMA instructions the instantiated kernel really issues per 16-row tile (csrc/ppo_update.hip: forward KKU x 8, heads
             # 32, dW2v 32, dh DHK x 8, dW1 KTM x 32): the padded SURVEY figure above is the contract's `frac`, this is the executed one
-            mfma_tile = int(L.pfa_ppo_mlp_grad_mfma_per_tile(49, 64, 8))
-            out['roofline']['mfma_per_tile'] = mfma_tile
-            out['roofline']['mfma_utilisation_pmc'] = pmc_mfma_utilisation('ppo_mlp_grad')
-            out['roofline']['frac_executed'] = (mfma_tile * 2048 / 16 * rows_per_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
-                                                if launches else 0.0)
+            import ctypes as _C
+            grad_path = int(L.pfa_ppo_mlp_grad_path(_C.byref(data.flat_params.dims), per_gpu // NMB))
+            out['roofline']['gradient_kernel'] = ('ppo_mlp_grad_bf16_kernel (csrc/ppo_bf16.hpp)' if grad_path == 1 else
+                                                  'ppo_mlp_grad_kernel (csrc/ppo_update.hip)')
+            if grad_path == 0:
+                mfma_tile = int(L.pfa_ppo_mlp_grad_mfma_per_tile(49, 64, 8))
+                out['roofline']['mfma_per_tile'] = mfma_tile
+                out['roofline']['mfma_utilisation_pmc'] = pmc_mfma_utilisation('ppo_mlp_grad')
+                out['roofline']['frac_executed'] = (mfma_tile * 2048 / 16 * rows_per_launch / (avg_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS
+                                                    if launches else 0.0)
+            else:
+                # v_mfma_f32_16x16x32_bf16 (16 384 FLOP each) per 32-row tile: 4 waves x (48 forward + 12 heads + 12 dW2v + 24 dh + 48 dW1)
+                out['roofline']['mfma_per_tile'] = 576
+                out['roofline']['frac_executed'] = (576 * 16384 / 32 * rows_per_launch / (avg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
+                                                    if launches else 0.0)
+                out['roofline']['frac_executed_is'] = 'issued bf16 MFMA flop / the bf16 dense peak (2500 TFLOP/s)'
+                out['roofline']['traffic'] = None        # the PMC summary holds the fp32 kernel
+                out['roofline']['traffic_source'] = None
         # north_star asks for the HBM side next to the MFMA side: the rollout kernel is the path's HBM-facing kernel (it writes the
         # experience rows, SURVEY 8d: 280 B per env step), and the end-to-end figure is 1420 B per env step
         roll = breakdown.get({'mlp': 'rollout_mlp_squared', 'lstm': 'rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'}.get(args.policy, ''))
@@ -736,6 +755,8 @@ def main():
                                                             'own: 4); 1 all-reduce of [episode-statistic sums | 6 GAE numbers per rank] at the end of '
                                                             'evaluate(), 1 of [advantage sums | explained-variance sums] after GAE'},
                            'transports': transports}
+        if world == 1 and args.no_cpu_baseline and args.self_check and args.policy == 'mlp':
+            out['self_check'] = self_check(data, pol)
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)
@@ -751,7 +772,9 @@ def main():
             del data, vec, pol
             torch.cuda.empty_cache()
             nb = ['--no-cpu-baseline']
-            out['extra_workloads'] = [extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),      # + its cpu_baseline
+            out['extra_workloads'] = [# the headline workload with the gradient step in the opt-in product form (csrc/ppo_bf16.hpp) + its oracle self-check
+                                      extra_workload(['--products', 'bf16x6', '--steps', '20', '--warmup', '3', '--sustained-seconds', '0', '--self-check'] + nb),
+                                      extra_workload(['--workload', 'c3', '--steps', '10', '--warmup', '2', '--sustained-seconds', '0']),      # + its cpu_baseline
                                       extra_workload(['--workload', 'c4', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0']),                # + its cpu_baseline
                                       # the same with the rows-form products on the bf16 matrix path (six-term split, fp32 accumulate)
                                       extra_workload(['--workload', 'c4', '--products', 'bf16x6', '--steps', '5', '--warmup', '1', '--sustained-seconds', '0'] + nb),

@@ -409,6 +409,10 @@ int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb, 
 /* MFMA instructions (v_mfma_f32_16x16x4_f32, 2048 FLOP each) the gradient kernel instantiated for these dimensions issues per
  * 16-row tile: what bench.py's roofline.frac_executed is computed from.  0 = unsupported dimensions. */
 int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_stride, int32_t num_actions);
+/* Which kernel pfa_ppo_mlp_grad / pfa_ppo_mlp_train launch for these dimensions and local minibatch rows under the current product
+ * form (pfa_igemm_set_products): 0 = ppo_mlp_grad_kernel (exact fp32 MFMA chains), 1 = ppo_mlp_grad_bf16_kernel (csrc/ppo_bf16.hpp:
+ * the opt-in form, the 7x7 grid on 64-float rows with minibatches of whole 32-row tiles; everything else stays on 0). */
+int pfa_ppo_mlp_grad_path(const pfa_mlp_dims *dims, int64_t mb_rows);
 /* clip_grad_norm_(max_grad_norm) + Adam(eps) step (:240-244; torch.optim.Adam single-tensor semantics, bias
  * correction with `step` = 1-based optimizer step count).  grad_scale multiplies grads first.
  * If loss_sums (the 16-float tail above) / losses (f64[8]) are given: losses[i] += sum_i * loss_scale for i < 6, i.e. the running
@@ -604,7 +608,8 @@ int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, const float
  * (models.py:126-135) leave it to the BLAS): 0 (default) = v_mfma_f32_16x16x4_f32, exact fp32 products in k order; 1 = every fp32
  * operand split into three bf16 pieces and each product issued as its six partial products above 2^-24 on the bf16 matrix path with
  * fp32 accumulation — as close to an f64 product as the fp32 chain, not the same bits.  Contractions that are not a multiple of 32
- * and 16-column outputs keep form 0. */
+ * and 16-column outputs keep form 0.  The same switch selects the bf16-path form of the fused 128-wide gradient step
+ * (pfa_ppo_mlp_grad_path). */
 int pfa_igemm_set_products(int32_t mode);
 int pfa_igemm_get_products(void);
 size_t pfa_igemm_weights_workspace_bytes(int64_t M, int32_t K, int32_t N);

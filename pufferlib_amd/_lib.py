@@ -241,6 +241,7 @@ _SIGNATURES = {
     'pfa_dist_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
     'pfa_dist_info': (C.c_int, [P]),
     'pfa_ppo_mlp_grad_mfma_per_tile': (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    'pfa_ppo_mlp_grad_path': (C.c_int, [C.POINTER(MlpDims), C.c_int64]),
     'pfa_heads_rows_sample': (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, C.c_uint32, P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P]),
     'pfa_heads_rows_eval': (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, C.c_uint32, P, P, P, P, P]),
     'pfa_heads_rows_loss_workspace_bytes': (C.c_size_t, [C.c_int64]),

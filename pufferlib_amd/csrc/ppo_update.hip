@@ -1318,6 +1318,8 @@ extern "C" int pfa_ppo_mlp_grad(const pfa_experience *exp, int64_t batch_rows, i
     return 0;
 }
 
+extern "C" int pfa_ppo_mlp_grad_path(const pfa_mlp_dims *dims, int64_t mb_rows) { return dims && grad_bf16(dims, mb_rows) ? 1 : 0; }
+
 // MFMA instructions per 16-row tile of the instantiation pfa_ppo_mlp_grad dispatches for these dimensions (see the switch there):
 // forward KKU x kMT, heads 4 x kMT, dW2v 4 x kMT, dh 4 x kMT, dW1 KTM x 4 x kMT.
 extern "C" int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_stride, int32_t num_actions) {

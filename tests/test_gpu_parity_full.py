@@ -86,12 +86,24 @@ def _compare(pol, opol, data, Lo, recurrent, tr, what):
     return float(err.max()), worst
 
 
-@pytest.mark.parametrize('recurrent,epochs,hidden', [(False, 4, 128), (True, 4, 128), (False, 4, 256), (False, 2, 512), (False, 4, 64)])
-def test_full_size_update_through_create_evaluate_train(recurrent, epochs, hidden, capsys):
+@pytest.mark.parametrize('recurrent,epochs,hidden,products', [(False, 4, 128, 'fp32'), (False, 4, 128, 'bf16x6'), (True, 4, 128, 'fp32'),
+                                                              (False, 4, 256, 'fp32'), (False, 2, 512, 'fp32'), (False, 4, 64, 'fp32')])
+def test_full_size_update_through_create_evaluate_train(recurrent, epochs, hidden, products, capsys):
     """BASELINE configs[1] (and configs[2]'s policy): 4096 envs x 128 steps, 4 minibatches of 131 072 rows, bptt 16.
     Both policies: all 4 epochs = the 16 optimizer steps one bench step runs (LSTM: state carried across the minibatches of an
     epoch, reset at every epoch).  hidden 64 / 256 / 512: the same configuration with Default(hidden_size=...) — the width-templated
-    persistent rollout and the fused gradient kernel of csrc/ppo_wide.hip (what `bench.py --hidden H` times)."""
+    persistent rollout and the fused gradient kernel of csrc/ppo_wide.hip (what `bench.py --hidden H` times).  products 'bf16x6':
+    the headline configuration with the gradient step on the bf16 matrix path (csrc/ppo_bf16.hpp, opt-in), same tolerance."""
+    from pufferlib_amd import _lib, clean_pufferl
+    from test_gpu_ppo import _config
+    _lib.check(_lib.lib().pfa_igemm_set_products(1 if products == 'bf16x6' else 0), 'set_products')
+    try:
+        _full_size(recurrent, epochs, hidden, products, capsys)
+    finally:
+        _lib.check(_lib.lib().pfa_igemm_set_products(0), 'set_products')
+
+
+def _full_size(recurrent, epochs, hidden, products, capsys):
     from pufferlib_amd import clean_pufferl
     from test_gpu_ppo import _config
     n, horizon, nmb, bptt = 4096, 128, 4, 16
@@ -112,7 +124,7 @@ def test_full_size_update_through_create_evaluate_train(recurrent, epochs, hidde
     loss_err, w_err = _compare(pol, opol, data, Lo, recurrent, tr, 'full size')
     np.testing.assert_allclose(data.losses.explained_variance, Lo['explained_variance'], rtol=1e-4, atol=1e-5)
     with capsys.disabled():
-        print(f'\n[parity full-size {"lstm" if recurrent else "mlp"} hidden {hidden}] max |loss err| {loss_err:.2e}, max |weight err| {w_err:.2e}')
+        print(f'\n[parity full-size {"lstm" if recurrent else "mlp"} hidden {hidden} products {products}] max |loss err| {loss_err:.2e}, max |weight err| {w_err:.2e}')
 
 
 FLAGS = [dict(norm_adv=False), dict(clip_vloss=False), dict(norm_adv=False, clip_vloss=False), dict(anneal_lr=False),
@@ -121,9 +133,12 @@ FLAGS = [dict(norm_adv=False), dict(clip_vloss=False), dict(norm_adv=False, clip
 
 @pytest.mark.parametrize('recurrent', [False, True, 'wide256'])
 @pytest.mark.parametrize('flags', FLAGS, ids=lambda f: ','.join(f'{k}={v}' for k, v in f.items()))
-def test_update_branches_vs_oracle_trainer(recurrent, flags):
+def test_update_branches_vs_oracle_trainer(recurrent, flags, matrix_products):
     """clean_pufferl.py:211-213 (norm_adv), :222-235 (clip_vloss), :256-258 (target_kl break after an epoch), :261-264
-    (anneal_lr) — each switched away from the default, two train() calls so the lr schedule matters."""
+    (anneal_lr) — each switched away from the default, two train() calls so the lr schedule matters.  The 128-wide MLP also with the
+    gradient step on the bf16 matrix path (opt-in product form)."""
+    if matrix_products == 'bf16x6' and recurrent is not False:
+        pytest.skip('the bf16-path fused gradient step covers the 128-wide MLP')
     from pufferlib_amd import clean_pufferl
     from test_gpu_ppo import _config
     n, horizon, nmb, bptt, epochs = 128, 32, 2, 8, 3

@@ -100,9 +100,12 @@ def test_create_evaluate_train_replays_golden(golden_dir):
     assert float(data.flat_params.flat[:H * DP].view(H, DP)[:, 49:].abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize('n,horizon,nmb,bptt', [(256, 64, 4, 16), (64, 32, 2, 4), (1024, 128, 4, 16)])
-def test_update_vs_torch_oracle(n, horizon, nmb, bptt):
-    """Same experience into the HIP update and the torch-fp32 restatement of clean_pufferl.train."""
+@pytest.mark.parametrize('n,horizon,nmb,bptt', [(256, 64, 4, 16), (64, 32, 2, 4), (1024, 128, 4, 16), (704, 64, 2, 16)])
+def test_update_vs_torch_oracle(n, horizon, nmb, bptt, matrix_products):
+    """Same experience into the HIP update and the torch-fp32 restatement of clean_pufferl.train.  Both product forms of the fused
+    gradient step: exact fp32 MFMA chains (csrc/ppo_update.hip) and the opt-in six bf16 partial products per fp32 product
+    (csrc/ppo_bf16.hpp: minibatches of whole 32-row tiles — 128, 32, 1024 and 704 tiles here, the last one a ragged second round of
+    the 512-workgroup grid; bptt 4 = tiles that straddle segments)."""
     from pufferlib_amd import clean_pufferl
     from oracle import c_oracle, ppo_torch
     hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
@@ -114,6 +117,9 @@ def test_update_vs_torch_oracle(n, horizon, nmb, bptt):
             p.add_(0.05 * torch.randn_like(p))     # move off the near-uniform init so ratios/clipping engage
     cfg = _config(n, horizon, B // nmb, bptt, 2, B * 10, hp)
     data = clean_pufferl.create(cfg, vec, pol)
+    import ctypes as C
+    from pufferlib_amd import _lib
+    assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(data.flat_params.dims), B // nmb) == (1 if matrix_products == 'bf16x6' else 0)
     w0 = {k[len('policy.'):]: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
     clean_pufferl.evaluate(data)          # Philox noise; fills the experience on device
     exp = data.experience
@@ -443,10 +449,11 @@ def test_deferred_readback_mode_gives_the_same_numbers(monkeypatch):
 
 
 @pytest.mark.parametrize('num_actions', [3, 11, 12, 15])
-def test_49_float_rows_with_other_action_counts_vs_oracle(num_actions):
+def test_49_float_rows_with_other_action_counts_vs_oracle(num_actions, matrix_products):
     """The 7x7-grid instantiation of the gradient kernel (3 dW1 k-tiles + the column-48 accumulators) keeps the head outputs in
     PERMUTED fragment rows for up to 11 actions (three outputs per lane group) and in natural rows above that: both against the
-    oracle trainer on a host vecenv with 49-float observations and 3 / 11 (permuted) and 12 / 15 (natural) actions."""
+    oracle trainer on a host vecenv with 49-float observations and 3 / 11 (permuted) and 12 / 15 (natural) actions; in both product
+    forms (the bf16-path kernel of csrc/ppo_bf16.hpp has the same two head layouts)."""
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
     from host_vecenv import HostMultiHead
