@@ -14,3 +14,20 @@ without the built extension, or calling them without a GPU, raises.
 from .namespace import namespace, Namespace  # noqa: F401
 
 __version__ = '0.1.0'
+
+
+def set_matrix_products(form):
+    """How the fp32 products of the matrix kernels are formed, process-wide (no reference counterpart: torch leaves this to its BLAS).
+    'fp32' (default): exact fp32 MFMA products.  'bf16x6': every fp32 operand as three bf16 pieces, each product as its six partial
+    products on the bf16 matrix path with fp32 accumulation — the conv / linear rows form (csrc/igemm.hip) and the fused 128-wide
+    gradient step on 7x7-grid rows (csrc/ppo_bf16.hpp).  Results agree to the tests' 1e-5, not bit for bit.  Also settable with the
+    environment variable PFA_MATRIX_PRODUCTS before the library is first used."""
+    from . import _lib
+    if form not in ('fp32', 'bf16x6'):
+        raise ValueError(f"matrix products {form!r}: expected 'fp32' or 'bf16x6'")
+    _lib.check(_lib.lib().pfa_igemm_set_products(1 if form == 'bf16x6' else 0), 'set_matrix_products')
+
+
+def get_matrix_products():
+    from . import _lib
+    return 'bf16x6' if _lib.lib().pfa_igemm_get_products() == 1 else 'fp32'

@@ -304,6 +304,11 @@ def lib():
         f.restype = res
         f.argtypes = args
     _lib = L
+    form = os.environ.get('PFA_MATRIX_PRODUCTS', 'fp32')
+    if form not in ('fp32', 'bf16x6'):
+        raise ExtensionError(f"PFA_MATRIX_PRODUCTS={form!r}: expected 'fp32' or 'bf16x6'")
+    if form == 'bf16x6':
+        check(L.pfa_igemm_set_products(1), 'PFA_MATRIX_PRODUCTS')
     return L
 
 

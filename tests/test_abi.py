@@ -116,3 +116,25 @@ def test_no_kernel_spills_registers_except_the_known_gradient_instantiations():
     # the one-launch reduce + Adam
     for frag in ('rollout_mlp_squared_kernel', 'ppo_wide_grad_kernel', 'ppo_reduce_adam_kernel', 'mlp_forward_sample_kernel', 'lstm_seq_bwd_kernel'):
         assert not any(frag in k and not any(a in k for a in allowed) for k in spills)
+
+
+def test_matrix_products_switch_is_host_state_and_validates_its_argument():
+    """pufferlib_amd.set_matrix_products / PFA_MATRIX_PRODUCTS: the opt-in product form is a process-wide flag of the library (no
+    GPU needed to flip it); anything but the two names raises."""
+    import pufferlib_amd
+    from pufferlib_amd import _lib
+    assert pufferlib_amd.get_matrix_products() == 'fp32'
+    try:
+        pufferlib_amd.set_matrix_products('bf16x6')
+        assert pufferlib_amd.get_matrix_products() == 'bf16x6' and _lib.lib().pfa_igemm_get_products() == 1
+        dims = _lib.MlpDims(49, 64, 128, 8, 0)
+        import ctypes as C
+        assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(dims), 131072) == 1       # the bench shape takes the bf16-path kernel ...
+        assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(dims), 131072 + 16) == 0  # ... minibatches that are not whole 32-row tiles do not
+        assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(_lib.MlpDims(64, 64, 128, 8, 0)), 131072) == 0   # nor other row widths
+    finally:
+        pufferlib_amd.set_matrix_products('fp32')
+    dims = _lib.MlpDims(49, 64, 128, 8, 0)
+    assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(dims), 131072) == 0
+    with pytest.raises(ValueError):
+        pufferlib_amd.set_matrix_products('tf32')
