@@ -717,8 +717,10 @@ def main():
                 out['roofline']['frac_executed'] = (576 * 16384 / 32 * rows_per_launch / (avg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS
                                                     if launches else 0.0)
                 out['roofline']['frac_executed_is'] = 'issued bf16 MFMA flop / the bf16 dense peak (2500 TFLOP/s)'
-                out['roofline']['traffic'] = None        # the PMC summary holds the fp32 kernel
-                out['roofline']['traffic_source'] = None
+                t_bf, src_bf = pmc_traffic('ppo_mlp_grad_bf16')
+                out['roofline']['traffic'] = t_bf
+                out['roofline']['traffic_source'] = src_bf if t_bf is not None else None
+                out['roofline']['traffic_note'] = None if t_bf is not None else src_bf
         # north_star asks for the HBM side next to the MFMA side: the rollout kernel is the path's HBM-facing kernel (it writes the
         # experience rows, SURVEY 8d: 280 B per env step), and the end-to-end figure is 1420 B per env step
         roll = breakdown.get({'mlp': 'rollout_mlp_squared', 'lstm': 'rollout_lstm_synth' if args.workload == 'c3' else 'rollout_lstm_squared'}.get(args.policy, ''))
