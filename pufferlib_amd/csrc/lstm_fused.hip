@@ -38,7 +38,7 @@ template <int DP>
 struct LstmLds {
     float xs[XTile<DP>::kFloats];   // observation tile (B operand of the encoder; the env writes its grids here)
     float xh[2][kXHTile];           // [xe | h] tiles; h_t lives in tile t&1, h_{t+1} is written into the other one
-    float part[4][kOut * 16];       // head partials per wave
+    float part[4][kPartFloats];       // head partials per wave
     float gbias[kLG];               // b_ih + b_hh
 };
 
@@ -70,12 +70,14 @@ __device__ __forceinline__ void lstm_tile_step(const LstmFrags<DP> &w, const flo
     __syncthreads();
 }
 
-__device__ __forceinline__ LaneSample lstm_sample(const float (*part)[kOut * 16], int le, int lo, int a, float q) {
-    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+__device__ __forceinline__ LaneSample lstm_sample(const float (*part)[kPartFloats], int le, int lo, int a, float q) {
+    const int i = lo * kPartStride + le;
+    const float mine = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
     return sample_row16(mine, lo, a, q);
 }
-__device__ __forceinline__ LaneSample lstm_sample_heads(const float (*part)[kOut * 16], int le, int lo, int a, uint32_t heads, float q) {
-    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+__device__ __forceinline__ LaneSample lstm_sample_heads(const float (*part)[kPartFloats], int le, int lo, int a, uint32_t heads, float q) {
+    const int i = lo * kPartStride + le;
+    const float mine = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
     return sample_row16_heads(mine, lo, a, heads, q);
 }
 

@@ -211,9 +211,9 @@ __device__ __forceinline__ void lstm_cell(f32x4 (&acc)[8], const float *gbias, f
         }
 }
 
-// This wave's K slice of decode_actions on the h half of an xh tile -> part[wave][o*16 + row].
+// This wave's K slice of decode_actions on the h half of an xh tile -> part[wave][o * kPartStride + row].
 template <int DP>
-__device__ __forceinline__ void lstm_heads(const LstmFrags<DP> &w, const float *xh, float (*part)[kOut * 16]) {
+__device__ __forceinline__ void lstm_heads(const LstmFrags<DP> &w, const float *xh, float (*part)[kPartFloats]) {
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
     f32x4 o0 = f32x4{w.bo[0], w.bo[1], w.bo[2], w.bo[3]};
 #pragma unroll
@@ -225,7 +225,7 @@ __device__ __forceinline__ void lstm_heads(const LstmFrags<DP> &w, const float *
         o0 = mfma16(w.w2f[j][3], b.w, o0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * 16 + c] = o0[r];
+    for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * kPartStride + c] = o0[r];
 }
 
 // c state <-> global [rows][128] in the cell layout (lane (c, g): row c, units 32w + 16sub + 4g + r).

@@ -21,6 +21,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kHidden = 128;
 constexpr int kMT = kHidden / 16;  // hidden tiles
 constexpr int kOut = 16;           // padded head rows
+// The rollout kernels' partial out^T tiles in LDS: [output o][row] with rows of 18 floats.  Thread (row le, output lo) reads
+// part[w][lo * kPartStride + le]; with rows of 16 the 8 even (odd) outputs of a 32-lane group met on ONE bank (ds_read_b32 banks are
+// word mod 32: 16 lo + le), an 8-way conflict on the dependent chain of every rollout step; 18 lo + le is conflict-free, and the
+// fragment-order stores (4g + r) * 18 + c stay 2-way, which a ds_write_b32 absorbs (MI355X_MICROARCH.md, LDS).
+constexpr int kPartStride = 18;
+constexpr int kPartFloats = kOut * kPartStride;
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(kRollThreads) mlp_forward_sample_kernel(const 
                                                                          long long *actions, float *logprob, float *entropy,
                                                                          float *value) {
     __shared__ float xs[XTile<DP>::kFloats];
-    __shared__ float part[kRollWaves][kOut * 16];
+    __shared__ float part[kRollWaves][kPartFloats];
     SliceFrags<DP, KS, MW> w;
     w.load(pv);
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_squared_kernel(Squar
                                                                           uint8_t *live_trunc, uint8_t *live_mask) {
     constexpr int XS = XTile<DP>::XS;
     __shared__ float xs[XTile<DP>::kFloats];
-    __shared__ float part[kRollWaves][kOut * 16];  // partial out^T[o][row] per wave
+    __shared__ float part[kRollWaves][kPartFloats];  // partial out^T[o][row] per wave
     __shared__ uint16_t tg[NT1 ? 1 : 16 * kMaxTargets];
     // One wave per SIMD on a dependent chain: whatever shares the CU (the reset-tape workgroup drawn on the side stream while
     // this kernel runs) must not win issue slots from it — the launch lasts as long as its slowest workgroup.

@@ -114,9 +114,9 @@ __device__ __forceinline__ void unstage_rows(const float *xs, float *dst, long l
     }
 }
 
-// This wave's slice of models.Default.forward (models.py:41-62) for the 16 rows in xs -> part[wave][o*16 + row].
+// This wave's slice of models.Default.forward (models.py:41-62) for the 16 rows in xs -> part[wave][o * kPartStride + row].
 template <int DP, int KS = DP / 4, int MW = kMW>   // MW = 1 or even
-__device__ __forceinline__ void forward_slice(const SliceFrags<DP, KS, MW> &w, const float *xs, float (*part)[kOut * 16]) {
+__device__ __forceinline__ void forward_slice(const SliceFrags<DP, KS, MW> &w, const float *xs, float (*part)[kPartFloats]) {
     constexpr int XS = XTile<DP>::XS;
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
     f32x4 h[MW];
@@ -140,16 +140,18 @@ __device__ __forceinline__ void forward_slice(const SliceFrags<DP, KS, MW> &w, c
     }
     const f32x4 po = o0 + o1;  // partial out^T[o = 4g + r][row = c]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * 16 + c] = po[r];
+    for (int r = 0; r < 4; ++r) part[wv][(4 * g + r) * kPartStride + c] = po[r];
 }
 
 // Sum of the four waves' head partials for (row le, output lo), then sample_row16 (sampler.hpp).
-__device__ __forceinline__ LaneSample sample_lanes(const float (*part)[kOut * 16], int le, int lo, int a, float q) {
-    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+__device__ __forceinline__ LaneSample sample_lanes(const float (*part)[kPartFloats], int le, int lo, int a, float q) {
+    const int i = lo * kPartStride + le;
+    const float mine = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
     return sample_row16(mine, lo, a, q);
 }
-__device__ __forceinline__ LaneSample sample_lanes_heads(const float (*part)[kOut * 16], int le, int lo, int a, uint32_t heads, float q) {
-    const float mine = (part[0][lo * 16 + le] + part[1][lo * 16 + le]) + (part[2][lo * 16 + le] + part[3][lo * 16 + le]);
+__device__ __forceinline__ LaneSample sample_lanes_heads(const float (*part)[kPartFloats], int le, int lo, int a, uint32_t heads, float q) {
+    const int i = lo * kPartStride + le;
+    const float mine = (part[0][i] + part[1][i]) + (part[2][i] + part[3][i]);
     return sample_row16_heads(mine, lo, a, heads, q);
 }
 

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(kRollThreads) rollout_mlp_stochastic_kernel(St
                                                                              uint8_t *live_mask) {
     constexpr int DP = kStoDP;
     __shared__ float xs[XTile<DP>::kFloats];
-    __shared__ float part[kRollWaves][kOut * 16];
+    __shared__ float part[kRollWaves][kPartFloats];
     const int le = threadIdx.x >> 4, lo = threadIdx.x & 15;
     const int e = blockIdx.x * 16 + le;
     const bool env_ok = e < v.n;

@@ -32,6 +32,14 @@ pmc c3 "--workload c3"
 pmc c4 "--workload c4"
 pmc hidden256 "--hidden 256"
 pmc mlp_bf16x6 "--products bf16x6"
+lds() {  # LDS counters of a workload (own pass; not part of the stamped summary)
+  bash profiles/collect_pmc.sh ${TAG}lds_$1 "$2" "sq2" > gpurun_out/${TAG}_lds_$1.log 2>&1; echo "lds $1 rc=$?"
+  cp gpurun_out/pmc_${TAG}lds_$1/summary.csv gpurun_out/${TAG}_lds_$1.csv
+  rm -rf gpurun_out/pmc_${TAG}lds_$1
+}
+lds c4 "--workload c4"
+lds c3 "--workload c3"
+lds mlp ""
 python profiles/make_pmc_summary.py gpurun_out/${TAG}_pmc_mlp.csv gpurun_out/${TAG}_pmc_c3.csv gpurun_out/${TAG}_pmc_c4.csv gpurun_out/${TAG}_pmc_hidden256.csv gpurun_out/${TAG}_pmc_mlp_bf16x6.csv > gpurun_out/${TAG}_pmc_summary.log 2>&1; echo "summary rc=$?"
 cp profiles/pmc_summary.json gpurun_out/${TAG}_pmc_summary.json
 # the default line LAST: it now finds a summary stamped with this build; shader clock and power sampled next to it
