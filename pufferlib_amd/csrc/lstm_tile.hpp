@@ -91,11 +91,27 @@ __device__ __forceinline__ void lstm_encode(const LstmFrags<DP> &w, const float 
     const int wv = wave_id(), c = lane_id() & 15, g = lane_id() >> 4;
     f32x4 h0 = f32x4{w.b1f[0][0], w.b1f[0][1], w.b1f[0][2], w.b1f[0][3]};
     f32x4 h1 = f32x4{w.b1f[1][0], w.b1f[1][1], w.b1f[1][2], w.b1f[1][3]};
+    // the B values of the row run eight k-steps ahead of their products (two register chunks): the compiler would otherwise sink
+    // every ds_read next to its two products and expose the LDS latency DP / 4 times; same products, same order
+    constexpr int KS = DP / 4, CH = 8, NCH = (KS + CH - 1) / CH;
+    float bv[2][CH];
 #pragma unroll
-    for (int kk = 0; kk < DP / 4; ++kk) {
-        const float b = xs[c * XS + 4 * kk + g];
-        h0 = mfma16(w.w1f[0][kk], b, h0);
-        h1 = mfma16(w.w1f[1][kk], b, h1);
+    for (int q = 0; q < CH; ++q) bv[0][q] = q < KS ? xs[c * XS + 4 * q + g] : 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch + 1 < NCH) {
+#pragma unroll
+            for (int q = 0; q < CH; ++q) bv[(ch + 1) & 1][q] = (ch + 1) * CH + q < KS ? xs[c * XS + 4 * ((ch + 1) * CH + q) + g] : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) {
+            const int kk = ch * CH + q;
+            if (kk < KS) {
+                h0 = mfma16(w.w1f[0][kk], bv[ch & 1][q], h0);
+                h1 = mfma16(w.w1f[1][kk], bv[ch & 1][q], h1);
+            }
+        }
     }
     float4 *dst = reinterpret_cast<float4 *>(xh + c * kXHS + 32 * wv + 4 * g);
     dst[0] = make_float4(fmaxf(h0[0], 0.f), fmaxf(h0[1], 0.f), fmaxf(h0[2], 0.f), fmaxf(h0[3], 0.f));

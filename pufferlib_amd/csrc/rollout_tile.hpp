@@ -122,11 +122,17 @@ __device__ __forceinline__ void forward_slice(const SliceFrags<DP, KS, MW> &w, c
     f32x4 h[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) h[i] = f32x4{w.b1f[i][0], w.b1f[i][1], w.b1f[i][2], w.b1f[i][3]};
+    // every B value of the row first, the products behind them: left to itself the compiler sinks each ds_read next to its products
+    // and drains lgkmcnt in front of every group (ISA of round 4: seven exposed LDS latencies per step of the rollout's dependent
+    // chain); same products in the same order, so the numbers do not change
+    float bv[KS];
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) bv[kk] = xs[c * XS + 4 * kk + g];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
-        const float b = xs[c * XS + 4 * kk + g];
 #pragma unroll
-        for (int i = 0; i < MW; ++i) h[i] = mfma16(w.w1f[i][kk], b, h[i]);
+        for (int i = 0; i < MW; ++i) h[i] = mfma16(w.w1f[i][kk], bv[kk], h[i]);
     }
     // the heads' contraction over this wave's 16 MW hidden units: two accumulator chains (even / odd tiles)
     f32x4 o0 = f32x4{w.bo[0], w.bo[1], w.bo[2], w.bo[3]}, o1 = f32x4{0.f, 0.f, 0.f, 0.f};
