@@ -153,6 +153,27 @@ def test_eight_ranks_full_update_equals_single_process_run(tmp_path):
     assert not np.array_equal(r[0]['0.obs'], r[7]['0.obs'])
 
 
+def test_two_ranks_equal_single_process_run_with_the_gradient_step_in_the_bf16x6_form(tmp_path, monkeypatch):
+    """The opt-in product form under data parallelism: the bf16-path gradient kernel (csrc/ppo_bf16.hpp) leaves 512 instead of 256
+    partials per launch in front of the reduce + Adam launch that carries the exchange; ranks inherit PFA_MATRIX_PRODUCTS, the
+    single-process reference run of this process switches with set_matrix_products."""
+    import ctypes as C
+    import pufferlib_amd
+    from pufferlib_amd import _lib
+    world = 2
+    N, T, _ = _sizes(False)
+    assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(_lib.MlpDims(49, 64, 128, 8, 0)), N * T // 2) == 0
+    monkeypatch.setenv('PFA_MATRIX_PRODUCTS', 'bf16x6')
+    pufferlib_amd.set_matrix_products('bf16x6')
+    try:
+        assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(_lib.MlpDims(49, 64, 128, 8, 0)), N * T // 2) == 1   # the rank-local minibatch takes it
+        _spawn(_worker, (world, _free_port(), False, str(tmp_path), 'p2p'), world)
+        r = _check_against_single_process(tmp_path, world, False)
+    finally:
+        pufferlib_amd.set_matrix_products('fp32')
+    assert tuple(int(x) for x in r[0]['native']) == (1, 1, 0)
+
+
 @pytest.mark.parametrize('recurrent,transport', [(False, 'torch'), (True, 'torch'), (False, 'p2p'), (True, 'p2p'), (False, 'rccl-refused'),
                                                  (CONV, 'torch'), (CONV, 'p2p'), (WIDE, 'torch'), (WIDE, 'p2p'), (False, 'p2p-unfused'), (False, 'p2p-late-gae'), (True, 'p2p-late-gae')])
 def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent, transport):
