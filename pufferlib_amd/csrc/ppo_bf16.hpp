@@ -12,17 +12,22 @@
 // keep the VALU work small and evenly spread instead of keeping the matrix pipe fed:
 //   * a workgroup is FOUR waves working on the same 32-row tile (32 = the contraction depth of the weight gradients, whose
 //     contraction index is the batch row); the hidden units are split over the waves (32 each), so a wave's slices of W1 / W2v and of
-//     every gradient live in its registers for the whole launch — no fragment tables, two workgroups per CU (<= 256 registers,
-//     72.5 KB of LDS);
-//   * forward:  hidden^T[u][row] = W1 . X^T with X as three bf16 planes in LDS (split once by the threads that stage the tile);
-//     a wave's hidden^T C fragments ARE the B fragments of its K = 32 slice of the heads (a K-permutation shared with the W2v
-//     fragment), partial out^T tiles meet in LDS;
-//   * loss: the 16 x 16 out^T tile of each 16-row half by ONE wave (two of the four per tile, alternating), d loss / d out as bf16
-//     planes [row][o] in LDS;
-//   * backward: dh^T = W2v^T . dout^T (B fragments straight from the dout planes), relu' on the C fragment; the three products that
-//     contract over batch rows (dW2v^T = hidden^T . dout, dW1^T = X^T . dh) take their operands from ROW-MAJOR bf16 planes through
-//     ds_read_b64_tr_b16 (the LDS transposes: tools/experiments/ds_read_tr_map.hip has the lane map) — hidden and dh through the
-//     wave's own patch, X and dout from the shared planes.  No operand is transposed by VALU code.
+//     every gradient live in its registers for the whole launch — no fragment tables, two workgroups per CU (238 registers,
+//     76.5 KB of LDS);
+//   * X(j + 2) travels HBM -> LDS by direct-to-LDS loads (no registers, no VALU work) issued behind barrier C of tile j into a landing
+//     buffer; behind barrier B of tile j + 1 the wave pair that does NOT compute that tile's loss splits it into the three bf16 planes
+//     of an X slot while the other pair runs the loss (a latency chain) — two workgroup barriers per tile, the pairs alternate;
+//   * forward:  hidden^T[u][row] = W1 . X^T, B fragments straight from the planes; a wave's hidden^T C fragments ARE the B fragments
+//     of its K = 32 slice of the heads (a K-permutation shared with the W2v fragment), partial out^T tiles meet in LDS;
+//   * loss: the 16 x 16 out^T tile of each 16-row half by ONE wave of the loss pair, d loss / d out as bf16 planes [row][o] in LDS;
+//   * backward: dW2v^T = hidden^T . dout takes both operands from ROW-MAJOR bf16 planes through ds_read_b64_tr_b16 (the LDS
+//     transposes: tools/experiments/ds_read_tr_map.hip has the lane map; hidden through the wave's own patch).  dh = dout . W2v is
+//     computed UNtransposed: lane (c, g) of the C fragments of its two M tiles holds dh[row 16mt + 4g + r][unit c], which after relu'
+//     (read off the hi piece the dW2v fragment already holds) and the split IS the B fragment of dW1^T = X^T . dh with the contraction
+//     index permuted to (g, e) <-> row 16 (e >> 2) + 4g + (e & 3); X^T comes through transposed reads with the same permutation.
+//     No operand is transposed or moved by VALU code;
+//   * LDS strides from the banking model of MI355X_MICROARCH.md (tools/lds_bank_model.py, tests/test_lds_layout.py): every read that
+//     runs four or more times per tile and wave is conflict-free.
 // The partial a workgroup leaves has the layout of ppo_mlp_grad_kernel<64, 0, 13, false, 3, true, PERM> (NativeLayout<64, 3, true>),
 // so ppo_reduce_kernel / ppo_reduce_adam_kernel and everything behind them are shared.
 #pragma once
