@@ -17,8 +17,9 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 LIB_PATH = os.path.join(LIB_DIR, 'libpufferlib_amd.so')
 SOURCES = ['common.cpp', 'dist.cpp', 'p2p.hip', 'gae.hip', 'squared.hip', 'rollout.hip', 'ppo_update.hip', 'lstm.hip', 'gemm.hip', 'lstm_fused.hip', 'lstm_seq.hip', 'stochastic.hip', 'memory.hip', 'bandit.hip', 'multiagent.hip', 'spaces.hip', 'synthetic.hip', 'nativize.hip', 'igemm.hip', 'cnn_heads.hip', 'general.hip', 'ppo_wide.hip']
-HEADERS = ['common.hpp', 'mt19937.hpp', 'philox.hpp', 'squared_env.hpp', 'mlp_tile.hpp', 'lane_ops.hpp', 'sampler.hpp', 'lstm_tile.hpp', 'rollout_tile.hpp', 'episode_fin.hpp', 'ppo_tile.hpp', 'memory_env.hpp', 'synth_env.hpp', 'p2p_ll.hpp',
-           os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
+# every header under csrc/ (sorted: the order is part of source_hash) + the public C header: a header missing from a hand-kept list is a
+# library that silently is not rebuilt when only that header changes
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith('.hpp')) + [os.path.join('..', '..', 'include', 'pufferlib_amd.h')]
 
 
 def _stale():

@@ -138,3 +138,15 @@ def test_matrix_products_switch_is_host_state_and_validates_its_argument():
     assert _lib.lib().pfa_ppo_mlp_grad_path(C.byref(dims), 131072) == 0
     with pytest.raises(ValueError):
         pufferlib_amd.set_matrix_products('tf32')
+
+
+def test_every_header_a_source_includes_is_a_build_dependency():
+    """_lib.HEADERS drives both the rebuild check and source_hash (the stamp of profiles/pmc_summary.json): a header a kernel source
+    includes but the list misses means a library that silently is not rebuilt, and a stamp that does not see the change."""
+    import re
+    from pufferlib_amd import _lib
+    listed = {os.path.basename(h) for h in _lib.HEADERS}
+    for f in _lib.SOURCES + [h for h in _lib.HEADERS if not h.startswith('..')]:
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(os.path.join(_lib.CSRC, f)).read()):
+            if inc.endswith(('.hpp', '.h')) and not inc.startswith('hip/'):
+                assert os.path.basename(inc) in listed, (f, inc)
