@@ -12,24 +12,22 @@
 // keep the VALU work small and evenly spread instead of keeping the matrix pipe fed:
 //   * a workgroup is FOUR waves working on the same 32-row tile (32 = the contraction depth of the weight gradients, whose
 //     contraction index is the batch row); the hidden units are split over the waves (32 each), so a wave's slices of W1 / W2v and of
-//     every gradient live in its registers for the whole launch — no fragment tables, two workgroups per CU (252 registers,
-//     70 KB of LDS);
-//   * two workgroup barriers per tile: behind barrier B (the partial out^T tiles) one wave pair computes the loss (a latency chain)
-//     while the other splits X(j + 1) — fetched into registers over the forward — into the three bf16 planes of the other X slot;
-//     the pairs alternate from tile to tile;
+//     every gradient live in its registers for the whole launch — no fragment tables, two workgroups per CU (238 registers,
+//     76.5 KB of LDS);
+//   * X(j + 2) travels HBM -> LDS by direct-to-LDS loads (no registers, no VALU work) issued behind barrier C of tile j into a landing
+//     buffer; behind barrier B of tile j + 1 the wave pair that does NOT compute that tile's loss splits it into the three bf16 planes
+//     of an X slot while the other pair runs the loss (a latency chain) — two workgroup barriers per tile, the pairs alternate;
 //   * forward:  hidden^T[u][row] = W1 . X^T, B fragments straight from the planes; a wave's hidden^T C fragments ARE the B fragments
 //     of its K = 32 slice of the heads (a K-permutation shared with the W2v fragment), partial out^T tiles meet in LDS;
 //   * loss: the 16 x 16 out^T tile of each 16-row half by ONE wave of the loss pair, d loss / d out as bf16 planes [row][o] in LDS;
 //   * backward: dW2v^T = hidden^T . dout takes both operands from ROW-MAJOR bf16 planes through ds_read_b64_tr_b16 (the LDS
 //     transposes: tools/experiments/ds_read_tr_map.hip has the lane map; hidden through the wave's own patch).  dh = dout . W2v is
-//     computed UNtransposed with the rows of its A operand permuted, so that lane (c, g) of the C fragments of its two M tiles holds
-//     dh[row 8g + 4mt + r][unit c] — after relu' (read off the hi piece the dW2v fragment already holds) and the split that pair IS
-//     the B fragment (k = row 8g + e) of dW1^T = X^T . dh; X^T comes through transposed reads.  No operand is transposed or moved by
-//     VALU code.
-// Measured and not kept (tools/experiments/ppo_bf16_glds_variant.hpp, docs/lab-notebook.md): X by direct-to-LDS loads into a landing
-// buffer with the row strides of every plane chosen conflict-free in the banking model (tools/lds_bank_model.py) — 47.6-48.0 us per
-// launch against this form's 46.5 in a same-box A/B: the landing buffer is one more LDS round trip for the staging pair, and with two
-// workgroups per CU the 2-way conflicts of this layout are not what the launch waits for.
+//     computed UNtransposed: lane (c, g) of the C fragments of its two M tiles holds dh[row 16mt + 4g + r][unit c], which after relu'
+//     (read off the hi piece the dW2v fragment already holds) and the split IS the B fragment of dW1^T = X^T . dh with the contraction
+//     index permuted to (g, e) <-> row 16 (e >> 2) + 4g + (e & 3); X^T comes through transposed reads with the same permutation.
+//     No operand is transposed or moved by VALU code;
+//   * LDS strides from the banking model of MI355X_MICROARCH.md (tools/lds_bank_model.py, tests/test_lds_layout.py): every read that
+//     runs four or more times per tile and wave is conflict-free.
 // The partial a workgroup leaves has the layout of ppo_mlp_grad_kernel<64, 0, 13, false, 3, true, PERM> (NativeLayout<64, 3, true>),
 // so ppo_reduce_kernel / ppo_reduce_adam_kernel and everything behind them are shared.
 #pragma once
@@ -51,11 +49,13 @@ __host__ __device__ constexpr int bf_slot_output(bool perm, int slot) {   // = s
     return !perm ? slot : ((slot & 3) == 3 ? 99 : 3 * (slot >> 2) + (slot & 3));
 }
 
-struct BfLds {   // bytes
-    static constexpr int XRS = 144;                 // row of an X plane: 64 bf16 + 16 bytes (2-way on the operand reads in the banking model: see the header)
+struct BfLds {   // bytes.  Strides chosen with the banking of MI355X_MICROARCH.md (LDS section): conflict-free for the reads that run
+                 // 4x per tile and wave (b128 operand reads, transposed reads of X and dout); the patch keeps 2-way transposed reads
+                 // (no stride serves both its b64 stores and its transposed reads)
+    static constexpr int XRS = 160;                 // row of an X plane: 64 bf16 + 32 bytes
     static constexpr int kXPlane = 32 * XRS;
     static constexpr int kXSlot = 3 * kXPlane;      // [piece][row][k]
-    static constexpr int DRS = 80;                  // row of a dout plane: 16 slots + 16 zero slots (the K = 32 padding of dh) + 16 bytes
+    static constexpr int DRS = 32;                  // row of a dout plane: the 16 slots, nothing else
     static constexpr int kDPlane = 32 * DRS;
     static constexpr int HRS = 72;                  // row of a wave's hidden patch plane: 32 units + 8 bytes
     static constexpr int kHPlane = 32 * HRS;
@@ -64,8 +64,10 @@ struct BfLds {   // bytes
     static constexpr int kD = kPart + 4 * 2 * 64 * 4 * 4;        // [3 pieces] dout planes
     static constexpr int kH = kD + 3 * kDPlane;                  // [4 waves][3 pieces] patches
     static constexpr int kRed = kH + 4 * 3 * kHPlane;            // [4 waves][32] floats: db2 / loss sums at the end
-    static constexpr int kBytes = kRed + 4 * 32 * 4;
+    static constexpr int kRaw = kRed + 4 * 32 * 4;               // [32 rows][64] floats: the next tile's X as it lands from HBM
+    static constexpr int kBytes = kRaw + 32 * 256;
 };
+static_assert(BfLds::kRaw % 256 == 0 && BfLds::kBytes <= 80 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ uint32_t bf_pk(float a, float b) {   // two floats -> two bf16 (round to nearest even), a in the low half
     f32x2_t v = {a, b};
@@ -98,14 +100,16 @@ __device__ __forceinline__ void bf_split8(const float *x, BfFrag3 &out) {
 __device__ __forceinline__ f32x4 bf_mfma(const BfFrag &a, const BfFrag &b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0); }
 constexpr int kBfTA[6] = {2, 0, 1, 1, 0, 0}, kBfTB[6] = {0, 2, 1, 0, 1, 0};
 
-// One operand fragment whose contraction index is the ROW of a row-major bf16 plane: element e <-> (row row0 + 8 g + e, column
-// col0 + c).  ds_read_b64_tr_b16: within a group of 16 lanes, lane 4 a + b receives element b of the 8 bytes lanes a, a + 4, a + 8,
-// a + 12 point at — so lane j of the group points at (row (j >> 2), columns 4 (j & 3) .. + 3) of a 4 x 16 block; two reads = 8 rows.
+// One operand fragment whose contraction index is the ROW of a row-major bf16 plane.  The contraction index of the three
+// weight-gradient products is permuted: element e of lane group g <-> row 16 (e >> 2) + 4g + (e & 3) — the rows the C fragments of
+// two 16-row M tiles hold in that lane group, so a C fragment pair is an operand fragment without any data movement.
+// ds_read_b64_tr_b16: within a group of 16 lanes, lane 4 a + b receives element b of the 8 bytes lanes a, a + 4, a + 8, a + 12 point
+// at — so lane j of the group points at (row (j >> 2), columns 4 (j & 3) .. + 3) of a 4 x 16 block; two reads = 8 rows.
 typedef __attribute__((address_space(3))) s16x4_t *bf_lds_s16x4;
-__device__ __forceinline__ void bf_tr8(const unsigned char *plane, int row_stride, int row0, int col0, int c, int g, BfFrag &f) {
-    const unsigned char *p = plane + (row0 + 8 * g + (c >> 2)) * row_stride + (col0 + 4 * (c & 3)) * 2;
+__device__ __forceinline__ void bf_tr8(const unsigned char *plane, int row_stride, int col0, int c, int g, BfFrag &f) {
+    const unsigned char *p = plane + (4 * g + (c >> 2)) * row_stride + (col0 + 4 * (c & 3)) * 2;
     f.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf_lds_s16x4)p);
-    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf_lds_s16x4)(p + 4 * row_stride));
+    f.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf_lds_s16x4)(p + 16 * row_stride));
 }
 
 #ifdef PFA_BF16_TRACE
@@ -163,9 +167,6 @@ __global__ void __launch_bounds__(kBfThreads, 2)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bo[r] = b2v_at(params, off, a, bf_slot_output(PERM, 4 * g + r));
     }
-    // the K-padding half of the dout planes (slots 16 .. 31) is read by dh's B fragments and never written: zero it once
-    for (int i = threadIdx.x; i < 3 * L::kDPlane / 4; i += kBfThreads) reinterpret_cast<uint32_t *>(dpl)[i] = 0u;
-
     // advantage normalisation (clean_pufferl.py:211-213): unbiased std over the GLOBAL minibatch
     float adv_mean = 0.0f, adv_den = 1.0f;
     if (hp.norm_adv) {
@@ -201,31 +202,34 @@ __global__ void __launch_bounds__(kBfThreads, 2)
                                   // staging is what the other pair would otherwise wait behind)
     const int st = threadIdx.x & 127;
     auto tile_of = [&](int j) { return (long long)blockIdx.x + (long long)j * gridDim.x; };
+    const unsigned char *raw = smem + L::kRaw;
 
-    // a pair stages a whole tile: four float4 of X per thread (idx = st + 128 q: row = idx >> 4, column quad = idx & 15; the rows of
-    // one q lie in one 16-row half)
-    float4 xpre[4];
-    auto load_x = [&](long long tile) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xpre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // X(j + 2) travels HBM -> LDS by direct-to-LDS loads (no registers, no VALU work), issued behind barrier C of tile j and consumed
+    // behind barrier B of tile j + 1: every wave fetches 8 rows as two 1 KB blocks (lane l of block b: row 4b + (l >> 4), 16 bytes l & 15)
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    auto issue_raw = [&](long long tile) {
         if (tile < tiles) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int idx = st + 128 * q, r = (idx >> 4) & 15, c4 = idx & 15;
-                const unsigned t16 = 2u * (unsigned)tile + (unsigned)(q >> 1);
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int b = 2 * wvu + b2;
+                const unsigned t16 = 2u * (unsigned)tile + (unsigned)(b >> 2);
                 const unsigned first = map.tile_first(t16);
-                const unsigned row = map.tile_row(t16, first, r, aligned);
-                xpre[q] = *reinterpret_cast<const float4 *>(ex.obs + (size_t)row * DP + 4 * c4);
+                const unsigned frow = map.tile_row(t16, first, (4 * b + (lane >> 4)) & 15, aligned);
+                const float *src = ex.obs + (size_t)frow * DP + 4 * (lane & 15);
+                __builtin_amdgcn_global_load_lds(src, (__attribute__((address_space(3))) void *)(smem + L::kRaw + 1024 * b), 16, 0, 0);
             }
         }
     };
-    auto store_x = [&](unsigned char *xs) {   // split into the three planes, 8 bytes (four bf16) per piece
+    // ... and a pair splits it into the three planes of an X slot: four 16-byte chunks per thread (idx = st + 128 q: row idx >> 4,
+    // chunk idx & 15), 8 bytes (four bf16) per piece and chunk
+    auto stage_x = [&](unsigned char *xs, bool ok) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int idx = st + 128 * q, row = idx >> 4, c4 = idx & 15;
+            const float4 v = ok ? *reinterpret_cast<const float4 *>(raw + row * 256 + c4 * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
             uint2 h, m, l;
-            bf_split2(xpre[q].x, xpre[q].y, h.x, m.x, l.x);
-            bf_split2(xpre[q].z, xpre[q].w, h.y, m.y, l.y);
+            bf_split2(v.x, v.y, h.x, m.x, l.x);
+            bf_split2(v.z, v.w, h.y, m.y, l.y);
             unsigned char *d = xs + row * L::XRS + c4 * 8;
             *reinterpret_cast<uint2 *>(d) = h;
             *reinterpret_cast<uint2 *>(d + L::kXPlane) = m;
@@ -242,20 +246,19 @@ __global__ void __launch_bounds__(kBfThreads, 2)
             rspre = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
         }
     };
-    // prologue: pair 0 stages X(0); both pairs fetch the scalars of their first loss tile (tiles 0 and 1)
+    // prologue: X(0) lands and pair 0 stages it, X(1) is on its way; both pairs fetch the scalars of their first loss tile (0 and 1)
+    issue_raw(tile_of(0));
     load_rs(tile_of(pairid));
-    if (pairid == 0) {
-        load_x(tile_of(0));
-        store_x(smem + L::kX);
-    }
-    __syncthreads();   // X(0) and the zeroed dout planes
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (pairid == 0) stage_x(smem + L::kX, tile_of(0) < tiles);
+    __syncthreads();
+    issue_raw(tile_of(1));
 
     for (int j = 0; j < J; ++j) {
         unsigned char *xs = smem + L::kX + (j & 1) * L::kXSlot;
         const bool loss_wave = pairid == (j & 1);
         BF_STAMP(0);
-        if (!loss_wave) load_x(tile_of(j + 1));   // in flight over the forward; staged behind barrier B
-        BF_STAMP(1);
 
         // ---- forward slice: hidden^T[32wv + 16i + 4g + r][row 16nt + c] ----------------------------------------------------------
         f32x4 h[2][2];   // [nt][i]
@@ -308,7 +311,8 @@ __global__ void __launch_bounds__(kBfThreads, 2)
                         make_uint2(hp3.p[p].w[2 * i], hp3.p[p].w[2 * i + 1]);
         }
         BF_STAMP(4);
-        __syncthreads();   // B: the four partials of out^T; every wave is done with tile j - 1 (dout planes, the other X slot)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's blocks of X(j + 1) have landed (issued a whole backward pass ago)
+        __syncthreads();   // B: the four partials of out^T, X(j + 1) in the landing buffer; every wave is done with tile j - 1
         BF_STAMP(5);
 
         if (loss_wave) {
@@ -345,42 +349,43 @@ __global__ void __launch_bounds__(kBfThreads, 2)
             load_rs(tile_of(j + 2));
         } else {
             // ---- ... while the other pair stages X(j + 1) into the slot tile j - 1 has left ---------------------------------------
-            store_x(smem + L::kX + ((j + 1) & 1) * L::kXSlot);
+            stage_x(smem + L::kX + ((j + 1) & 1) * L::kXSlot, tile_of(j + 1) < tiles);
         }
 #ifdef PFA_BF16_TRACE
         if (db2[0] == 12345.678f) BF_STAMP(15);
 #endif
         BF_STAMP(6);
-        __syncthreads();   // C: d loss / d out of both halves, X(j + 1)
+        __syncthreads();   // C: d loss / d out of both halves, X(j + 1); the landing buffer is free
         BF_STAMP(7);
+        issue_raw(tile_of(j + 2));
 
         // ---- backward slice -----------------------------------------------------------------------------------------------------
-        // dW2v^T[u][slot] += sum over the 32 rows of hidden[row][u] dout[row][slot]: both operands by transposed reads (element e of a
-        // fragment = row 8g + e)
+        // dW2v^T[u][slot] += sum over the 32 rows of hidden[row][u] dout[row][slot]: both operands by transposed reads
         BfFrag ha[2][3];
         {
             BfFrag db_[3];
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                bf_tr8(dpl + p * L::kDPlane, L::DRS, 0, 0, c, g, db_[p]);
+                bf_tr8(dpl + p * L::kDPlane, L::DRS, 0, c, g, db_[p]);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) bf_tr8(patch + p * L::kHPlane, L::HRS, 0, 16 * i, c, g, ha[i][p]);
+                for (int i = 0; i < 2; ++i) bf_tr8(patch + p * L::kHPlane, L::HRS, 16 * i, c, g, ha[i][p]);
             }
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc_dw2[i] = bf_mfma(ha[i][kBfTA[t]], db_[kBfTB[t]], acc_dw2[i]);
         }
-        // dh[row][u] = sum over the slots of dout[row][slot] W2v[slot][u], NOT transposed: with the rows of the A operand permuted
-        // (lane c = 4g' + r' of M tile mt <-> row 8g' + 4mt + r'), lane (c, g) of the C fragments holds dh[row 8g + 4mt + r][unit c] —
-        // after relu' and the split that IS the B fragment (k = row 8g + e, n = unit) of the weight gradient below: no transpose.
+        // dh[row][u] = sum over the slots of dout[row][slot] W2v[slot][u], NOT transposed: lane (c, g) of the C fragment of M tile mt
+        // holds dh[row 16mt + 4g + r][unit c] — after relu' and the split, the pair of M tiles IS the B fragment (k = row
+        // 16 (e >> 2) + 4g + (e & 3), n = unit) of the weight gradient below: no transpose.  K = 16 slots padded to 32: the B operand
+        // (wT) is zero for lane groups 2 and 3, which therefore read the slots of groups 0 and 1 again instead of a zero half.
         f32x4 dh[2][2];   // [mt][i]
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            BfFrag dA[3];   // A[m = row pi(mt, c)][k = slot 8g + e]; slots 16 .. 31 are the zero half
+            BfFrag dA[3];   // A[m = row 16mt + c][k = slot 8g + e]
 #pragma unroll
             for (int p = 0; p < 3; ++p)
-                dA[p].v = *reinterpret_cast<const bf16x8 *>(dpl + p * L::kDPlane + (8 * (c >> 2) + 4 * mt + (c & 3)) * L::DRS + 16 * g);
+                dA[p].v = *reinterpret_cast<const bf16x8 *>(dpl + p * L::kDPlane + (16 * mt + c) * L::DRS + 16 * (g & 1));
 #pragma unroll
             for (int i = 0; i < 2; ++i) dh[mt][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(kBfThreads, 2)
         if (dh[0][0][0] == 12345.678f || acc_dw2[0][0] == 12345.678f) BF_STAMP(15);
 #endif
         BF_STAMP(8);
-        // relu' from the hi piece of hidden the dW2v fragment already holds (element 4mt + r of ha[i] = row 8g + 4mt + r, unit 16i + c:
+        // relu' from the hi piece of hidden the dW2v fragment already holds (element 4mt + r of ha[i] = row 16mt + 4g + r, unit 16i + c:
         // hidden >= 0, so "piece != 0" is "hidden > 0"); db1; the three pieces of dh as B fragments
         BfFrag3 dhb[2];
 #pragma unroll
@@ -414,7 +419,7 @@ __global__ void __launch_bounds__(kBfThreads, 2)
         for (int kt = 0; kt < 4; ++kt) {
             BfFrag xa[3];
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf_tr8(xs + p * L::kXPlane, L::XRS, 0, 16 * kt, c, g, xa[p]);
+            for (int p = 0; p < 3; ++p) bf_tr8(xs + p * L::kXPlane, L::XRS, 16 * kt, c, g, xa[p]);
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
