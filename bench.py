@@ -13,8 +13,10 @@ Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     dominant kernel ppo_mlp_grad (fp32 MFMA bound): algorithmic FLOPs per launch / average launch
                duration measured with HIP events on the launch stream over the timed region (every 5th launch
                bracketed: the event packets serialise the queue)
-  cpu_baseline the CPU oracle port (C env + torch-fp32 policy/update, oracle/) timed on a bounded sample of
-               the same workload on this box's host cores (rank 0, N = 1 only)
+  cpu_baseline kind "reference": the UNMODIFIED reference's Serial CPU path timed on this box model by tools/gpu_jobs/
+               with_reference.sh (profiles/r05_reference_cpu_on_gpu_box.json; used when the box fingerprint matches), with the
+               live timing of the CPU oracle port (C env + torch-fp32 policy/update, oracle/) on a bounded sample of the same
+               workload on this box's host cores riding along (`port_live`; it IS the baseline when no record matches)
 """
 import argparse
 import ctypes as C
@@ -85,11 +87,38 @@ def _oracle_trainer(n, seed=1):
     return tr, np.random.default_rng(0)
 
 
+def reference_cpu_baseline(config_key, port):
+    """cpu_baseline with kind = "reference": the UNMODIFIED reference's own CPU path (clean_pufferl + pufferlib.vector.Serial + c_gae.pyx),
+    timed on a box of THIS model by tools/gpu_jobs/with_reference.sh and recorded in profiles/r05_reference_cpu_on_gpu_box.json
+    (the reference cannot be read at bench time: /root/reference does not exist on the GPU box; the job ships it once in a git-ignored
+    staging directory).  Used only when the record's box fingerprint (CPU model + logical core count) is this box's; otherwise, and
+    when the file is absent, the live port timing `port` is returned unchanged.  The live port timing of this run rides along."""
+    path = os.path.join(REPO, 'profiles', 'r05_reference_cpu_on_gpu_box.json')
+    try:
+        doc = json.load(open(path))
+        box, s = doc['box'], doc['summary'][config_key]
+    except Exception:
+        return port
+    if box.get('cpu_model') != _cpu_model() or box.get('cores_logical') != (os.cpu_count() or 1):
+        return dict(port, reference_record_refused=f"{os.path.relpath(path, REPO)} was taken on {box.get('cpu_model')} x{box.get('cores_logical')}, "
+                                                   f"this box is {_cpu_model()} x{os.cpu_count()}")
+    ser, best = s['serial'], s['best']
+    return dict(value=ser['value'], unit='env_steps/s', cores=max(int(ser['torch_threads']), int(ser['cores_used'])), cores_available=box['cores_logical'],
+                cores_physical=box['cores_physical'], cpu_model=box['cpu_model'], kind='reference',
+                sample=f"{ser['iterations']} evaluate+train iteration(s) of {ser['envs']} envs x {ser['horizon']} steps after 1 warm-up: {ser['what']}; "
+                       f"env stepping on 1 core (Serial), torch on {ser['torch_threads']} threads",
+                measured='recorded on a box of this model (fingerprint matched: CPU model + logical cores), not re-timed in this run',
+                source=os.path.relpath(path, REPO) + ' (tools/gpu_jobs/with_reference.sh -> tools/time_reference.py)',
+                breakdown_s_per_iter=dict(evaluate=ser['evaluate_s_per_iter'], train=ser['train_s_per_iter'], **ser['profile']),
+                best_vectoriser=dict(value=best['value'], backend=best['backend'], workers=best['workers'], torch_threads=best['torch_threads']),
+                port_live={k: port[k] for k in ('value', 'unit', 'cores', 'kind', 'sample') if k in port})
+
+
 def cpu_baseline(budget_s=24.0):
     """The CPU oracle port (oracle/: C restatement of Serial(Squared) on 1 core + the torch-fp32 restatement of the policy and
     of clean_pufferl.train) timed on the SAME configuration the GPU number is quoted on — 4096 envs x 128 steps, 4 minibatches
-    x 4 epochs — for 1 warm-up + as many evaluate+train iterations as fit the budget (at least 1).  The unmodified reference
-    itself cannot travel to the GPU box; its own measurement (survey container) rides along as `reference_measured`."""
+    x 4 epochs — for 1 warm-up + as many evaluate+train iterations as fit the budget (at least 1).  The unmodified reference's own
+    timing on this box model is reference_cpu_baseline() above; this live port timing rides along with it."""
     import torch
     cores_avail = os.cpu_count() or 1
     # threads actually used: the reference's torch CPU path scales poorly past a socket's worth of cores on these tiny GEMMs
@@ -117,14 +146,7 @@ def cpu_baseline(budget_s=24.0):
     dt = time.perf_counter() - t0
     return dict(value=iters * B / dt, unit='env_steps/s', cores=cores, cores_available=cores_avail, cpu_model=_cpu_model(), kind='port',
                 sample=f'{iters} evaluate+train iteration(s) of {n} envs x {HORIZON} steps (batch {B}, {NMB} minibatches x {EPOCHS} '
-                       f'epochs: the bench configuration itself) after 1 warm-up; C env on 1 core, torch-fp32 on {cores} threads',
-                reference_measured=dict(value=74.0e3, unit='env_steps/s', config='the unmodified reference (clean_pufferl + '
-                                        'pufferlib.vector.Serial + c_gae), squared 4096 envs x 128, MLP, 4 minibatches x 4 epochs, 3 iterations '
-                                        'after a warm-up', best_vectoriser=dict(value=112.5e3, backend='pufferlib.vector.Multiprocessing, 4 workers '
-                                        '+ 4 torch threads (the best split of the 8 cores)'),
-                                        box='8-core Xeon @ 2.1 GHz, build container (no GPU)',
-                                        source='profiles/r02_reference_cpu_timing.json (tools/time_reference.py); BASELINE.md section 2 has the '
-                                               'survey container\'s single-iteration figure, 47.8e3'))
+                       f'epochs: the bench configuration itself) after 1 warm-up; C env on 1 core, torch-fp32 on {cores} threads')
 
 
 def cpu_baseline_c4(n=32, horizon=16):
@@ -765,9 +787,9 @@ def main():
             if args.workload == 'c4' and not cnn_lstm:
                 out['cpu_baseline'] = cpu_baseline_c4()
             elif args.workload == 'c3':
-                out['cpu_baseline'] = cpu_baseline_c3()
+                out['cpu_baseline'] = reference_cpu_baseline('c3', cpu_baseline_c3())
             elif args.policy == 'mlp':          # the headline configuration
-                out['cpu_baseline'] = cpu_baseline()
+                out['cpu_baseline'] = reference_cpu_baseline('c2', cpu_baseline())
         if world == 1 and args.workload == 'squared' and args.policy == 'mlp' and not args.no_extra:
             # BASELINE configs[2] / configs[3] as short side runs (own processes, after everything of the headline is measured):
             # not the metric, but driver-run instead of builder-run numbers for the recurrent and the conv path

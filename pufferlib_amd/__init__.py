@@ -11,7 +11,36 @@ Only the hot path named in BASELINE.json is here:
 All compute goes through libpufferlib_amd.so (HIP).  There is no CPU fallback: importing the kernels
 without the built extension, or calling them without a GPU, raises.
 """
+import os as _os
+import sys as _sys
+
 from .namespace import namespace, Namespace  # noqa: F401
+
+
+def _ipc_mode_guard():
+    """The peer-mapped exchange of the data-parallel update (csrc/p2p.hip) shares device memory between processes with dmabuf IPC,
+    which the HSA runtime only offers when HSA_ENABLE_IPC_MODE_LEGACY=0 was in the environment WHEN HIP INITIALISED.  So the variable
+    is set at import of this package (before anything of it touches the device), and what was found is recorded: a process that had
+    already initialised HIP without it cannot be fixed any more — dist.init_p2p then leaves the peer path closed (the update runs on
+    RCCL / torch.distributed) and says why, instead of discovering it in the self-test."""
+    had = _os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')
+    torch = _sys.modules.get('torch')
+    hip_up = False
+    try:
+        hip_up = bool(torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        pass
+    if had is None:
+        _os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    ok = had == '0' or (had is None and not hip_up)
+    reason = None
+    if not ok:
+        reason = (f'HSA_ENABLE_IPC_MODE_LEGACY={had} in the environment (the peer path needs 0)' if had is not None else
+                  'HIP was initialised before pufferlib_amd was imported, without HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment')
+    return dict(value_at_import=had, hip_initialised_at_import=hip_up, ok=ok, reason=reason)
+
+
+IPC_MODE = _ipc_mode_guard()
 
 __version__ = '0.1.0'
 

@@ -179,6 +179,8 @@ class Profile:
                   'train_time', 'train_forward_time', 'learn_time', 'train_misc_time'):
             yield k, getattr(self, k)
 
+    # epoch_time / update: deliberate mirror of clean_pufferl.py:342-366 — the reference's dashboard and wandb logging read exactly
+    # these fields with exactly this update rule.  Interface, not hot path.
     @property
     def epoch_time(self):
         return self.train_time + self.eval_time

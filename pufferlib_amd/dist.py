@@ -126,7 +126,7 @@ def gae_fold_published(pub, rank, gamma, lam):
     return x, last_map(rank)
 
 
-_native = dict(ready=False, world=1, rccl=False, p2p=False, p2p_selftest=None)
+_native = dict(ready=False, world=1, rccl=False, p2p=False, p2p_selftest=None, p2p_reason=None)
 
 
 def native_ready():
@@ -148,9 +148,18 @@ def init_p2p(bucket_bytes):
     if w <= 1 or w > 8:
         return False
     L = _lib.lib()
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # dmabuf IPC has to be chosen before HIP initialises: pufferlib_amd/__init__.py sets the variable at import and records what it
+    # found.  A rank whose process cannot share memory any more reports failure here, and EVERY rank then stays off the peer path
+    # (the flag travels with the handles below), with the reason logged once.
+    from . import IPC_MODE
     handle = np.zeros(64, np.uint8)
-    ok = int(L.pfa_p2p_alloc(int(bucket_bytes), w, handle.ctypes.data_as(C.c_void_p)) == 0)
+    ipc_ok = bool(IPC_MODE['ok']) and os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') == '0'
+    if not ipc_ok:
+        _native['p2p_reason'] = IPC_MODE['reason'] or 'HSA_ENABLE_IPC_MODE_LEGACY was changed after import'
+        import warnings
+        warnings.warn('pufferlib_amd: peer-mapped all-reduce disabled on rank %d: %s; the update uses RCCL / torch.distributed'
+                      % (rank, _native['p2p_reason']))
+    ok = int(ipc_ok and L.pfa_p2p_alloc(int(bucket_bytes), w, handle.ctypes.data_as(C.c_void_p)) == 0)
     table = torch.zeros(w, 65, dtype=torch.int32, device='cuda')     # 64 handle bytes + the rank's success flag
     table[rank, :64] = torch.from_numpy(handle.astype(np.int32)).cuda()
     table[rank, 64] = ok
@@ -260,7 +269,8 @@ def transport_info():
     _lib.check(_lib.lib().pfa_dist_info(out), 'dist_info')
     return dict(native=bool(_native['ready']), rccl=bool(out[0]), rccl_nranks=int(out[1]), p2p=bool(out[2]), p2p_world=int(out[3]),
                 p2p_slot_bytes=int(out[4]), p2p_calls=int(out[5]), rccl_calls=int(out[6]), p2p_status=int(out[7]),
-                p2p_selftest=_native.get('p2p_selftest'), p2p_ll_calls=int(_lib.lib().pfa_p2p_ll_calls()))
+                p2p_selftest=_native.get('p2p_selftest'), p2p_ll_calls=int(_lib.lib().pfa_p2p_ll_calls()),
+                p2p_reason=_native.get('p2p_reason'))
 
 
 def raise_if_peer_lost():

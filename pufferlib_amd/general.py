@@ -430,7 +430,9 @@ class Engine:
         # ... and the fused forward + loss + backward kernel of csrc/ppo_wide.hip for the widths it is built for (64 / 256 / 512)
         import os
         self.wide_ws = self._wide_gview = None
+        # (pfa_ppo_wide_grad tiles minibatches in 16-row blocks: any other minibatch size trains through the GEMM path of update())
         if (self.mlp_view is not None and os.environ.get('PFA_WIDE_FUSED', '1') != '0'
+                and (experience is None or experience.minibatch_size % 16 == 0)
                 and _lib.lib().pfa_ppo_wide_supported(C.byref(self.mlp_view))):
             self.wide_ws = torch.empty(int(_lib.lib().pfa_ppo_wide_workspace_bytes(C.byref(self.mlp_view))), dtype=torch.uint8, device=self.dev)
         if num_agents:

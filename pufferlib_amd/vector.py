@@ -20,6 +20,8 @@ from . import _lib, spaces
 from .exceptions import APIUsageError
 from .namespace import Namespace, namespace
 
+# Deliberate interface mirror of pufferlib/vector.py:17-53 (flag constants, recv/send prechecks, reset/step helpers): callers of a
+# drop-in backend compare against these constants and match on these messages.  Interface, not hot path.
 RESET = 0
 STEP = 1
 SEND = 2
@@ -1030,7 +1032,10 @@ class Multiagent(_DeviceVecEnv):
 
 
 def make(env_creator_or_creators, env_args=None, env_kwargs=None, backend=Squared, num_envs=1, **kwargs):
-    """pufferlib.vector.make (vector.py:577-637): same argument validation and error messages."""
+    """pufferlib.vector.make (vector.py:577-637): same argument validation and error messages.
+
+    Deliberate interface mirror of vector.py:579-624 — the reference's tests (tests/test_api.py:15-131) and user code match on these
+    APIUsageError messages, so the checks keep the reference's order and wording.  Interface, not hot path."""
     if num_envs < 1:
         raise APIUsageError('num_envs must be at least 1')
     if num_envs != int(num_envs):

@@ -282,6 +282,32 @@ def test_wide_default_policy_rollout_and_update_vs_oracle(hidden, d, matrix_prod
     _check_update(data, pol, opol, tr, lambda k: 'policy.' + k)
 
 
+@pytest.mark.parametrize('hidden', [64, 256])
+def test_wide_default_policy_with_a_minibatch_that_is_no_multiple_of_16(hidden, matrix_products):
+    """24 envs x 5 steps, 2 minibatches of 60 rows: pfa_ppo_wide_grad tiles minibatches in 16-row blocks, so the engine must leave the
+    fused wide kernel off and train through the GEMM path (which takes any minibatch size, like the 128-wide fused kernel)."""
+    from pufferlib_amd import clean_pufferl, cleanrl, models
+    from test_gpu_ppo import _config
+    from oracle import c_oracle, ppo_torch
+    n, horizon, nmb, bptt, d = 24, 5, 2, 5, 3
+    B = n * horizon
+    vec = _squared(n, d)
+    pol = cleanrl.Policy(models.Default(vec.driver_env, hidden_size=hidden))
+    _perturb(pol)
+    data = clean_pufferl.create(_config(n, horizon, B // nmb, bptt, 2, B * 10, HP), vec, pol)
+    assert data.gen_engine is not None and data.gen_engine.wide_ws is None
+    w0 = _weights(pol)
+    noise = torch.empty(horizon, n, 8).exponential_(1)
+    data.noise = noise
+    clean_pufferl.evaluate(data)
+    opol = ppo_torch.Policy(w0)
+    tr = ppo_torch.Trainer(opol, c_oracle.SquaredSerial(n, d, 1), batch_size=B, minibatch_size=B // nmb, bptt_horizon=bptt, update_epochs=2,
+                           learning_rate=HP[0], gamma=HP[1], gae_lambda=HP[2], clip_coef=HP[3], vf_coef=HP[4], vf_clip_coef=HP[5],
+                           max_grad_norm=HP[6], ent_coef=HP[7], total_timesteps=B * 10, seed=1)
+    tr.evaluate(noise.numpy())
+    _check_update(data, pol, opol, tr, lambda k: 'policy.' + k)
+
+
 def test_wide_observations_and_many_logits_on_a_host_vecenv():
     """Rows of 300 floats (beyond the fused kernels' 128) and 40 logits (beyond their 15) through the host-vecenv path."""
     from host_vecenv import HostMultiHead
