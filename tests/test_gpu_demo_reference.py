@@ -26,6 +26,7 @@ import json, sys
 sys.dont_write_bytecode = True
 from pufferlib_amd import demo, clean_pufferl as ours, readback
 record = dict(iterations=[], created=None, closed=False)
+OUT = sys.argv[2]            # (demo.main replaces sys.argv with demo.py's own)
 _create, _train, _close = ours.create, ours.train, ours.close
 
 def create(config, vecenv, policy, *a, **k):
@@ -38,11 +39,14 @@ def create(config, vecenv, policy, *a, **k):
                              device=str(config.device), batch_size=int(config.batch_size), minibatch_size=int(config.minibatch_size),
                              bptt_horizon=int(config.bptt_horizon), learning_rate=float(config.learning_rate),
                              total_timesteps=int(config.total_timesteps), serial_is_factory=hasattr(pufferlib.vector.Serial, 'host_backend'))
+    print('[driver] created', record['created'], file=sys.stderr, flush=True)
     return data
 
 def train(data):
     stats = dict(readback.materialize(data.stats))
     r = _train(data)
+    if len(record['iterations']) < 3:
+        print('[driver] train', len(record['iterations']), int(data.global_step), stats, file=sys.stderr, flush=True)
     record['iterations'].append(dict(global_step=int(data.global_step), epoch=int(data.epoch),
                                      score=stats.get('score'), episode_return=stats.get('episode_return'),
                                      episode_length=stats.get('episode_length'),
@@ -54,10 +58,23 @@ def close(data):
     record['closed'] = True
     record['final_global_step'] = int(data.global_step)
     r = _close(data)
-    json.dump(record, open(sys.argv[2], 'w'))
+    json.dump(record, open(OUT, 'w'))
     return r
 
-ours.create, ours.train, ours.close = create, train, close
+def loud(fn):            # demo.py:196-198 prints a swallowed exception through rich and os._exit(0)s; say it on stderr first
+    def wrapped(*a, **k):
+        try:
+            return fn(*a, **k)
+        except BaseException:
+            import traceback
+            print('[driver] exception inside', fn.__name__, 'after', len(record['iterations']), 'iterations', file=sys.stderr, flush=True)
+            traceback.print_exc(file=sys.stderr)
+            sys.stderr.flush()
+            raise
+    wrapped.__name__ = fn.__name__
+    return wrapped
+
+ours.create, ours.train, ours.close, ours.evaluate = loud(create), loud(train), loud(close), loud(ours.evaluate)
 demo.main(['--reference', sys.argv[1], '--'] + sys.argv[3:])
 '''
 
@@ -69,9 +86,12 @@ def run_demo(tmp_path, extra, timeout=900):
         shutil.copy(os.path.join(STAGE, 'config.yaml'), tmp_path / 'config.yaml')
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([REPO, os.path.join(REPO, 'tests', 'shims')]), PYTHONDONTWRITEBYTECODE='1',
                PYTHONUNBUFFERED='1')      # demo.py prints a swallowed exception and os._exit(0)s: unbuffered, or the traceback is lost
-    r = subprocess.run([sys.executable, '-c', DRIVER, STAGE, str(out)] + extra, cwd=tmp_path, env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, '-X', 'faulthandler', '-c', DRIVER, STAGE, str(out)] + extra, cwd=tmp_path, env=env, capture_output=True, text=True,
                        timeout=timeout)
-    assert out.exists(), ('demo.py did not reach clean_pufferl.close()', r.stdout[-3000:], r.stderr[-3000:])
+    os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
+    with open(os.path.join(REPO, 'gpurun_out', 'r05_demo_process_output.txt'), 'a') as f:   # (pytest elides long assertion messages)
+        f.write(f'==== {extra}\n---- returncode {r.returncode}\n---- stdout\n{r.stdout[-20000:]}\n---- stderr\n{r.stderr[-20000:]}\n')
+    assert out.exists(), ('demo.py did not reach clean_pufferl.close()', r.stdout[-1500:], r.stderr[-1500:])
     return json.load(open(out)), r
 
 
