@@ -46,6 +46,21 @@ size_t pfa_gae_workspace_bytes(int64_t n);
 int pfa_gae_f32(const float *dones, const float *values, const float *rewards, float *advantages,
                 float *returns, int64_t n, float gamma, float gae_lambda, void *workspace,
                 pfa_stream_t stream);
+/* compute_gae together with what the update and its log line need from the advantages, in one pass over the rows
+ * (replaces pfa_gae_f32 + pfa_ppo_adv_stats + the sums of pfa_train_log_sums: three launches instead of six):
+ *   adv_stats[2 m + k]  sum adv, sum adv^2 of minibatch m's rows (clean_pufferl.py:211-213 normalisation; minibatch m =
+ *                       segments {m + k nmb} of bptt_horizon rows, clean_pufferl.py:455-457), f64
+ *   ev4[0..3]           sum y_true, sum y_true^2, sum adv, sum adv^2 with y_true = adv + values in storage (step-major)
+ *                       order — the reference's explained-variance inputs (clean_pufferl.py:266-270, 476), f64
+ *   zero8 (nullable)    eight doubles cleared by the last launch (the caller's running loss sums)
+ * Fixed-order f64 reductions (deterministic).  Shapes: bptt_horizon a multiple of 8, (bptt_horizon / 8) * num_minibatches a
+ * power of two <= 256, num_minibatches <= 32, n a multiple of num_envs and of num_minibatches * bptt_horizon —
+ * pfa_gae_sums_supported says; other shapes use the separate entry points.  workspace >= pfa_gae_sums_workspace_bytes. */
+int pfa_gae_sums_supported(int64_t n, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon);
+size_t pfa_gae_sums_workspace_bytes(int64_t n, int32_t num_minibatches);
+int pfa_gae_sums_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
+                     int64_t n, float gamma, float gae_lambda, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon,
+                     double *adv_stats, double *ev4, double *zero8, void *workspace, pfa_stream_t stream);
 /* Data-parallel form: the array is one rank's SHARD of the reference's single flat batch (rank-major order).
  * pass1 writes the shard's affine map {C, D} (f64, device) to shard_map[2]; the caller all-gathers the maps and
  * folds those of the later shards into carry_in[1] (f64, device) = the advantage of the first element after this

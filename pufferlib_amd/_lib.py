@@ -138,6 +138,9 @@ _SIGNATURES = {
     'pfa_timing_read': (C.c_int, [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     'pfa_gae_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'pfa_gae_f32': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_float, C.c_float, P, P]),
+    'pfa_gae_sums_supported': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    'pfa_gae_sums_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32]),
+    'pfa_gae_sums_f32': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P]),
     'pfa_gae_shard_pass1': (C.c_int, [P, P, P, C.c_int64, C.c_int, C.c_float, C.c_float, P, P, P]),
     'pfa_gae_shard_pass2': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_int, C.c_float, C.c_float, P, P, P]),
     'pfa_gae_shard_publish': (C.c_int, [P, P, P, C.c_int64, C.c_float, C.c_float, P, P, C.c_int32, P, C.c_int32, C.c_int32, P]),

@@ -350,7 +350,8 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     # (likewise the GEMM-path engine: a wide flat observation would otherwise reserve 256 fused-kernel partials of 128 x obs_stride floats)
     dims = _lib.MlpDims(64, 64, 128, 4, 0) if (conv or gen_engine is not None) else fp.dims
     ws_bytes = max(L.pfa_ppo_workspace_bytes(C.byref(dims), config.batch_size, C.byref(hp)),
-                   L.pfa_gae_workspace_bytes(config.batch_size))
+                   L.pfa_gae_workspace_bytes(config.batch_size),
+                   L.pfa_gae_sums_workspace_bytes(config.batch_size, experience.num_minibatches))
     dp_sums = torch.zeros(2 * experience.num_minibatches + 4, dtype=torch.float64, device=device)
     data = namespace(
         config=config, vecenv=vecenv, policy=policy, uncompiled_policy=policy, optimizer=optimizer,
@@ -434,12 +435,21 @@ def evaluate(data):
         else:
             if noise is None:
                 # the whole rollout's Philox action noise in one launch (same numbers the kernel would draw in place): keeps 40
-                # quarter-rate integer multiplies per step off the rollout's dependent chain; the kernel prefetches a step ahead
-                if getattr(data, '_noise_buf', None) is None or tuple(data._noise_buf.shape) != (T, N, fp.num_actions):
-                    data._noise_buf = torch.empty(T, N, fp.num_actions, dtype=torch.float32, device=vecenv.device)
-                noise = data._noise_buf
-                _lib.check(L.pfa_philox_exp_noise(_lib.ptr(noise), T, N, fp.num_actions, C.byref(key), vecenv.env_offset,
-                                                  _lib.stream_handle()), 'philox_exp_noise')
+                # quarter-rate integer multiplies per step off the rollout's dependent chain; the kernel prefetches a step ahead.
+                # The stream is a pure function of (seed, step, global env index), so the previous evaluate() already drew THIS
+                # rollout's numbers on the side stream behind the reset tape (vecenv.tape_event, waited for in ensure_tape above,
+                # covers them); anything that moved the stream position in between (policy(obs) calls, a checkpoint load, another
+                # seed) fails the tag comparison and the numbers are drawn here, on the compute stream, as before.
+                tag = (int(policy.noise_seed), int(policy.noise_step), T, N, int(fp.num_actions), int(vecenv.env_offset))
+                pre = getattr(data, '_noise_next', None)
+                if pre is not None and pre[0] == tag:
+                    noise = pre[1]
+                else:
+                    noise = _noise_buffer(data, T, N, fp.num_actions, vecenv.device)
+                    _lib.check(L.pfa_philox_exp_noise(_lib.ptr(noise), T, N, fp.num_actions, C.byref(key), vecenv.env_offset,
+                                                      _lib.stream_handle()), 'philox_exp_noise')
+                data._noise_next = None
+                data._noise_cur = noise
             if wide_view is not None:     # Default(hidden 64 / 256 / 512): the same persistent kernel, W1 fragments of that width in registers
                 _lib.check(L.pfa_rollout_mlp_view_squared(
                     _lib.ptr(vecenv.state), C.byref(vecenv.cfg), C.byref(wide_view), C.byref(experience.c),
@@ -461,10 +471,28 @@ def evaluate(data):
             with torch.cuda.stream(data.tape_stream):
                 data.tape_stream.wait_event(start_point)
                 vecenv.ensure_tape(T)
+                if (data.noise is None and data.lstm_engine is None and os.environ.get('PFA_NOISE_PREFETCH', '1') != '0'
+                        and getattr(data, '_noise_cur', None) is not None):
+                    # ... and the NEXT rollout's action noise (16.8 MB of writes that depend on nothing but the stream position),
+                    # into the buffer the running rollout is not reading
+                    nxt = _noise_buffer(data, T, N, fp.num_actions, vecenv.device, other_than=data._noise_cur)
+                    nkey = _lib.NoiseKey(policy.noise_seed, policy.noise_step + T)
+                    _lib.check(L.pfa_philox_exp_noise(_lib.ptr(nxt), T, N, fp.num_actions, C.byref(nkey), vecenv.env_offset,
+                                                      _lib.stream_handle()), 'philox_exp_noise (prefetch)')
+                    data._noise_next = ((int(policy.noise_seed), int(policy.noise_step) + T, T, N, int(fp.num_actions),
+                                         int(vecenv.env_offset)), nxt)
                 ev = torch.cuda.Event()
                 ev.record(data.tape_stream)
                 vecenv.tape_event = ev           # the vecenv owns it: send()/async_reset() outside evaluate() wait on it too
     return _finish_evaluate(data, N, T)
+
+
+def _noise_buffer(data, T, N, A, device, other_than=None):
+    """One of the two [T][N][A] action-noise buffers of the MLP rollout (the rollout reads one while the side stream fills the other)."""
+    bufs = getattr(data, '_noise_bufs', None)
+    if bufs is None or tuple(bufs[0].shape) != (T, N, A):
+        bufs = data._noise_bufs = [torch.empty(T, N, A, dtype=torch.float32, device=device) for _ in range(2)]
+    return bufs[1] if (other_than is not None and other_than.data_ptr() == bufs[0].data_ptr()) else bufs[0]
 
 
 def _frames_policy(data):
@@ -626,13 +654,24 @@ def train(data):
 
     with profile.train_misc:
         # compute_gae over the env-major batch (clean_pufferl.py:163-169) + returns (:482)
+        # single rank: GAE, the per-minibatch advantage sums and the explained-variance sums in ONE pass over the rows
+        # (pfa_gae_sums_f32: 3 launches; the separate entry points below: 6) where the partition allows it
+        fused_sums = (world == 1 and os.environ.get('PFA_GAE_SUMS', '1') != '0'
+                      and not (getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference')
+                      and bool(L.pfa_gae_sums_supported(B, experience.num_envs, nmb, int(config.bptt_horizon))))
         if world > 1:
             _finish_gae(data, rank, world, stream)
+        elif fused_sums:
+            _lib.check(L.pfa_gae_sums_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
+                                          _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
+                                          float(config.gae_lambda), experience.num_envs, nmb, int(config.bptt_horizon),
+                                          _lib.ptr(data.adv_stats), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(data.loss_acc),
+                                          _lib.ptr(data.workspace), stream), 'gae_sums')
         else:
             _lib.check(L.pfa_gae_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
                                      _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
                                      float(config.gae_lambda), _lib.ptr(data.workspace), stream), 'gae')
-        if config.norm_adv:
+        if config.norm_adv and not fused_sums:
             _lib.check(L.pfa_ppo_adv_stats(C.byref(experience.c), B, C.byref(hp), _lib.ptr(data.adv_stats),
                                            _lib.ptr(data.workspace), stream), 'adv_stats')
         # data parallel: the four explained-variance sums only need advantages and values, so they ride the all-reduce of the
@@ -652,7 +691,8 @@ def train(data):
                 _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(data.adv_stats), data.adv_stats.numel(), stream), 'adv all-reduce')
             elif world > 1:
                 dist.all_reduce(data.adv_stats)
-        data.loss_acc.zero_()
+        if not fused_sums:                      # (the fused pass cleared it)
+            data.loss_acc.zero_()
         experience.ptr = 0
         experience.step = 0
 
@@ -720,7 +760,7 @@ def train(data):
 
         # losses + explained variance exactly as the reference logs them (clean_pufferl.py:249-254,266-270, App. A.8):
         # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
-        if early_ev:                                            # the sums were all-reduced with the advantage sums
+        if early_ev or fused_sums:                              # the sums exist since GAE (data parallel: all-reduced with the advantage sums)
             _lib.check(L.pfa_train_log_pack(_lib.ptr(data.loss_acc), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(data.log_sums),
                                             stream), 'train_log_pack')
         else:

@@ -111,12 +111,28 @@ __global__ void __launch_bounds__(kGaeThreads) gae_aggregate_kernel(const float 
     if (threadIdx.x == 0) agg[blockIdx.x] = mine;
 }
 
+// SUMS: the same pass also leaves, per block, what the update and its log line need from the advantages (one pass over the
+// 20 B/row stream instead of three: this kernel, adv_stats_partial_kernel, ev_partial_kernel of ppo_update.hip):
+//   part[block][0 .. 2 nmb)   sum adv, sum adv^2 of every minibatch's rows in this block (clean_pufferl.py:211-213; minibatch m =
+//                             segments {m + k nmb} of `bptt` rows, :455-457)
+//   part[block][2 nmb + 0..3] sum y_true, sum y_true^2, sum adv, sum adv^2 with y_true = adv + values in STORAGE (step-major)
+//                             order — the reference's mis-aligned explained-variance inputs (clean_pufferl.py:266-270, App. A.8)
+// all in f64, reduced in a fixed tree (deterministic).  A thread's 8 rows lie in ONE segment (bptt % 8 == 0), thread t's minibatch
+// is ((t / G) % nmb) with G = bptt / 8 threads per segment in EVERY block (the block size is a multiple of the cycle P = G nmb, a
+// power of two <= 256: gae_sums_supported).
+struct GaeSums {
+    double *part;          // [nblocks][2 nmb + 4]
+    int nmb, bptt;         // minibatches, rows per segment
+    int num_envs, horizon; // storage order j = t * num_envs + e  <->  env-major e * horizon + t
+};
+template <bool SUMS>
 __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *dones, const float *values,
                                                                const float *rewards, float *adv, float *ret, long long n,
                                                                float gamma, float lam, const Affine *agg, int nblocks,
-                                                               const double *carry_in, int halo) {
+                                                               const double *carry_in, int halo, GaeSums sums) {
     __shared__ Affine sh[kGaeThreads / 64];
     __shared__ double s_carry;
+    __shared__ double sh_s[SUMS ? 4 : 1][SUMS ? kGaeThreads : 1];
     // carry-in of this block = (agg[b+1] o agg[b+2] o ... o agg[nblocks-1])(0), composed in order by wave 0
     if (wave_id() == 0) {
         const int first = blockIdx.x + 1, cnt = nblocks - first;
@@ -141,6 +157,11 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
     Affine mine = gae_thread_map(it, s, n, gamma, lam, halo == 0), after;
     block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
     float last = (float)(after.c * s_carry + after.d);  // adv at the first element after this thread's items
+    float advv[SUMS ? kGaeItems : 1];
+    if constexpr (SUMS) {
+#pragma unroll
+        for (int i = 0; i < kGaeItems; ++i) advv[i] = 0.0f;
+    }
     {
     PFA_GAE_FP   // the reference's x86-64 build multiplies and adds separately
 #pragma unroll
@@ -157,8 +178,76 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
         }
         adv[t] = last;
         if (ret) ret[t] = last + it.v[i];
+        if constexpr (SUMS) advv[i] = last;
     }
     }
+    if constexpr (SUMS) {
+        // y_pred of flat index j is values[(j % N) * T + j / N]: issue the thread's eight gathers together
+        float yp[kGaeItems];
+        const long long e0 = s % sums.num_envs, t0 = s / sums.num_envs;
+#pragma unroll
+        for (int i = 0; i < kGaeItems; ++i) {
+            long long e = e0 + i, t = t0;
+            while (e >= sums.num_envs) {   // (at most once unless num_envs < 8)
+                e -= sums.num_envs;
+                ++t;
+            }
+            yp[i] = s + i < n ? values[e * sums.horizon + t] : 0.0f;
+        }
+        double a1 = 0.0, a2 = 0.0, y1 = 0.0, y2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < kGaeItems; ++i) {
+            if (s + i >= n) continue;
+            const double a = (double)advv[i], y = a + (double)yp[i];
+            a1 += a;
+            a2 += a * a;
+            y1 += y;
+            y2 += y * y;
+        }
+        const int tid = threadIdx.x;
+        sh_s[0][tid] = a1;
+        sh_s[1][tid] = a2;
+        sh_s[2][tid] = y1;
+        sh_s[3][tid] = y2;
+        __syncthreads();
+        const int G = sums.bptt / kGaeItems, P = G * sums.nmb;   // threads per segment, per cycle of minibatches
+        // fixed tree down to one entry per (minibatch, position in the segment): t and t + stride share both while stride >= P
+        for (int stride = kGaeThreads / 2; stride >= P; stride >>= 1) {
+            if (tid < stride) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sh_s[q][tid] += sh_s[q][tid + stride];
+            }
+            __syncthreads();
+        }
+        double *out = sums.part + (size_t)blockIdx.x * (2 * sums.nmb + 4);
+        if (tid < 2 * sums.nmb) {          // thread (m, k): sum of statistic k over the G entries of minibatch m, in order
+            const int m = tid >> 1, k = tid & 1;
+            double v = 0.0;
+            for (int g = 0; g < G; ++g) v += sh_s[k][m * G + g];
+            out[tid] = v;
+        } else if (tid >= 64 && tid < 68) {   // the four whole-block sums, entries 0 .. P-1 in order
+            const int k = tid - 64, src = k < 2 ? 2 + k : k - 2;   // out: y1, y2, a1, a2
+            double v = 0.0;
+            for (int g = 0; g < P; ++g) v += sh_s[src][g];
+            out[2 * sums.nmb + k] = v;
+        }
+    }
+}
+
+// Sum of the per-block pieces in a fixed order: one 64-lane workgroup per output (2 nmb + 4 of them).
+// adv_stats[2 m + k] <- minibatch sums; ev4[0..3] <- sum y_true, sum y_true^2, sum adv, sum adv^2; zero8 (optional): 8 doubles
+// cleared here (the update's running loss sums, clean_pufferl.train's loss_acc — saves its own fill launch).
+__global__ void __launch_bounds__(64) gae_sums_final_kernel(const double *part, int nblocks, int nmb, double *adv_stats, double *ev4, double *zero8) {
+    const int q = blockIdx.x, lane = threadIdx.x, width = 2 * nmb + 4;
+    double v = 0.0;
+    for (int b = lane; b < nblocks; b += 64) v += part[(size_t)b * width + q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) {
+        if (q < 2 * nmb) adv_stats[q] = v;
+        else ev4[q - 2 * nmb] = v;
+    }
+    if (q == 0 && zero8 && lane < 8) zero8[lane] = 0.0;
 }
 
 // Composition of all block maps of this array = the affine map of the whole shard (data-parallel GAE: rank r's
@@ -268,8 +357,47 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
     hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
                        rewards, (long long)n, gamma, gae_lambda, agg, 0);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_apply_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb, (const double *)nullptr, 0);
+    hipLaunchKernelGGL(gae_apply_kernel<false>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb, (const double *)nullptr, 0, GaeSums{});
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// compute_gae + the advantage statistics of the update in one pass (see GaeSums): what pfa_gae_f32, pfa_ppo_adv_stats and the
+// sums of pfa_train_log_sums leave, in three launches instead of six.  Supported when a thread's 8 rows never straddle a segment
+// and the minibatch cycle divides the block (pfa_gae_sums_supported); the caller falls back to the separate entry points otherwise.
+static bool gae_sums_ok(int64_t n, int num_envs, int nmb, int bptt) {
+    if (n < 1 || num_envs < 1 || nmb < 1 || bptt < kGaeItems || bptt % kGaeItems) return false;
+    if (n % num_envs || n % ((int64_t)nmb * bptt)) return false;
+    const int64_t P = (int64_t)(bptt / kGaeItems) * nmb;
+    return P <= kGaeThreads && (P & (P - 1)) == 0 && 2 * nmb <= 64;
+}
+extern "C" int pfa_gae_sums_supported(int64_t n, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon) {
+    return gae_sums_ok(n, num_envs, num_minibatches, bptt_horizon) ? 1 : 0;
+}
+extern "C" size_t pfa_gae_sums_workspace_bytes(int64_t n, int32_t num_minibatches) {
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    return align_up((size_t)(nb > 0 ? nb : 1) * sizeof(Affine), 256) + (size_t)(nb > 0 ? nb : 1) * (2 * (size_t)num_minibatches + 4) * sizeof(double);
+}
+extern "C" int pfa_gae_sums_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
+                                int64_t n, float gamma, float gae_lambda, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon,
+                                double *adv_stats, double *ev4, double *zero8, void *workspace, pfa_stream_t stream) {
+    PFA_REQUIRE(gae_sums_ok(n, num_envs, num_minibatches, bptt_horizon), "gae_sums: unsupported partition (pfa_gae_sums_supported)");
+    PFA_REQUIRE(dones && values && rewards && advantages && adv_stats && ev4 && workspace, "gae_sums: null buffer");
+    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
+    PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
+    Affine *agg = (Affine *)workspace;
+    GaeSums sums{(double *)((char *)workspace + align_up((size_t)nb * sizeof(Affine), 256)), num_minibatches, bptt_horizon, num_envs,
+                 (int)(n / num_envs)};
+    ScopedKernelTimer timer("gae", (hipStream_t)stream);  // all three launches
+    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
+                       rewards, (long long)n, gamma, gae_lambda, agg, 0);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gae_apply_kernel<true>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb, (const double *)nullptr, 0, sums);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nb,
+                       (int)num_minibatches, adv_stats, ev4, zero8);
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -301,9 +429,9 @@ extern "C" int pfa_gae_shard_pass2(const float *dones, const float *values, cons
     PFA_REQUIRE(n >= 1 && dones && values && rewards && advantages && workspace, "gae_shard: bad arguments");
     PFA_REQUIRE(!has_next || carry_in, "gae_shard: a shard with a successor needs carry_in");
     const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
-    hipLaunchKernelGGL(gae_apply_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+    hipLaunchKernelGGL(gae_apply_kernel<false>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
                        advantages, returns, (long long)n, gamma, gae_lambda, (const Affine *)workspace, (int)nb,
-                       has_next ? carry_in : (const double *)nullptr, has_next ? 1 : 0);
+                       has_next ? carry_in : (const double *)nullptr, has_next ? 1 : 0, GaeSums{});
     PFA_LAUNCH_CHECK();
     return 0;
 }

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2)
                            long long K, long long k_per_split, float *__restrict__ partial) {
     using Cfg = GemmTnCfg<WR, WC, MI, NI>;
     __shared__ float lds[2 * Cfg::kStageFloats];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
     const int c = lane & 15, g = lane >> 4;
     const int wr = wv / WC, wc = wv % WC;
     const int tiles_n = no / Cfg::TN;

@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_kernel(IgA A, int M,
     constexpr int TM = 64 * MI, TN = 16 * NI;
     constexpr int kStage = (TM + TN) * kIgLS;
     __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), c = lane & 15, g = lane >> 4;
     // Workgroups are dealt round-robin to the 8 XCDs (each with its own L2); neighbouring row tiles read overlapping patches of the
     // same frames, so the tile index is permuted to give every XCD one contiguous run of tiles (grid.x is a multiple of 8).
     const int per_xcd = gridDim.x >> 3;
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_rows_split_kernel(IgA A, 
     constexpr bool kAInt = MODE == kAIm2colU8;                // A = bytes as floats: exact in ONE bf16 piece
     static_assert(TN % RPP == 0 && LB >= 1 && LB <= 2, "the split form takes 32- and 64-column tiles");
     __shared__ __attribute__((aligned(16))) unsigned char lds[3 * PLANE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), c = lane & 15, g = lane >> 4;
     const int per_xcd = gridDim.x >> 3;
     const int tile_m = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     const int m0 = tile_m * TM, n0 = blockIdx.y * TN;
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
     constexpr int kStage = kIgBK * (SA + SB);
     constexpr int kDThreads = kIgBK * TN / 4;
     __shared__ __attribute__((aligned(16))) float lds[2 * kStage];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id(), c = lane & 15, g = lane >> 4;
     const int tiles_n = N / TN;
     const int ktile = blockIdx.x / tiles_n, k0 = ktile * TK, n0 = (blockIdx.x % tiles_n) * TN;
     const int m_lo = blockIdx.y * rows_per_split;

@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256) lstm_heads_loss_kernel(const float *h, lo
         if (threadIdx.x < kOut) b2v[threadIdx.x] = b2v_at(params, off, a, threadIdx.x);
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wv = wave_id(), c = lane & 15, g = lane >> 4;
     const int le = wv * 4 + g, lo = c;      // (le: one of the workgroup's 16 DPP rows; lo: the head output this lane owns)
     // B fragments come from the LDS copy at their point of use (in registers they cost 64 VGPRs and half the occupancy that hides
     // this kernel's gather latencies).  Heads: contraction index k = 16 j + 4 g + e (the A operand is read as float4

@@ -153,6 +153,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     constexpr int XS = L::XS, HS = L::HS, DS = L::DS, KS = DP / 4, V = DP / 4, W1S = L::W1S;
     constexpr int NLD = (16 * V + 63) / 64;  // float4 loads per lane per tile
     constexpr int kGradPairs = grad_pairs(DP), kGradThreads = grad_threads(DP);
+    constexpr bool kQuad = kGradPairs == 4 && 4 * NL::kCount <= L::kFloats;   // epilogue: four reduction buffers side by side
     // the software-pipelined instruction order costs ~40 registers (double-buffered fragments, all eight dh / hidden-tile fragments
     // live at once): taken where the instantiation stays inside its register budget without spilling (checked in the ISA)
     constexpr bool kPipe = PFA_GRAD_PIPE && (DP <= 32 || (DP == 64 && KTM <= 3));
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     constexpr int KKM = FCOL ? 4 * KTM : KKU;
     static_assert(!PERM || (kPipe && !MH), "the permuted head layout is wired into the pipelined single-head form");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
+    const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;   // (wv is a scalar: common.hpp)
     const int pair = wv & (kGradPairs - 1);
     const bool producer = wv < kGradPairs;
     float *pl = lds + pair * L::kPairFloats;
@@ -503,10 +504,12 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
         for (int i = 0; i < 6; ++i)
 #pragma unroll
             for (int s = 1; s < 16; s <<= 1) stats[i] += __shfl_xor(stats[i], s, 64);
-        float *red = lds + (pair & 1) * NL::kCount;  // buffer 0: even pairs, buffer 1: odd pairs
-        for (int turn = 0; turn < kGradPairs / 2; ++turn) {
-            if ((pair >> 1) == turn) {
-                const bool first = turn == 0;
+        // one reduction buffer per pair where the tile / table area holds them all (kQuad: the 64-float-row instantiations), else
+        // buffer 0 for the even pairs and buffer 1 for the odd ones, in turns; the sum is (p0 + p2) + (p1 + p3) either way
+        float *red = lds + (kQuad ? pair : (pair & 1)) * NL::kCount;
+        for (int turn = 0; turn < (kQuad ? 1 : kGradPairs / 2); ++turn) {
+            if (kQuad || (pair >> 1) == turn) {
+                const bool first = kQuad || turn == 0;
 #pragma unroll
                 for (int m = 0; m < kMT; ++m)
 #pragma unroll
@@ -661,10 +664,10 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
             db1[m] += __shfl_xor(db1[m], 32, 64);
             if (COL) acc_col[m] = gsum<true>(acc_col[m]);   // over the lane groups: all 16 rows of the tile
         }
-        float *red = lds + (pair & 1) * NL::kCount;
-        for (int turn = 0; turn < kGradPairs / 2; ++turn) {
-            if ((pair >> 1) == turn) {
-                const bool first = turn == 0;
+        float *red = lds + (kQuad ? pair : (pair & 1)) * NL::kCount;
+        for (int turn = 0; turn < (kQuad ? 1 : kGradPairs / 2); ++turn) {
+            if (kQuad || (pair >> 1) == turn) {
+                const bool first = kQuad || turn == 0;
 #pragma unroll
                 for (int kt = 0; kt < KTM; ++kt)
 #pragma unroll
@@ -693,7 +696,12 @@ __global__ void __launch_bounds__(grad_threads(DP), grad_waves_per_simd(DP))
     if (blockIdx.x != 0xFFFF) return;
 #endif
     float *dst = partials + (size_t)blockIdx.x * NL::kCount;
-    for (int i = threadIdx.x; i < NL::kCount; i += kGradThreads) dst[i] = lds[i] + lds[NL::kCount + i];
+    if constexpr (kQuad) {
+        for (int i = threadIdx.x; i < NL::kCount; i += kGradThreads)
+            dst[i] = (lds[i] + lds[2 * NL::kCount + i]) + (lds[NL::kCount + i] + lds[3 * NL::kCount + i]);
+    } else {
+        for (int i = threadIdx.x; i < NL::kCount; i += kGradThreads) dst[i] = lds[i] + lds[NL::kCount + i];
+    }
 }
 
 // Fixed-order sum of the workgroup partials (native layout) + scatter into the flat gradient layout, plus one

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView 
     __shared__ Sampler s_sm;
     __shared__ long long s_produced;
     __shared__ int s_idx;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
     int cur = 0;
     if (tid < kMtN) {
         mt[0][tid] = v.hdr->mt[tid];
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(kSelThreads) squared_tape_select_kernel(Square
     __shared__ int s_wave[kSelThreads / 64];
     __shared__ long long s_last;     // stream position of the word that produced the last draw (-1: not in this workgroup)
     const TapeJob job = *jobp;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
     const int n_pop = 8 * v.d, bits = 32 - __clz(n_pop);
     // draws produced by the workgroups before this one
     long long before = 0;

@@ -154,3 +154,49 @@ def test_sharded_one_exchange_form_equals_flat_scan(n, shards, p_done):
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
     assert np.abs(got - want).max() <= 8 * np.finfo(np.float32).eps * max(1.0, np.abs(want).max())
     assert got[-1] == 0.0
+
+
+@pytest.mark.parametrize('N,T,nmb,bptt', [(4096, 128, 4, 16), (64, 128, 4, 16), (48, 32, 2, 8), (5, 16, 1, 16), (256, 64, 8, 32),
+                                          (1000, 24, 1, 8), (8, 128, 32, 8)])
+def test_one_pass_gae_with_sums_equals_the_separate_entry_points(N, T, nmb, bptt):
+    """pfa_gae_sums_f32 = pfa_gae_f32 (advantages / returns bit for bit) + the per-minibatch advantage sums (numpy f64 over the
+    minibatch's rows, clean_pufferl.py:455-457 partition) + the explained-variance sums over the storage-order values
+    (clean_pufferl.py:266-270)."""
+    import torch
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    n = N * T
+    assert L.pfa_gae_sums_supported(n, N, nmb, bptt) == 1
+    rng = np.random.RandomState(N + T)
+    d = (rng.rand(n) < 0.05).astype(np.float32)
+    v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    want_adv, want_ret = hip_gae(d, v, r, 0.99, 0.95, want_returns=True)
+    dev = 'cuda'
+    dt, vt, rt = (torch.as_tensor(x).to(dev) for x in (d, v, r))
+    adv = torch.full((n,), float('nan'), device=dev)
+    ret = torch.full((n,), float('nan'), device=dev)
+    stats = torch.full((nmb, 2), float('nan'), dtype=torch.float64, device=dev)
+    ev4 = torch.full((4,), float('nan'), dtype=torch.float64, device=dev)
+    zero8 = torch.ones(8, dtype=torch.float64, device=dev)
+    ws = torch.zeros(L.pfa_gae_sums_workspace_bytes(n, nmb), dtype=torch.uint8, device=dev)
+    for _ in range(2):   # (twice: the workspace is reused as it is)
+        _lib.check(L.pfa_gae_sums_f32(_lib.ptr(dt), _lib.ptr(vt), _lib.ptr(rt), _lib.ptr(adv), _lib.ptr(ret), n, 0.99, 0.95, N, nmb, bptt,
+                                      _lib.ptr(stats), _lib.ptr(ev4), _lib.ptr(zero8), _lib.ptr(ws), _lib.stream_handle()), 'gae_sums')
+    assert np.array_equal(adv.cpu().numpy(), want_adv) and np.array_equal(ret.cpu().numpy(), want_ret)
+    assert float(zero8.abs().sum()) == 0.0
+    a = want_adv.astype(np.float64)
+    seg = a.reshape(n // bptt, bptt)
+    for m in range(nmb):
+        rows = seg[m::nmb].ravel()
+        np.testing.assert_allclose(stats[m].cpu().numpy(), [rows.sum(), (rows * rows).sum()], rtol=1e-12, atol=1e-9)
+    yp = v.reshape(N, T).T.ravel().astype(np.float64)          # storage (step-major) order of the env-major value buffer
+    yt = a + yp
+    np.testing.assert_allclose(ev4.cpu().numpy(), [yt.sum(), (yt * yt).sum(), a.sum(), (a * a).sum()], rtol=1e-12, atol=1e-8)
+
+
+def test_one_pass_gae_with_sums_refuses_partitions_it_cannot_bin():
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    assert L.pfa_gae_sums_supported(8 * 128, 8, 8, 4) == 0       # bptt 4: a thread's 8 rows span two segments (ocean's config)
+    assert L.pfa_gae_sums_supported(96 * 48, 96, 3, 16) == 0     # 3 minibatches: the cycle is no power of two
+    assert L.pfa_gae_sums_supported(4096 * 128, 4096, 4, 16) == 1
