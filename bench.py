@@ -301,6 +301,122 @@ def self_check(data, pol):
                 tolerance=1e-5, checker='oracle/ppo_torch.py + oracle/puffer_oracle.c')
 
 
+class _StubVec:
+    """What oracle.ppo_torch.Trainer asks of a vecenv when its experience is injected (never stepped)."""
+
+    def __init__(self, n, shape, dtype):
+        import numpy as np
+        self.num_envs = n
+        self.observations = np.zeros((n,) + tuple(shape), dtype)
+
+    def async_reset(self, seed):
+        pass
+
+
+def _inject_adam(tr, opol, data, key_of):
+    """The oracle trainer starts from fresh Adam moments; give it the device's (the trainer has been running)."""
+    import torch
+    m, v = data.flat_params.split(data.optimizer.exp_avg), data.flat_params.split(data.optimizer.exp_avg_sq)
+    for i, name in enumerate(opol.names):
+        p = opol.params[i]
+        tr.opt.state[p] = dict(step=torch.tensor(float(data.optimizer.step_count)), exp_avg=m[key_of(name)].detach().cpu().to(p.dtype).clone(),
+                               exp_avg_sq=v[key_of(name)].detach().cpu().to(p.dtype).clone())
+
+
+def self_check_c3(data, pol):
+    """The c3 leg at the size it is timed: one more (untimed) evaluate + train with ONE epoch
+    (4 optimizer steps over all 524 288 rows of 160 floats, LSTM state carried over the minibatches), the train replayed by the
+    torch-fp32 oracle trainer on the device rollout's experience: losses and post-update weights within north_star's 1e-5."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle, ppo_torch
+    from pufferlib_amd import clean_pufferl
+    n, T = NUM_ENVS, HORIZON
+    B = n * T
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    clean_pufferl.evaluate(data)
+    exp = data.experience
+    opol = ppo_torch.Policy.from_reference_state_dict({k: v.detach().cpu().clone() for k, v in pol.state_dict().items()})
+    epochs_saved = data.config.update_epochs
+    data.config.update_epochs = 1
+    tr = ppo_torch.Trainer(opol, _StubVec(n, (160,), np.float32), batch_size=B, minibatch_size=B // NMB, bptt_horizon=BPTT, update_epochs=1,
+                           learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, vf_coef=0.5, vf_clip_coef=0.1, max_grad_norm=0.5,
+                           ent_coef=0.01, total_timesteps=data.config.total_timesteps, seed=1)
+    sm = lambda x: x.view(n, T, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
+    tr.obs = torch.as_tensor(sm(exp.obs)[:, :160].copy())
+    tr.actions = sm(exp.actions).astype(np.int64)
+    tr.logprobs, tr.rewards, tr.dones, tr.values = (sm(x).copy() for x in (exp.logprobs, exp.rewards, exp.dones, exp.values))
+    tr.global_step = data.global_step
+    tr.opt.param_groups[0]['lr'] = data.optimizer.param_groups[0]['lr']
+    _inject_adam(tr, opol, data, lambda name: ('recurrent.' + name) if name.endswith('_l0') else name)
+    t0 = time.perf_counter()
+    Lo = tr.train()
+    host_s = time.perf_counter() - t0
+    clean_pufferl.train(data)
+    data.config.update_epochs = epochs_saved
+    keys = ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac')
+    loss_err = max(abs(float(getattr(data.losses, k)) - float(Lo[k])) for k in keys)
+    sd = pol.state_dict()
+    w_err = max(float(np.abs(sd[('policy.recurrent.' + k) if k.endswith('_l0') else ('policy.policy.' + k)].cpu().numpy() - arr).max())
+                for k, arr in opol.state_arrays().items())
+    adv_err = float(np.abs(exp.advantages.cpu().numpy() - c_oracle.compute_gae(
+        exp.dones.cpu().numpy(), exp.values.cpu().numpy(), exp.rewards.cpu().numpy(), 0.99, 0.95)).max())
+    assert loss_err <= 1e-5 and w_err <= 1e-5 and adv_err <= 1e-5, (loss_err, w_err, adv_err)
+    return dict(rows=B, optimizer_steps=NMB, max_abs_loss_err=loss_err, max_abs_weight_err=w_err, max_abs_advantage_err=adv_err,
+                tolerance=1e-5, oracle_seconds=round(host_s, 1), checker='oracle/ppo_torch.py (torch fp32, LSTM state carried over the minibatches) + oracle/puffer_oracle.c')
+
+
+def self_check_c4():
+    """The c4 leg at the minibatch size it is timed: ONE optimizer step over a 65 536-frame minibatch
+    — cnn.Engine walks it in eight 8192-frame chunks, as in the timed loop — forward + PPO loss + backward through all four layers
+    + clip + Adam, against the oracle trainer in DOUBLE precision on the same uint8 frames (2048 envs x 32 steps of a fresh
+    vector.Frames; the host time of the f64 replay is what bounds the size: ~1 minute).  fp32 torch convolutions on the host differ
+    from double precision by as much as the kernels do, so the yardstick is f64."""
+    import numpy as np
+    import torch
+    from oracle import ppo_torch
+    from pufferlib_amd import clean_pufferl, cleanrl, models, vector
+    n, T = 2048, 32
+    B = n * T
+    vec = vector.make(vector.make_frames, env_kwargs=dict(framestack=4, num_actions=4, episode_length=100), num_envs=n, backend=vector.Frames)
+    torch.manual_seed(3)
+    pol = cleanrl.Policy(models.Convolutional(vec.driver_env, framestack=4))
+    cfg = make_config(B * 10, env='frames')
+    cfg.batch_size, cfg.minibatch_size, cfg.update_epochs = B, B, 1
+    data = clean_pufferl.create(cfg, vec, pol)
+    assert data.cnn_engine.chunk == 8192
+    start = {k[len('policy.'):]: v.detach().cpu().numpy().copy() for k, v in pol.state_dict().items()}
+    clean_pufferl.evaluate(data)
+    e = data.experience
+    sm = lambda x: x.view(n, T, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()  # noqa: E731
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    t0 = time.perf_counter()
+    try:
+        torch.set_default_dtype(torch.float64)
+        opol = ppo_torch.ConvPolicy(start, dtype=torch.float64)
+        tr = ppo_torch.Trainer(opol, _StubVec(n, (1,), np.uint8), batch_size=B, minibatch_size=B, bptt_horizon=BPTT, update_epochs=1,
+                               learning_rate=2.5e-4, gamma=0.99, gae_lambda=0.95, clip_coef=0.1, vf_coef=0.5, vf_clip_coef=0.1, max_grad_norm=0.5,
+                               ent_coef=0.01, total_timesteps=B * 10, seed=1)
+        tr.obs = torch.as_tensor(sm(e.obs)).to(torch.float64)
+        tr.actions = sm(e.actions).astype(np.int64)
+        tr.logprobs, tr.rewards, tr.dones, tr.values = (sm(x).copy() for x in (e.logprobs, e.rewards, e.dones, e.values))
+        tr.global_step = data.global_step
+        Lo = tr.train()
+    finally:
+        torch.set_default_dtype(torch.float32)
+    host_s = time.perf_counter() - t0
+    clean_pufferl.train(data)
+    keys = ('policy_loss', 'value_loss', 'entropy', 'old_approx_kl', 'approx_kl', 'clipfrac')
+    loss_err = max(abs(float(getattr(data.losses, k)) - float(Lo[k])) for k in keys)
+    sd = pol.state_dict()
+    errs = {k: float(np.abs(sd['policy.' + k].cpu().numpy() - arr).max()) for k, arr in opol.state_arrays().items()}
+    w_err = max(errs.values())
+    assert loss_err <= 1e-5 and w_err <= 1e-5, (loss_err, errs)
+    return dict(frames=B, chunks=B // 8192, optimizer_steps=1, max_abs_loss_err=loss_err, max_abs_weight_err=w_err,
+                max_abs_weight_err_by_tensor={k: float('%.3g' % v) for k, v in errs.items()}, tolerance=1e-5, oracle_seconds=round(host_s, 1),
+                checker='oracle/ppo_torch.py ConvPolicy in float64')
+
+
 def _free_port():
     import socket
     so = socket.socket()
@@ -784,6 +900,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)
+            elif args.workload == 'c3':
+                out['self_check'] = self_check_c3(data, pol)
+            elif args.workload == 'c4' and not cnn_lstm and args.products == 'fp32':
+                del data, vec, pol
+                torch.cuda.empty_cache()
+                out['self_check'] = self_check_c4()
+                data = vec = pol = None
             if args.workload == 'c4' and not cnn_lstm:
                 out['cpu_baseline'] = cpu_baseline_c4()
             elif args.workload == 'c3':

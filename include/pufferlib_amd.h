@@ -693,18 +693,26 @@ int pfa_rows_perm(const float *src, int32_t lds_, float *dst, int32_t ldd, const
  * (any transport) and passes them, rank order, to pfa_p2p_open.  Once open, pfa_dist_all_reduce_* and the native train loop
  * use it for every bucket that fits.  World size <= 8 (one node).  The flag waits are bounded (PFA_P2P_TIMEOUT_MS, default
  * 30 000): a wait that runs out fills its part of the bucket with NaN and raises the status word.  pfa_p2p_status (a plain
- * host read, no synchronisation): 0 ok, 1 a peer never arrived, -1 not open. */
+ * host read, no synchronisation): 0 ok, 1 a wait of this rank ran out (a peer never arrived), 2 a peer reported one (the ranks' status
+ * words ride every flag-in-data exchange: csrc/p2p_ll.hpp), -1 not open.
+ * Recovery: pfa_p2p_seq() = this rank's sequence number; after agreeing on base >= every rank's (any transport), every rank calls
+ * pfa_p2p_reset(base) between two barriers: clears the status word and restarts both sequence counters from base (nothing a late peer
+ * still writes with an old number can satisfy a wait of the new epoch).  The replicas' parameters are
+ * the caller's to repair (reload / re-broadcast).  pfa_p2p_debug_set_status: tests only. */
 int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64_host);
 int pfa_p2p_open(const uint8_t *handles_host, int32_t rank, int32_t world);
 int pfa_p2p_close(void);
 int pfa_p2p_status(void);
+int64_t pfa_p2p_seq(void);
+int pfa_p2p_reset(int64_t base);
+int pfa_p2p_debug_set_status(int value);
 int pfa_p2p_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
 int pfa_p2p_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
 /* The flag-in-data form of the same exchange (csrc/p2p_ll.hpp): every float travels as one 8-byte {value, sequence number} store
  * into the peers' memory and is summed, rank order, as soon as the local copies carry this call's number — no flag, no fence, no
  * assumption about the order in which a peer's stores land.  This is what pfa_ppo_mlp_train runs INSIDE its reduce + Adam launch
  * when data parallel (no all-reduce launch at all); the stand-alone entry serves the start-up self-test and the tests.  Up to
- * cap_bytes / 4 + 2304 floats; collective (every rank must make the same sequence of calls).  pfa_p2p_ll_calls: exchanges so far
+ * cap_bytes / 4 + 2303 floats (the slot's last entry carries the status words); collective (every rank must make the same sequence of calls).  pfa_p2p_ll_calls: exchanges so far
  * (stand-alone + fused). */
 int pfa_p2p_ll_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
 int64_t pfa_p2p_ll_calls(void);

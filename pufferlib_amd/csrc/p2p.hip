@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers pe
 // ppo_reduce_adam_kernel): one entry per float.
 __global__ void __launch_bounds__(256) p2p_ll_all_reduce_kernel(LlArgs d, float *buf, unsigned n) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) ll_status_exchange(d);   // as in the fused optimizer step: every exchange carries the ranks' status words
     if (i >= n) return;
     const float v = buf[i];
     ll_push(d, i, v);
@@ -243,9 +244,35 @@ extern "C" int pfa_p2p_close(void) {
     return 0;
 }
 
-extern "C" int pfa_p2p_status(void) {   // 0 ok, 1 a wait ran out (a peer never arrived), -1 not initialised.  A plain host read.
+extern "C" int pfa_p2p_status(void) {   // 0 ok, 1 a wait of THIS rank ran out, 2 a peer reported one (p2p_ll.hpp), -1 not initialised.  A plain host read.
     if (!g_p2p.ready || !g_p2p.status) return -1;
     return *(volatile int *)g_p2p.status;
+}
+
+// Recovery after a raised status word (a timed-out exchange): every rank calls pfa_p2p_seq(), the caller agrees on
+// base >= every rank's value (e.g. MAX all-reduce over torch.distributed, + a margin), and every rank calls pfa_p2p_reset(base)
+// between two barriers: the status word is cleared and both sequence counters restart from `base`, so nothing a late peer may still
+// write with an old sequence number can satisfy a wait of the new epoch (flags and flag-in-data entries compare sequence numbers).
+// The parameters of the replicas are NOT repaired here (a timed-out rank holds NaN): reload them (clean_pufferl.try_load_checkpoint)
+// or re-broadcast them before training on.
+extern "C" int64_t pfa_p2p_seq(void) {
+    const unsigned long long a = g_p2p.seq, b = g_p2p.ll_seq;
+    return (int64_t)(a > b ? a : b);
+}
+extern "C" int pfa_p2p_reset(int64_t base) {
+    PFA_REQUIRE(g_p2p.ready && g_p2p.status, "p2p.reset: not initialised");
+    PFA_REQUIRE(base >= pfa_p2p_seq() && base < 0xffffff00ll, "p2p.reset: base %lld must be >= this rank's sequence number %lld (and < 2^32)",
+                (long long)base, (long long)pfa_p2p_seq());
+    PFA_CHECK_HIP(hipDeviceSynchronize());
+    *(volatile int *)g_p2p.status = 0;
+    g_p2p.seq = (unsigned long long)base;
+    g_p2p.ll_seq = (unsigned)base;
+    return 0;
+}
+extern "C" int pfa_p2p_debug_set_status(int value) {   // tests: what a timed-out wait leaves behind, without waiting for one
+    PFA_REQUIRE(g_p2p.ready && g_p2p.status, "p2p: not initialised");
+    *(volatile int *)g_p2p.status = value;
+    return 0;
 }
 
 extern "C" int pfa_p2p_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream) {
@@ -262,7 +289,8 @@ extern "C" int pfa_p2p_all_reduce_f64(double *buf, int64_t count, pfa_stream_t s
 extern "C" int pfa_p2p_ll_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream) {
     PFA_REQUIRE(buf && count >= 0, "p2p.ll_all_reduce: bad arguments");
     PFA_REQUIRE(g_p2p.ready, "p2p: not initialised");
-    PFA_REQUIRE((size_t)count <= g_p2p.ll_entries, "p2p.ll_all_reduce: %lld floats exceed the %u entries of a slot", (long long)count, g_p2p.ll_entries);
+    PFA_REQUIRE((size_t)count + 1 <= g_p2p.ll_entries, "p2p.ll_all_reduce: %lld floats exceed the %u entries of a slot (the last one carries the status)",
+                (long long)count, g_p2p.ll_entries - 1);
     if (count == 0 || g_p2p.world == 1) return 0;
     const LlArgs d = p2p_ll_next();
     ScopedKernelTimer timer("p2p_ll_all_reduce", (hipStream_t)stream);

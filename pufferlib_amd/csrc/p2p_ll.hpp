@@ -70,6 +70,22 @@ __device__ __forceinline__ float ll_wait_sum(const LlArgs &d, unsigned idx, floa
     return s;
 }
 
+// A timeout is every rank's business: the rank whose wait ran out holds NaN from then on, but a peer that was merely late sees a
+// complete exchange and would train on with a diverged replica.  So every exchange also carries the ranks' status words (the LAST
+// entry of the slot, one lane per launch): a rank that has a raised status pushes 1, everybody sums, and a rank that sees a non-zero
+// (or unreadable) sum raises its own word to 2 ("a peer reported a lost exchange").  clean_pufferl.train() checks the word after
+// every update on every rank, so the timeout of optimizer step k is an error on ALL ranks in the same train() for every k but the
+// update's last step (that one is reported by the first exchange of the next update).  A lane whose own status is already raised
+// does not wait again (its peers may be gone: one bounded wait per launch is enough).
+__device__ __forceinline__ void ll_status_exchange(const LlArgs &d) {
+    const unsigned idx = d.entries - 1u;
+    const int mine = __hip_atomic_load(d.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    ll_push(d, idx, mine ? 1.0f : 0.0f);
+    if (mine) return;
+    const float tot = ll_wait_sum(d, idx, 0.0f);        // (raises the word to 1 itself when the wait runs out)
+    if (tot > 0.0f) __hip_atomic_store(d.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // csrc/p2p.hip
 bool p2p_ll_ready(size_t entries_needed);
 LlArgs p2p_ll_next();   // arguments of the next call: bumps the sequence number

@@ -936,6 +936,7 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
             hi = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats)), hi);
             lo = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats) + 1), lo);
         }
+        if (blockIdx.x == 0 && ql == 0) ll_status_exchange(ll);   // the ranks' status words ride the exchange (p2p_ll.hpp)
     }
     if (p >= 0) grads[p] = s;
     if (stat) {
@@ -1402,7 +1403,7 @@ static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float
     PFA_LAUNCH_CHECK();
     return 0;
 }
-static size_t ll_entries_needed(const pfa_mlp_dims *dims) { return native_count(dims->obs_stride) + kTailFloats; }
+static size_t ll_entries_needed(const pfa_mlp_dims *dims) { return native_count(dims->obs_stride) + kTailFloats + 1; }   // + the status entry
 static bool env_on(const char *name, bool dflt) {
     const char *e = std::getenv(name);
     return e ? e[0] != '0' : dflt;

@@ -192,7 +192,7 @@ def init_p2p(bucket_bytes):
             good = 0
     # ... and the flag-in-data form (csrc/p2p_ll.hpp) the fused optimizer step uses, twice per phase
     for j in range(4):
-        n = min(int(bucket_bytes) // 4 + 2304, 1 << 16)
+        n = min(int(bucket_bytes) // 4 + 2303, 1 << 16)     # (the slot's last entry carries the ranks' status words)
         x = (((torch.arange(n, device='cuda') + 7 * j) % 127) * (rank + 1)).float()
         want = x.clone()
         d.all_reduce(want)
@@ -273,13 +273,45 @@ def transport_info():
                 p2p_reason=_native.get('p2p_reason'))
 
 
+def reset_p2p():
+    """Collective recovery after a raised status word (a timed-out exchange: `raise_if_peer_lost` raised on every rank): agree on a
+    sequence number past every rank's, clear the status words, and check the path with one flag-in-data all-reduce.  The replicas'
+    PARAMETERS are not repaired here — a timed-out rank holds NaN: reload a checkpoint (clean_pufferl.try_load_checkpoint) or
+    broadcast rank 0's before training on.  Returns True when the path answers again on every rank; False closes nothing (the caller
+    may retry or set PFA_ALLREDUCE=rccl and re-create)."""
+    import torch
+    from . import _lib
+    d, rank, w = world()
+    if not _native.get('p2p') or w <= 1:
+        return False
+    L = _lib.lib()
+    torch.cuda.synchronize()
+    seq = torch.tensor([int(L.pfa_p2p_seq())], dtype=torch.int64, device='cuda')
+    d.all_reduce(seq, op=d.ReduceOp.MAX)
+    d.barrier()                                        # nobody is still inside an exchange of the old epoch
+    _lib.check(L.pfa_p2p_reset(int(seq.item()) + 64), 'p2p_reset')
+    d.barrier()
+    x = (torch.arange(4096, device='cuda') % 97 * (rank + 1)).float()
+    want = x.clone()
+    d.all_reduce(want)
+    ok = int(L.pfa_p2p_ll_all_reduce_f32(x.data_ptr(), x.numel(), _lib.stream_handle()) == 0)
+    torch.cuda.synchronize()
+    ok = int(ok and L.pfa_p2p_status() == 0 and torch.equal(x, want))
+    flag = torch.tensor([ok], dtype=torch.int32, device='cuda')
+    d.all_reduce(flag, op=d.ReduceOp.MIN)
+    return bool(int(flag.item()))
+
+
 def raise_if_peer_lost():
     """The peer all-reduce's waits are bounded (csrc/p2p.hip): when one ran out the bucket was filled with NaN and the status word
     raised.  Called where train()/evaluate() read their results back, so a dead or stalled rank ends the run with an error."""
     from . import _lib
-    if _native.get('p2p') and _lib.lib().pfa_p2p_status() > 0:
-        raise RuntimeError('data-parallel all-reduce over the peer path timed out waiting for a rank (PFA_P2P_TIMEOUT_MS); '
-                           'the gradients of this update are invalid')
+    st = _lib.lib().pfa_p2p_status() if _native.get('p2p') else 0
+    if st > 0:
+        raise RuntimeError(('data-parallel all-reduce over the peer path timed out waiting for a rank (PFA_P2P_TIMEOUT_MS)' if st == 1 else
+                            'a peer rank reported a timed-out exchange over the peer path (its replica holds NaN)')
+                           + '; the gradients of this update are invalid on every rank.  Recovery: restore the parameters '
+                             '(try_load_checkpoint / broadcast) and call pufferlib_amd.dist.reset_p2p() on every rank')
 
 
 def finalize_native():

@@ -151,6 +151,22 @@ def test_eight_ranks_full_update_equals_single_process_run(tmp_path):
         assert tuple(int(x) for x in r[q]['native']) == (1, 1, 0)
         assert int(r[q]['ll_calls'][0]) == 4 + ITERS * 2 * 2          # self-test + iterations x epochs x minibatches, nothing else
     assert not np.array_equal(r[0]['0.obs'], r[7]['0.obs'])
+    # SURVEY 8e's parity definition for the env side: rank q is one reference process over ITS shard — a Serial(Squared) of N envs
+    # seeded seed + q N (+ env index: make_seeds, vector.py:639-641), the shared random.sample stream process-local — so its
+    # trajectory under its own recorded actions is bit-exact against the C oracle seeded that way, continuously across updates
+    from oracle import c_oracle
+    N, T = N_PER_RANK, HORIZON
+    for q in range(world):
+        ovec = c_oracle.SquaredSerial(N, 3, 1)
+        ovec.async_reset(21 + q * N)
+        for it in range(ITERS):
+            obs = r[q][f'{it}.obs'].reshape(N, T, -1)[:, :, :49]
+            act, rew, don = (r[q][f'{it}.{k}'].reshape(N, T) for k in ('actions', 'rewards', 'dones'))
+            for t in range(T):
+                o, rr, dd = ovec.recv()[:3]
+                assert np.array_equal(obs[:, t], o.reshape(N, -1)), (q, it, t)
+                assert np.array_equal(rew[:, t].view(np.uint32), rr.view(np.uint32)) and np.array_equal(don[:, t] != 0, dd), (q, it, t)
+                ovec.send(act[:, t].astype(np.int64))
 
 
 def test_two_ranks_equal_single_process_run_with_the_gradient_step_in_the_bf16x6_form(tmp_path, monkeypatch):
@@ -315,7 +331,16 @@ def _p2p_lost_peer_worker(rank, world, port, out_dir):
             res['raised'] = False
         except RuntimeError:
             res['raised'] = True
-        np.savez(os.path.join(out_dir, 'lost.npz'), **{k: np.array([int(v)]) for k, v in res.items()})
+    # recovery (round 5): the ranks' sequence numbers differ now (rank 1 skipped a call); reset_p2p agrees on a new epoch on every rank
+    pdist._native['p2p'] = True
+    recovered = pdist.reset_p2p()
+    y = torch.full((3000,), float(rank + 1), device='cuda')
+    _lib.check(L.pfa_p2p_all_reduce_f32(_lib.ptr(y), y.numel(), _lib.stream_handle()), 'p2p all-reduce after reset')
+    z = torch.full((3000,), float(rank + 1), device='cuda')
+    _lib.check(L.pfa_p2p_ll_all_reduce_f32(_lib.ptr(z), z.numel(), _lib.stream_handle()), 'p2p ll all-reduce after reset')
+    torch.cuda.synchronize()
+    res.update(recovered=recovered, status_after=L.pfa_p2p_status(), sum_ok=bool((y == 3.0).all() and (z == 3.0).all()))
+    np.savez(os.path.join(out_dir, f'lost{rank}.npz'), **{k: np.array([int(v)]) for k, v in res.items()})
     dist.barrier()
     L.pfa_p2p_close()
     dist.destroy_process_group()
@@ -325,5 +350,49 @@ def test_lost_peer_is_an_error_not_a_stale_sum(tmp_path):
     """a rank that never arrives must not leave the others with whatever was in the slots.  The wait is bounded
     in wall-clock time, the bucket comes back all-NaN, the status word is raised and clean_pufferl's readback check raises."""
     _spawn(_p2p_lost_peer_worker, (2, _free_port(), str(tmp_path)), 2, timeout_s=180)
-    r = np.load(tmp_path / 'lost.npz')
+    r = np.load(tmp_path / 'lost0.npz')
     assert int(r['status_before'][0]) == 0 and int(r['status'][0]) == 1 and int(r['all_nan'][0]) == 1 and int(r['raised'][0]) == 1
+    for q in range(2):   # ... and pufferlib_amd.dist.reset_p2p() brings the path back on both ranks (VERDICT round 4, next 6b)
+        r = np.load(tmp_path / f'lost{q}.npz')
+        assert int(r['recovered'][0]) == 1 and int(r['status_after'][0]) == 0 and int(r['sum_ok'][0]) == 1, (q, dict(r))
+
+
+def _p2p_status_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='2000')
+    sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from pufferlib_amd import _lib, dist as pdist
+    assert pdist.init_p2p(1 << 16)
+    pdist._native['p2p'] = True
+    L = _lib.lib()
+    if rank == 1:
+        _lib.check(L.pfa_p2p_debug_set_status(1), 'set_status')      # what a timed-out wait leaves on ONE rank
+    x = torch.full((2000,), float(rank + 1), device='cuda')
+    _lib.check(L.pfa_p2p_ll_all_reduce_f32(_lib.ptr(x), x.numel(), _lib.stream_handle()), 'll all-reduce')
+    torch.cuda.synchronize()
+    res = dict(status=L.pfa_p2p_status())
+    try:
+        pdist.raise_if_peer_lost()
+        res['raised'] = 0
+    except RuntimeError:
+        res['raised'] = 1
+    res['recovered'] = int(pdist.reset_p2p())
+    res['status_after'] = L.pfa_p2p_status()
+    np.savez(os.path.join(out_dir, f'st{rank}.npz'), **{k: np.array([int(v)]) for k, v in res.items()})
+    dist.barrier()
+    L.pfa_p2p_close()
+    dist.destroy_process_group()
+
+
+def test_a_timeout_on_one_rank_is_an_error_on_every_rank_in_the_same_update(tmp_path):
+    """VERDICT round 4 (weak 4 / next 6b): only the rank whose wait ran out used to raise; a peer that was merely late saw a complete
+    exchange and trained on.  The ranks' status words ride every flag-in-data exchange (csrc/p2p_ll.hpp: ll_status_exchange, also inside
+    ppo_reduce_adam_kernel), so the next exchange raises the word on every rank: 1 where the wait ran out, 2 where a peer reported it."""
+    world = 3
+    _spawn(_p2p_status_worker, (world, _free_port(), str(tmp_path)), world, timeout_s=240)
+    got = [np.load(tmp_path / f'st{q}.npz') for q in range(world)]
+    assert [int(g['status'][0]) for g in got] == [2, 1, 2]
+    assert all(int(g['raised'][0]) == 1 and int(g['recovered'][0]) == 1 and int(g['status_after'][0]) == 0 for g in got)
