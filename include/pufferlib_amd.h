@@ -427,6 +427,10 @@ int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_stride, int32_t 
 /* Which kernel pfa_ppo_mlp_grad / pfa_ppo_mlp_train launch for these dimensions and local minibatch rows under the current product
  * form (pfa_igemm_set_products): 0 = ppo_mlp_grad_kernel (exact fp32 MFMA chains), 1 = ppo_mlp_grad_bf16_kernel (csrc/ppo_bf16.hpp:
  * the opt-in form, the 7x7 grid on 64-float rows with minibatches of whole 32-row tiles; everything else stays on 0). */
+/* pfa_ppo_mlp_train's reduce + Adam launch hands the clip norm's pieces over grid-wide; the wait is bounded (PFA_GRID_TIMEOUT_MS,
+ * default 10 000) and the one-launch form is only used when the runtime's occupancy says all its workgroups are resident at once.
+ * 0 = ok, 1 = a wait ran out (the parameters hold NaN since).  A plain host read, no synchronisation. */
+int pfa_ppo_grid_status(void);
 int pfa_ppo_mlp_grad_path(const pfa_mlp_dims *dims, int64_t mb_rows);
 /* clip_grad_norm_(max_grad_norm) + Adam(eps) step (:240-244; torch.optim.Adam single-tensor semantics, bias
  * correction with `step` = 1-based optimizer step count).  grad_scale multiplies grads first.

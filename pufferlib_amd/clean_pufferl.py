@@ -548,6 +548,8 @@ def _finish_evaluate(data, N, T):
     profile, experience, vecenv, policy = data.profile, data.experience, data.vecenv, data.policy
     L = _lib.lib()
     with profile.eval_misc:
+        if data.lstm_engine is not None:
+            data.lstm_engine.invalidate_obs_cache()     # new experience rows: per-update caches keyed on them are stale (advisor, round 4)
         policy.noise_step += T
         data.noise = None
         experience.ptr = experience.batch_size
@@ -619,6 +621,7 @@ def _publish_gae(data, extra=None):
     else:
         dist.all_reduce(buf)
     data._gae_published = True
+    data._gae_pub_version = getattr(ex, '_rdv', ex.rewards)._version     # in-place edits of rewards / dones / values bump it
     return buf[:n_extra]
 
 
@@ -629,6 +632,13 @@ def _finish_gae(data, rank, world, stream):
     L, B = _lib.lib(), ex.batch_size
     if not data._gae_published:           # evaluate() did not publish (host vecenv path, PFA_DP_EARLY_GAE=0): exchange here
         _publish_gae(data, None)
+    elif getattr(ex, '_rdv', ex.rewards)._version != data._gae_pub_version:
+        # advisor (round 4): the shard's interior map / last value / first row were published at the end of evaluate(); rewards,
+        # values or dones edited since (reward shaping, value re-bootstrapping) would silently meet stale numbers at the shard
+        # boundaries.  Re-publishing is a collective every rank would have to agree on, so this is an error with the way out named.
+        raise RuntimeError('experience.rewards / values / dones were modified in place between evaluate() and train() on a '
+                           'data-parallel run: the sharded GAE published its boundary numbers at the end of evaluate().  Set '
+                           'PFA_DP_EARLY_GAE=0 on every rank (the exchange then happens inside train())')
     gathered = data._dp_eval[data._dp_eval.numel() - 6 * world:]
     has_next = int(rank < world - 1)
     args = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
@@ -783,6 +793,10 @@ def train(data):
         def finish(acc, losses=losses, Bg=Bg, check_peers=bool(data.native_dp)):
             if check_peers:
                 pdist.raise_if_peer_lost()           # the peer all-reduce's bounded waits: a lost rank is an error here, never a stale sum
+            if _lib.lib().pfa_ppo_grid_status() != 0:
+                raise RuntimeError('the grid-wide hand-off of the fused reduce + Adam launch timed out (PFA_GRID_TIMEOUT_MS): the '
+                                   'device is shared or CU-masked so that its workgroups were not resident together; the parameters '
+                                   'hold NaN.  Set PFA_FUSED_ADAM=0 (two-kernel form) and restore a checkpoint')
             s_y, s_yy, s_a, s_aa = acc[6:10]
             var_y = s_yy / Bg - (s_y / Bg) ** 2
             var_res = s_aa / Bg - (s_a / Bg) ** 2                    # y_true - y_pred = advantages

@@ -838,6 +838,8 @@ constexpr int kAdamThreads = 256;   // adam_clip_kernel's workgroup: its norm su
 struct GridWords {
     unsigned long long *words;   // [workgroups][2], zeroed once per pfa_ppo_mlp_train call
     unsigned gen;                // never 0, different for every launch of the process
+    int *status;                 // host-pinned word: raised when the hand-off's bounded wait ran out (pfa_ppo_grid_status)
+    long long timeout_ticks;     // of the 100 MHz wall clock (PFA_GRID_TIMEOUT_MS, default 10 s)
 };
 struct AdamArgs {
     float *params, *exp_avg, *exp_avg_sq;
@@ -959,12 +961,33 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
     for (int w = 0; w < kAdamThreads / 64; ++w) {
         double ss = 0.0;
         for (int i = 64 * w + ql; i < npart; i += kAdamThreads) {
+            // The wait is bounded (advisor, round 4): the hand-off relies on every workgroup of the launch being resident at once.
+            // The host checks that once per shape (reduce_adam_coresident: occupancy x CUs >= workgroups, else the two-kernel
+            // form runs), but a device shared with other processes or masked down to fewer CUs can still starve a workgroup; then
+            // the wait runs out, the status word is raised (clean_pufferl.train raises) and the norm becomes NaN, which poisons the
+            // parameters instead of hanging the GPU.
             unsigned long long w0, w1;
+            long long t0 = 0;
+            int spin = 0;
+            bool lost = false;
             while (true) {
                 w0 = __hip_atomic_load(gw.words + 2 * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 w1 = __hip_atomic_load(gw.words + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if ((unsigned)(w0 >> 32) == gw.gen && (unsigned)(w1 >> 32) == gw.gen) break;
                 __builtin_amdgcn_s_sleep(1);
+                if ((++spin & 255) == 0) {
+                    const long long now = (long long)wall_clock64();
+                    if (t0 == 0) t0 = now;
+                    else if (now - t0 > gw.timeout_ticks) {
+                        lost = true;
+                        break;
+                    }
+                }
+            }
+            if (lost) {
+                __hip_atomic_store(gw.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ss = __builtin_nan("");
+                break;
             }
             ss += __longlong_as_double((long long)(((w1 & 0xffffffffull) << 32) | (w0 & 0xffffffffull)));
         }
@@ -1366,6 +1389,61 @@ static unsigned long long *grid_words_of(void *workspace, const pfa_mlp_dims *di
     return (unsigned long long *)norm_partials_of(workspace, dims);
 }
 static size_t grid_words_bytes(const pfa_mlp_dims *dims) { return (size_t)norm_blocks(dims) * 2 * sizeof(unsigned long long); }
+static int *grid_status_word() {   // host-pinned, device-visible, one per process
+    static int *word = nullptr;
+    if (!word) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) return nullptr;
+        *(volatile int *)p = 0;
+        word = (int *)p;
+    }
+    return word;
+}
+static long long grid_timeout_ticks() {
+    static const long long ticks = [] {
+        long long ms = 10000;
+        if (const char *e = std::getenv("PFA_GRID_TIMEOUT_MS")) {
+            const long long v = std::atoll(e);
+            if (v > 0) ms = v;
+        }
+        return ms * 100000;   // wall_clock64: 100 MHz
+    }();
+    return ticks;
+}
+// The one-launch form needs all of its workgroups resident at once (its grid-wide hand-off spins on the others' words): checked
+// against the occupancy the runtime reports for the instantiation this shape launches, once per shape; otherwise (a smaller part, a
+// CU mask) pfa_ppo_mlp_train runs the two-kernel form, which has no such requirement.
+template <typename K>
+static bool coresident(K kernel, int blocks) {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)kernel, 64 * kRedSl, 0) != hipSuccess) return false;
+    return (long long)per_cu * cus >= blocks;
+}
+static bool reduce_adam_coresident(const pfa_mlp_dims *dims, bool dist) {
+    static int cache[2][8] = {};   // [dist][shape slot]: 0 unknown, 1 yes, 2 no
+    const int slot = dims->obs_stride == 16 ? 0 : dims->obs_stride == 32 ? 1 : dims->obs_stride == 96 ? 2 : dims->obs_stride == 128 ? 3
+                   : (grad_trimmed(dims) && grad_perm(dims)) ? 4 : grad_trimmed(dims) ? 5 : 6;
+    int &c = cache[dist ? 1 : 0][slot];
+    if (c) return c == 1;
+    const int blocks = norm_blocks(dims);
+    bool ok;
+#define PFA_CO(DPV, KTMV, COLV, PERMV) \
+    ok = dist ? coresident(ppo_reduce_adam_kernel<DPV, KTMV, COLV, PERMV, true>, blocks) : coresident(ppo_reduce_adam_kernel<DPV, KTMV, COLV, PERMV, false>, blocks)
+    switch (slot) {
+        case 0: PFA_CO(16, 1, false, false); break;
+        case 1: PFA_CO(32, 2, false, false); break;
+        case 2: PFA_CO(96, 6, false, false); break;
+        case 3: PFA_CO(128, 8, false, false); break;
+        case 4: PFA_CO(64, 3, true, true); break;
+        case 5: PFA_CO(64, 3, true, false); break;
+        default: PFA_CO(64, 4, false, false); break;
+    }
+#undef PFA_CO
+    c = ok ? 1 : 2;
+    return ok;
+}
 static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
                               float lr, float beta1, float beta2, float eps, int64_t step, float max_grad_norm, double *losses,
                               double loss_scale, void *workspace, const LlArgs *ll, hipStream_t stream) {
@@ -1376,7 +1454,9 @@ static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float
     static unsigned long long launches = 0;
     unsigned gen = (unsigned)(++launches);
     if (gen == 0) gen = (unsigned)(++launches);
-    const GridWords gw{grid_words_of(workspace, dims), gen};
+    int *gstatus = grid_status_word();
+    PFA_REQUIRE(gstatus, "ppo.train: cannot allocate the grid hand-off's status word");
+    const GridWords gw{grid_words_of(workspace, dims), gen, gstatus, grid_timeout_ticks()};
     (void)nmb;
     const LlArgs none{};
     ScopedKernelTimer timer("ppo_reduce_adam", stream);
@@ -1409,6 +1489,12 @@ static bool env_on(const char *name, bool dflt) {
     return e ? e[0] != '0' : dflt;
 }
 
+// 0 = ok, 1 = the grid-wide hand-off of a reduce + Adam launch ran out of its bounded wait (the parameters hold NaN since).  A plain host read.
+extern "C" int pfa_ppo_grid_status(void) {
+    int *w = grid_status_word();
+    return w ? *(volatile int *)w : 0;
+}
+
 extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                                  const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                                  float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
@@ -1424,8 +1510,9 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
     const double loss_scale = 1.0 / ((double)global_mbs * hp->num_minibatches);
     // PFA_FUSED_ADAM=0: the two-kernel form (sum of the partials, then clip + Adam) for A/B timing; data parallel, the exchange
     // rides inside the fused launch when the peer path's flag-in-data area is open (PFA_FUSED_DP=0: all-reduce as its own step)
-    const bool fused = env_on("PFA_FUSED_ADAM", true);
-    const bool fused_dp = fused && data_parallel && world > 1 && env_on("PFA_FUSED_DP", true) && p2p_ll_ready(ll_entries_needed(dims));
+    const bool fused_dp_wanted = data_parallel && world > 1 && env_on("PFA_FUSED_DP", true) && p2p_ll_ready(ll_entries_needed(dims));
+    const bool fused = env_on("PFA_FUSED_ADAM", true) && reduce_adam_coresident(dims, fused_dp_wanted);
+    const bool fused_dp = fused && fused_dp_wanted;
     const bool one_launch = fused && (!data_parallel || fused_dp);   // (a 1-rank communicator keeps exercising the all-reduce call)
     if (one_launch)
         PFA_CHECK_HIP(hipMemsetAsync(grid_words_of(workspace, dims), 0, grid_words_bytes(dims), (hipStream_t)stream));

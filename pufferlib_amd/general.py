@@ -190,12 +190,17 @@ class Net:
             self.wcat = torch.zeros(4 * Hl, I + Hl, device=dev)
             self.bcat = torch.zeros(4 * Hl, device=dev)
             self.wcatT = torch.zeros(I + Hl, 4 * Hl, device=dev)
-        self.packed_version = -1
+        self.packed_version = None
         self.version = 0
+        self._probe = next(iter(views.values()))     # any parameter view: views of one flat buffer share its in-place version counter
 
     def pack(self):
         """Refresh the padded / stacked / transposed operand copies after the parameters changed (optimizer step, load)."""
-        if self.packed_version == self.version:
+        # `version` is bumped by the trainer's own writers (optimizer step kernels, checkpoint loader: raw-pointer writes torch does
+        # not see); torch-level in-place writes to any parameter view (p.copy_(), load_state_dict on an inner module, dist.broadcast,
+        # a torch optimizer) bump the shared version counter of the flat buffer the views alias — both are part of the key
+        key = (self.version, self._probe._version)
+        if self.packed_version == key:
             return
         v, nm = self.views, self.names
         with torch.no_grad():
@@ -219,7 +224,7 @@ class Net:
         if self.conv is not None:
             self.conv.version = self.version
             self.conv.pack()
-        self.packed_version = self.version
+        self.packed_version = key
 
     # ---------------------------------------------------------------------------------------------------------------- forward
     def encode(self, obs, rows, out, ldo):

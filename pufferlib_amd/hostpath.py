@@ -117,6 +117,8 @@ def evaluate(data):
     A = fp.num_actions
     stream = _lib.stream_handle()
     infos = defaultdict(list)
+    if getattr(data, 'lstm_engine', None) is not None:
+        data.lstm_engine.invalidate_obs_cache()     # the experience rows are about to be rewritten
     bridge.counters.zero_()
     bridge.stored_dropped.zero_()
     recvs = 0

@@ -65,10 +65,11 @@ class Engine:
         DP = fp.obs_stride
         # the minibatches' observation rows in time-major order: the rows do not change between the epochs of an update, so each
         # minibatch is gathered once per update (epoch 0) and kept — one buffer per minibatch, up to PFA_LSTM_OBS_CACHE_MB (default
-        # 2048) in total, else one buffer re-gathered every time as before
+        # 1024: a second copy of the observation batch) in total, else one buffer re-gathered every time as before.  The cache is
+        # dropped whenever the experience is rewritten (clean_pufferl._finish_evaluate / hostpath.evaluate call invalidate_obs_cache)
         import os
         nmb = experience.num_minibatches
-        keep = nmb * M * DP * 4 <= int(os.environ.get('PFA_LSTM_OBS_CACHE_MB', '2048')) << 20
+        keep = nmb * M * DP * 4 <= int(os.environ.get('PFA_LSTM_OBS_CACHE_MB', '1024')) << 20
         self.obs_tm_all = [torch.empty(M, DP, device=dev) for _ in range(nmb if keep else 1)]
         self.obs_tm = self.obs_tm_all[0]
         self._gathered = set()              # (update id, minibatch) pairs present in obs_tm_all
@@ -131,6 +132,10 @@ class Engine:
                                           _lib.ptr(vec.masks_u8), stream), 'send')
             vec.sends += 1
         vec.sends -= T      # the caller (clean_pufferl.evaluate) accounts for the T sends of a rollout
+
+    def invalidate_obs_cache(self):
+        """The experience rows were rewritten (a new rollout): the gathered time-major copies are stale whoever drives update()."""
+        self._gathered = set()
 
     # -------------------------------------------------------------------------------------------- update
     def update(self, mb, hp, adv_stats, global_mb_rows, grads, B):
