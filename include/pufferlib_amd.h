@@ -39,7 +39,9 @@ int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms
 /* ------------------------------------------------------------------------------------------
  * GAE — replaces c_gae.compute_gae (c_gae.pyx:11-32), called from clean_pufferl.py:168-169.
  * One reverse affine scan over the whole flat (env-major) batch, crossing env boundaries exactly
- * like the reference; advantages[n-1] = 0.  `returns` (nullable) = advantages + values
+ * like the reference; advantages[n-1] = 0.  The result is the BIT PATTERN of the reference's sequential fp32 loop (every thread
+ * warms up on the elements behind its own until it sits on the reference's rounded sequence: csrc/gae.hip gae_exact_kernel) for
+ * gamma * gae_lambda up to ~0.985, within a few ulps above.  `returns` (nullable) = advantages + values
  * (clean_pufferl.py:482).  workspace >= pfa_gae_workspace_bytes(n).
  * ------------------------------------------------------------------------------------------ */
 size_t pfa_gae_workspace_bytes(int64_t n);
@@ -54,7 +56,7 @@ int pfa_gae_f32(const float *dones, const float *values, const float *rewards, f
  *                       order — the reference's explained-variance inputs (clean_pufferl.py:266-270, 476), f64
  *   zero8 (nullable)    eight doubles cleared by the last launch (the caller's running loss sums)
  * Fixed-order f64 reductions (deterministic).  Shapes: bptt_horizon a multiple of 8, (bptt_horizon / 8) * num_minibatches a
- * power of two <= 256, num_minibatches <= 32, n a multiple of num_envs and of num_minibatches * bptt_horizon —
+ * power of two <= 128, num_minibatches <= 32, n a multiple of num_envs and of num_minibatches * bptt_horizon —
  * pfa_gae_sums_supported says; other shapes use the separate entry points.  workspace >= pfa_gae_sums_workspace_bytes. */
 int pfa_gae_sums_supported(int64_t n, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon);
 size_t pfa_gae_sums_workspace_bytes(int64_t n, int32_t num_minibatches);

@@ -49,10 +49,12 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     procs = []
+    import shlex
+    extra = shlex.split(os.environ.get('PFA_HIPCC_FLAGS', ''))     # developer A/B builds (-DPFA_GAE_FMA=0, -DPFA_PROBES ...)
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, os.path.splitext(src)[0] + '.o')
         objs.append(obj)
-        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-x', 'hip', '-c',
+        cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC'] + extra + ['-x', 'hip', '-c',
                os.path.join(CSRC, src), '-o', obj]
         if verbose:
             print(' '.join(cmd))

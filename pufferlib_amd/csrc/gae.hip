@@ -15,13 +15,16 @@
 //           Only the carry-in is re-associated (and it is the more accurate fp64 value), so the result stays
 //           within a few fp32 ulps of the sequential code: parity is allclose(atol=1e-5, rtol=1e-5).
 // Roofline: HBM.  Algorithmic bytes: read r,v,d (12 B) + write adv, returns (8 B) = 20 B per element.
+#include <cmath>
+
 #include "common.hpp"
 
 // Floating-point contraction is switched off where the reference's arithmetic is restated (hipcc's __fmul_rn / __fadd_rn wrappers
-// contract like plain operators — checked in the ISA — so the code below uses plain operators under this pragma), and the ONE
-// fused multiply-add it keeps is written out: the recurrence's last operation, adv = fma(coef, adv_next, delta).  That is one
-// rounding fewer per step than the reference's x86-64 build (<= 1 ulp per step apart, and closer to the exact value); the conv
-// policy's update test against the DOUBLE-precision oracle (tests/test_gpu_cnn_ppo.py) sits at its 1e-5 only with it.
+// contract like plain operators — checked in the ISA — so the code below uses plain operators under this pragma): every product and
+// every sum of c_gae.pyx:27-30 is rounded on its own, as the reference's x86-64 build rounds them.  (Rounds 1-4 kept ONE fma, the
+// recurrence's last operation, because the conv policy's update test against the double-precision oracle passed only with it; the
+// cause was the few-ulp distance of ANY re-associated scan from the reference's own rounded sequence — gae_exact_kernel below
+// removes that distance instead.)
 #define PFA_GAE_FP _Pragma("clang fp contract(off)")
 
 namespace pfa {
@@ -82,6 +85,7 @@ __device__ __forceinline__ Affine gae_thread_map(const GaeItems &it, long long s
 
 // Inclusive suffix scan over the 256 threads of the block: on return `mine` = F_tid o F_tid+1 o ... o F_255,
 // and `after` = F_tid+1 o ... o F_255 (identity for the last thread).  sh must hold 2*4 Affines.
+template <int NT = kGaeThreads>
 __device__ __forceinline__ void block_suffix_scan(Affine &mine, Affine &after, Affine *sh) {
     const int lane = lane_id(), wv = wave_id();
 #pragma unroll
@@ -92,47 +96,35 @@ __device__ __forceinline__ void block_suffix_scan(Affine &mine, Affine &after, A
     if (lane == 0) sh[wv] = mine;
     __syncthreads();
     Affine tail = {1.0, 0.0};  // composition of all later waves
-    for (int q = kGaeThreads / 64 - 1; q > wv; --q) tail = compose(sh[q], tail);
+    for (int q = NT / 64 - 1; q > wv; --q) tail = compose(sh[q], tail);
     mine = compose(mine, tail);
     after = shfl_down_affine(mine, 1);
     if (lane == 63) after = tail;
     __syncthreads();
 }
 
-__global__ void __launch_bounds__(kGaeThreads) gae_aggregate_kernel(const float *dones, const float *values,
-                                                                   const float *rewards, long long n, float gamma,
-                                                                   float lam, Affine *agg, int halo) {
-    __shared__ Affine sh[kGaeThreads / 64];
-    const long long s = (long long)blockIdx.x * kGaeBlock + (long long)threadIdx.x * kGaeItems;
+template <int NT = kGaeThreads>
+__global__ void __launch_bounds__(NT) gae_aggregate_kernel(const float *dones, const float *values,
+                                                          const float *rewards, long long n, float gamma,
+                                                          float lam, Affine *agg, int halo) {
+    __shared__ Affine sh[NT / 64];
+    const long long s = (long long)blockIdx.x * (NT * kGaeItems) + (long long)threadIdx.x * kGaeItems;
     GaeItems it;
     gae_load(dones, values, rewards, s, n + halo, it);
     Affine mine = gae_thread_map(it, s, n, gamma, lam, halo == 0), after;
-    block_suffix_scan(mine, after, sh);
+    block_suffix_scan<NT>(mine, after, sh);
     if (threadIdx.x == 0) agg[blockIdx.x] = mine;
 }
 
-// SUMS: the same pass also leaves, per block, what the update and its log line need from the advantages (one pass over the
-// 20 B/row stream instead of three: this kernel, adv_stats_partial_kernel, ev_partial_kernel of ppo_update.hip):
-//   part[block][0 .. 2 nmb)   sum adv, sum adv^2 of every minibatch's rows in this block (clean_pufferl.py:211-213; minibatch m =
-//                             segments {m + k nmb} of `bptt` rows, :455-457)
-//   part[block][2 nmb + 0..3] sum y_true, sum y_true^2, sum adv, sum adv^2 with y_true = adv + values in STORAGE (step-major)
-//                             order — the reference's mis-aligned explained-variance inputs (clean_pufferl.py:266-270, App. A.8)
-// all in f64, reduced in a fixed tree (deterministic).  A thread's 8 rows lie in ONE segment (bptt % 8 == 0), thread t's minibatch
-// is ((t / G) % nmb) with G = bptt / 8 threads per segment in EVERY block (the block size is a multiple of the cycle P = G nmb, a
-// power of two <= 256: gae_sums_supported).
-struct GaeSums {
-    double *part;          // [nblocks][2 nmb + 4]
-    int nmb, bptt;         // minibatches, rows per segment
-    int num_envs, horizon; // storage order j = t * num_envs + e  <->  env-major e * horizon + t
-};
-template <bool SUMS>
+// The data-parallel shard form's pass 2 (pfa_gae_shard_pass2): the carry-in is the f64 composition of the later blocks, every thread
+// then runs the reference's fp32 recurrence over its own 8 items from the (re-associated, f64-accurate) value behind them — within
+// a few fp32 ulps of the sequential code (the start value is not the reference's own rounded one).
 __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *dones, const float *values,
                                                                const float *rewards, float *adv, float *ret, long long n,
                                                                float gamma, float lam, const Affine *agg, int nblocks,
-                                                               const double *carry_in, int halo, GaeSums sums) {
+                                                               const double *carry_in, int halo) {
     __shared__ Affine sh[kGaeThreads / 64];
     __shared__ double s_carry;
-    __shared__ double sh_s[SUMS ? 4 : 1][SUMS ? kGaeThreads : 1];
     // carry-in of this block = (agg[b+1] o agg[b+2] o ... o agg[nblocks-1])(0), composed in order by wave 0
     if (wave_id() == 0) {
         const int first = blockIdx.x + 1, cnt = nblocks - first;
@@ -157,11 +149,6 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
     Affine mine = gae_thread_map(it, s, n, gamma, lam, halo == 0), after;
     block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
     float last = (float)(after.c * s_carry + after.d);  // adv at the first element after this thread's items
-    float advv[SUMS ? kGaeItems : 1];
-    if constexpr (SUMS) {
-#pragma unroll
-        for (int i = 0; i < kGaeItems; ++i) advv[i] = 0.0f;
-    }
     {
     PFA_GAE_FP   // the reference's x86-64 build multiplies and adds separately
 #pragma unroll
@@ -171,48 +158,157 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
         if (t == n - 1 && halo == 0) {
             last = 0.0f;
         } else {  // the reference's statement order and rounding (c_gae.pyx:27-30)
-            // delta as the reference's x86-64 build rounds it (every product and sum on its own); the step itself is one fma
             const float nnt = 1.0f - it.d[i + 1];
             const float delta = (it.r[i + 1] + (gamma * it.v[i + 1]) * nnt) - it.v[i];
-            last = fmaf((gamma * lam) * nnt, last, delta);
+            last = delta + ((gamma * lam) * nnt) * last;
         }
         adv[t] = last;
         if (ret) ret[t] = last + it.v[i];
-        if constexpr (SUMS) advv[i] = last;
     }
+    }
+}
+
+// ---- single-array form: the reference's OWN fp32 sequence, in parallel (round 5) ---------------------------------------------
+// c_gae.pyx:24-30 is one sequential fp32 chain from the end of the batch; a parallel scan re-associates it, and however accurate
+// the re-associated start value of a thread's items is (f64 above), it is not the value the reference's chain has ROUNDED itself
+// to at that point — a few ulps apart, which Adam's 1 / (|g| + eps) amplifies into the conv update's thin margin against the
+// double-precision oracle.  But the recurrence is a contraction: x -> delta + coef x with
+// coef <= gamma lambda < 1, and a `done` row (coef = 0) or the pinned last element restarts it exactly.  Two fp32 sequences that
+// run the SAME rounded operations from start values a few ulps apart are at distance <= (gamma lambda)^k ulps after k steps and, once
+// equal, stay equal.  So every thread starts W elements BEHIND its own items from the f64-accurate value there, runs the
+// reference's exact fp32 statement over those W elements for nothing but its state, and arrives at its own items on the
+// reference's sequence: W = ln(1e-7) / ln(gamma lambda) steps (264 at the defaults; capped at 1024, the window).  Advantages come
+// out BIT-IDENTICAL to c_gae (tests/test_gpu_gae.py asserts array_equal at B = 524 288) for gamma lambda <= ~0.985; above that the
+// start error has not fully died after 1024 steps and single entries may sit 1 ulp off — what every entry was before.
+//
+// Layout: the array is cut into chunks of 1024 elements (pass 1: one f64 affine map per chunk).  Workgroup b owns chunk b and
+// reads chunk b + 1 as its warm-up window: 256 threads x 8 elements = both chunks; all of them take part in the f64 suffix scan
+// (which yields the f64-accurate advantage at every 8-element boundary of the window, carry-in = the maps of chunks b + 2 ...) and
+// leave the (coef, delta) pairs of their elements in LDS; threads 0..127 then walk W + 8 elements each.  LDS index of element i is
+// i + i / 8 (a lane's elements are 9 float2 apart: 2 lanes per bank instead of 16).
+//
+// SUMS: the same pass also leaves, per chunk, what the update and its log line need from the advantages (one pass over the
+// 20 B/row stream instead of three: this kernel, adv_stats_partial_kernel, ev_partial_kernel of ppo_update.hip):
+//   part[chunk][0 .. 2 nmb)   sum adv, sum adv^2 of every minibatch's rows in this chunk (clean_pufferl.py:211-213; minibatch m =
+//                             segments {m + k nmb} of `bptt` rows, :455-457)
+//   part[chunk][2 nmb + 0..3] sum y_true, sum y_true^2, sum adv, sum adv^2 with y_true = adv + values in STORAGE (step-major)
+//                             order — the reference's mis-aligned explained-variance inputs (clean_pufferl.py:266-270, App. A.8)
+// all in f64, reduced in a fixed tree (deterministic).  A thread's 8 rows lie in ONE segment (bptt % 8 == 0), thread t's minibatch
+// is ((t / G) % nmb) with G = bptt / 8 threads per segment in EVERY chunk (the chunk's 128 threads are a multiple of the cycle
+// P = G nmb, a power of two <= 128: gae_sums_ok).
+constexpr int kGaeChunkThreads = 128;
+constexpr int kGaeChunk = kGaeChunkThreads * kGaeItems;   // 1024
+struct GaeSums {
+    double *part;          // [chunks][2 nmb + 4]
+    int nmb, bptt;         // minibatches, rows per segment
+    int num_envs, horizon; // storage order j = t * num_envs + e  <->  env-major e * horizon + t
+};
+template <bool SUMS>
+__global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *dones, const float *values, const float *rewards, float *adv,
+                                                               float *ret, long long n, float gamma, float lam, const Affine *agg,
+                                                               int nchunks, int warm, GaeSums sums) {
+    __shared__ Affine sh[kGaeThreads / 64];
+    __shared__ double s_carry;
+    __shared__ float2 cd[kGaeBlock + kGaeBlock / 8];      // (coef, delta) of the window's elements, index i + i / 8
+    __shared__ float start[kGaeThreads];                  // f64-accurate advantage at element 8 (t + 1) of the window
+    __shared__ double sh_s[SUMS ? 4 : 1][SUMS ? kGaeChunkThreads : 1];
+    const int tid = threadIdx.x;
+    // carry-in of the WINDOW (chunks b, b + 1) = (agg[b+2] o ... o agg[nchunks-1])(0), composed in order by wave 0
+    if (wave_id() == 0) {
+        const int first = blockIdx.x + 2, cnt = nchunks - first;
+        const int per = cnt > 0 ? (cnt + 63) / 64 : 0;
+        const int lane = lane_id();
+        Affine f = {1.0, 0.0};
+        for (int i = per - 1; i >= 0; --i) {
+            const int b = first + lane * per + i;
+            if (b < nchunks) f = compose(agg[b], f);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const Affine o = shfl_down_affine(f, off);
+            if (lane + off < 64) f = compose(f, o);
+        }
+        if (lane == 0) s_carry = f.d;   // applied to 0: nothing follows the array
+    }
+    const long long s = (long long)blockIdx.x * kGaeChunk + (long long)tid * kGaeItems;
+    GaeItems it;
+    gae_load(dones, values, rewards, s, n, it);
+    Affine mine = gae_thread_map(it, s, n, gamma, lam, true), after;
+    block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
+    start[tid] = (float)(after.c * s_carry + after.d);
+    {
+    PFA_GAE_FP   // the reference's x86-64 build multiplies and adds separately (c_gae.pyx:27-30)
+#pragma unroll
+    for (int i = 0; i < kGaeItems; ++i) {
+        const long long t = s + i;
+        float2 e = make_float2(0.0f, 0.0f);           // t >= n - 1: adv = 0 (the pinned last element; nothing beyond the array)
+        if (t < n - 1) {
+            const float nnt = 1.0f - it.d[i + 1];
+            e.y = (it.r[i + 1] + (gamma * it.v[i + 1]) * nnt) - it.v[i];
+            e.x = (gamma * lam) * nnt;
+        }
+        const int li = tid * kGaeItems + i;
+        cd[li + (li >> 3)] = e;
+    }
+    }
+    __syncthreads();
+    float advv[kGaeItems];
+#pragma unroll
+    for (int i = 0; i < kGaeItems; ++i) advv[i] = 0.0f;
+    if (tid < kGaeChunkThreads) {
+        PFA_GAE_FP
+        const int first = tid * kGaeItems + kGaeItems;          // window element behind this thread's items
+        float x = start[tid + (warm >> 3)];                     // advantage at window element first + warm (8-aligned)
+        for (int li = first + warm - 1; li >= first; --li) {    // warm-up: the reference's statement, for the state only
+            const float2 e = cd[li + (li >> 3)];
+            x = e.y + e.x * x;
+        }
+#pragma unroll
+        for (int i = kGaeItems - 1; i >= 0; --i) {
+            const int li = tid * kGaeItems + i;
+            const float2 e = cd[li + (li >> 3)];
+            x = e.y + e.x * x;                                  // lastgaelam = delta + gamma * gae_lambda * nextnonterminal * lastgaelam
+            advv[i] = x;
+            const long long t = s + i;
+            if (t < n) {
+                adv[t] = x;
+                if (ret) ret[t] = x + it.v[i];
+            }
+        }
     }
     if constexpr (SUMS) {
-        // y_pred of flat index j is values[(j % N) * T + j / N]: issue the thread's eight gathers together
-        float yp[kGaeItems];
-        const long long e0 = s % sums.num_envs, t0 = s / sums.num_envs;
-#pragma unroll
-        for (int i = 0; i < kGaeItems; ++i) {
-            long long e = e0 + i, t = t0;
-            while (e >= sums.num_envs) {   // (at most once unless num_envs < 8)
-                e -= sums.num_envs;
-                ++t;
-            }
-            yp[i] = s + i < n ? values[e * sums.horizon + t] : 0.0f;
-        }
         double a1 = 0.0, a2 = 0.0, y1 = 0.0, y2 = 0.0;
+        if (tid < kGaeChunkThreads) {
+            // y_pred of flat index j is values[(j % N) * T + j / N]: issue the thread's eight gathers together
+            float yp[kGaeItems];
+            const long long e0 = s % sums.num_envs, t0 = s / sums.num_envs;
 #pragma unroll
-        for (int i = 0; i < kGaeItems; ++i) {
-            if (s + i >= n) continue;
-            const double a = (double)advv[i], y = a + (double)yp[i];
-            a1 += a;
-            a2 += a * a;
-            y1 += y;
-            y2 += y * y;
+            for (int i = 0; i < kGaeItems; ++i) {
+                long long e = e0 + i, t = t0;
+                while (e >= sums.num_envs) {   // (at most once unless num_envs < 8)
+                    e -= sums.num_envs;
+                    ++t;
+                }
+                yp[i] = s + i < n ? values[e * sums.horizon + t] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < kGaeItems; ++i) {
+                if (s + i >= n) continue;
+                const double a = (double)advv[i], y = a + (double)yp[i];
+                a1 += a;
+                a2 += a * a;
+                y1 += y;
+                y2 += y * y;
+            }
+            sh_s[0][tid] = a1;
+            sh_s[1][tid] = a2;
+            sh_s[2][tid] = y1;
+            sh_s[3][tid] = y2;
         }
-        const int tid = threadIdx.x;
-        sh_s[0][tid] = a1;
-        sh_s[1][tid] = a2;
-        sh_s[2][tid] = y1;
-        sh_s[3][tid] = y2;
         __syncthreads();
         const int G = sums.bptt / kGaeItems, P = G * sums.nmb;   // threads per segment, per cycle of minibatches
         // fixed tree down to one entry per (minibatch, position in the segment): t and t + stride share both while stride >= P
-        for (int stride = kGaeThreads / 2; stride >= P; stride >>= 1) {
+        for (int stride = kGaeChunkThreads / 2; stride >= P; stride >>= 1) {
             if (tid < stride) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sh_s[q][tid] += sh_s[q][tid + stride];
@@ -225,7 +321,7 @@ __global__ void __launch_bounds__(kGaeThreads) gae_apply_kernel(const float *don
             double v = 0.0;
             for (int g = 0; g < G; ++g) v += sh_s[k][m * G + g];
             out[tid] = v;
-        } else if (tid >= 64 && tid < 68) {   // the four whole-block sums, entries 0 .. P-1 in order
+        } else if (tid >= 64 && tid < 68) {   // the four whole-chunk sums, entries 0 .. P-1 in order
             const int k = tid - 64, src = k < 2 ? 2 + k : k - 2;   // out: y1, y2, a1, a2
             double v = 0.0;
             for (int g = 0; g < P; ++g) v += sh_s[src][g];
@@ -340,9 +436,18 @@ __global__ void gae_shard_fold_kernel(const double *pub, int rank, int world, lo
 
 using namespace pfa;
 
-extern "C" size_t pfa_gae_workspace_bytes(int64_t n) {
-    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
-    return (size_t)(nb > 0 ? nb : 1) * sizeof(Affine);
+extern "C" size_t pfa_gae_workspace_bytes(int64_t n) {   // one f64 affine map per 1024-element chunk (covers the shard forms' 2048-element blocks)
+    const int64_t nc = (n + kGaeChunk - 1) / kGaeChunk;
+    return (size_t)(nc > 0 ? nc : 1) * sizeof(Affine);
+}
+
+// Warm-up elements of gae_exact_kernel: the start error (a few ulps) times (gamma lambda)^W must be far below one ulp.
+static int gae_warm(float gamma, float lam) {
+    const double gl = (double)(gamma * lam);
+    if (!(gl > 0.0)) return 8;                       // coef = 0 everywhere: every element restarts the chain
+    if (gl >= 0.999) return kGaeChunk;
+    const double w = std::ceil(std::log(1e-7) / std::log(gl) / 8.0) * 8.0;
+    return (int)(w < 8.0 ? 8.0 : (w > (double)kGaeChunk ? (double)kGaeChunk : w));
 }
 
 extern "C" int pfa_gae_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
@@ -350,53 +455,53 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
     PFA_REQUIRE(n >= 0, "gae: negative length");
     if (n == 0) return 0;
     PFA_REQUIRE(dones && values && rewards && advantages && workspace, "gae: null buffer");
-    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
-    PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
+    const int64_t nc = (n + kGaeChunk - 1) / kGaeChunk;
+    PFA_REQUIRE(nc <= 0x7fffffff, "gae: batch too large");
     Affine *agg = (Affine *)workspace;
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // both passes
-    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
+    hipLaunchKernelGGL(gae_aggregate_kernel<kGaeChunkThreads>, dim3((unsigned)nc), dim3(kGaeChunkThreads), 0, (hipStream_t)stream, dones, values,
                        rewards, (long long)n, gamma, gae_lambda, agg, 0);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_apply_kernel<false>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb, (const double *)nullptr, 0, GaeSums{});
+    hipLaunchKernelGGL(gae_exact_kernel<false>, dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), GaeSums{});
     PFA_LAUNCH_CHECK();
     return 0;
 }
 
 // compute_gae + the advantage statistics of the update in one pass (see GaeSums): what pfa_gae_f32, pfa_ppo_adv_stats and the
 // sums of pfa_train_log_sums leave, in three launches instead of six.  Supported when a thread's 8 rows never straddle a segment
-// and the minibatch cycle divides the block (pfa_gae_sums_supported); the caller falls back to the separate entry points otherwise.
+// and the minibatch cycle divides the chunk (pfa_gae_sums_supported); the caller falls back to the separate entry points otherwise.
 static bool gae_sums_ok(int64_t n, int num_envs, int nmb, int bptt) {
     if (n < 1 || num_envs < 1 || nmb < 1 || bptt < kGaeItems || bptt % kGaeItems) return false;
     if (n % num_envs || n % ((int64_t)nmb * bptt)) return false;
     const int64_t P = (int64_t)(bptt / kGaeItems) * nmb;
-    return P <= kGaeThreads && (P & (P - 1)) == 0 && 2 * nmb <= 64;
+    return P <= kGaeChunkThreads && (P & (P - 1)) == 0 && 2 * nmb <= 64;
 }
 extern "C" int pfa_gae_sums_supported(int64_t n, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon) {
     return gae_sums_ok(n, num_envs, num_minibatches, bptt_horizon) ? 1 : 0;
 }
 extern "C" size_t pfa_gae_sums_workspace_bytes(int64_t n, int32_t num_minibatches) {
-    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
-    return align_up((size_t)(nb > 0 ? nb : 1) * sizeof(Affine), 256) + (size_t)(nb > 0 ? nb : 1) * (2 * (size_t)num_minibatches + 4) * sizeof(double);
+    const int64_t nc = (n + kGaeChunk - 1) / kGaeChunk;
+    return align_up((size_t)(nc > 0 ? nc : 1) * sizeof(Affine), 256) + (size_t)(nc > 0 ? nc : 1) * (2 * (size_t)num_minibatches + 4) * sizeof(double);
 }
 extern "C" int pfa_gae_sums_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
                                 int64_t n, float gamma, float gae_lambda, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon,
                                 double *adv_stats, double *ev4, double *zero8, void *workspace, pfa_stream_t stream) {
     PFA_REQUIRE(gae_sums_ok(n, num_envs, num_minibatches, bptt_horizon), "gae_sums: unsupported partition (pfa_gae_sums_supported)");
     PFA_REQUIRE(dones && values && rewards && advantages && adv_stats && ev4 && workspace, "gae_sums: null buffer");
-    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
-    PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
+    const int64_t nc = (n + kGaeChunk - 1) / kGaeChunk;
+    PFA_REQUIRE(nc <= 0x7fffffff, "gae: batch too large");
     Affine *agg = (Affine *)workspace;
-    GaeSums sums{(double *)((char *)workspace + align_up((size_t)nb * sizeof(Affine), 256)), num_minibatches, bptt_horizon, num_envs,
+    GaeSums sums{(double *)((char *)workspace + align_up((size_t)nc * sizeof(Affine), 256)), num_minibatches, bptt_horizon, num_envs,
                  (int)(n / num_envs)};
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // all three launches
-    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
+    hipLaunchKernelGGL(gae_aggregate_kernel<kGaeChunkThreads>, dim3((unsigned)nc), dim3(kGaeChunkThreads), 0, (hipStream_t)stream, dones, values,
                        rewards, (long long)n, gamma, gae_lambda, agg, 0);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_apply_kernel<true>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nb, (const double *)nullptr, 0, sums);
+    hipLaunchKernelGGL(gae_exact_kernel<true>, dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), sums);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nb,
+    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nc,
                        (int)num_minibatches, adv_stats, ev4, zero8);
     PFA_LAUNCH_CHECK();
     return 0;
@@ -415,7 +520,7 @@ extern "C" int pfa_gae_shard_pass1(const float *dones, const float *values, cons
     const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
     PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
     Affine *agg = (Affine *)workspace;
-    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
+    hipLaunchKernelGGL(gae_aggregate_kernel<kGaeThreads>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
                        rewards, (long long)n, gamma, gae_lambda, agg, has_next ? 1 : 0);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(gae_shard_aggregate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, agg, (int)nb, shard_map);
@@ -429,9 +534,9 @@ extern "C" int pfa_gae_shard_pass2(const float *dones, const float *values, cons
     PFA_REQUIRE(n >= 1 && dones && values && rewards && advantages && workspace, "gae_shard: bad arguments");
     PFA_REQUIRE(!has_next || carry_in, "gae_shard: a shard with a successor needs carry_in");
     const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
-    hipLaunchKernelGGL(gae_apply_kernel<false>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+    hipLaunchKernelGGL(gae_apply_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
                        advantages, returns, (long long)n, gamma, gae_lambda, (const Affine *)workspace, (int)nb,
-                       has_next ? carry_in : (const double *)nullptr, has_next ? 1 : 0, GaeSums{});
+                       has_next ? carry_in : (const double *)nullptr, has_next ? 1 : 0);
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -449,7 +554,7 @@ extern "C" int pfa_gae_shard_publish(const float *dones, const float *values, co
     PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
     Affine *agg = (Affine *)workspace;
     // interior map: elements 0 .. n-2 (each reads its successor, element n-1 at most); the blocks are those of the n-element pass 2
-    hipLaunchKernelGGL(gae_aggregate_kernel, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+    hipLaunchKernelGGL(gae_aggregate_kernel<kGaeThreads>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
                        (long long)(n - 1), gamma, gae_lambda, agg, 1);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(gae_shard_publish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, agg, (int)nb, dones, values, rewards, (long long)n,

@@ -34,7 +34,7 @@ def test_size_helpers(L):
     assert b'num_envs' in L.pfa_last_error()
     dims = _lib.MlpDims(49, 64, 128, 8)
     assert L.pfa_mlp_param_count(C.byref(dims)) == 128 * 64 + 128 + 8 * 128 + 8 + 128 + 1
-    assert L.pfa_gae_workspace_bytes(524288) == 256 * 16
+    assert L.pfa_gae_workspace_bytes(524288) == 512 * 16      # one f64 affine map per 1024-element chunk
 
 
 def test_weight_gradient_workspace_never_shrinks_with_more_rows(L):

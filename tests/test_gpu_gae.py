@@ -49,6 +49,27 @@ def test_vs_oracle_full_size(n, p_done):
     np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
     # tighter than the contract: a few ulps of the largest advantage
     assert np.abs(got - want).max() <= 8 * np.finfo(np.float32).eps * max(1.0, np.abs(want).max())
+    # round 5: the parallel kernel lands on the reference's OWN fp32 sequence (warm-up contraction, csrc/gae.hip gae_exact_kernel):
+    # every advantage is the bit pattern c_gae's sequential loop produces
+    assert np.array_equal(got, want), (int((got != want).sum()), float(np.abs(got - want).max()))
+
+
+@pytest.mark.parametrize('gamma,lam', [(0.99, 0.95), (0.9, 0.8), (0.997, 0.97), (1.0, 1.0), (0.5, 0.0)])
+def test_bit_identical_to_the_sequential_loop_for_other_discounts(gamma, lam):
+    """gamma lambda up to ~0.985 (here 0.967): the warm-up (ln 1e-7 / ln(gamma lambda) elements, at most 1024) has contracted the
+    start error away and the result is c_gae's bit pattern; at gamma = lambda = 1 nothing contracts and the kernel is what every scan
+    is: within a few ulps."""
+    from oracle import c_oracle
+    n = 300000
+    rng = np.random.RandomState(7)
+    d = (rng.rand(n) < 0.002).astype(np.float32)
+    v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    want = c_oracle.compute_gae(d, v, r, gamma, lam)
+    got = hip_gae(d, v, r, gamma, lam)
+    if gamma * lam < 0.98:
+        assert np.array_equal(got, want), (int((got != want).sum()), float(np.abs(got - want).max()))
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-4 * max(1.0, float(np.abs(want).max())))
 
 
 def test_linearity_property():
