@@ -122,7 +122,7 @@ def _full_size(recurrent, epochs, hidden, products, capsys):
     elif not recurrent:       # the configuration under test is the specialised one bench.py runs
         assert data.flat_params.obs_dim == 49 and data.flat_params.obs_stride == 64 and data.experience.minibatch_size == 131072
     loss_err, w_err = _compare(pol, opol, data, Lo, recurrent, tr, 'full size')
-    np.testing.assert_allclose(data.losses.explained_variance, Lo['explained_variance'], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(data.losses.explained_variance, Lo['explained_variance'], rtol=1e-5, atol=1e-5)
     with capsys.disabled():
         print(f'\n[parity full-size {"lstm" if recurrent else "mlp"} hidden {hidden} products {products}] max |loss err| {loss_err:.2e}, max |weight err| {w_err:.2e}')
 

@@ -92,8 +92,8 @@ def test_create_evaluate_train_replays_golden(golden_dir):
         for k in sd:
             np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'it{it}.w.{k}'], err_msg=k, **TOL)
             short = k[len('policy.'):]
-            np.testing.assert_allclose(m_[short].cpu().numpy(), g[f'it{it}.m.{k}'], rtol=1e-4, atol=1e-6, err_msg=k)
-            np.testing.assert_allclose(v_[short].cpu().numpy(), g[f'it{it}.v.{k}'], rtol=1e-4, atol=1e-8, err_msg=k)
+            np.testing.assert_allclose(m_[short].cpu().numpy(), g[f'it{it}.m.{k}'], rtol=1e-5, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(v_[short].cpu().numpy(), g[f'it{it}.v.{k}'], rtol=1e-5, atol=1e-8, err_msg=k)
         assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-12
     # pad columns of the encoder never move
     H, DP = 128, vec.obs_stride
