@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 evidence job, second edition (adds the opt-in bf16x6 form of the headline workload; one gpurun call): GPU suite, smoke, rocprofv3 kernel stats of the bench command for every workload, the PMC
+# Round-5 evidence job (one gpurun call): GPU suite, smoke, rocprofv3 kernel stats of the bench command for every workload, the PMC
 # passes of every workload merged into ONE stamped pmc_summary.json (so the side lines carry `traffic` too), then the default
 # bench line (which runs the side workloads as child processes).  Outputs under gpurun_out/<tag>_*; copy what is judged into profiles/.
-TAG=${1:-r04b}
+TAG=${1:-r05}
 SKIP_TESTS=${2:-0}
 mkdir -p gpurun_out
 ROOT=$PWD
@@ -21,7 +21,6 @@ ks mlp --steps 10
 ks c3 --workload c3 --steps 4 --warmup 1
 ks c4 --workload c4 --steps 4 --warmup 1
 ks hidden256 --hidden 256 --steps 4 --warmup 1
-ks mlp_bf16x6 --products bf16x6 --steps 10
 pmc() {  # name, bench flags (one string)
   bash profiles/collect_pmc.sh ${TAG}_$1 "$2" "sq1 fetch write" > gpurun_out/${TAG}_pmc_$1.log 2>&1; echo "pmc $1 rc=$?"
   cp gpurun_out/pmc_${TAG}_$1/summary.csv gpurun_out/${TAG}_pmc_$1.csv
@@ -31,16 +30,7 @@ pmc mlp ""
 pmc c3 "--workload c3"
 pmc c4 "--workload c4"
 pmc hidden256 "--hidden 256"
-pmc mlp_bf16x6 "--products bf16x6"
-lds() {  # LDS counters of a workload (own pass; not part of the stamped summary)
-  bash profiles/collect_pmc.sh ${TAG}lds_$1 "$2" "sq2" > gpurun_out/${TAG}_lds_$1.log 2>&1; echo "lds $1 rc=$?"
-  cp gpurun_out/pmc_${TAG}lds_$1/summary.csv gpurun_out/${TAG}_lds_$1.csv
-  rm -rf gpurun_out/pmc_${TAG}lds_$1
-}
-lds c4 "--workload c4"
-lds c3 "--workload c3"
-lds mlp ""
-python profiles/make_pmc_summary.py gpurun_out/${TAG}_pmc_mlp.csv gpurun_out/${TAG}_pmc_c3.csv gpurun_out/${TAG}_pmc_c4.csv gpurun_out/${TAG}_pmc_hidden256.csv gpurun_out/${TAG}_pmc_mlp_bf16x6.csv > gpurun_out/${TAG}_pmc_summary.log 2>&1; echo "summary rc=$?"
+python profiles/make_pmc_summary.py gpurun_out/${TAG}_pmc_mlp.csv gpurun_out/${TAG}_pmc_c3.csv gpurun_out/${TAG}_pmc_c4.csv gpurun_out/${TAG}_pmc_hidden256.csv > gpurun_out/${TAG}_pmc_summary.log 2>&1; echo "summary rc=$?"
 cp profiles/pmc_summary.json gpurun_out/${TAG}_pmc_summary.json
 # the default line LAST: it now finds a summary stamped with this build; shader clock and power sampled next to it
 ( for i in $(seq 1 400); do rocm-smi --showclocks --showpower 2>/dev/null | grep -E "sclk|Power" | tr '\n' ' '; echo; sleep 0.5; done > gpurun_out/${TAG}_smi_during_bench.txt ) &
