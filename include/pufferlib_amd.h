@@ -408,6 +408,8 @@ typedef struct {
     int32_t bptt_horizon;    /* segment length; minibatch m = segments {m + k*nmb} (:455-457) */
 } pfa_ppo_hparams;
 
+/* The workspace must be allocated ZERO-INITIALISED once (its last region holds the {value, generation} hand-off words of
+ * pfa_ppo_mlp_train's one-launch reduce + Adam: nothing else writes there and the library never clears it). */
 size_t pfa_ppo_workspace_bytes(const pfa_mlp_dims *dims, int64_t batch_rows, const pfa_ppo_hparams *hp);
 /* Per-minibatch advantage statistics (sum, sum of squares in f64; count) for norm_adv (:211-213).
  * stats: f64 [nmb][2] on device.  Call once per update after GAE; with several ranks, all-reduce(sum)

@@ -555,7 +555,11 @@ def _finish_evaluate(data, N, T):
         experience.ptr = experience.batch_size
         experience.step = T
         data.global_step += N * T * data.world_size      # sum(mask) per recv (clean_pufferl.py:90), all ranks
-        st = vecenv.stats_with_flag(reset=True)         # 4 sums + the tape underrun flag
+        direct_stats = (data.world_size == 1 and type(vecenv) is Squared and readback.direct_ok(vecenv.device))
+        if direct_stats:                                # single rank: the five numbers go straight into the readback's pinned buffer
+            st = vecenv.stats_with_flag(reset=True, out=data._rb_eval.direct_buffer(5, torch.float64))
+        else:
+            st = vecenv.stats_with_flag(reset=True)     # 4 sums + the tape underrun flag
         if data.world_size > 1 and _early_gae() and getattr(experience, '_rdv', None) is not None:
             # data parallel: the episode statistics and the six numbers per rank the sharded GAE needs (csrc/gae.hip: interior map,
             # last value, first row — all from this rank's own rows, complete once the rollout is) ride ONE all-reduce; train()
@@ -580,7 +584,10 @@ def _finish_evaluate(data, N, T):
             stats.fill(m)
             infos.fill({k: [v] for k, v in m.items()})
         data.stats = stats
-        data._rb_eval.submit(st, finish)
+        if direct_stats:
+            data._rb_eval.submit_direct(finish, vecenv.device)
+        else:
+            data._rb_eval.submit(st, finish)
     return stats, infos
 
 
@@ -770,8 +777,12 @@ def train(data):
 
         # losses + explained variance exactly as the reference logs them (clean_pufferl.py:249-254,266-270, App. A.8):
         # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
+        direct_log = False
         if early_ev or fused_sums:                              # the sums exist since GAE (data parallel: all-reduced with the advantage sums)
-            _lib.check(L.pfa_train_log_pack(_lib.ptr(data.loss_acc), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(data.log_sums),
+            # ... and the ten numbers go straight into the pinned host buffer of the readback (no device-to-host copy launch behind it)
+            direct_log = readback.direct_ok(experience.device)
+            log_out = data._rb_train.direct_buffer(10, torch.float64) if direct_log else data.log_sums
+            _lib.check(L.pfa_train_log_pack(_lib.ptr(data.loss_acc), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(log_out),
                                             stream), 'train_log_pack')
         else:
             _lib.check(L.pfa_train_log_sums(C.byref(experience.c), B, experience.num_envs, _lib.ptr(data.loss_acc),
@@ -804,7 +815,10 @@ def train(data):
             losses.fill(policy_loss=float(acc[0]), value_loss=float(acc[1]), entropy=float(acc[2]), old_approx_kl=float(acc[3]),
                         approx_kl=float(acc[4]), clipfrac=float(acc[5]), explained_variance=ev)
         losses.attach(data._rb_train)
-        data._rb_train.submit(data.log_sums, finish)
+        if direct_log:
+            data._rb_train.submit_direct(finish, experience.device)
+        else:
+            data._rb_train.submit(data.log_sums, finish)
         data.epoch += 1
 
         done_training = data.global_step >= config.total_timesteps

@@ -259,9 +259,16 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
         PFA_GAE_FP
         const int first = tid * kGaeItems + kGaeItems;          // window element behind this thread's items
         float x = start[tid + (warm >> 3)];                     // advantage at window element first + warm (8-aligned)
-        for (int li = first + warm - 1; li >= first; --li) {    // warm-up: the reference's statement, for the state only
-            const float2 e = cd[li + (li >> 3)];
-            x = e.y + e.x * x;
+        // warm-up: the reference's statement, for the state only.  Groups of 8 elements (warm and first are multiples of 8, so a
+        // group is 8 consecutive float2 in LDS): the group's reads are issued together, then its 8 dependent steps — left as one
+        // read per step the loop is a chain of LDS latencies (28.8 us per launch measured; the arithmetic is 2 instructions a step)
+        for (int li = first + warm - kGaeItems; li >= first; li -= kGaeItems) {
+            const float2 *grp = cd + li + (li >> 3);
+            float2 e[kGaeItems];
+#pragma unroll
+            for (int k = 0; k < kGaeItems; ++k) e[k] = grp[k];
+#pragma unroll
+            for (int k = kGaeItems - 1; k >= 0; --k) x = e[k].y + e[k].x * x;
         }
 #pragma unroll
         for (int i = kGaeItems - 1; i >= 0; --i) {

@@ -1171,6 +1171,14 @@ static size_t partials_bytes(const pfa_mlp_dims *dims) {   // (the opt-in bf16 f
 static double *norm_partials_of(void *workspace, const pfa_mlp_dims *dims) {  // after the gradient partials
     return (double *)((char *)workspace + partials_bytes(dims));
 }
+// The grid hand-off words live behind everything else in the workspace, in a region nothing but ppo_reduce_adam_kernel writes: a word
+// only ever holds {value bits, generation of the launch that wrote it}, generations never repeat within a process, and the buffer
+// starts zeroed (generation 0 is never used) — so the region needs no clearing between calls (rounds 4: one hipMemsetAsync per
+// pfa_ppo_mlp_train call, 4.4 us + a dispatch gap per update, because the words shared their place with f64 norm pieces of the
+// two-kernel form whose bit patterns could pass for a generation).  The caller allocates the workspace zero-initialised ONCE.
+static size_t grid_words_bytes_max(const pfa_mlp_dims *dims) {
+    return align_up(((native_count(dims->obs_stride) + 63) / 64) * 2 * sizeof(unsigned long long), 256) + 256;
+}
 static size_t tail_bytes(const pfa_mlp_dims *dims, int nmb) {   // what follows the partials: adv-stat partials / norm pieces (shared)
     const size_t native = native_count(dims->obs_stride);
     const size_t advp = align_up((size_t)nmb * 64 * 2 * sizeof(double), 256);
@@ -1193,7 +1201,8 @@ extern "C" size_t pfa_ppo_workspace_bytes(const pfa_mlp_dims *dims, int64_t batc
     if (!dims || !hp || hp->num_minibatches < 1) return 0;
     (void)batch_rows;
     static_assert(kAdvChunks == 64, "tail_bytes assumes 64 chunks");
-    return partials_bytes(dims) + tail_bytes(dims, hp->num_minibatches) + 256;
+    // [gradient partials | adv-stat partials / norm pieces (shared) | grid hand-off words of the one-launch reduce + Adam]
+    return partials_bytes(dims) + tail_bytes(dims, hp->num_minibatches) + 256 + grid_words_bytes_max(dims);
 }
 
 extern "C" int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_ppo_hparams *hp, double *stats,
@@ -1385,10 +1394,9 @@ extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_
 }
 
 // Kernels B + C in one launch (ppo_reduce_adam_kernel); `ll` non-null: with the data-parallel exchange inside.
-static unsigned long long *grid_words_of(void *workspace, const pfa_mlp_dims *dims) {   // the norm-piece area behind the partials
-    return (unsigned long long *)norm_partials_of(workspace, dims);
+static unsigned long long *grid_words_of(void *workspace, const pfa_mlp_dims *dims, int nmb) {   // their own region at the end of the workspace
+    return (unsigned long long *)((char *)workspace + partials_bytes(dims) + tail_bytes(dims, nmb) + 256);
 }
-static size_t grid_words_bytes(const pfa_mlp_dims *dims) { return (size_t)norm_blocks(dims) * 2 * sizeof(unsigned long long); }
 static int *grid_status_word() {   // host-pinned, device-visible, one per process
     static int *word = nullptr;
     if (!word) {
@@ -1456,8 +1464,7 @@ static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float
     if (gen == 0) gen = (unsigned)(++launches);
     int *gstatus = grid_status_word();
     PFA_REQUIRE(gstatus, "ppo.train: cannot allocate the grid hand-off's status word");
-    const GridWords gw{grid_words_of(workspace, dims), gen, gstatus, grid_timeout_ticks()};
-    (void)nmb;
+    const GridWords gw{grid_words_of(workspace, dims, nmb), gen, gstatus, grid_timeout_ticks()};
     const LlArgs none{};
     ScopedKernelTimer timer("ppo_reduce_adam", stream);
 #define PFA_LAUNCH_RA(DPV, KTMV, COLV, PERMV)                                                                                        \
@@ -1514,8 +1521,6 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
     const bool fused = env_on("PFA_FUSED_ADAM", true) && reduce_adam_coresident(dims, fused_dp_wanted);
     const bool fused_dp = fused && fused_dp_wanted;
     const bool one_launch = fused && (!data_parallel || fused_dp);   // (a 1-rank communicator keeps exercising the all-reduce call)
-    if (one_launch)
-        PFA_CHECK_HIP(hipMemsetAsync(grid_words_of(workspace, dims), 0, grid_words_bytes(dims), (hipStream_t)stream));
     for (int e = 0; e < update_epochs; ++e)
         for (int mb = 0; mb < hp->num_minibatches; ++mb) {
             if (one_launch) {

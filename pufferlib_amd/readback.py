@@ -24,6 +24,32 @@ def eager():
     return os.environ.get('PFA_LAZY_READBACK', '0') in ('', '0')
 
 
+_direct = {'ok': None}
+
+
+def direct_ok(device):
+    """True when a kernel can write the trainer's report numbers straight into pinned host memory (PFA_DIRECT_READBACK=0 turns it
+    off): checked ONCE with a real launch — pfa_train_log_pack into a pinned buffer, known numbers back after an event wait — so a
+    runtime where pinned host memory is not device-writable falls back to the copy instead of reporting garbage."""
+    if _direct['ok'] is None:
+        ok = os.environ.get('PFA_DIRECT_READBACK', '1') not in ('', '0')
+        if ok:
+            try:
+                import torch
+                from . import _lib
+                src = torch.arange(1, 11, dtype=torch.float64, device=device) * 0.5
+                host = torch.full((10,), -1.0, dtype=torch.float64).pin_memory()
+                _lib.check(_lib.lib().pfa_train_log_pack(_lib.ptr(src[:6]), _lib.ptr(src[6:]), _lib.ptr(host), _lib.stream_handle()), 'log_pack probe')
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(device))
+                ev.synchronize()
+                ok = bool(torch.equal(host, src.cpu()))
+            except Exception:
+                ok = False
+        _direct['ok'] = ok
+    return _direct['ok']
+
+
 class Pending:
     """One in-flight readback: ``submit`` enqueues the copy of ``src`` (device tensor) into this object's pinned buffer on
     the current stream and records the event; ``resolve`` waits for it once and hands the host array to ``finish``."""
@@ -41,6 +67,27 @@ class Pending:
             self.event = torch.cuda.Event()
         self.host.copy_(src, non_blocking=True)
         self.event.record(torch.cuda.current_stream(src.device))
+        self.finish = finish
+        if eager():
+            self.resolve()
+        return self
+
+    def direct_buffer(self, shape, dtype):
+        """The pinned host buffer itself, for a kernel that writes its (few) result numbers straight into host memory — no
+        device-to-host copy launch behind it.  Any readback still in flight is resolved first (its numbers live in this buffer).
+        Follow with ``submit_direct``."""
+        import torch
+        self.resolve()
+        shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        if self.host is None or tuple(self.host.shape) != shape or self.host.dtype != dtype:
+            self.host = torch.empty(shape, dtype=dtype, pin_memory=True)
+            self.event = torch.cuda.Event()
+        return self.host
+
+    def submit_direct(self, finish, device=None):
+        """The producing kernel (already enqueued on the current stream) writes into ``direct_buffer``: record the event behind it."""
+        import torch
+        self.event.record(torch.cuda.current_stream(device))
         self.finish = finish
         if eager():
             self.resolve()

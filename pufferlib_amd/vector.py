@@ -338,7 +338,13 @@ class Squared:
 
     stats_from_sums = staticmethod(episode_means)
 
-    def stats_with_flag(self, reset=True):
+    def stats_with_flag(self, reset=True, out=None):
+        """The four sums + the tape underrun flag; `out`: a 5-element f64 buffer the kernel writes instead of the vecenv's own
+        (the trainer's pinned readback buffer: no device-to-host copy launch behind the kernel)."""
+        if out is not None:
+            _lib.check(self.L.pfa_squared_episode_stats(_lib.ptr(self.state), C.byref(self.cfg), _lib.ptr(out),
+                                                        1 if reset else 0, _lib.stream_handle()), 'episode_stats')
+            return out
         self.episode_stats(reset)
         return self._stats
 
