@@ -33,7 +33,6 @@ namespace pfa {
 constexpr int kIgThreads = 256;
 constexpr int kIgBK = 16;
 constexpr int kIgLS = kIgBK + 4;   // LDS row stride (floats) of a [row][16 k] slab
-constexpr int kIgFlush = 32;       // weight form: slabs between two folds of the MFMA accumulators into the second level
 
 enum IgAMode : int { kADense = 0, kAIm2colF32 = 1, kAIm2colU8 = 2, kACol2im = 3 };
 enum IgEpilogue : int { kEpiNone = 0, kEpiBias = 1, kEpiBiasRelu = 2, kEpiMask = 3 };
@@ -527,15 +526,11 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
         }
     }
     const int dr = tid / (TN / 4), dc = (tid % (TN / 4)) * 4;
-    // Two-level accumulation (round 5): a split's rows_per_split (thousands of) products per entry as ONE fp32 chain is where the
-    // weight gradient's rounding error came from (the conv update sat 2x inside the 1e-5 contract against the f64 oracle); the MFMA
-    // accumulators are folded into a second set every kIgFlush slabs (512 rows), so no fp32 chain is longer than 512 products or
-    // rows_per_split / 512 partial sums — the error's random walk shrinks by ~sqrt(rows_per_split / 512).
-    f32x4 acc[KJ][NI], acc2[KJ][NI];
+    f32x4 acc[KJ][NI];
 #pragma unroll
     for (int a = 0; a < KJ; ++a)
 #pragma unroll
-        for (int b = 0; b < NI; ++b) acc[a][b] = acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NI; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     double colsum = 0.0;
     float4 ra[KJ], rb;
     int mrow = m_lo;          // first row of the slab the cursors point at
@@ -598,15 +593,6 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
         if (s + 1 < stages) fetch(ra, rb);
         multiply(s & 1);
         if (s + 1 < stages) stash((s & 1) ^ 1, ra, rb);
-        if ((s & (kIgFlush - 1)) == kIgFlush - 1) {
-#pragma unroll
-            for (int a = 0; a < KJ; ++a)
-#pragma unroll
-                for (int b = 0; b < NI; ++b) {
-                    acc2[a][b] += acc[a][b];
-                    acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-        }
         __syncthreads();
     }
     float *out = partial + (size_t)blockIdx.y * K * N;
@@ -617,7 +603,7 @@ __global__ void __launch_bounds__(kIgThreads, 2) igemm_weights_kernel(IgA A, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int k = k0 + (wv * KJ + a) * 16 + 4 * g + r;
-                if (k < K) out[(size_t)k * N + n0 + b * 16 + c] = acc2[a][b][r] + acc[a][b][r];
+                if (k < K) out[(size_t)k * N + n0 + b * 16 + c] = acc[a][b][r];
             }
     if (ktile == 0 && tid < TN) colpart[(size_t)blockIdx.y * N + n0 + tid] = colsum;
 }

@@ -8,7 +8,7 @@ mkdir -p gpurun_out
 ROOT=$PWD
 if [ "$SKIP_TESTS" != "1" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?"
-  tail -3 gpurun_out/${TAG}_tests.log
+  grep -E 'passed|failed' gpurun_out/${TAG}_tests.log | tail -2
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"
 fi
 ks() {  # name, bench flags
