@@ -37,6 +37,10 @@ cp profiles/pmc_summary.json gpurun_out/${TAG}_pmc_summary.json
 SMI=$!
 ( time timeout 900 python bench.py > gpurun_out/${TAG}_bench_mlp.json 2> gpurun_out/${TAG}_bench_mlp.err ) 2> gpurun_out/${TAG}_bench_wall.txt; echo "bench rc=$?"
 kill $SMI 2>/dev/null
+# a 25 s leg of the same loop (~19 000 iterations: 10^10 env steps): no drift, no NaN, no tape underrun, generations / sequence numbers far past 2^16
+timeout 300 python bench.py --no-extra --no-cpu-baseline --no-breakdown --sustained-seconds 25 > gpurun_out/${TAG}_bench_mlp_sustained25.json 2> gpurun_out/${TAG}_bench_sus.err; echo "sustained rc=$?"
+# the deferred-readback mode through a slice of the suite (readback.py's direct buffers in lazy mode)
+PFA_LAZY_READBACK=1 timeout 600 python -m pytest tests/test_gpu_ppo.py tests/test_gpu_squared.py tests/test_gpu_learning.py tests/test_gpu_lstm.py -q -x > gpurun_out/${TAG}_tests_lazy.log 2>&1; echo "lazy tests rc=$?"; grep -E 'passed|failed' gpurun_out/${TAG}_tests_lazy.log | tail -1
 timeout 400 python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-extra --no-cpu-baseline > gpurun_out/${TAG}_bench_g2_shared_device.json 2> gpurun_out/${TAG}_bench_g2.err; echo "g2 rc=$?"
 timeout 900 python3 bench.py --gpus 8 --steps 5 --warmup 2 --no-extra --no-cpu-baseline --no-breakdown --sustained-seconds 0 > gpurun_out/${TAG}_bench_g8_shared_device.json 2> gpurun_out/${TAG}_bench_g8.err; echo "g8 rc=$?"
 python - "$TAG" <<'PY'
