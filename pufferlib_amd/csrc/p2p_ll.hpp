@@ -77,14 +77,20 @@ __device__ __forceinline__ float ll_wait_sum(const LlArgs &d, unsigned idx, floa
 // every update on every rank, so the timeout of optimizer step k is an error on ALL ranks in the same train() for every k but the
 // update's last step (that one is reported by the first exchange of the next update).  A lane whose own status is already raised
 // does not wait again (its peers may be gone: one bounded wait per launch is enough).
-__device__ __forceinline__ void ll_status_exchange(const LlArgs &d) {
-    const unsigned idx = d.entries - 1u;
+// Two halves, so that a kernel can put the slow parts where they cost nothing: the status word lives in host-pinned memory (a read
+// over PCIe, ~1.5 us) — ll_status_push reads and publishes it at the START of the launch, under the partial sums; ll_status_wait
+// collects the peers' words late, next to another wait.
+__device__ __forceinline__ int ll_status_push(const LlArgs &d) {
     const int mine = __hip_atomic_load(d.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    ll_push(d, idx, mine ? 1.0f : 0.0f);
+    ll_push(d, d.entries - 1u, mine ? 1.0f : 0.0f);
+    return mine;
+}
+__device__ __forceinline__ void ll_status_wait(const LlArgs &d, int mine) {
     if (mine) return;
-    const float tot = ll_wait_sum(d, idx, 0.0f);        // (raises the word to 1 itself when the wait runs out)
+    const float tot = ll_wait_sum(d, d.entries - 1u, 0.0f);        // (raises the word to 1 itself when the wait runs out)
     if (tot > 0.0f) __hip_atomic_store(d.status, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__device__ __forceinline__ void ll_status_exchange(const LlArgs &d) { ll_status_wait(d, ll_status_push(d)); }
 
 // csrc/p2p.hip
 bool p2p_ll_ready(size_t entries_needed);

@@ -855,6 +855,13 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
     __shared__ double shd[kRedSl][64];   // the loss-sum slots are carried in f64
     const int ql = threadIdx.x & 63, sl = threadIdx.x >> 6;
     const int q = blockIdx.x * 64 + ql;
+    // data parallel: one lane of the launch reads this rank's status word (host-pinned: a PCIe round trip) and publishes it to the peers
+    // NOW, under the partial sums; the peers' words are collected behind the norm hand-off's publish further down (p2p_ll.hpp)
+    const bool status_lane = DIST && blockIdx.x == 0 && threadIdx.x == 0;
+    int status_mine = 0;
+    if constexpr (DIST) {
+        if (status_lane) status_mine = ll_status_push(ll);
+    }
     float acc = 0.0f;
     double dacc = 0.0;
     if (q < NL::kCount) {
@@ -938,7 +945,6 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
             hi = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats)), hi);
             lo = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats) + 1), lo);
         }
-        if (blockIdx.x == 0 && ql == 0) ll_status_exchange(ll);   // the ranks' status words ride the exchange (p2p_ll.hpp)
     }
     if (p >= 0) grads[p] = s;
     if (stat) {
@@ -953,6 +959,9 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
         const unsigned long long bits = (unsigned long long)__double_as_longlong(sq);
         const unsigned half = ql == 0 ? (unsigned)bits : (unsigned)(bits >> 32);
         __hip_atomic_store(gw.words + 2 * blockIdx.x + ql, ((unsigned long long)gw.gen << 32) | half, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (DIST) {   // the ranks' status words ride the exchange: this workgroup's norm piece is out, nobody waits for this lane
+        if (status_lane) ll_status_wait(ll, status_mine);
     }
     // the norm in adam_clip_kernel's order: 256 strided partial sums, a butterfly per 64, then the four in order
     const int npart = (int)gridDim.x;
