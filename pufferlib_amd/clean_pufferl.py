@@ -585,9 +585,22 @@ def _finish_evaluate(data, N, T):
             infos.fill({k: [v] for k, v in m.items()})
         data.stats = stats
         if direct_stats:
-            data._rb_eval.submit_direct(finish, vecenv.device)
+            data._rb_eval.submit_direct(finish, vecenv.device, defer=True)
         else:
-            data._rb_eval.submit(st, finish)
+            data._rb_eval.submit(st, finish, defer=True)
+        # The update's first pass — compute_gae + the advantage statistics (train() below) — reads nothing but the rows this rollout
+        # just wrote, so it is enqueued HERE, behind the event of the episode statistics: the host waits for the five numbers (and
+        # then walks back through the caller into train()) while the device already runs the ~35 us pass instead of idling through
+        # that round trip.  train() recognises the pass by its key (_gae_key: storage version of rewards / dones / values,
+        # hyper-parameters, partition) and launches it itself when anything changed in between (reward shaping, value
+        # re-bootstrapping, another gamma) or when evaluate() was not the previous call.  PFA_EARLY_GAE=0: always in train().
+        data._gae_done = None
+        if (os.environ.get('PFA_EARLY_GAE', '1') != '0' and experience.full and data.host_bridge is None
+                and _fused_sums_ok(data, data.world_size)):
+            _launch_gae_sums(data)
+            data._gae_done = _gae_key(data)
+        if readback.eager():
+            data._rb_eval.resolve()
     return stats, infos
 
 
@@ -607,6 +620,38 @@ def _all_gather_small(dist, x, rank, world, native=False):
 
 def _early_gae():
     return os.environ.get('PFA_DP_EARLY_GAE', '1') != '0'
+
+
+def _fused_sums_ok(data, world):
+    """Single rank: GAE, the per-minibatch advantage sums and the explained-variance sums in ONE pass over the rows
+    (pfa_gae_sums_f32: 3 launches; the separate entry points: 6) where the partition allows it."""
+    config, experience = data.config, data.experience
+    return (world == 1 and os.environ.get('PFA_GAE_SUMS', '1') != '0'
+            and not (getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference')
+            and bool(_lib.lib().pfa_gae_sums_supported(experience.batch_size, experience.num_envs, experience.num_minibatches,
+                                                       int(config.bptt_horizon))))
+
+
+def _gae_key(data):
+    """What the GAE pass is a function of, as far as the host can see it: the version counter of the rewards / dones / values
+    storage (every in-place torch write through any view bumps it; the library's kernels write through raw pointers and do not),
+    the hyper-parameters and the partition."""
+    config, ex = data.config, data.experience
+    rdv = getattr(ex, '_rdv', None)
+    ver = rdv._version if rdv is not None else (ex.rewards._version, ex.dones._version, ex.values._version)
+    return (ver, ex.batch_size, float(config.gamma), float(config.gae_lambda), ex.num_envs, ex.num_minibatches,
+            int(config.bptt_horizon), bool(config.norm_adv))
+
+
+def _launch_gae_sums(data):
+    """compute_gae over the env-major batch (clean_pufferl.py:163-169) + returns (:482) + the update's advantage statistics, fused form."""
+    config, experience = data.config, data.experience
+    nmb = experience.num_minibatches
+    _lib.check(_lib.lib().pfa_gae_sums_f32(
+        _lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards), _lib.ptr(experience.advantages),
+        _lib.ptr(experience.returns), experience.batch_size, float(config.gamma), float(config.gae_lambda), experience.num_envs, nmb,
+        int(config.bptt_horizon), _lib.ptr(data.adv_stats), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(data.loss_acc),
+        _lib.ptr(data.workspace), _lib.stream_handle()), 'gae_sums')
 
 
 def _publish_gae(data, extra=None):
@@ -673,17 +718,13 @@ def train(data):
         # compute_gae over the env-major batch (clean_pufferl.py:163-169) + returns (:482)
         # single rank: GAE, the per-minibatch advantage sums and the explained-variance sums in ONE pass over the rows
         # (pfa_gae_sums_f32: 3 launches; the separate entry points below: 6) where the partition allows it
-        fused_sums = (world == 1 and os.environ.get('PFA_GAE_SUMS', '1') != '0'
-                      and not (getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference')
-                      and bool(L.pfa_gae_sums_supported(B, experience.num_envs, nmb, int(config.bptt_horizon))))
+        fused_sums = _fused_sums_ok(data, world)
+        early_key, data._gae_done = getattr(data, '_gae_done', None), None      # (one use: a second train() on the same rows runs its own pass)
         if world > 1:
             _finish_gae(data, rank, world, stream)
         elif fused_sums:
-            _lib.check(L.pfa_gae_sums_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
-                                          _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
-                                          float(config.gae_lambda), experience.num_envs, nmb, int(config.bptt_horizon),
-                                          _lib.ptr(data.adv_stats), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(data.loss_acc),
-                                          _lib.ptr(data.workspace), stream), 'gae_sums')
+            if early_key is None or early_key != _gae_key(data):                # evaluate() already ran this very pass otherwise
+                _launch_gae_sums(data)
         else:
             _lib.check(L.pfa_gae_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
                                      _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),

@@ -16,12 +16,39 @@ drains, which is what the ~0.05 ms of host bubbles per 1.5 ms iteration buys bac
 a slow Python side; the GPU test suite passes in both modes.
 """
 import os
+import time
 
 from .namespace import Namespace
 
 
 def eager():
     return os.environ.get('PFA_LAZY_READBACK', '0') in ('', '0')
+
+
+def _spin_us():
+    try:
+        return max(0.0, float(os.environ.get('PFA_SPIN_WAIT_US', '2000')))
+    except ValueError:
+        return 2000.0
+
+
+def wait_event(event):
+    """Wait for a recorded event the way a latency-bound caller wants it: poll ``event.query()`` for up to PFA_SPIN_WAIT_US
+    microseconds (default 2000; 0 = block at once), then fall back to the runtime's blocking wait.  The two readbacks of an
+    iteration are waited for while the device still has ~0.2-1 ms of queued work, so the runtime's own wait has long left its
+    short active phase and parked the thread by the time the event fires — the wake-up then costs tens of microseconds of idle
+    device, twice per iteration.  A polling host thread sees the event within a query's latency.  Long waits (a 0.7 s conv
+    update) burn the poll window once and then block as before."""
+    spin = _spin_us()
+    if spin > 0:
+        query = event.query
+        deadline = time.perf_counter() + spin * 1e-6
+        while not query():
+            if time.perf_counter() > deadline:
+                event.synchronize()
+                return
+        return
+    event.synchronize()
 
 
 _direct = {'ok': None}
@@ -59,7 +86,9 @@ class Pending:
         self.event = None
         self.finish = None
 
-    def submit(self, src, finish):
+    def submit(self, src, finish, defer=False):
+        """``defer``: leave the wait to the caller even in the default (eager) mode — it enqueues more work behind the event first
+        and then calls ``resolve()`` itself (clean_pufferl._finish_evaluate: the update's GAE pass runs under the host's wait)."""
         import torch
         self.resolve()                      # the buffer is about to be reused
         if self.host is None or self.host.shape != src.shape or self.host.dtype != src.dtype:
@@ -68,7 +97,7 @@ class Pending:
         self.host.copy_(src, non_blocking=True)
         self.event.record(torch.cuda.current_stream(src.device))
         self.finish = finish
-        if eager():
+        if eager() and not defer:
             self.resolve()
         return self
 
@@ -84,12 +113,13 @@ class Pending:
             self.event = torch.cuda.Event()
         return self.host
 
-    def submit_direct(self, finish, device=None):
-        """The producing kernel (already enqueued on the current stream) writes into ``direct_buffer``: record the event behind it."""
+    def submit_direct(self, finish, device=None, defer=False):
+        """The producing kernel (already enqueued on the current stream) writes into ``direct_buffer``: record the event behind it.
+        ``defer``: as in ``submit``."""
         import torch
         self.event.record(torch.cuda.current_stream(device))
         self.finish = finish
-        if eager():
+        if eager() and not defer:
             self.resolve()
         return self
 
@@ -102,7 +132,7 @@ class Pending:
         if finish is None:
             return
         self.finish = None
-        self.event.synchronize()
+        wait_event(self.event)
         finish(self.host.numpy().copy())
 
 

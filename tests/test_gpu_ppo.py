@@ -502,3 +502,40 @@ def test_49_float_rows_with_other_action_counts_vs_oracle(num_actions, matrix_pr
     sd = pol.state_dict()
     for k, arr in opol.state_arrays().items():
         np.testing.assert_allclose(sd['policy.' + k].cpu().numpy(), arr, err_msg=k, **TOL)
+
+
+def test_early_gae_pass_is_the_same_update_and_yields_to_in_place_edits(monkeypatch):
+    """evaluate() enqueues the update's GAE + advantage-statistics pass behind its statistics readback (the device runs it while
+    the host walks from evaluate() into train()); train() reuses it only while its key holds (clean_pufferl._gae_key).
+    (a) three iterations with the early pass == three iterations with PFA_EARLY_GAE=0, bit for bit (statistics, losses, weights,
+    advantages); (b) rewards scaled IN PLACE between evaluate() and train() (reward shaping): train() runs its own pass over the
+    edited rows — same numbers as the run that never had an early pass; (c) a second train() on the same rows runs its own pass."""
+    from pufferlib_amd import clean_pufferl
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    n, horizon = 256, 32
+    runs = []
+    for early in ('1', '0'):
+        monkeypatch.setenv('PFA_EARLY_GAE', early)
+        torch.manual_seed(3)
+        vec, pol = _make(n)
+        data = clean_pufferl.create(_config(n, horizon, n * horizon // 4, 16, 2, n * horizon * 16, hp, seed=5), vec, pol)
+        out = []
+        for it in range(5):
+            stats, infos = clean_pufferl.evaluate(data)
+            assert (data._gae_done is not None) == (early == '1')
+            if it == 2:                                   # reward shaping between the two calls
+                data.experience.rewards.mul_(0.5)
+                assert early == '0' or data._gae_done != clean_pufferl._gae_key(data)
+            clean_pufferl.train(data)
+            assert data._gae_done is None
+            if it == 3:                                   # the same rows again: no early pass to reuse
+                clean_pufferl.train(data)
+            out.append((dict(stats), dict(data.losses), data.experience.advantages.clone(), data.experience.returns.clone(),
+                        data.adv_stats.clone()))
+        runs.append((out, data.flat_params.flat.clone()))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert repr(a[:2]) == repr(b[:2])
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[4], b[4])
+    assert torch.equal(runs[0][1], runs[1][1])
+    shaped, plain = runs[0][0][2][2], runs[0][0][1][2]
+    assert not torch.equal(shaped, plain) and float(shaped.abs().max()) > 0

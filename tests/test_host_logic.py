@@ -437,3 +437,64 @@ def test_six_term_bf16_split_is_as_close_to_f64_as_the_fp32_chain():
         e3, e6, ec = (np.abs(c.astype(np.float64) - exact).max() / scale for c in (x3, x6, chain))
         assert e6 <= 2.0 * ec + 1e-7 and e6 < 1e-6, (K, e6, ec)
         assert e3 > 4.0 * e6, (K, e3, e6)
+
+
+class _FakeEvent:
+    """An event that completes after `ready_after` queries (None: never by query); counts what the waiter did."""
+
+    def __init__(self, ready_after):
+        self.ready_after, self.queries, self.syncs = ready_after, 0, 0
+
+    def query(self):
+        self.queries += 1
+        return self.ready_after is not None and self.queries > self.ready_after
+
+    def synchronize(self):
+        self.syncs += 1
+
+
+def test_readback_wait_polls_first_and_blocks_after_the_window(monkeypatch):
+    """readback.wait_event: the two per-iteration readbacks are polled (no parked thread to wake while the device idles); a wait
+    that outlasts PFA_SPIN_WAIT_US falls back to the runtime's blocking wait, and PFA_SPIN_WAIT_US=0 blocks at once."""
+    from pufferlib_amd import readback as rb
+    monkeypatch.setenv('PFA_SPIN_WAIT_US', '100000')
+    ev = _FakeEvent(ready_after=5)
+    rb.wait_event(ev)
+    assert ev.queries == 6 and ev.syncs == 0
+    monkeypatch.setenv('PFA_SPIN_WAIT_US', '200')
+    ev = _FakeEvent(ready_after=None)
+    rb.wait_event(ev)
+    assert ev.queries >= 1 and ev.syncs == 1
+    monkeypatch.setenv('PFA_SPIN_WAIT_US', '0')
+    ev = _FakeEvent(ready_after=0)
+    rb.wait_event(ev)
+    assert ev.queries == 0 and ev.syncs == 1
+    monkeypatch.setenv('PFA_SPIN_WAIT_US', 'not a number')
+    assert rb._spin_us() == 2000.0
+
+
+def test_early_gae_key_follows_in_place_edits_and_hyperparameters():
+    """clean_pufferl._gae_key: evaluate() runs the update's GAE pass behind its statistics readback and train() reuses it only
+    when this key still holds — an in-place write to rewards / dones / values through ANY view (reward shaping, value
+    re-bootstrapping) or another gamma / lambda / partition makes train() run its own pass."""
+    import torch
+    from pufferlib_amd import clean_pufferl as cp
+    from pufferlib_amd.namespace import Namespace
+    B = 64
+    rdv = torch.zeros(3, B + 1)
+    ex = Namespace(_rdv=rdv, rewards=rdv[0, :B], dones=rdv[1, :B], values=rdv[2, :B], batch_size=B, num_envs=4, num_minibatches=2)
+    data = Namespace(config=Namespace(gamma=0.99, gae_lambda=0.95, bptt_horizon=8, norm_adv=True), experience=ex)
+    k0 = cp._gae_key(data)
+    assert cp._gae_key(data) == k0
+    ex.rewards[3] = 1.0                                   # a view of the shared storage: the storage's version counter moves
+    k1 = cp._gae_key(data)
+    assert k1 != k0
+    ex.values.mul_(0.5)
+    k2 = cp._gae_key(data)
+    assert k2 != k1
+    data.config.gamma = 0.98
+    assert cp._gae_key(data) != k2
+    data.config.gamma = 0.99
+    assert cp._gae_key(data) == k2
+    ex.num_minibatches = 4
+    assert cp._gae_key(data) != k2
