@@ -465,6 +465,18 @@ int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *para
                       float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
                       float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
                       int32_t data_parallel, pfa_stream_t stream);
+/* pfa_ppo_mlp_train + the report clean_pufferl.train ends with (clean_pufferl.py:249-254, 266-270): when the update runs in the
+ * one-launch form, its LAST reduce + Adam launch also writes log_out10 = { losses[0..5], log_ev4[0..3] } — what
+ * pfa_train_log_pack leaves, without a launch of its own behind the update (the report is what the host waits for).
+ * *log_packed (host memory, may be NULL) = 1 when it did, 0 when the caller still has to call pfa_train_log_pack (two-kernel
+ * form, all-reduce as its own step, update_epochs == 0).  log_ev4 / log_out10 NULL: exactly pfa_ppo_mlp_train.
+ * log_out10 may be device-visible pinned host memory. */
+int pfa_ppo_mlp_train_logged(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
+                             const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
+                             float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
+                             float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
+                             int32_t data_parallel, const double *log_ev4, double *log_out10, int32_t *log_packed,
+                             pfa_stream_t stream);
 
 /* The minibatch step of clean_pufferl.train (clean_pufferl.py:175-244 up to loss.backward()) for a pfa_mlp_view policy (declared with the rollout kernels above) with hidden in
  * {64, 256, 512} (csrc/ppo_wide.hip: the hidden dimension split over the four wavefronts of a workgroup, every wave's slice of the

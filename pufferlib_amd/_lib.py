@@ -215,6 +215,9 @@ _SIGNATURES = {
     'pfa_ppo_mlp_train': (C.c_int, [C.POINTER(Experience), C.c_int64, P, C.POINTER(MlpDims), C.POINTER(PpoHparams), P, P, P, P,
                                     C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P,
                                     C.c_int32, P]),
+    'pfa_ppo_mlp_train_logged': (C.c_int, [C.POINTER(Experience), C.c_int64, P, C.POINTER(MlpDims), C.POINTER(PpoHparams), P, P, P, P,
+                                           C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, P, P,
+                                           C.c_int32, P, P, C.POINTER(C.c_int32), P]),
     'pfa_store_step': (C.c_int, [C.POINTER(Experience), C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P]),
     'pfa_store_rows': (C.c_int, [C.POINTER(Experience), C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P, P, P, P, P, P, P]),
     'pfa_gather_obs_time_major': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, C.POINTER(PpoHparams), C.c_int32, P, P]),

@@ -776,17 +776,24 @@ def train(data):
                 if float(data.grads[fp.count + 8:fp.count + 10].double().sum().item()) / global_mb_rows > config.target_kl:
                     break
     native_loop = eng is None and (world == 1 or data.native_dp) and config.target_kl is None
+    direct_log, log_out, log_packed = False, None, C.c_int32(0)
     if native_loop:
         # no early exit: the whole epoch x minibatch loop (incl. the per-step RCCL all-reduce when data parallel) is
         # enqueued by one native call on the compute stream
         with profile.learn:
             g = opt.param_groups[0]
-            _lib.check(L.pfa_ppo_mlp_train(
+            if (early_ev or fused_sums) and os.environ.get('PFA_FUSED_LOG', '1') != '0':
+                # the report (six loss sums + the four explained-variance sums, known since GAE) rides the update's last launch,
+                # straight into the readback's pinned buffer where the runtime allows it
+                direct_log = readback.direct_ok(experience.device)
+                log_out = data._rb_train.direct_buffer(10, torch.float64) if direct_log else data.log_sums
+            _lib.check(L.pfa_ppo_mlp_train_logged(
                 C.byref(experience.c), B, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hp), _lib.ptr(data.adv_stats),
                 _lib.ptr(data.grads), _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), opt.step_count, float(g['lr']),
                 float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(config.max_grad_norm),
                 int(config.update_epochs), _lib.ptr(data.loss_acc), _lib.ptr(data.workspace),
-                1 if data.native_dp else 0, stream), 'ppo_train')
+                1 if data.native_dp else 0, C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb) if log_out is not None else None,
+                _lib.ptr(log_out), C.byref(log_packed), stream), 'ppo_train')
             opt.step_count += config.update_epochs * nmb
     for epoch in range(0 if (native_loop or eng is not None) else config.update_epochs):
         for mb in range(nmb):
@@ -818,14 +825,17 @@ def train(data):
 
         # losses + explained variance exactly as the reference logs them (clean_pufferl.py:249-254,266-270, App. A.8):
         # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
-        direct_log = False
-        if early_ev or fused_sums:                              # the sums exist since GAE (data parallel: all-reduced with the advantage sums)
+        if log_packed.value:                                    # the update's last launch already left the ten numbers (pfa_ppo_mlp_train_logged)
+            pass
+        elif early_ev or fused_sums:                            # the sums exist since GAE (data parallel: all-reduced with the advantage sums)
             # ... and the ten numbers go straight into the pinned host buffer of the readback (no device-to-host copy launch behind it)
-            direct_log = readback.direct_ok(experience.device)
-            log_out = data._rb_train.direct_buffer(10, torch.float64) if direct_log else data.log_sums
+            if log_out is None:
+                direct_log = readback.direct_ok(experience.device)
+                log_out = data._rb_train.direct_buffer(10, torch.float64) if direct_log else data.log_sums
             _lib.check(L.pfa_train_log_pack(_lib.ptr(data.loss_acc), C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb), _lib.ptr(log_out),
                                             stream), 'train_log_pack')
         else:
+            direct_log = False
             _lib.check(L.pfa_train_log_sums(C.byref(experience.c), B, experience.num_envs, _lib.ptr(data.loss_acc),
                                             _lib.ptr(data.log_sums), _lib.ptr(data.workspace), stream), 'train_log_sums')
             if getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference':

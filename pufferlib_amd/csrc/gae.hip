@@ -16,6 +16,7 @@
 //           within a few fp32 ulps of the sequential code: parity is allclose(atol=1e-5, rtol=1e-5).
 // Roofline: HBM.  Algorithmic bytes: read r,v,d (12 B) + write adv, returns (8 B) = 20 B per element.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -203,18 +204,24 @@ struct GaeSums {
     int nmb, bptt;         // minibatches, rows per segment
     int num_envs, horizon; // storage order j = t * num_envs + e  <->  env-major e * horizon + t
 };
-template <bool SUMS>
+// SELF (gamma lambda small enough for the window to do it alone, gae_warm_self below): no f64 carry at all — neither the chunk maps
+// of pass 1 (no gae_aggregate launch) nor the block scan.  Every walker starts from x = 0 at `warm` elements behind its items: the
+// start error is then the advantage itself instead of a few of its ulps, and 24 more binary orders of contraction
+// ((gamma lambda)^warm <= 1e-7 * 2^-24) bring it as far below one ulp as the f64-seeded form is after its shorter warm-up — 536
+// elements instead of 264 at the defaults, inside the 1024-element window for gamma lambda <= 0.968.  Beyond the end of the array
+// the window holds (0, 0) pairs, where x = 0 IS the reference's value (adv[n-1] = 0, c_gae.pyx:24).
+template <bool SUMS, bool SELF>
 __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *dones, const float *values, const float *rewards, float *adv,
                                                                float *ret, long long n, float gamma, float lam, const Affine *agg,
                                                                int nchunks, int warm, GaeSums sums) {
-    __shared__ Affine sh[kGaeThreads / 64];
+    __shared__ Affine sh[SELF ? 1 : kGaeThreads / 64];
     __shared__ double s_carry;
     __shared__ float2 cd[kGaeBlock + kGaeBlock / 8];      // (coef, delta) of the window's elements, index i + i / 8
-    __shared__ float start[kGaeThreads];                  // f64-accurate advantage at element 8 (t + 1) of the window
+    __shared__ float start[SELF ? 1 : kGaeThreads];       // f64-accurate advantage at element 8 (t + 1) of the window
     __shared__ double sh_s[SUMS ? 4 : 1][SUMS ? kGaeChunkThreads : 1];
     const int tid = threadIdx.x;
     // carry-in of the WINDOW (chunks b, b + 1) = (agg[b+2] o ... o agg[nchunks-1])(0), composed in order by wave 0
-    if (wave_id() == 0) {
+    if (!SELF && wave_id() == 0) {
         const int first = blockIdx.x + 2, cnt = nchunks - first;
         const int per = cnt > 0 ? (cnt + 63) / 64 : 0;
         const int lane = lane_id();
@@ -232,11 +239,15 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
     }
     const long long s = (long long)blockIdx.x * kGaeChunk + (long long)tid * kGaeItems;
     GaeItems it;
-    gae_load(dones, values, rewards, s, n, it);
-    Affine mine = gae_thread_map(it, s, n, gamma, lam, true), after;
-    block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
-    start[tid] = (float)(after.c * s_carry + after.d);
-    {
+    // SELF: only the window elements a walker can reach are fetched (the last walker starts at element 1024 + 8 + warm)
+    const bool feeds = !SELF || tid * kGaeItems < kGaeChunk + kGaeItems + warm;
+    if (feeds) gae_load(dones, values, rewards, s, n, it);
+    if constexpr (!SELF) {
+        Affine mine = gae_thread_map(it, s, n, gamma, lam, true), after;
+        block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
+        start[tid] = (float)(after.c * s_carry + after.d);
+    }
+    if (feeds) {
     PFA_GAE_FP   // the reference's x86-64 build multiplies and adds separately (c_gae.pyx:27-30)
 #pragma unroll
     for (int i = 0; i < kGaeItems; ++i) {
@@ -258,7 +269,7 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
     if (tid < kGaeChunkThreads) {
         PFA_GAE_FP
         const int first = tid * kGaeItems + kGaeItems;          // window element behind this thread's items
-        float x = start[tid + (warm >> 3)];                     // advantage at window element first + warm (8-aligned)
+        float x = SELF ? 0.0f : start[tid + (warm >> 3)];       // advantage at window element first + warm (8-aligned); SELF: see above
         // warm-up: the reference's statement, for the state only.  Groups of 8 elements (warm and first are multiples of 8, so a
         // group is 8 consecutive float2 in LDS): the group's reads are issued together, then its 8 dependent steps — left as one
         // read per step the loop is a chain of LDS latencies (28.8 us per launch measured; the arithmetic is 2 instructions a step)
@@ -457,6 +468,19 @@ static int gae_warm(float gamma, float lam) {
     return (int)(w < 8.0 ? 8.0 : (w > (double)kGaeChunk ? (double)kGaeChunk : w));
 }
 
+// Warm-up elements of the self-starting form (gae_exact_kernel<.., SELF>): the start error is the advantage itself, so the
+// contraction has to cover the 24 bits of an fp32 mantissa on top of gae_warm's margin.  0 = the window (1024 elements) is too
+// short for this gamma lambda (> 0.968): the f64-seeded two-launch form runs.  PFA_GAE_SELF=0 forces the latter (A/B, fallback).
+static int gae_warm_self(float gamma, float lam) {
+    const char *e = std::getenv("PFA_GAE_SELF");   // (read per call: the tests flip it inside one process)
+    if (e && e[0] == '0') return 0;
+    const double gl = (double)(gamma * lam);
+    if (!(gl > 0.0)) return 8;
+    if (gl >= 0.999) return 0;
+    const double w = std::ceil(std::log(1e-7 * 5.9604644775390625e-08) / std::log(gl) / 8.0) * 8.0;
+    return w <= (double)kGaeChunk ? (int)(w < 8.0 ? 8.0 : w) : 0;
+}
+
 extern "C" int pfa_gae_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
                            int64_t n, float gamma, float gae_lambda, void *workspace, pfa_stream_t stream) {
     PFA_REQUIRE(n >= 0, "gae: negative length");
@@ -466,10 +490,16 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
     PFA_REQUIRE(nc <= 0x7fffffff, "gae: batch too large");
     Affine *agg = (Affine *)workspace;
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // both passes
+    if (const int ws = gae_warm_self(gamma, gae_lambda)) {   // one launch: the window warms itself up (no chunk maps)
+        hipLaunchKernelGGL((gae_exact_kernel<false, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                           advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, GaeSums{});
+        PFA_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(gae_aggregate_kernel<kGaeChunkThreads>, dim3((unsigned)nc), dim3(kGaeChunkThreads), 0, (hipStream_t)stream, dones, values,
                        rewards, (long long)n, gamma, gae_lambda, agg, 0);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_exact_kernel<false>, dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+    hipLaunchKernelGGL((gae_exact_kernel<false, false>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
                        advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), GaeSums{});
     PFA_LAUNCH_CHECK();
     return 0;
@@ -501,12 +531,17 @@ extern "C" int pfa_gae_sums_f32(const float *dones, const float *values, const f
     Affine *agg = (Affine *)workspace;
     GaeSums sums{(double *)((char *)workspace + align_up((size_t)nc * sizeof(Affine), 256)), num_minibatches, bptt_horizon, num_envs,
                  (int)(n / num_envs)};
-    ScopedKernelTimer timer("gae", (hipStream_t)stream);  // all three launches
-    hipLaunchKernelGGL(gae_aggregate_kernel<kGaeChunkThreads>, dim3((unsigned)nc), dim3(kGaeChunkThreads), 0, (hipStream_t)stream, dones, values,
-                       rewards, (long long)n, gamma, gae_lambda, agg, 0);
-    PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_exact_kernel<true>, dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), sums);
+    ScopedKernelTimer timer("gae", (hipStream_t)stream);  // all launches (three; two in the self-starting form)
+    if (const int ws = gae_warm_self(gamma, gae_lambda)) {
+        hipLaunchKernelGGL((gae_exact_kernel<true, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                           advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, sums);
+    } else {
+        hipLaunchKernelGGL(gae_aggregate_kernel<kGaeChunkThreads>, dim3((unsigned)nc), dim3(kGaeChunkThreads), 0, (hipStream_t)stream, dones, values,
+                           rewards, (long long)n, gamma, gae_lambda, agg, 0);
+        PFA_LAUNCH_CHECK();
+        hipLaunchKernelGGL((gae_exact_kernel<true, false>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                           advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), sums);
+    }
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nc,
                        (int)num_minibatches, adv_stats, ev4, zero8);

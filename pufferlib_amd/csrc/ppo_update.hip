@@ -846,6 +846,10 @@ struct AdamArgs {
     float neg_step_size, bc2_sqrt, beta1, beta2, eps, max_grad_norm;
     double *losses;
     double loss_scale;
+    // the update's LAST launch only (pfa_ppo_mlp_train_logged): the lanes that own the loss sums also leave train()'s report,
+    // out10 = { losses[0..5] after this step, ev4[0..3] } — what log_pack_kernel would write in a launch of its own behind this one
+    const double *log_ev4;
+    double *log_out10;
 };
 template <int DP, int KTM, bool COL, bool PERM, bool DIST>
 __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const float *partials, int nparts, int a, int obs_dim, float *grads,
@@ -1011,7 +1015,23 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
         ad.exp_avg[p] = m_i;
         ad.exp_avg_sq[p] = v_i;
     }
-    if (stat && ad.losses && q - NL::kStats < 6) ad.losses[q - NL::kStats] += ((double)hi + (double)lo) * ad.loss_scale;
+    if (stat) {
+        const int i = q - NL::kStats;
+        double run = 0.0;
+        if (ad.losses && i < 6) {
+            run = ad.losses[i] + ((double)hi + (double)lo) * ad.loss_scale;
+            ad.losses[i] = run;
+        }
+        if (ad.log_out10) {
+            static_assert(kNumStats == 8, "slots 6 and 7 carry the four explained-variance sums of the report");
+            if (i < 6) {
+                ad.log_out10[i] = run;
+            } else {
+                ad.log_out10[6 + 2 * (i - 6)] = ad.log_ev4[2 * (i - 6)];
+                ad.log_out10[7 + 2 * (i - 6)] = ad.log_ev4[2 * (i - 6) + 1];
+            }
+        }
+    }
 }
 
 // Per-minibatch advantage sums (f64).  grid = (chunks, nmb); deterministic two-stage reduction.
@@ -1463,10 +1483,12 @@ static bool reduce_adam_coresident(const pfa_mlp_dims *dims, bool dist) {
 }
 static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float *params, float *grads, float *exp_avg, float *exp_avg_sq,
                               float lr, float beta1, float beta2, float eps, int64_t step, float max_grad_norm, double *losses,
-                              double loss_scale, void *workspace, const LlArgs *ll, hipStream_t stream) {
+                              double loss_scale, void *workspace, const LlArgs *ll, hipStream_t stream, const double *log_ev4 = nullptr,
+                              double *log_out10 = nullptr) {
     const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
     const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
-    AdamArgs ad{params, exp_avg, exp_avg_sq, (float)(-(double)lr / bc1), (float)std::sqrt(bc2), beta1, beta2, eps, max_grad_norm, losses, loss_scale};
+    AdamArgs ad{params, exp_avg, exp_avg_sq, (float)(-(double)lr / bc1), (float)std::sqrt(bc2), beta1, beta2, eps, max_grad_norm, losses, loss_scale,
+                log_ev4, log_out10};
     const float *partials = (const float *)workspace;
     static unsigned long long launches = 0;
     unsigned gen = (unsigned)(++launches);
@@ -1511,11 +1533,33 @@ extern "C" int pfa_ppo_grid_status(void) {
     return w ? *(volatile int *)w : 0;
 }
 
+extern "C" int pfa_ppo_mlp_train_logged(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
+                                        const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
+                                        float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
+                                        float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
+                                        int32_t data_parallel, const double *log_ev4, double *log_out10, int32_t *log_packed,
+                                        pfa_stream_t stream);
 extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                                  const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                                  float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
                                  float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
                                  int32_t data_parallel, pfa_stream_t stream) {
+    return pfa_ppo_mlp_train_logged(exp, batch_rows, params, dims, hp, adv_stats, grads, exp_avg, exp_avg_sq, opt_step, lr, beta1, beta2, eps,
+                                    max_grad_norm, update_epochs, losses, workspace, data_parallel, nullptr, nullptr, nullptr, stream);
+}
+
+// pfa_ppo_mlp_train + train()'s report: when the update runs in the one-launch form, its LAST reduce + Adam launch also writes
+// log_out10 = { losses[0..5], log_ev4[0..3] } (what pfa_train_log_pack leaves, minus its launch: the report is what the host waits
+// for at the end of train()); *log_packed (host) says whether it did — 0: call pfa_train_log_pack as before (two-kernel form, the
+// all-reduce as its own step, no optimizer step at all).  log_out10 may be pinned host memory.
+extern "C" int pfa_ppo_mlp_train_logged(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
+                                        const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
+                                        float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
+                                        float max_grad_norm, int32_t update_epochs, double *losses, void *workspace,
+                                        int32_t data_parallel, const double *log_ev4, double *log_out10, int32_t *log_packed,
+                                        pfa_stream_t stream) {
+    if (log_packed) *log_packed = 0;
+    PFA_REQUIRE(!log_out10 || (log_ev4 && losses), "ppo.train: the report needs the explained-variance sums and the loss accumulator");
     if (int rc = check_update_args(exp, batch_rows, dims, hp)) return rc;
     PFA_REQUIRE(update_epochs >= 0 && opt_step >= 0, "ppo.train: bad epoch / step count");
     PFA_REQUIRE(!data_parallel || dist_ready(), "ppo.train: data_parallel needs pfa_dist_init first");
@@ -1538,10 +1582,12 @@ extern "C" int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, 
                 ++opt_step;
                 LlArgs ll{};
                 if (fused_dp) ll = p2p_ll_next();
+                const bool last = log_out10 && e == update_epochs - 1 && mb == hp->num_minibatches - 1;
                 if (int rc = launch_reduce_adam(dims, hp->num_minibatches, grid, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps,
                                                 opt_step, max_grad_norm, losses, loss_scale, workspace, fused_dp ? &ll : nullptr,
-                                                (hipStream_t)stream))
+                                                (hipStream_t)stream, last ? log_ev4 : nullptr, last ? log_out10 : nullptr))
                     return rc;
+                if (last && log_packed) *log_packed = 1;
                 continue;
             }
             if (int rc = pfa_ppo_mlp_grad(exp, batch_rows, mb, params, dims, hp, adv_stats, global_mbs, grads, workspace, stream))

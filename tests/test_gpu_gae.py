@@ -37,9 +37,18 @@ def test_golden_cases(golden_dir):
         assert adv[-1] == 0.0
 
 
+@pytest.fixture(params=['self-starting window', 'f64-seeded window'])
+def gae_form(request, monkeypatch):
+    """Both single-array forms of csrc/gae.hip: one launch whose walkers start from 0 far enough behind their items (the default
+    where gamma lambda lets the 1024-element window do it), and pass 1's f64 chunk maps seeding a shorter warm-up (PFA_GAE_SELF=0;
+    what runs for gamma lambda > 0.968)."""
+    monkeypatch.setenv('PFA_GAE_SELF', '1' if request.param.startswith('self') else '0')
+    return request.param
+
+
 @pytest.mark.parametrize('n,p_done', [(524288, 0.0), (524288, 0.01), (524288, 0.25), (2048, 0.1), (2049, 0.1),
-                                       (65537, 0.5), (3, 0.0)])
-def test_vs_oracle_full_size(n, p_done):
+                                       (65537, 0.5), (3, 0.0), (1023, 0.0), (1025, 0.02), (9, 0.0)])
+def test_vs_oracle_full_size(n, p_done, gae_form):
     from oracle import c_oracle
     rng = np.random.RandomState(n % 1000 + int(p_done * 100))
     d = (rng.rand(n) < p_done).astype(np.float32)
@@ -55,7 +64,7 @@ def test_vs_oracle_full_size(n, p_done):
 
 
 @pytest.mark.parametrize('gamma,lam', [(0.99, 0.95), (0.9, 0.8), (0.997, 0.97), (1.0, 1.0), (0.5, 0.0)])
-def test_bit_identical_to_the_sequential_loop_for_other_discounts(gamma, lam):
+def test_bit_identical_to_the_sequential_loop_for_other_discounts(gamma, lam, gae_form):
     """gamma lambda up to ~0.985 (here 0.967): the warm-up (ln 1e-7 / ln(gamma lambda) elements, at most 1024) has contracted the
     start error away and the result is c_gae's bit pattern; at gamma = lambda = 1 nothing contracts and the kernel is what every scan
     is: within a few ulps."""
@@ -179,7 +188,7 @@ def test_sharded_one_exchange_form_equals_flat_scan(n, shards, p_done):
 
 @pytest.mark.parametrize('N,T,nmb,bptt', [(4096, 128, 4, 16), (64, 128, 4, 16), (48, 32, 2, 8), (5, 16, 1, 16), (256, 64, 8, 32),
                                           (1000, 24, 1, 8), (8, 128, 32, 8)])
-def test_one_pass_gae_with_sums_equals_the_separate_entry_points(N, T, nmb, bptt):
+def test_one_pass_gae_with_sums_equals_the_separate_entry_points(N, T, nmb, bptt, gae_form):
     """pfa_gae_sums_f32 = pfa_gae_f32 (advantages / returns bit for bit) + the per-minibatch advantage sums (numpy f64 over the
     minibatch's rows, clean_pufferl.py:455-457 partition) + the explained-variance sums over the storage-order values
     (clean_pufferl.py:266-270)."""

@@ -539,3 +539,46 @@ def test_early_gae_pass_is_the_same_update_and_yields_to_in_place_edits(monkeypa
     assert torch.equal(runs[0][1], runs[1][1])
     shaped, plain = runs[0][0][2][2], runs[0][0][1][2]
     assert not torch.equal(shaped, plain) and float(shaped.abs().max()) > 0
+
+
+@pytest.mark.parametrize('n,horizon,epochs', [(256, 32, 2), (64, 32, 1)])
+def test_report_from_the_updates_last_launch_equals_the_packing_launch(monkeypatch, n, horizon, epochs):
+    """pfa_ppo_mlp_train_logged: the last reduce + Adam launch of an update writes train()'s ten report numbers itself (the lanes
+    that own the loss sums); PFA_FUSED_LOG=0 packs them in a launch of its own behind the update, as rounds 1-4 did.  Same losses,
+    same explained variance, same weights, bit for bit; and the call says which of the two happened."""
+    import ctypes as C
+    from pufferlib_amd import _lib, clean_pufferl
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    runs = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('PFA_FUSED_LOG', fused)
+        torch.manual_seed(3)
+        vec, pol = _make(n)
+        data = clean_pufferl.create(_config(n, horizon, n * horizon // 4, 16, epochs, n * horizon * 8, hp, seed=5), vec, pol)
+        out = []
+        for it in range(3):
+            clean_pufferl.evaluate(data)
+            clean_pufferl.train(data)
+            out.append(dict(data.losses))
+        assert all(np.isfinite(v) for o in out for k, v in o.items() if k != 'explained_variance')
+        runs.append((out, data.flat_params.flat.clone()))
+    assert repr(runs[0][0]) == repr(runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert runs[0][0][-1]['value_loss'] > 0 and runs[0][0][-1]['entropy'] > 0
+    # the entry point itself: report written by the update (log_packed = 1) == losses + ev4 packed by hand
+    L = _lib.lib()
+    ex, fp, opt = data.experience, data.flat_params, data.optimizer
+    nmb = ex.num_minibatches
+    hpar = clean_pufferl._make_hparams(data.config, ex)
+    ev4 = torch.arange(1, 5, dtype=torch.float64, device='cuda') * 0.25
+    out10 = torch.full((10,), -1.0, dtype=torch.float64, device='cuda')
+    acc = torch.zeros(8, dtype=torch.float64, device='cuda')
+    packed = C.c_int32(-1)
+    g = opt.param_groups[0]
+    _lib.check(L.pfa_ppo_mlp_train_logged(
+        C.byref(ex.c), ex.batch_size, _lib.ptr(fp.flat), C.byref(fp.dims), C.byref(hpar), _lib.ptr(data.adv_stats), _lib.ptr(data.grads),
+        _lib.ptr(opt.exp_avg), _lib.ptr(opt.exp_avg_sq), opt.step_count, float(g['lr']), 0.9, 0.999, 1e-5, 0.5, epochs, _lib.ptr(acc),
+        _lib.ptr(data.workspace), 0, _lib.ptr(ev4), _lib.ptr(out10), C.byref(packed), _lib.stream_handle()), 'train_logged')
+    torch.cuda.synchronize()
+    assert packed.value == 1
+    assert torch.equal(out10[:6], acc[:6]) and torch.equal(out10[6:], ev4) and float(acc[:3].abs().sum()) > 0
