@@ -11,7 +11,7 @@ optimizer step over RCCL.  Inputs are synthetic by construction (the env IS the 
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline     dominant kernel ppo_mlp_grad (fp32 MFMA bound): algorithmic FLOPs per launch / average launch
-               duration measured with HIP events on the launch stream over the timed region (every 5th launch
+               duration measured with HIP events on the launch stream over the timed region (every 17th launch
                bracketed: the event packets serialise the queue)
   cpu_baseline kind "reference": the UNMODIFIED reference's Serial CPU path timed on this box model by tools/gpu_jobs/
                with_reference.sh (profiles/r05_reference_cpu_on_gpu_box.json; used when the box fingerprint matches), with the
@@ -614,9 +614,10 @@ def main():
     L.pfa_timing_select(dominant.encode())
     # The event pair around a launch serialises the queue (~7 us of dispatch bubble each: 16 bracketed launches per step cost
     # the headline 7 %, measured).  The dominant kernel's launches all have the same shape in the MLP / LSTM updates, so every
-    # 5th one is bracketed (5 is coprime to the 16 launches of a step: every epoch x minibatch position gets sampled); the conv
-    # update's launches differ in shape and are all bracketed.
-    event_stride = 1 if (args.policy in ('cnn', 'wide') and not wide_fused) else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '5'))
+    # 17th one is bracketed (17 is coprime to the 16 launches of a step: every epoch x minibatch position gets sampled, ~19 launches
+    # of a 20-step region; rounds 2-5 bracketed every 5th, which tools/step_times.py shows as ~20 us of every 1.27 ms step — the
+    # same loop without the brackets, from a cold start); the conv update's launches differ in shape and are all bracketed.
+    event_stride = 1 if (args.policy in ('cnn', 'wide') and not wide_fused) else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '17'))
     L.pfa_timing_stride(event_stride)
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
