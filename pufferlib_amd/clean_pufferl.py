@@ -590,7 +590,7 @@ def _finish_evaluate(data, N, T):
             data._rb_eval.submit(st, finish, defer=True)
         # The update's first pass — compute_gae + the advantage statistics (train() below) — reads nothing but the rows this rollout
         # just wrote, so it is enqueued HERE, behind the event of the episode statistics: the host waits for the five numbers (and
-        # then walks back through the caller into train()) while the device already runs the ~35 us pass instead of idling through
+        # then walks back through the caller into train()) while the device already runs the ~25 us pass instead of idling through
         # that round trip.  train() recognises the pass by its key (_gae_key: storage version of rewards / dones / values,
         # hyper-parameters, partition) and launches it itself when anything changed in between (reward shaping, value
         # re-bootstrapping, another gamma) or when evaluate() was not the previous call.  PFA_EARLY_GAE=0: always in train().

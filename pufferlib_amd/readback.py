@@ -10,10 +10,12 @@ where the reference has its numbers (two stream syncs per iteration).
 copy's event and fills the container in; a readback is also resolved before its buffer is reused one iteration later, so
 the host never runs more than one iteration ahead of the device and an error carried by the numbers (the reset-tape
 underrun flag) surfaces at most one ``evaluate()`` late.  It removes the two host round trips per iteration from the
-device's timeline — and measured no gain on MI355X for the headline workload (round 2: 351 M env steps/s deferred against
-356 M immediate): the iteration is matrix-pipe- and power-bound, and every kernel runs ~2 % slower when the queue never
-drains, which is what the ~0.05 ms of host bubbles per 1.5 ms iteration buys back.  It stays as an option for hosts with
-a slow Python side; the GPU test suite passes in both modes.
+device's timeline.  History of what that is worth on MI355X for the headline workload: nothing in round 2 (351 M deferred
+against 356 M immediate), 2-3.5 % on the kernels of round 5's first half (406-416 M against 392-401 M) — and nothing again
+since ``evaluate()`` enqueues the update's GAE pass behind its statistics event (clean_pufferl._finish_evaluate: the device
+works through the host's round trip) and the waits poll instead of parking the thread (``wait_event`` below): 408.9 / 408.2 M
+deferred against 407.5 / 408.2 M immediate on one box (profiles/r05_ab_host_levers.txt).  The mode stays as an option for
+hosts with a slow Python side; the GPU test suite passes in both modes.
 """
 import os
 import time
