@@ -63,18 +63,33 @@ size_t pfa_gae_sums_workspace_bytes(int64_t n, int32_t num_minibatches);
 int pfa_gae_sums_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
                      int64_t n, float gamma, float gae_lambda, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon,
                      double *adv_stats, double *ev4, double *zero8, void *workspace, pfa_stream_t stream);
-/* Data-parallel form: the array is one rank's SHARD of the reference's single flat batch (rank-major order).
- * pass1 writes the shard's affine map {C, D} (f64, device) to shard_map[2]; the caller all-gathers the maps and
- * folds those of the later shards into carry_in[1] (f64, device) = the advantage of the first element after this
- * shard; pass2 (same workspace, untouched in between) finishes the scan.  has_next != 0: a later shard exists, the
- * three input arrays hold n+1 readable elements (element n = the next shard's first row) and the last element is
- * an interior row; has_next == 0: last shard, advantages[n-1] = 0 and carry_in is ignored. */
-int pfa_gae_shard_pass1(const float *dones, const float *values, const float *rewards, int64_t n, int has_next,
-                        float gamma, float gae_lambda, void *workspace, double *shard_map, pfa_stream_t stream);
+/* Data-parallel forms: the array is one rank's SHARD of the reference's single flat batch (rank-major order; c_gae.pyx:11-32 runs
+ * across env boundaries, so it also runs across shard boundaries).
+ *
+ * Halo form (the one clean_pufferl runs; csrc/gae.hip gae_halo_*): every rank publishes the bit patterns of its first
+ * min(n, H) rows, H = pfa_gae_halo_rows(gamma, gae_lambda), next to `n_extra` other f64 sums of the caller (episode statistics);
+ * ONE all-reduce(SUM) of out[n_extra + 3 world min(n, H)]; every rank drops the rows that follow its shard behind its arrays
+ * (which hold n + H elements) and runs the single-rank kernel over them: advantages are the BITS of the single flat scan.
+ *   pfa_gae_halo_rows      H (a multiple of 8, <= 1032); 0 = gamma * gae_lambda > 0.968: use the f64-carry form below
+ *   pfa_gae_halo_publish   out[0 .. n_extra) = extra, then [world][3][min(n, H)] bit patterns as f64 (zeros in the peers' places)
+ *   pfa_gae_halo_unpack    gathered = out + n_extra; returns halo_len = min(H, rows that follow this shard) (>= 0), < 0 on error
+ *   pfa_gae_halo_f32       the scan; adv_stats != NULL: + this rank's share of pfa_gae_sums_f32's sums (same shape rules) */
+int32_t pfa_gae_halo_rows(float gamma, float gae_lambda);
+int pfa_gae_halo_publish(const float *dones, const float *values, const float *rewards, int64_t n, float gamma, float gae_lambda,
+                         const double *extra, int32_t n_extra, double *out, int32_t rank, int32_t world, pfa_stream_t stream);
+int pfa_gae_halo_unpack(const double *gathered, int32_t rank, int32_t world, int64_t n, float gamma, float gae_lambda, float *dones,
+                        float *values, float *rewards, pfa_stream_t stream);
+int pfa_gae_halo_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns, int64_t n,
+                     int32_t halo_len, float gamma, float gae_lambda, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon,
+                     double *adv_stats, double *ev4, double *zero8, void *workspace, pfa_stream_t stream);
+/* f64-carry form (any gamma * gae_lambda; within a few fp32 ulps of the flat scan): pass 2 finishes the scan from the block
+ * aggregates in `workspace` and carry_in[1] (f64, device) = the advantage of the first element after this shard.
+ * has_next != 0: a later shard exists, the three input arrays hold n+1 readable elements (element n = the next shard's first
+ * row) and the last element is an interior row; has_next == 0: last shard, advantages[n-1] = 0 and carry_in is ignored. */
 int pfa_gae_shard_pass2(const float *dones, const float *values, const float *rewards, float *advantages,
                         float *returns, int64_t n, int has_next, float gamma, float gae_lambda,
                         const void *workspace, const double *carry_in, pfa_stream_t stream);
-/* Data-parallel GAE with ONE exchange (csrc/gae.hip): a shard's affine map is (interior) o (last element) and only the last
+/* ... with ONE exchange (csrc/gae.hip): a shard's affine map is (interior) o (last element) and only the last
  * element needs the next shard's first row, so every rank publishes six numbers it can compute from its own rows — interior map
  * (C, D), values[n-1], first row (done, value, reward) — next to `n_extra` other f64 sums of the caller (episode statistics):
  *   pfa_gae_shard_publish   out[0 .. n_extra) = extra, out[n_extra + 6 q + j] = the six numbers for q == rank, 0 elsewhere
@@ -736,6 +751,11 @@ int pfa_p2p_all_reduce_f64(double *buf, int64_t count, pfa_stream_t stream);
  * (stand-alone + fused). */
 int pfa_p2p_ll_all_reduce_f32(float *buf, int64_t count, pfa_stream_t stream);
 int64_t pfa_p2p_ll_calls(void);
+/* Peer-wait telemetry: out4 = { ticks, workgroups } of the flag-in-data exchanges (the optimizer steps' exchange inside the reduce +
+ * Adam launch), { ticks, chunks } of the flag-based all-reduces (the small f64 exchanges): 100 MHz ticks a workgroup stood waiting
+ * for its slowest peer (its longest lane), summed since the last reset.  ticks / workgroups = the mean wait of a launch — transport
+ * latency when the ranks arrive together, rank skew on top when they do not.  Synchronises the device; reset != 0 clears. */
+int pfa_p2p_wait_stats(int64_t *out4_host, int reset);
 /* Routing switch for A/B measurements (call it on every rank alike): on = 0 makes pfa_dist_all_reduce_* and pfa_ppo_mlp_train stop
  * using the peer path — they fall to the RCCL communicator of pfa_dist_init — while the buffers stay mapped; on = 1 routes over it
  * again.  Returns the previous setting. */

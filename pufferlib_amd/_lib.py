@@ -143,7 +143,10 @@ _SIGNATURES = {
     'pfa_gae_sums_supported': (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     'pfa_gae_sums_workspace_bytes': (C.c_size_t, [C.c_int64, C.c_int32]),
     'pfa_gae_sums_f32': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P]),
-    'pfa_gae_shard_pass1': (C.c_int, [P, P, P, C.c_int64, C.c_int, C.c_float, C.c_float, P, P, P]),
+    'pfa_gae_halo_rows': (C.c_int32, [C.c_float, C.c_float]),
+    'pfa_gae_halo_publish': (C.c_int, [P, P, P, C.c_int64, C.c_float, C.c_float, P, C.c_int32, P, C.c_int32, C.c_int32, P]),
+    'pfa_gae_halo_unpack': (C.c_int, [P, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_float, P, P, P, P]),
+    'pfa_gae_halo_f32': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32, C.c_int32, P, P, P, P, P]),
     'pfa_gae_shard_pass2': (C.c_int, [P, P, P, P, P, C.c_int64, C.c_int, C.c_float, C.c_float, P, P, P]),
     'pfa_gae_shard_publish': (C.c_int, [P, P, P, C.c_int64, C.c_float, C.c_float, P, P, C.c_int32, P, C.c_int32, C.c_int32, P]),
     'pfa_gae_shard_fold': (C.c_int, [P, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_float, P, P, P, P, P, P]),
@@ -286,6 +289,7 @@ _SIGNATURES = {
     'pfa_p2p_all_reduce_f64': (C.c_int, [P, C.c_int64, P]),
     'pfa_p2p_ll_all_reduce_f32': (C.c_int, [P, C.c_int64, P]),
     'pfa_p2p_ll_calls': (C.c_int64, []),
+    'pfa_p2p_wait_stats': (C.c_int, [P, C.c_int]),
     'pfa_p2p_enable': (C.c_int, [C.c_int]),
     'pfa_train_log_sums': (C.c_int, [C.POINTER(Experience), C.c_int64, C.c_int32, P, P, P, P]),
     'pfa_adam_clip_step': (C.c_int, [P, P, P, P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int64,

@@ -11,14 +11,18 @@ losses, wandb, global_step, epoch, stats, msg, last_log_time, utilization), so t
 
 What is different underneath: there is no host round-trip per step.  For a
 pufferlib_amd.vector.Squared vecenv and an MLP policy evaluate() is ONE persistent kernel (csrc/rollout.hip) and
-train() is GAE (2 launches) + per optimizer step 3 launches (fused fwd/loss/bwd, partial reduce, clip+Adam).
+train() is one native call that enqueues, per optimizer step, the gradient kernel (fused fwd / loss / bwd) and the reduce + clip +
+Adam kernel; GAE and the advantage statistics (2 launches) already ran at the end of evaluate(), under the host's wait for the episode
+statistics.
 Experience is stored env-major on device, which is the order the reference gets after sort_training_data
 (clean_pufferl.py:452-464), so there is no sort and no gather.
 
 Data parallel (no reference counterpart): one process per GPU; rank r owns envs
 [r*N, (r+1)*N) (seeds seed + global index), parameters are broadcast from rank 0 at create(), and every
-optimizer step all-reduces one flat bucket (gradient + 8 loss sums as float pairs) over RCCL; the advantage-normalisation sums
-are all-reduced once per update so every rank normalises with the global-minibatch mean/std.
+optimizer step all-reduces one flat bucket (gradient + 8 loss sums as float pairs) — inside the reduce + Adam launch over the
+peer-mapped path, else RCCL; at the end of evaluate() two small all-reduces (episode statistics + the GAE halo rows; the
+advantage-normalisation and explained-variance sums) so that every rank scans the flat batch's own bits and normalises with the
+global-minibatch mean/std, and train() holds no collective but its optimizer steps'.
 
 Interface mirroring, stated plainly: `Profile` / `Profile.update` (the timer fields the dashboard and wandb logging read,
 clean_pufferl.py:341-367), the `Utilization` sampling loop, the `rollout()` viewer's render / step lines and the tmp-then-rename
@@ -95,6 +99,9 @@ class HipAdam:
         self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
 
 
+GAE_HALO_MAX = 1032
+
+
 class Experience:
     """clean_pufferl.Experience (clean_pufferl.py:380-482) as device tensors in env-major order:
     row (env e, step t) at flat index e*T + t."""
@@ -123,8 +130,9 @@ class Experience:
             self.obs = torch.zeros(B, obs_stride, dtype=torch.float32, device=device)
         self.actions = torch.zeros(B, dtype=torch.int32, device=device)
         self.logprobs = torch.zeros(B, dtype=torch.float32, device=device)
-        # one spare element behind rewards/dones/values: the halo row of the data-parallel GAE (next rank's first row)
-        self._rdv = torch.zeros(3, B + 1, dtype=torch.float32, device=device)
+        # room behind rewards / dones / values for the halo of the data-parallel GAE: the rows that follow this rank's shard in the
+        # rank-major flat batch (csrc/gae.hip gae_halo_*: at most the self-starting window's 1024 + 8)
+        self._rdv = torch.zeros(3, B + GAE_HALO_MAX, dtype=torch.float32, device=device)
         self.rewards, self.dones, self.values = self._rdv[0, :B], self._rdv[1, :B], self._rdv[2, :B]
         self.advantages = torch.zeros(B, dtype=torch.float32, device=device)
         self.returns = torch.zeros(B, dtype=torch.float32, device=device)
@@ -314,7 +322,9 @@ def create(config, vecenv, policy, optimizer=None, wandb=None):
     if world > 1:
         dist.broadcast(fp.flat, src=0)
         # RCCL communicator inside the native library and / or the one-shot peer path for this policy's bucket, else torch fallback
-        native_dp = pdist.init_native(bucket_bytes=(fp.count + 16) * 4)
+        # (the other exchange the slots must hold: episode statistics + the GAE halo rows of every rank as f64 bit patterns, _publish_gae)
+        native_dp = pdist.init_native(bucket_bytes=(fp.count + 16) * 4,
+                                      small_bytes=8 * (16 + 3 * world * min(config.batch_size, GAE_HALO_MAX)))
     elif _cfg(config, 'force_native_dp', False):
         native_dp = pdist.init_native(force_single=True)   # 1-rank communicator: exercises the DP code path in tests
     policy.noise_seed = int(config.seed)
@@ -560,11 +570,10 @@ def _finish_evaluate(data, N, T):
             st = vecenv.stats_with_flag(reset=True, out=data._rb_eval.direct_buffer(5, torch.float64))
         else:
             st = vecenv.stats_with_flag(reset=True)     # 4 sums + the tape underrun flag
-        if data.world_size > 1 and _early_gae() and getattr(experience, '_rdv', None) is not None:
-            # data parallel: the episode statistics and the six numbers per rank the sharded GAE needs (csrc/gae.hip: interior map,
-            # last value, first row — all from this rank's own rows, complete once the rollout is) ride ONE all-reduce; train()
-            # finishes the scan from them without another exchange.  (PFA_DP_EARLY_GAE=0 for callers that rewrite rewards / values /
-            # dones between evaluate() and train(): the GAE exchange then happens in train().)
+        early = _early_gae() and experience.full and data.host_bridge is None
+        if data.world_size > 1 and early:
+            # data parallel: the episode statistics and what the sharded GAE needs from the other ranks (csrc/gae.hip: the first rows
+            # of the shards that follow — all from every rank's own rows, complete once its rollout is) ride ONE all-reduce
             st = _publish_gae(data, st)
         elif data.native_dp:
             _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(st), st.numel(), _lib.stream_handle()), 'stats all-reduce')
@@ -594,9 +603,13 @@ def _finish_evaluate(data, N, T):
         # that round trip.  train() recognises the pass by its key (_gae_key: storage version of rewards / dones / values,
         # hyper-parameters, partition) and launches it itself when anything changed in between (reward shaping, value
         # re-bootstrapping, another gamma) or when evaluate() was not the previous call.  PFA_EARLY_GAE=0: always in train().
+        # Data parallel the pass includes its two exchanges (the halo rows with the episode statistics above, the advantage sums
+        # here); a caller that edits the rows between the two calls does so on EVERY rank (train() then repeats both, collectively).
         data._gae_done = None
-        if (os.environ.get('PFA_EARLY_GAE', '1') != '0' and experience.full and data.host_bridge is None
-                and _fused_sums_ok(data, data.world_size)):
+        if early and data.world_size > 1:
+            _finish_gae(data)                   # the scan, this rank's sums, ONE all-reduce of them: train() holds no collective but its optimizer steps'
+            data._gae_done = _gae_key(data)
+        elif early and _fused_sums_ok(data, data.world_size):
             _launch_gae_sums(data)
             data._gae_done = _gae_key(data)
         if readback.eager():
@@ -604,42 +617,35 @@ def _finish_evaluate(data, N, T):
     return stats, infos
 
 
-def _all_gather_small(dist, x, rank, world, native=False):
-    """all_gather of a tiny tensor as one all-reduce(SUM) of a zero-padded [world, ...] buffer: exact (every slot has one
-    non-zero contributor) and available for device tensors on every backend (gloo has no device all_gather).  `native`: through
-    the native communicator on the compute stream (no stream hand-off), like every other collective of the update."""
-    buf = torch.zeros((world,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-    buf[rank] = x
-    if native:
-        fn = _lib.lib().pfa_dist_all_reduce_f64 if x.dtype == torch.float64 else _lib.lib().pfa_dist_all_reduce_f32
-        _lib.check(fn(_lib.ptr(buf), buf.numel(), _lib.stream_handle()), 'all_gather_small')
-    else:
-        dist.all_reduce(buf)
-    return buf
-
-
 def _early_gae():
-    return os.environ.get('PFA_DP_EARLY_GAE', '1') != '0'
+    return os.environ.get('PFA_EARLY_GAE', '1') != '0'
 
 
-def _fused_sums_ok(data, world):
-    """Single rank: GAE, the per-minibatch advantage sums and the explained-variance sums in ONE pass over the rows
-    (pfa_gae_sums_f32: 3 launches; the separate entry points: 6) where the partition allows it."""
+def _ev_with_gae(data, world):
+    """The four explained-variance sums only need advantages and values, so they are taken with the advantage sums (data parallel:
+    they ride that all-reduce) — except in the one mode whose y_pred is the host path's arrival-order value buffer."""
+    return not (getattr(data, 'arrival_values', None) is not None and _cfg(data.config, 'async_store', 'balanced') == 'reference')
+
+
+def _fused_sums_ok(data, world=1):
+    """GAE, the per-minibatch advantage sums and the explained-variance sums in ONE pass over the rows (pfa_gae_sums_f32 /
+    pfa_gae_halo_f32 with sums) where the partition allows it; the separate entry points otherwise."""
     config, experience = data.config, data.experience
-    return (world == 1 and os.environ.get('PFA_GAE_SUMS', '1') != '0'
-            and not (getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference')
+    return (_ev_with_gae(data, world)
             and bool(_lib.lib().pfa_gae_sums_supported(experience.batch_size, experience.num_envs, experience.num_minibatches,
                                                        int(config.bptt_horizon))))
 
 
 def _gae_key(data):
-    """What the GAE pass is a function of, as far as the host can see it: the version counter of the rewards / dones / values
-    storage (every in-place torch write through any view bumps it; the library's kernels write through raw pointers and do not),
-    the hyper-parameters and the partition."""
+    """What the GAE pass is a function of, as far as the host can see it: the storage (address + version counter: every in-place
+    torch write through any view bumps it) of rewards / dones / values, the buffers it writes, the hyper-parameters and the
+    partition.  The library's own kernels and writes through numpy / raw-pointer views are invisible to the counter: a pipeline
+    that rewrites the rows that way between evaluate() and train() sets ``data._gae_done = None`` (or PFA_EARLY_GAE=0)."""
     config, ex = data.config, data.experience
     rdv = getattr(ex, '_rdv', None)
     ver = rdv._version if rdv is not None else (ex.rewards._version, ex.dones._version, ex.values._version)
-    return (ver, ex.batch_size, float(config.gamma), float(config.gae_lambda), ex.num_envs, ex.num_minibatches,
+    ptrs = tuple(int(getattr(ex, k).data_ptr()) for k in ('rewards', 'dones', 'values', 'advantages', 'returns'))
+    return (ver, ptrs, ex.batch_size, float(config.gamma), float(config.gae_lambda), ex.num_envs, ex.num_minibatches,
             int(config.bptt_horizon), bool(config.norm_adv))
 
 
@@ -654,52 +660,86 @@ def _launch_gae_sums(data):
         _lib.ptr(data.workspace), _lib.stream_handle()), 'gae_sums')
 
 
+def _all_reduce_f64(data, buf, what):
+    if data.native_dp:
+        _lib.check(_lib.lib().pfa_dist_all_reduce_f64(_lib.ptr(buf), buf.numel(), _lib.stream_handle()), what)
+    else:
+        _dist()[0].all_reduce(buf)
+
+
 def _publish_gae(data, extra=None):
-    """First half of the data-parallel GAE (csrc/gae.hip, one-exchange form): this rank's six numbers + `extra` (f64 sums that
-    ride along: the episode statistics) -> ONE all-reduce(SUM).  Returns the all-reduced `extra` (a view of the exchange buffer);
-    the gathered GAE numbers stay in data._dp_eval for _finish_gae."""
+    """First half of the data-parallel GAE: what the other ranks need from this rank's rows + `extra` (f64 sums that ride along: the
+    episode statistics) -> ONE all-reduce(SUM).  Returns the all-reduced `extra` (a view of the exchange buffer).
+    Halo form (csrc/gae.hip gae_halo_*, gamma lambda <= 0.968): the bit patterns of the shard's first rows, so that every rank runs
+    the single-rank kernel over its rows + the rows that follow them — the flat scan's own bits.  Otherwise the f64-carry form: six
+    numbers per rank (interior map, last value, first row), a few ulps from the flat scan at the shard ends."""
     config, ex = data.config, data.experience
     L, B, stream = _lib.lib(), ex.batch_size, _lib.stream_handle()
-    dist, rank, world = _dist()
+    _, rank, world = _dist()
+    gamma, lam = float(config.gamma), float(config.gae_lambda)
     n_extra = 0 if extra is None else extra.numel()
-    if data._dp_eval is None or data._dp_eval.numel() != n_extra + 6 * world:
-        data._dp_eval = torch.zeros(n_extra + 6 * world, dtype=torch.float64, device=ex.device)
+    H = int(L.pfa_gae_halo_rows(gamma, lam))
+    if getattr(ex, '_rdv', None) is None or ex._rdv.shape[1] < B + H:
+        H = 0                          # a caller-built Experience without room behind its arrays
+    size = n_extra + (3 * world * min(B, H) if H else 6 * world)
+    if data._dp_eval is None or data._dp_eval.numel() != size:
+        data._dp_eval = torch.zeros(size, dtype=torch.float64, device=ex.device)
     buf = data._dp_eval
-    _lib.check(L.pfa_gae_shard_publish(_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards), B, float(config.gamma),
-                                       float(config.gae_lambda), _lib.ptr(data.gae_ws), _lib.ptr(extra), n_extra, _lib.ptr(buf),
-                                       rank, world, stream), 'gae publish')
-    if data.native_dp:
-        _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(buf), buf.numel(), stream), 'stats + gae all-reduce')
+    rows = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
+    if H:
+        _lib.check(L.pfa_gae_halo_publish(*rows, B, gamma, lam, _lib.ptr(extra), n_extra, _lib.ptr(buf), rank, world, stream), 'gae halo publish')
     else:
-        dist.all_reduce(buf)
-    data._gae_published = True
-    data._gae_pub_version = getattr(ex, '_rdv', ex.rewards)._version     # in-place edits of rewards / dones / values bump it
+        _lib.check(L.pfa_gae_shard_publish(*rows, B, gamma, lam, _lib.ptr(data.gae_ws), _lib.ptr(extra), n_extra, _lib.ptr(buf), rank, world,
+                                           stream), 'gae publish')
+    _all_reduce_f64(data, buf, 'stats + gae all-reduce')
+    data._gae_published = (H, n_extra)
     return buf[:n_extra]
 
 
-def _finish_gae(data, rank, world, stream):
-    """compute_gae over the GLOBAL rank-major flat batch (c_gae.pyx:11-32 crosses env boundaries, so it also crosses shard
-    boundaries) from the numbers _publish_gae gathered: fold the later shards into the carry-in, then the local scan."""
+def _finish_gae(data):
+    """Second half: compute_gae over the GLOBAL rank-major flat batch (c_gae.pyx:11-32 crosses env boundaries, so it also crosses
+    shard boundaries) from what _publish_gae gathered, this rank's share of the update's sums (per-minibatch advantage sums, the
+    explained-variance sums) and ONE all-reduce of those — every rank then normalises with the global-minibatch mean / std."""
     config, ex = data.config, data.experience
-    L, B = _lib.lib(), ex.batch_size
-    if not data._gae_published:           # evaluate() did not publish (host vecenv path, PFA_DP_EARLY_GAE=0): exchange here
+    L, B, stream = _lib.lib(), ex.batch_size, _lib.stream_handle()
+    _, rank, world = _dist()
+    gamma, lam = float(config.gamma), float(config.gae_lambda)
+    nmb = ex.num_minibatches
+    if not data._gae_published:
         _publish_gae(data, None)
-    elif getattr(ex, '_rdv', ex.rewards)._version != data._gae_pub_version:
-        # advisor (round 4): the shard's interior map / last value / first row were published at the end of evaluate(); rewards,
-        # values or dones edited since (reward shaping, value re-bootstrapping) would silently meet stale numbers at the shard
-        # boundaries.  Re-publishing is a collective every rank would have to agree on, so this is an error with the way out named.
-        raise RuntimeError('experience.rewards / values / dones were modified in place between evaluate() and train() on a '
-                           'data-parallel run: the sharded GAE published its boundary numbers at the end of evaluate().  Set '
-                           'PFA_DP_EARLY_GAE=0 on every rank (the exchange then happens inside train())')
-    gathered = data._dp_eval[data._dp_eval.numel() - 6 * world:]
-    has_next = int(rank < world - 1)
-    args = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
-    _lib.check(L.pfa_gae_shard_fold(_lib.ptr(gathered), rank, world, B, float(config.gamma), float(config.gae_lambda),
-                                    _lib.ptr(data.gae_ws), *args, _lib.ptr(data.gae_carry), stream), 'gae fold')
-    _lib.check(L.pfa_gae_shard_pass2(*args, _lib.ptr(ex.advantages), _lib.ptr(ex.returns), B, has_next,
-                                     float(config.gamma), float(config.gae_lambda), _lib.ptr(data.gae_ws),
-                                     _lib.ptr(data.gae_carry) if has_next else None, stream), 'gae pass 2')
-    data._gae_published = False
+    H, n_extra = data._gae_published
+    data._gae_published = None
+    gathered = data._dp_eval[n_extra:]
+    rows = (_lib.ptr(ex.dones), _lib.ptr(ex.values), _lib.ptr(ex.rewards))
+    ev4 = C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb)
+    fused = bool(H) and _fused_sums_ok(data, world)
+    if H:
+        halo_len = L.pfa_gae_halo_unpack(_lib.ptr(gathered), rank, world, B, gamma, lam, *rows, stream)
+        if halo_len < 0:
+            _lib.check(halo_len, 'gae halo unpack')
+        _lib.check(L.pfa_gae_halo_f32(*rows, _lib.ptr(ex.advantages), _lib.ptr(ex.returns), B, halo_len, gamma, lam, ex.num_envs, nmb,
+                                      int(config.bptt_horizon), _lib.ptr(data.adv_stats) if fused else None, ev4, _lib.ptr(data.loss_acc),
+                                      _lib.ptr(data.workspace), stream), 'gae halo')
+    else:
+        has_next = int(rank < world - 1)
+        _lib.check(L.pfa_gae_shard_fold(_lib.ptr(gathered), rank, world, B, gamma, lam, _lib.ptr(data.gae_ws), *rows,
+                                        _lib.ptr(data.gae_carry), stream), 'gae fold')
+        _lib.check(L.pfa_gae_shard_pass2(*rows, _lib.ptr(ex.advantages), _lib.ptr(ex.returns), B, has_next, gamma, lam,
+                                         _lib.ptr(data.gae_ws), _lib.ptr(data.gae_carry) if has_next else None, stream), 'gae pass 2')
+    with_ev = _ev_with_gae(data, world)
+    if not fused:
+        hp = _make_hparams(config, ex)
+        if config.norm_adv:
+            _lib.check(L.pfa_ppo_adv_stats(C.byref(ex.c), B, C.byref(hp), _lib.ptr(data.adv_stats), _lib.ptr(data.workspace), stream), 'adv_stats')
+        else:
+            data.adv_stats.zero_()
+        if with_ev:
+            _lib.check(L.pfa_train_ev_sums(C.byref(ex.c), B, ex.num_envs, ev4, _lib.ptr(data.workspace), stream), 'train_ev_sums')
+        data.loss_acc.zero_()
+    if with_ev:
+        _all_reduce_f64(data, data.dp_sums, 'adv + ev all-reduce')
+    elif config.norm_adv:
+        _all_reduce_f64(data, data.adv_stats, 'adv all-reduce')
 
 
 @utils.profile
@@ -718,38 +758,24 @@ def train(data):
         # compute_gae over the env-major batch (clean_pufferl.py:163-169) + returns (:482)
         # single rank: GAE, the per-minibatch advantage sums and the explained-variance sums in ONE pass over the rows
         # (pfa_gae_sums_f32: 3 launches; the separate entry points below: 6) where the partition allows it
-        fused_sums = _fused_sums_ok(data, world)
         early_key, data._gae_done = getattr(data, '_gae_done', None), None      # (one use: a second train() on the same rows runs its own pass)
+        fresh = early_key is not None and early_key == _gae_key(data)           # evaluate() already ran this very pass
+        early_ev = _ev_with_gae(data, world)          # the explained-variance sums exist since the GAE pass (else: taken at the end)
+        fused_sums = world == 1 and _fused_sums_ok(data, world)
         if world > 1:
-            _finish_gae(data, rank, world, stream)
+            if not fresh:                             # (host vecenv, PFA_EARLY_GAE=0, rows edited since — on every rank: both exchanges are collectives)
+                _finish_gae(data)
         elif fused_sums:
-            if early_key is None or early_key != _gae_key(data):                # evaluate() already ran this very pass otherwise
+            if not fresh:
                 _launch_gae_sums(data)
         else:
+            early_ev = False
             _lib.check(L.pfa_gae_f32(_lib.ptr(experience.dones), _lib.ptr(experience.values), _lib.ptr(experience.rewards),
                                      _lib.ptr(experience.advantages), _lib.ptr(experience.returns), B, float(config.gamma),
                                      float(config.gae_lambda), _lib.ptr(data.workspace), stream), 'gae')
-        if config.norm_adv and not fused_sums:
-            _lib.check(L.pfa_ppo_adv_stats(C.byref(experience.c), B, C.byref(hp), _lib.ptr(data.adv_stats),
-                                           _lib.ptr(data.workspace), stream), 'adv_stats')
-        # data parallel: the four explained-variance sums only need advantages and values, so they ride the all-reduce of the
-        # advantage sums instead of one of their own at the end of train()
-        early_ev = world > 1 and not (getattr(data, 'arrival_values', None) is not None and _cfg(config, 'async_store', 'balanced') == 'reference')
-        if early_ev:
-            _lib.check(L.pfa_train_ev_sums(C.byref(experience.c), B, experience.num_envs, C.c_void_p(data.dp_sums.data_ptr() + 16 * nmb),
-                                           _lib.ptr(data.workspace), stream), 'train_ev_sums')
-            if not config.norm_adv:
-                data.adv_stats.zero_()
-            if data.native_dp:
-                _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(data.dp_sums), data.dp_sums.numel(), stream), 'adv + ev all-reduce')
-            else:
-                dist.all_reduce(data.dp_sums)
-        elif config.norm_adv:
-            if data.native_dp:
-                _lib.check(L.pfa_dist_all_reduce_f64(_lib.ptr(data.adv_stats), data.adv_stats.numel(), stream), 'adv all-reduce')
-            elif world > 1:
-                dist.all_reduce(data.adv_stats)
-        if not fused_sums:                      # (the fused pass cleared it)
+            if config.norm_adv:
+                _lib.check(L.pfa_ppo_adv_stats(C.byref(experience.c), B, C.byref(hp), _lib.ptr(data.adv_stats),
+                                               _lib.ptr(data.workspace), stream), 'adv_stats')
             data.loss_acc.zero_()
         experience.ptr = 0
         experience.step = 0
@@ -782,7 +808,7 @@ def train(data):
         # enqueued by one native call on the compute stream
         with profile.learn:
             g = opt.param_groups[0]
-            if (early_ev or fused_sums) and os.environ.get('PFA_FUSED_LOG', '1') != '0':
+            if early_ev:
                 # the report (six loss sums + the four explained-variance sums, known since GAE) rides the update's last launch,
                 # straight into the readback's pinned buffer where the runtime allows it
                 direct_log = readback.direct_ok(experience.device)
@@ -827,7 +853,7 @@ def train(data):
         # y_pred = values in STORAGE (step-major) order, y_true = advantages (env-major) + y_pred; one D2H of 10 f64
         if log_packed.value:                                    # the update's last launch already left the ten numbers (pfa_ppo_mlp_train_logged)
             pass
-        elif early_ev or fused_sums:                            # the sums exist since GAE (data parallel: all-reduced with the advantage sums)
+        elif early_ev:                                          # the sums exist since GAE (data parallel: all-reduced with the advantage sums)
             # ... and the ten numbers go straight into the pinned host buffer of the readback (no device-to-host copy launch behind it)
             if log_out is None:
                 direct_log = readback.direct_ok(experience.device)

@@ -212,8 +212,8 @@ struct GaeSums {
 // the window holds (0, 0) pairs, where x = 0 IS the reference's value (adv[n-1] = 0, c_gae.pyx:24).
 template <bool SUMS, bool SELF>
 __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *dones, const float *values, const float *rewards, float *adv,
-                                                               float *ret, long long n, float gamma, float lam, const Affine *agg,
-                                                               int nchunks, int warm, GaeSums sums) {
+                                                               float *ret, long long n, long long n_read, float gamma, float lam,
+                                                               const Affine *agg, int nchunks, int warm, GaeSums sums) {
     __shared__ Affine sh[SELF ? 1 : kGaeThreads / 64];
     __shared__ double s_carry;
     __shared__ float2 cd[kGaeBlock + kGaeBlock / 8];      // (coef, delta) of the window's elements, index i + i / 8
@@ -241,7 +241,7 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
     GaeItems it;
     // SELF: only the window elements a walker can reach are fetched (the last walker starts at element 1024 + 8 + warm)
     const bool feeds = !SELF || tid * kGaeItems < kGaeChunk + kGaeItems + warm;
-    if (feeds) gae_load(dones, values, rewards, s, n, it);
+    if (feeds) gae_load(dones, values, rewards, s, n_read, it);
     if constexpr (!SELF) {
         Affine mine = gae_thread_map(it, s, n, gamma, lam, true), after;
         block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
@@ -252,8 +252,8 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
 #pragma unroll
     for (int i = 0; i < kGaeItems; ++i) {
         const long long t = s + i;
-        float2 e = make_float2(0.0f, 0.0f);           // t >= n - 1: adv = 0 (the pinned last element; nothing beyond the array)
-        if (t < n - 1) {
+        float2 e = make_float2(0.0f, 0.0f);           // t >= n_read - 1: adv = 0 (the pinned last element; nothing beyond the array)
+        if (t < n_read - 1) {
             const float nnt = 1.0f - it.d[i + 1];
             e.y = (it.r[i + 1] + (gamma * it.v[i + 1]) * nnt) - it.v[i];
             e.x = (gamma * lam) * nnt;
@@ -364,29 +364,6 @@ __global__ void __launch_bounds__(64) gae_sums_final_kernel(const double *part, 
     if (q == 0 && zero8 && lane < 8) zero8[lane] = 0.0;
 }
 
-// Composition of all block maps of this array = the affine map of the whole shard (data-parallel GAE: rank r's
-// carry-in is (shard_{r+1} o ... o shard_{R-1})(0), so one all-gather of these pairs restores the reference's
-// single flat scan across shard boundaries).
-__global__ void gae_shard_aggregate_kernel(const Affine *agg, int nblocks, double *out2) {
-    const int lane = lane_id();
-    const int per = (nblocks + 63) / 64;
-    Affine f = {1.0, 0.0};
-    for (int i = per - 1; i >= 0; --i) {
-        const int b = lane * per + i;
-        if (b < nblocks) f = compose(agg[b], f);
-    }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const Affine o = shfl_down_affine(f, off);
-        if (lane + off < 64) f = compose(f, o);
-    }
-    if (lane == 0) {
-        out2[0] = f.c;
-        out2[1] = f.d;
-    }
-}
-
-
 // ---- data-parallel GAE with ONE exchange -------------------------------------------------------------------------------------
 // A shard's map is (interior) o (last element), and only the last element's map needs the next shard's first row.  So every rank
 // publishes six numbers that come from its OWN rows alone — the interior map (C, D) of elements 0 .. n-2, values[n-1], and its
@@ -450,6 +427,44 @@ __global__ void gae_shard_fold_kernel(const double *pub, int rank, int world, lo
     }
 }
 
+// ---- data-parallel GAE, halo form: the flat scan's own bits on every rank (round 6) ------------------------------------------
+// The self-starting window (gae_exact_kernel<.., SELF>) needs nothing from the rows behind a walker's items but the rows
+// themselves: `warm` of them.  For a shard of the rank-major flat batch those rows are its own, except behind its last items, where
+// they are the first rows of the NEXT shard(s).  So every rank publishes its first min(n, H) rows (done, value, reward),
+// H = warm + 8, one all-reduce gathers them (next to the episode statistics), every rank drops the H rows that follow its shard
+// behind its arrays and runs the SAME kernel the single-rank path runs with n_read = n + halo: every walker is then on the
+// reference's own rounded sequence exactly as in the flat scan, shard boundary or not (tests/test_gpu_dp.py: array_equal at 8 ranks).
+// The rows travel as their BIT PATTERNS in f64 (an integer < 2^32 plus zeros from the other ranks sums exactly; a float sum would
+// turn -0.0 into +0.0).  Layout of the exchange buffer: out[0 .. n_extra) = extra, out[n_extra + (3 q + k) hp + i] = bits of
+// {dones, values, rewards}[k][i] of rank q, hp = min(n, H).
+__global__ void __launch_bounds__(256) gae_halo_publish_kernel(const float *dones, const float *values, const float *rewards, int hp,
+                                                               const double *extra, int n_extra, double *out, int rank, int world) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n_extra) {
+        out[i] = extra[i];
+        return;
+    }
+    const long long j = i - n_extra;
+    if (j >= (long long)world * 3 * hp) return;
+    const int q = (int)(j / (3 * hp)), k = (int)(j % (3 * hp)) / hp, row = (int)(j % hp);
+    double v = 0.0;
+    if (q == rank) v = (double)__float_as_uint((k == 0 ? dones : k == 1 ? values : rewards)[row]);
+    out[i] = v;
+}
+
+// Halo element i of rank `rank` = row (i % n) of rank rank + 1 + i / n (all shards hold n rows); halo_len <= (world - 1 - rank) n.
+__global__ void __launch_bounds__(256) gae_halo_unpack_kernel(const double *gathered, int hp, int rank, long long n, int halo_len, float *dones,
+                                                              float *values, float *rewards) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= halo_len) return;
+    const int q = rank + 1 + (int)(i / n), row = (int)(i % n);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const unsigned bits = (unsigned)gathered[((size_t)3 * q + k) * hp + row];
+        (k == 0 ? dones : k == 1 ? values : rewards)[n + i] = __uint_as_float(bits);
+    }
+}
+
 }  // namespace pfa
 
 using namespace pfa;
@@ -492,7 +507,7 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // both passes
     if (const int ws = gae_warm_self(gamma, gae_lambda)) {   // one launch: the window warms itself up (no chunk maps)
         hipLaunchKernelGGL((gae_exact_kernel<false, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                           advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, GaeSums{});
+                           advantages, returns, (long long)n, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, GaeSums{});
         PFA_LAUNCH_CHECK();
         return 0;
     }
@@ -500,7 +515,7 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
                        rewards, (long long)n, gamma, gae_lambda, agg, 0);
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL((gae_exact_kernel<false, false>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                       advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), GaeSums{});
+                       advantages, returns, (long long)n, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), GaeSums{});
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -534,13 +549,13 @@ extern "C" int pfa_gae_sums_f32(const float *dones, const float *values, const f
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // all launches (three; two in the self-starting form)
     if (const int ws = gae_warm_self(gamma, gae_lambda)) {
         hipLaunchKernelGGL((gae_exact_kernel<true, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                           advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, sums);
+                           advantages, returns, (long long)n, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, sums);
     } else {
         hipLaunchKernelGGL(gae_aggregate_kernel<kGaeChunkThreads>, dim3((unsigned)nc), dim3(kGaeChunkThreads), 0, (hipStream_t)stream, dones, values,
                            rewards, (long long)n, gamma, gae_lambda, agg, 0);
         PFA_LAUNCH_CHECK();
         hipLaunchKernelGGL((gae_exact_kernel<true, false>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                           advantages, returns, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), sums);
+                           advantages, returns, (long long)n, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), sums);
     }
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nc,
@@ -549,27 +564,9 @@ extern "C" int pfa_gae_sums_f32(const float *dones, const float *values, const f
     return 0;
 }
 
-// Two-call form for an array that is one SHARD of a longer flat batch (data parallel).  Pass 1 leaves this shard's
-// affine map (C, D) in shard_map[2] (f64, device); the host side all-gathers the maps, folds the LATER shards' maps
-// into carry_in = adv of the first element after this shard, and pass 2 finishes the scan.  has_next != 0 means a
-// later shard exists: the arrays then hold n+1 readable elements, element n being the next shard's first row (its
-// done / value / reward enter this shard's last delta), and the last element is an interior row instead of the
-// pinned adv = 0.
-extern "C" int pfa_gae_shard_pass1(const float *dones, const float *values, const float *rewards, int64_t n, int has_next,
-                                   float gamma, float gae_lambda, void *workspace, double *shard_map,
-                                   pfa_stream_t stream) {
-    PFA_REQUIRE(n >= 1 && dones && values && rewards && workspace && shard_map, "gae_shard: bad arguments");
-    const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
-    PFA_REQUIRE(nb <= 0x7fffffff, "gae: batch too large");
-    Affine *agg = (Affine *)workspace;
-    hipLaunchKernelGGL(gae_aggregate_kernel<kGaeThreads>, dim3((unsigned)nb), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values,
-                       rewards, (long long)n, gamma, gae_lambda, agg, has_next ? 1 : 0);
-    PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_shard_aggregate_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, agg, (int)nb, shard_map);
-    PFA_LAUNCH_CHECK();
-    return 0;
-}
-
+// Pass 2 of the f64-carry shard form (see pfa_gae_shard_publish below): has_next != 0 means a later shard exists — the arrays then
+// hold n+1 readable elements, element n being the next shard's first row (its done / value / reward enter this shard's last
+// delta), and the last element is an interior row instead of the pinned adv = 0.
 extern "C" int pfa_gae_shard_pass2(const float *dones, const float *values, const float *rewards, float *advantages,
                                    float *returns, int64_t n, int has_next, float gamma, float gae_lambda,
                                    const void *workspace, const double *carry_in, pfa_stream_t stream) {
@@ -612,6 +609,77 @@ extern "C" int pfa_gae_shard_fold(const double *gathered, int32_t rank, int32_t 
     const int64_t nb = (n + kGaeBlock - 1) / kGaeBlock;
     hipLaunchKernelGGL(gae_shard_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, (int)rank, (int)world, (long long)n, gamma,
                        gae_lambda, (Affine *)workspace, (int)nb, dones, values, rewards, carry_out);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// Halo form of the data-parallel scan (see gae_halo_publish_kernel).  pfa_gae_halo_rows: H for this gamma lambda, 0 when the
+// self-starting window cannot serve it (gamma lambda > 0.968, or PFA_GAE_SELF=0): the f64-carry form above runs then.
+//   publish  out[n_extra + 3 world min(n, H)] <- extra | this rank's first rows as bit patterns (zeros in the other ranks' places)
+//   (the caller all-reduces `out`, SUM)
+//   unpack   gathered = out + n_extra: rows n .. n + halo_len of the three arrays <- the rows that follow this shard in the
+//            rank-major flat batch, halo_len = min(H, (world - 1 - rank) n) (returned); the arrays hold n + H elements
+//   pfa_gae_halo_f32   the scan over n rows reading n + halo_len; adv_stats != NULL: + the update's sums (pfa_gae_sums_f32's, over
+//            this rank's rows: the caller all-reduces them)
+extern "C" int32_t pfa_gae_halo_rows(float gamma, float gae_lambda) {
+    const int ws = gae_warm_self(gamma, gae_lambda);
+    return ws ? ws + kGaeItems : 0;
+}
+static int gae_halo_len(int64_t n, int32_t rank, int32_t world, int H) {
+    const int64_t follow = (int64_t)(world - 1 - rank) * n;
+    return (int)(follow < H ? follow : H);
+}
+extern "C" int pfa_gae_halo_publish(const float *dones, const float *values, const float *rewards, int64_t n, float gamma, float gae_lambda,
+                                    const double *extra, int32_t n_extra, double *out, int32_t rank, int32_t world, pfa_stream_t stream) {
+    const int H = pfa_gae_halo_rows(gamma, gae_lambda);
+    PFA_REQUIRE(H > 0, "gae_halo: gamma * lambda = %g is outside the self-starting window (pfa_gae_halo_rows)", (double)(gamma * gae_lambda));
+    PFA_REQUIRE(n >= 1 && dones && values && rewards && out && world >= 1 && rank >= 0 && rank < world && n_extra >= 0 && (n_extra == 0 || extra),
+                "gae_halo_publish: bad arguments");
+    const int hp = (int)(n < H ? n : H);
+    const long long total = (long long)n_extra + (long long)world * 3 * hp;
+    hipLaunchKernelGGL(gae_halo_publish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dones, values, rewards, hp,
+                       extra, (int)n_extra, out, (int)rank, (int)world);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int pfa_gae_halo_unpack(const double *gathered, int32_t rank, int32_t world, int64_t n, float gamma, float gae_lambda, float *dones,
+                                   float *values, float *rewards, pfa_stream_t stream) {
+    const int H = pfa_gae_halo_rows(gamma, gae_lambda);
+    PFA_REQUIRE(H > 0, "gae_halo: gamma * lambda = %g is outside the self-starting window (pfa_gae_halo_rows)", (double)(gamma * gae_lambda));
+    PFA_REQUIRE(gathered && dones && values && rewards && n >= 1 && world >= 1 && rank >= 0 && rank < world, "gae_halo_unpack: bad arguments");
+    const int len = gae_halo_len(n, rank, world, H);
+    if (len > 0) {
+        hipLaunchKernelGGL(gae_halo_unpack_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gathered,
+                           (int)(n < H ? n : H), (int)rank, (long long)n, len, dones, values, rewards);
+        PFA_LAUNCH_CHECK();
+    }
+    return len;
+}
+extern "C" int pfa_gae_halo_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns, int64_t n,
+                                int32_t halo_len, float gamma, float gae_lambda, int32_t num_envs, int32_t num_minibatches, int32_t bptt_horizon,
+                                double *adv_stats, double *ev4, double *zero8, void *workspace, pfa_stream_t stream) {
+    const int ws = gae_warm_self(gamma, gae_lambda);
+    PFA_REQUIRE(ws > 0, "gae_halo: gamma * lambda = %g is outside the self-starting window (pfa_gae_halo_rows)", (double)(gamma * gae_lambda));
+    PFA_REQUIRE(n >= 1 && halo_len >= 0 && halo_len <= ws + kGaeItems && dones && values && rewards && advantages, "gae_halo: bad arguments");
+    const int64_t nc = (n + kGaeChunk - 1) / kGaeChunk;
+    PFA_REQUIRE(nc <= 0x7fffffff, "gae: batch too large");
+    ScopedKernelTimer timer("gae", (hipStream_t)stream);
+    if (!adv_stats) {
+        hipLaunchKernelGGL((gae_exact_kernel<false, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                           advantages, returns, (long long)n, (long long)(n + halo_len), gamma, gae_lambda, (const Affine *)nullptr, (int)nc, ws,
+                           GaeSums{});
+        PFA_LAUNCH_CHECK();
+        return 0;
+    }
+    PFA_REQUIRE(gae_sums_ok(n, num_envs, num_minibatches, bptt_horizon), "gae_halo: unsupported partition for the sums (pfa_gae_sums_supported)");
+    PFA_REQUIRE(ev4 && workspace, "gae_halo: null buffer");
+    GaeSums sums{(double *)((char *)workspace + align_up((size_t)nc * sizeof(Affine), 256)), num_minibatches, bptt_horizon, num_envs,
+                 (int)(n / num_envs)};
+    hipLaunchKernelGGL((gae_exact_kernel<true, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
+                       advantages, returns, (long long)n, (long long)(n + halo_len), gamma, gae_lambda, (const Affine *)nullptr, (int)nc, ws, sums);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nc,
+                       (int)num_minibatches, adv_stats, ev4, zero8);
     PFA_LAUNCH_CHECK();
     return 0;
 }

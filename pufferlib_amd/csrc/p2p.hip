@@ -49,6 +49,8 @@ struct P2pState {
     size_t ll_offset = 0;
     unsigned ll_entries = 0, ll_seq = 0;
     unsigned long long ll_calls = 0;
+    // peer-wait telemetry (device): [0] ticks / [1] workgroups of the flag-in-data exchanges, [2] / [3] of the flag-based all-reduces
+    unsigned long long *wait_stats = nullptr;
 };
 static P2pState g_p2p;
 
@@ -67,9 +69,13 @@ static size_t p2p_total_bytes(size_t cap, int world) {
 template <typename T>
 __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers peers, int rank, int world, size_t cap, int phase,
                                                                     unsigned long long seq, T *buf, long long n, int *status,
-                                                                    long long timeout_ticks) {
+                                                                    long long timeout_ticks, unsigned long long *wait_stats) {
     __shared__ int timed_out;
-    if (threadIdx.x == 0) timed_out = 0;
+    __shared__ unsigned long long wait_max;
+    if (threadIdx.x == 0) {
+        timed_out = 0;
+        wait_max = 0;
+    }
     const int w = blockIdx.x;
     const long long per = (n + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)w * per, hi = lo + per < n ? lo + per : n;
@@ -98,9 +104,14 @@ __global__ void __launch_bounds__(kP2pThreads) p2p_all_reduce_kernel(P2pPeers pe
             }
             __builtin_amdgcn_s_sleep(2);
         }
+        if (spin) atomicMax(&wait_max, (unsigned long long)((long long)wall_clock64() - t0));
     }
     __syncthreads();
     __threadfence_system();
+    if (wait_stats && threadIdx.x == 0) {   // peer-wait telemetry (pfa_p2p_wait_stats): this chunk's longest wait for a peer's flag
+        atomicAdd(wait_stats + 2, wait_max);
+        atomicAdd(wait_stats + 3, 1ull);
+    }
     if (timed_out) {   // never hand back a partial sum
         T nan_v = (T)__builtin_nanf("");
         for (long long i = lo + threadIdx.x; i < hi; i += kP2pThreads) buf[i] = nan_v;
@@ -137,6 +148,7 @@ LlArgs p2p_ll_next() {
     d.seq = g_p2p.ll_seq;
     d.status = g_p2p.status;
     d.timeout_ticks = g_p2p.timeout_ticks;
+    d.wait_stats = g_p2p.wait_stats;
     ++g_p2p.ll_calls;
     return d;
 }
@@ -169,10 +181,10 @@ int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
     ScopedKernelTimer timer("p2p_all_reduce", stream);
     if (f64)
         hipLaunchKernelGGL(p2p_all_reduce_kernel<double>, dim3((unsigned)chunks), dim3(kP2pThreads), 0, stream, g_p2p.peers, g_p2p.rank,
-                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (double *)buf, (long long)count, g_p2p.status, g_p2p.timeout_ticks);
+                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (double *)buf, (long long)count, g_p2p.status, g_p2p.timeout_ticks, g_p2p.wait_stats);
     else
         hipLaunchKernelGGL(p2p_all_reduce_kernel<float>, dim3((unsigned)chunks), dim3(kP2pThreads), 0, stream, g_p2p.peers, g_p2p.rank,
-                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (float *)buf, (long long)count, g_p2p.status, g_p2p.timeout_ticks);
+                           g_p2p.world, g_p2p.cap_bytes, phase, seq, (float *)buf, (long long)count, g_p2p.status, g_p2p.timeout_ticks, g_p2p.wait_stats);
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -210,6 +222,10 @@ extern "C" int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64
         if (v > 0) ms = v;
     }
     g_p2p.timeout_ticks = ms * 100000;   // wall_clock64: 100 MHz
+    void *wsp = nullptr;
+    PFA_CHECK_HIP(hipMalloc(&wsp, 4 * sizeof(unsigned long long)));
+    PFA_CHECK_HIP(hipMemset(wsp, 0, 4 * sizeof(unsigned long long)));
+    g_p2p.wait_stats = (unsigned long long *)wsp;
     return 0;
 }
 
@@ -240,6 +256,7 @@ extern "C" int pfa_p2p_close(void) {
             if (q != g_p2p.rank && g_p2p.peers.base[q]) (void)hipIpcCloseMemHandle(g_p2p.peers.base[q]);
     if (g_p2p.local) (void)hipFree(g_p2p.local);
     if (g_p2p.status) (void)hipHostFree(g_p2p.status);
+    if (g_p2p.wait_stats) (void)hipFree(g_p2p.wait_stats);
     g_p2p = P2pState{};
     return 0;
 }
@@ -299,6 +316,18 @@ extern "C" int pfa_p2p_ll_all_reduce_f32(float *buf, int64_t count, pfa_stream_t
     return 0;
 }
 extern "C" int64_t pfa_p2p_ll_calls(void) { return (int64_t)g_p2p.ll_calls; }
+// Peer-wait telemetry: out4 = { ticks, workgroups } of the flag-in-data exchanges (the optimizer steps inside ppo_reduce_adam_kernel),
+// { ticks, chunks } of the flag-based all-reduces (the small f64 exchanges) — 100 MHz ticks a workgroup stood waiting for its slowest
+// peer, summed since the last reset.  Synchronises the device (a 32-byte copy); reset != 0 clears the counters afterwards.
+extern "C" int pfa_p2p_wait_stats(int64_t *out4_host, int reset) {
+    PFA_REQUIRE(out4_host != nullptr, "p2p.wait_stats: null buffer");
+    for (int i = 0; i < 4; ++i) out4_host[i] = 0;
+    if (!g_p2p.wait_stats) return 0;
+    PFA_CHECK_HIP(hipDeviceSynchronize());
+    PFA_CHECK_HIP(hipMemcpy(out4_host, g_p2p.wait_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (reset) PFA_CHECK_HIP(hipMemset(g_p2p.wait_stats, 0, 4 * sizeof(unsigned long long)));
+    return 0;
+}
 // Routing switch (bench.py's per-transport A/B, all ranks alike): 0 = pfa_dist_all_reduce_* and the native train loop stop using
 // the peer path (they fall to the RCCL communicator) although it stays open; 1 = use it again.  Returns the previous setting.
 extern "C" int pfa_p2p_enable(int on) {

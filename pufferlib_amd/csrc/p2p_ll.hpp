@@ -24,6 +24,7 @@ struct LlArgs {
     unsigned seq;                             // this call's sequence number (never 0: the area starts zeroed)
     int *status;                              // host-pinned status word (shared with the flag-based path)
     long long timeout_ticks;
+    unsigned long long *wait_stats;           // device counters (pfa_p2p_wait_stats): [0] += ticks a workgroup spent waiting for peers, [1] += 1
 };
 
 __device__ __forceinline__ unsigned long long ll_pack(float v, unsigned seq) {
@@ -39,7 +40,8 @@ __device__ __forceinline__ void ll_push(const LlArgs &d, unsigned idx, float v) 
 }
 
 // Sum of entry idx over all ranks in rank order (this rank's own term from the register).  Identical bits on every rank.
-__device__ __forceinline__ float ll_wait_sum(const LlArgs &d, unsigned idx, float mine) {
+// `waited` (optional) += the 100 MHz ticks this lane spent spinning for entries that had not arrived yet.
+__device__ __forceinline__ float ll_wait_sum(const LlArgs &d, unsigned idx, float mine, long long *waited = nullptr) {
     float s = 0.0f;
     bool lost = false;
     for (int r = 0; r < d.world; ++r) {
@@ -58,6 +60,7 @@ __device__ __forceinline__ float ll_wait_sum(const LlArgs &d, unsigned idx, floa
                         break;
                     }
                 } while ((unsigned)(w >> 32) != d.seq);
+                if (waited) *waited += (long long)wall_clock64() - t0;
             }
             v = __uint_as_float((unsigned)w);
         }
@@ -68,6 +71,21 @@ __device__ __forceinline__ float ll_wait_sum(const LlArgs &d, unsigned idx, floa
         s = __builtin_nanf("");
     }
     return s;
+}
+
+// Peer-wait telemetry: the longest wait of a workgroup's exchange wave (all 64 lanes active) goes into the device counters, one
+// atomic pair per workgroup.  Summed over a run, ticks / workgroups = the mean time a launch stood waiting for its slowest peer —
+// transport latency when the ranks arrive together, rank skew on top of it when they do not (bench.py: dist.wait_us_per_step).
+__device__ __forceinline__ void ll_wait_report(const LlArgs &d, long long waited) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long other = __shfl_xor(waited, o, 64);
+        waited = other > waited ? other : waited;
+    }
+    if (d.wait_stats && (threadIdx.x & 63) == 0) {
+        atomicAdd(d.wait_stats, (unsigned long long)waited);
+        atomicAdd(d.wait_stats + 1, 1ull);
+    }
 }
 
 // A timeout is every rank's business: the rank whose wait ran out holds NaN from then on, but a peer that was merely late sees a

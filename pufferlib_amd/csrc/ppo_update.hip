@@ -944,11 +944,13 @@ __global__ void __launch_bounds__(64 * kRedSl) ppo_reduce_adam_kernel(const floa
             ll_push(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats)), hi);
             ll_push(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats) + 1), lo);
         }
-        if (p >= 0) s = ll_wait_sum(ll, (unsigned)q, s);
+        long long waited = 0;
+        if (p >= 0) s = ll_wait_sum(ll, (unsigned)q, s, &waited);
         if (stat) {
-            hi = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats)), hi);
-            lo = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats) + 1), lo);
+            hi = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats)), hi, &waited);
+            lo = ll_wait_sum(ll, (unsigned)(NL::kStats + 2 * (q - NL::kStats) + 1), lo, &waited);
         }
+        ll_wait_report(ll, waited);
     }
     if (p >= 0) grads[p] = s;
     if (stat) {

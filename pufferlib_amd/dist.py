@@ -10,10 +10,12 @@ Sharding contract
   * every rank keeps its own env-major experience and applies the reference's minibatch partition locally; because
     ``N * (T / bptt_horizon) % num_minibatches == 0`` (checked) local minibatch m is exactly this rank's share of
     global minibatch m;
-  * GAE is the reference's single scan over the rank-major flat batch: per update two tiny all-gathers (first rows
-    = halo of the previous rank; the shards' affine maps) feed csrc/gae.hip's two-pass shard form;
-  * per update ONE all-reduce(SUM) of the per-minibatch advantage sums [nmb][2] (f64) so every rank normalises with the
-    global-minibatch mean / unbiased std; per optimizer step ONE all-reduce(SUM) of the flat bucket
+  * GAE is the reference's single scan over the rank-major flat batch, bit for bit: every rank's first rows travel (as bit
+    patterns, next to the episode statistics) in ONE all-reduce at the end of evaluate(), every rank runs the single-rank kernel
+    over its shard + the rows that follow it (csrc/gae.hip gae_halo_*; gamma lambda > 0.968: six numbers per rank and an f64 carry,
+    a few ulps at the shard ends);
+  * then ONE all-reduce(SUM) of the per-minibatch advantage sums [nmb][2] and the explained-variance sums (f64) so every rank
+    normalises with the global-minibatch mean / unbiased std — also at the end of evaluate(); per optimizer step ONE all-reduce(SUM) of the flat bucket
     [gradient (already divided by the GLOBAL minibatch rows) | 8 loss sums]; the clip norm is taken after it, so
     every rank applies the identical Adam step to identical parameters (broadcast once at create()).
 """
@@ -44,8 +46,100 @@ def init_from_env(backend='nccl', device=None):
         local = int(os.environ.get('LOCAL_RANK', '0'))
         torch.cuda.set_device(local)
         kw['device_id'] = torch.device(f'cuda:{local}')
+        pin_rank(local, device_index=local)
     dist.init_process_group(backend, rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']), **kw)
     return world()
+
+
+def _parse_cpulist(text):
+    """'0-63,128-191' -> sorted list of CPU numbers (the format of /sys/devices/system/node/node*/cpulist)."""
+    cpus = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.extend(range(int(lo), int(hi or lo) + 1))
+    return sorted(set(cpus))
+
+
+def _gpu_numa_node(device_index):
+    """NUMA node of HIP device `device_index` from the amdgpu driver's sysfs entry of its PCI function; -1 = unknown (no NUMA
+    information in a VM / container, no GPU)."""
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(device_index)
+        with open(f'/sys/bus/pci/devices/{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0/numa_node') as f:
+            return int(f.read().strip())
+    except Exception:
+        return -1
+
+
+def plan_affinity(local_rank, local_world, nodes, node_cpus, allowed):
+    """Pure planning step of pin_rank (unit-tested on the CPU): `nodes[i]` = NUMA node of local rank i's GPU (-1 unknown),
+    `node_cpus[n]` = CPUs of node n, `allowed` = the process's current affinity mask.  A rank gets its share of the CPUs of its GPU's
+    node, split evenly among the local ranks whose GPUs sit on the same node (whole cores of a 2-socket host stay with the GPUs next
+    to them; two ranks never compete for one core); without NUMA information, its share of the allowed CPUs.  Never empty: a share
+    that would be empty falls back to the whole candidate set."""
+    allowed = sorted(allowed)
+    node = nodes[local_rank] if 0 <= local_rank < len(nodes) else -1
+    pool = sorted(set(node_cpus.get(node, [])) & set(allowed)) if node >= 0 else []
+    if pool:
+        peers = [i for i in range(local_world) if nodes[i] == node]
+    else:
+        pool, peers, node = allowed, list(range(local_world)), -1
+    k, n = peers.index(local_rank), len(peers)
+    per = len(pool) // n
+    share = pool[k * per:(k + 1) * per] if per >= 1 else pool
+    return node, share or pool
+
+
+def pin_rank(local_rank=None, local_world=None, device_index=None):
+    """Pin this rank's process (all of its threads created from here on) to the CPU cores next to its GPU: os.sched_setaffinity to
+    its share of the NUMA node of the device (plan_affinity).  An iteration makes two host round trips with polled waits of ~2 ms;
+    on a 2-socket, 256-thread host an unpinned rank migrates between sockets, its waits and launches jitter, and with an exchange
+    inside every optimizer step every rank waits for the slowest one 16 times per update — host jitter becomes rank skew.
+    PFA_RANK_AFFINITY=0 leaves the mask alone.  Returns (and remembers for bench.py's `dist` block) {numa_node, cpus, first, last}."""
+    import torch
+    info = dict(numa_node=-1, cpus=0, first=-1, last=-1, pinned=False)
+    try:
+        if os.environ.get('PFA_RANK_AFFINITY', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+            raise RuntimeError('off')
+        local_rank = int(os.environ.get('LOCAL_RANK', '0')) if local_rank is None else local_rank
+        local_world = int(os.environ.get('LOCAL_WORLD_SIZE', os.environ.get('WORLD_SIZE', '1'))) if local_world is None else local_world
+        ndev = max(torch.cuda.device_count(), 1)
+        nodes = [_gpu_numa_node(i % ndev) for i in range(local_world)]
+        if device_index is not None:
+            nodes[local_rank] = _gpu_numa_node(device_index)
+        node_cpus = {}
+        for n in set(x for x in nodes if x >= 0):
+            try:
+                with open(f'/sys/devices/system/node/node{n}/cpulist') as f:
+                    node_cpus[n] = _parse_cpulist(f.read())
+            except OSError:
+                pass
+        allowed = os.sched_getaffinity(0)
+        node, share = plan_affinity(local_rank, local_world, nodes, node_cpus, allowed)
+        if local_world > 1 or node >= 0:
+            os.sched_setaffinity(0, share)
+            info.update(pinned=True)
+        info.update(numa_node=node, cpus=len(share), first=share[0], last=share[-1])
+    except Exception:
+        pass
+    _native['affinity'] = info
+    return info
+
+
+def wait_stats(reset=False):
+    """Peer-wait telemetry of the peer path (csrc/p2p_ll.hpp ll_wait_report, csrc/p2p.hip): mean microseconds a launch stood
+    waiting for its slowest peer, for the optimizer steps' flag-in-data exchange and for the small flag-based all-reduces, and how
+    many workgroups reported.  Synchronises the device."""
+    import ctypes as C
+    from . import _lib
+    out = (C.c_int64 * 4)()
+    _lib.check(_lib.lib().pfa_p2p_wait_stats(out, 1 if reset else 0), 'p2p_wait_stats')
+    us = lambda ticks, n: (ticks / n / 100.0) if n else 0.0       # 100 MHz ticks
+    return dict(grad_exchange_wait_us=us(out[0], out[1]), grad_exchange_workgroups=int(out[1]),
+                small_exchange_wait_us=us(out[2], out[3]), small_exchange_chunks=int(out[3]))
 
 
 def env_offset(rank, envs_per_rank):
@@ -82,13 +176,41 @@ def normalisation_from_sums(s1, s2, count):
     return mean, math.sqrt(var)
 
 
-def gae_fold_later(maps, rank):
-    """Carry-in of rank's shard = (M_{rank+1} o ... o M_{R-1})(0) where M_q(x) = C_q*x + D_q is shard q's affine map
-    (csrc/gae.hip pass 1).  ``maps`` is a list of R 2-element f64 tensors (or arrays); stays on their device."""
-    x = maps[-1][1] * 0.0
-    for q in range(len(maps) - 1, rank, -1):
-        x = maps[q][0] * x + maps[q][1]
-    return x.reshape(1) if hasattr(x, 'reshape') else x
+def gae_halo_rows(gamma, lam):
+    """Host mirror of pfa_gae_halo_rows (csrc/gae.hip): rows a shard needs from behind its end so that every walker of the
+    self-starting window sits on the flat scan's rounded sequence — warm-up ((gamma lambda)^warm <= 1e-7 * 2^-24, a multiple of 8)
+    + 8; 0 when that exceeds the kernel's 1024-element window (gamma lambda > 0.968)."""
+    import numpy as np
+    gl = float(np.float32(gamma) * np.float32(lam))
+    if not gl > 0.0:
+        return 16
+    if gl >= 0.999:
+        return 0
+    w = math.ceil(math.log(1e-7 * 2.0 ** -24) / math.log(gl) / 8.0) * 8
+    return int(max(w, 8)) + 8 if w <= 1024 else 0
+
+
+def gae_halo_pack(dones, values, rewards, rank, world, H):
+    """Host mirror of gae_halo_publish_kernel: [world][3][min(n, H)] f64, this rank's first rows as BIT PATTERNS (exact under a
+    SUM with the other ranks' zeros, sign of zero included), zeros elsewhere."""
+    import numpy as np
+    hp = min(len(values), H)
+    out = np.zeros((world, 3, hp), np.float64)
+    for k, x in enumerate((dones, values, rewards)):
+        out[rank, k] = np.ascontiguousarray(x[:hp], np.float32).view(np.uint32).astype(np.float64)
+    return out.reshape(-1)
+
+
+def gae_halo_unpack(gathered, rank, world, n, H):
+    """Host mirror of gae_halo_unpack_kernel: the (dones, values, rewards) rows that follow shard `rank` in the rank-major flat
+    batch, min(H, (world - 1 - rank) n) of them — from several later shards when those are shorter than the halo."""
+    import numpy as np
+    hp = min(n, H)
+    g = np.asarray(gathered, np.float64).reshape(world, 3, hp)
+    halo_len = min(H, (world - 1 - rank) * n)
+    i = np.arange(halo_len)
+    q, row = rank + 1 + i // n, i % n
+    return tuple(g[q, k, row].astype(np.uint32).view(np.float32) for k in range(3))
 
 
 def gae_publish_numbers(dones, values, rewards, gamma, lam):
@@ -210,7 +332,7 @@ def init_p2p(bucket_bytes):
     return True
 
 
-def init_native(force_single=False, bucket_bytes=0):
+def init_native(force_single=False, bucket_bytes=0, small_bytes=0):
     """Native collectives for the update: the optimizer-step all-reduce (and the few small reductions around it) are enqueued
     from native code on the compute stream, with no stream hand-off.  Two transports, picked by ``PFA_ALLREDUCE``:
       ``rccl``            this process's own RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp); the 128-byte id
@@ -219,6 +341,8 @@ def init_native(force_single=False, bucket_bytes=0):
       ``p2p`` (default)   additionally the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every bucket of up to
                           ``bucket_bytes`` (<= 1 MiB) — one hop over the xGMI mesh instead of a ring; it is opened only if its
                           self-test against torch.distributed passes on every rank; larger buckets stay on RCCL.
+    ``small_bytes``: the largest of the update's other (f64) exchanges — the GAE halo rows next to the episode statistics — so that the
+    peer path's slots hold it too and no exchange of an iteration needs a second transport.
     Returns True when a native transport is up on EVERY rank (agreement by MIN all-reduce); otherwise all ranks use
     torch.distributed collectives.  ``force_single`` builds a 1-rank RCCL communicator without a process group (tests)."""
     import ctypes as C
@@ -230,7 +354,7 @@ def init_native(force_single=False, bucket_bytes=0):
     p2p_ok = False
     # one hop pays for latency-bound buckets; a multi-MB bucket (the conv policy's 6.7 MB) is bandwidth-bound and stays on RCCL
     if 'p2p' in mode and w > 1 and 0 < bucket_bytes <= P2P_MAX_BUCKET:
-        p2p_ok = init_p2p(max(int(bucket_bytes), 65536))
+        p2p_ok = init_p2p(max(int(bucket_bytes), int(small_bytes), 65536))
         _native.update(p2p=p2p_ok)
     if os.environ.get('PFA_NATIVE_RCCL', '1') == '0':
         _native.update(ready=p2p_ok, world=w if p2p_ok else 1)

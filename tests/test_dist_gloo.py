@@ -147,66 +147,60 @@ def test_normalisation_from_sums_matches_torch():
     assert abs(mean - float(a.mean())) < 1e-12 and abs(std - float(a.std())) < 1e-10
 
 
-def _gae_shard_worker(rank, world, port, out_dir):
-    """Host protocol of clean_pufferl._sharded_gae over gloo, with the shard scan done in numpy f64 (the device kernels are
-    covered by tests/test_gpu_gae.py): halo all-gather -> shard affine map -> map all-gather -> fold -> apply."""
+def _gae_halo_worker(rank, world, port, out_dir, n, gamma, lam):
+    """Host protocol of the halo form clean_pufferl runs (_publish_gae / _finish_gae over csrc/gae.hip's gae_halo_* kernels; here their
+    host mirrors in pufferlib_amd.dist and the numpy model of the kernel's walkers, tests/test_gae_window_model.py): every rank
+    publishes the bit patterns of its first rows next to other f64 sums, ONE all-reduce(SUM), every rank scans its rows + the rows
+    that follow them."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
     from pufferlib_amd import dist as pdist
+    from test_gae_window_model import warm_self, window_gae
     d, _, _ = pdist.init_from_env('gloo')
-    rng = np.random.RandomState(5)
-    n, gamma, lam = 600, 0.99, 0.95
-    dn = (rng.rand(n) < 0.1).astype(np.float64)
-    v, r = rng.randn(n), rng.randn(n)
+    dn, v, r = _gae_inputs(n)
     m = n // world
     lo = rank * m
-    has_next = rank < world - 1
-    first = torch.tensor([r[lo], dn[lo], v[lo]])
-    rows = [torch.empty_like(first) for _ in range(world)]
-    d.all_gather(rows, first)
-    rr, dd, vv = (np.concatenate([x[lo:lo + m], [float(rows[rank + 1][i])] if has_next else []])
-                  for i, x in enumerate((r, dn, v)))
-    coef, delta = np.zeros(m), np.zeros(m)
-    for t in range(m):
-        if t == m - 1 and not has_next:
-            continue                      # pinned: the map x -> 0
-        nnt = 1.0 - dd[t + 1]
-        delta[t] = rr[t + 1] + gamma * vv[t + 1] * nnt - vv[t]
-        coef[t] = gamma * lam * nnt
-    Cq, Dq = 1.0, 0.0
-    for t in range(m - 1, -1, -1):        # compose(f_t, acc)
-        Cq, Dq = coef[t] * Cq, delta[t] + coef[t] * Dq
-    smap = torch.tensor([Cq, Dq], dtype=torch.float64)
-    maps = [torch.empty_like(smap) for _ in range(world)]
-    d.all_gather(maps, smap)
-    x = float(pdist.gae_fold_later(maps, rank)[0])
-    adv = np.zeros(m)
-    for t in range(m - 1, -1, -1):
-        x = delta[t] + coef[t] * x
-        adv[t] = x
+    H = pdist.gae_halo_rows(gamma, lam)
+    assert H == warm_self(gamma, lam) + 8
+    extra = np.array([1.0 + rank, 10.0 * (rank + 1)])                 # e.g. episode-return sum and episode count
+    buf = torch.from_numpy(np.concatenate([extra, pdist.gae_halo_pack(dn[lo:lo + m], v[lo:lo + m], r[lo:lo + m], rank, world, H)]))
+    d.all_reduce(buf)                                                 # the ONE exchange
+    hd, hv, hr = pdist.gae_halo_unpack(buf[2:].numpy(), rank, world, m, H)
+    own = [np.concatenate([x[lo:lo + m], h]) for x, h in ((r, hr), (v, hv), (dn, hd))]
+    adv = window_gae(*own, gamma, lam, H - 8)[:m]                     # n_read = m + halo: the kernel pins element n_read - 1
     np.save(os.path.join(out_dir, f'adv{rank}.npy'), adv)
+    np.save(os.path.join(out_dir, f'extra{rank}.npy'), buf[:2].numpy())
     d.barrier()
     d.destroy_process_group()
 
 
-def test_sharded_gae_protocol_equals_flat_scan(tmp_path):
-    world = 3
-    mp.spawn(_gae_shard_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    got = np.concatenate([np.load(tmp_path / f'adv{q}.npy') for q in range(world)])
+def _gae_inputs(n):
     rng = np.random.RandomState(5)
-    n = 600
-    dn = (rng.rand(n) < 0.1).astype(np.float32)
+    dn = (rng.rand(n) < 0.02).astype(np.float32)
     v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
+    v[n // 2], r[n // 3] = -0.0, -0.0                                 # sign bits an arithmetic gather would lose (n // 3 = a shard's first row at world 3)
+    return dn, v, r
+
+
+@pytest.mark.parametrize('n,world,gl', [(3000, 3, (0.99, 0.95)), (600, 3, (0.99, 0.95)), (1200, 2, (0.995, 0.97))])
+def test_halo_sharded_gae_is_the_flat_scan_bit_for_bit(tmp_path, n, world, gl):
+    """3000 / 3: the halo (544 rows) comes from the next shard alone; 600 / 3: shards of 200 rows — rank 0's halo is all of rank 1
+    and rank 2, and the pinned last element of the batch sits inside it; 0.995 x 0.97: a 936-row halo."""
+    mp.spawn(_gae_halo_worker, args=(world, _free_port(), str(tmp_path), n, *gl), nprocs=world, join=True)
+    got = np.concatenate([np.load(tmp_path / f'adv{q}.npy') for q in range(world)]).astype(np.float32)
     sys.path.insert(0, REPO)
     from oracle import c_oracle
-    # the workers ran in f64 on the un-rounded inputs; compare against the f32 oracle on the rounded ones
-    want = c_oracle.compute_gae(dn, v, r, 0.99, 0.95)
-    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    dn, v, r = _gae_inputs(n)
+    want = np.asarray(c_oracle.compute_gae(dn, v, r, *gl), np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert got[-1] == 0.0
+    for q in range(world):                                            # the sums that rode along are the global sums on every rank
+        assert np.array_equal(np.load(tmp_path / f'extra{q}.npy'), np.array([sum(1.0 + k for k in range(world)), sum(10.0 * (k + 1) for k in range(world))]))
 
 
 def _gae_one_exchange_worker(rank, world, port, out_dir):
-    """The one-exchange form clean_pufferl runs since round 4 (_publish_gae / _finish_gae over csrc/gae.hip's publish and fold
+    """The f64-carry one-exchange form clean_pufferl runs where gamma lambda is outside the halo form's window (csrc/gae.hip's publish and fold
     kernels; here their host mirrors in pufferlib_amd.dist): every rank publishes six numbers computed from its OWN rows —
     interior map, last value, first row — next to other f64 sums (the episode statistics), ONE all-reduce(SUM) of the zero-padded
     [extra | world x 6] buffer, fold, local scan."""

@@ -99,44 +99,89 @@ def test_empty_is_noop():
     assert L.pfa_gae_f32(None, None, None, None, None, 0, .99, .95, None, None) == 0
 
 
-@pytest.mark.parametrize('n,shards,p_done', [(524288, 8, 0.01), (12288, 3, 0.2), (4100, 2, 0.0), (7, 7, 0.3)])
-def test_sharded_two_pass_equals_flat_scan(n, shards, p_done):
-    """Data-parallel form: R shards of the rank-major flat batch, each run through pfa_gae_shard_pass1/2 with the halo
-    row and the folded carry-in (what clean_pufferl._sharded_gae does over all_gather), reproduce the single scan."""
+@pytest.mark.parametrize('n,shards,p_done,gl', [(524288, 8, 0.01, (0.99, 0.95)), (524288, 8, 0.0, (0.99, 0.95)), (12288, 3, 0.2, (0.99, 0.95)),
+                                                  (4096, 8, 0.0, (0.99, 0.95)), (4100, 2, 0.0, (0.99, 0.95)), (1600, 8, 0.02, (0.995, 0.97)),
+                                                  (7, 7, 0.3, (0.99, 0.95)), (16, 8, 0.5, (0.9, 0.8)), (64 * 48, 4, 0.05, (0.99, 0.95))])
+def test_sharded_halo_form_is_the_flat_scan_bit_for_bit(n, shards, p_done, gl):
+    """The form clean_pufferl runs data parallel (round 6): every shard publishes the bit patterns of its first min(m, H) rows
+    (pfa_gae_halo_publish, next to extra sums that ride along), the host sums the zero-padded buffers (the all-reduce), every shard
+    drops the rows that follow it behind its arrays (pfa_gae_halo_unpack: from ONE later shard when m >= H, from several when the
+    shards are shorter than the halo — 4096 / 8 = 512 < 544, 7 / 7 = one row each) and runs the single-rank kernel over n + halo rows
+    (pfa_gae_halo_f32).  Advantages and returns == the single flat scan, and == c_gae, as bit patterns; with sums: the per-minibatch
+    advantage sums and explained-variance sums of all shards add up to the flat batch's."""
     import torch
     from oracle import c_oracle
-    from pufferlib_amd import _lib, dist as pdist
+    from pufferlib_amd import _lib
     L = _lib.lib()
+    gamma, lam = gl
     rng = np.random.RandomState(n % 977 + shards)
     d = (rng.rand(n) < p_done).astype(np.float32)
     v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
-    want = c_oracle.compute_gae(d, v, r, 0.99, 0.95)
+    v[n // 3] = -0.0                                                  # a sign bit an arithmetic gather would lose
+    r[(n // shards) % n] = -0.0                                       # ... in a published row
+    want = np.asarray(c_oracle.compute_gae(d, v, r, gamma, lam), np.float32)
+    flat = hip_gae(d, v, r, gamma, lam)
     m = n // shards
+    H = int(L.pfa_gae_halo_rows(gamma, lam))
+    assert H > 0 and H % 8 == 0 and H <= 1032
+    hp = min(m, H)
     st = _lib.stream_handle()
-    bufs, maps = [], []
+    size = 3 + 3 * shards * hp
+    bufs, total = [], torch.zeros(size, dtype=torch.float64, device='cuda')
     for q in range(shards):
-        has_next = int(q < shards - 1)
-        sl = slice(q * m, (q + 1) * m + has_next)
-        t = [torch.as_tensor(x[sl].copy()).cuda() for x in (d, v, r)]
-        ws = torch.zeros(max(1, L.pfa_gae_workspace_bytes(m)), dtype=torch.uint8, device='cuda')
-        smap = torch.zeros(2, dtype=torch.float64, device='cuda')
-        _lib.check(L.pfa_gae_shard_pass1(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), m, has_next, 0.99, 0.95,
-                                         _lib.ptr(ws), _lib.ptr(smap), st), 'pass1')
-        bufs.append((t, ws, has_next))
-        maps.append(smap)
+        t = [torch.cat([torch.as_tensor(x[q * m:(q + 1) * m].copy()), torch.full((H,), float('nan'))]).cuda() for x in (d, v, r)]   # + halo room
+        extra = torch.tensor([1.0, 2.0 * q, -0.5], dtype=torch.float64, device='cuda')
+        out = torch.full((size,), float('nan'), dtype=torch.float64, device='cuda')
+        _lib.check(L.pfa_gae_halo_publish(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), m, gamma, lam, _lib.ptr(extra), 3, _lib.ptr(out), q,
+                                          shards, st), 'publish')
+        o = out[3:].view(shards, 3 * hp)
+        assert bool(torch.isfinite(out).all()) and all(float(o[k].abs().sum()) == 0.0 for k in range(shards) if k != q)
+        total += out
+        bufs.append(t)
+    assert total[:3].tolist() == [float(shards), float(shards * (shards - 1)), -0.5 * shards]
+    # sums: minibatches of 2 x bptt 8 where the shard allows it (its rows as m / 8 "envs" of 8 steps... any partition the kernel accepts)
+    N_loc, nmb, bptt = (m // 16, 2, 16) if m % 32 == 0 else (0, 0, 0)
+    with_sums = N_loc > 0 and L.pfa_gae_sums_supported(m, N_loc, nmb, bptt) == 1
     got = np.empty(n, np.float32)
-    for q, (t, ws, has_next) in enumerate(bufs):
-        carry = pdist.gae_fold_later(maps, q)
+    stats_sum, ev_sum = np.zeros((max(nmb, 1), 2)), np.zeros(4)
+    for q, t in enumerate(bufs):
+        halo_len = L.pfa_gae_halo_unpack(_lib.ptr(total[3:]), q, shards, m, gamma, lam, _lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), st)
+        assert halo_len == min(H, (shards - 1 - q) * m)
+        for x, src in zip(t, (d, v, r)):                              # the rows that follow the shard in the flat batch, bit for bit
+            assert np.array_equal(x[m:m + halo_len].cpu().numpy().view(np.uint32), src[(q + 1) * m:(q + 1) * m + halo_len].view(np.uint32))
         adv = torch.full((m,), float('nan'), device='cuda')
         ret = torch.full((m,), float('nan'), device='cuda')
-        _lib.check(L.pfa_gae_shard_pass2(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.ptr(adv), _lib.ptr(ret), m,
-                                         has_next, 0.99, 0.95, _lib.ptr(ws), _lib.ptr(carry) if has_next else None, st),
-                   'pass2')
+        ws = torch.zeros(max(16, L.pfa_gae_sums_workspace_bytes(m, max(nmb, 1))), dtype=torch.uint8, device='cuda')
+        stats = torch.full((max(nmb, 1), 2), float('nan'), dtype=torch.float64, device='cuda')
+        ev4 = torch.full((4,), float('nan'), dtype=torch.float64, device='cuda')
+        zero8 = torch.ones(8, dtype=torch.float64, device='cuda')
+        _lib.check(L.pfa_gae_halo_f32(_lib.ptr(t[0]), _lib.ptr(t[1]), _lib.ptr(t[2]), _lib.ptr(adv), _lib.ptr(ret), m, halo_len, gamma, lam,
+                                      N_loc, nmb, bptt, _lib.ptr(stats) if with_sums else None, _lib.ptr(ev4), _lib.ptr(zero8), _lib.ptr(ws), st),
+                   'halo gae')
         got[q * m:(q + 1) * m] = adv.cpu().numpy()
-        np.testing.assert_allclose(ret.cpu().numpy(), got[q * m:(q + 1) * m] + v[q * m:(q + 1) * m], rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(got, want, rtol=RTOL, atol=ATOL)
-    assert np.abs(got - want).max() <= 8 * np.finfo(np.float32).eps * max(1.0, np.abs(want).max())
+        assert np.array_equal(ret.cpu().numpy(), got[q * m:(q + 1) * m] + v[q * m:(q + 1) * m])
+        if with_sums:
+            assert float(zero8.abs().sum()) == 0.0
+            a = got[q * m:(q + 1) * m].astype(np.float64)
+            seg = a.reshape(m // bptt, bptt)
+            for k in range(nmb):
+                rows = seg[k::nmb].ravel()
+                np.testing.assert_allclose(stats[k].cpu().numpy(), [rows.sum(), (rows * rows).sum()], rtol=1e-12, atol=1e-9)
+            yp = v[q * m:(q + 1) * m].reshape(N_loc, m // N_loc).T.ravel().astype(np.float64)
+            yt = a + yp
+            np.testing.assert_allclose(ev4.cpu().numpy(), [yt.sum(), (yt * yt).sum(), a.sum(), (a * a).sum()], rtol=1e-12, atol=1e-8)
+    assert np.array_equal(got.view(np.uint32), flat.view(np.uint32))          # the single-rank kernel's bits
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))          # ... which are c_gae's
     assert got[-1] == 0.0
+
+
+def test_halo_form_is_refused_outside_the_self_starting_window():
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    assert L.pfa_gae_halo_rows(0.99, 0.95) == 544 and L.pfa_gae_halo_rows(0.9, 0.8) % 8 == 0
+    assert L.pfa_gae_halo_rows(0.999, 0.99) == 0                   # the f64-carry form (pfa_gae_shard_publish / fold / pass2) serves these
+    assert L.pfa_gae_halo_publish(None, None, None, 16, 0.999, 0.99, None, 0, None, 0, 2, None) != 0
+    assert b'self-starting' in L.pfa_last_error()
 
 
 @pytest.mark.parametrize('n,shards,p_done', [(524288, 8, 0.01), (12288, 3, 0.2), (4100, 2, 0.0), (4098, 2, 0.05), (7, 7, 0.3), (16, 8, 0.5)])

@@ -542,29 +542,23 @@ def test_early_gae_pass_is_the_same_update_and_yields_to_in_place_edits(monkeypa
 
 
 @pytest.mark.parametrize('n,horizon,epochs', [(256, 32, 2), (64, 32, 1)])
-def test_report_from_the_updates_last_launch_equals_the_packing_launch(monkeypatch, n, horizon, epochs):
+def test_report_rides_the_updates_last_launch(n, horizon, epochs):
     """pfa_ppo_mlp_train_logged: the last reduce + Adam launch of an update writes train()'s ten report numbers itself (the lanes
-    that own the loss sums); PFA_FUSED_LOG=0 packs them in a launch of its own behind the update, as rounds 1-4 did.  Same losses,
-    same explained variance, same weights, bit for bit; and the call says which of the two happened."""
+    that own the loss sums) — losses and explained variance == the oracle's on the same rows are covered by the golden replays; here:
+    the report is there and finite, and the entry point says what it did."""
     import ctypes as C
     from pufferlib_amd import _lib, clean_pufferl
     hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
-    runs = []
-    for fused in ('1', '0'):
-        monkeypatch.setenv('PFA_FUSED_LOG', fused)
-        torch.manual_seed(3)
-        vec, pol = _make(n)
-        data = clean_pufferl.create(_config(n, horizon, n * horizon // 4, 16, epochs, n * horizon * 8, hp, seed=5), vec, pol)
-        out = []
-        for it in range(3):
-            clean_pufferl.evaluate(data)
-            clean_pufferl.train(data)
-            out.append(dict(data.losses))
-        assert all(np.isfinite(v) for o in out for k, v in o.items() if k != 'explained_variance')
-        runs.append((out, data.flat_params.flat.clone()))
-    assert repr(runs[0][0]) == repr(runs[1][0])
-    assert torch.equal(runs[0][1], runs[1][1])
-    assert runs[0][0][-1]['value_loss'] > 0 and runs[0][0][-1]['entropy'] > 0
+    torch.manual_seed(3)
+    vec, pol = _make(n)
+    data = clean_pufferl.create(_config(n, horizon, n * horizon // 4, 16, epochs, n * horizon * 8, hp, seed=5), vec, pol)
+    out = []
+    for it in range(3):
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+        out.append(dict(data.losses))
+    assert all(np.isfinite(v) for o in out for k, v in o.items() if k != 'explained_variance')
+    assert out[-1]['value_loss'] > 0 and out[-1]['entropy'] > 0
     # the entry point itself: report written by the update (log_packed = 1) == losses + ev4 packed by hand
     L = _lib.lib()
     ex, fp, opt = data.experience, data.flat_params, data.optimizer

@@ -83,14 +83,22 @@ def test_experience_shape_checks_raise_before_touching_the_gpu():
         Experience(16 * 24, 16, 128, 64, 16, 'cpu')    # rows per env not a whole number of bptt segments
 
 
-def test_gae_fold_later_composes_affine_maps_in_order():
+def test_gae_halo_rows_travel_as_bit_patterns_and_come_from_as_many_later_shards_as_it_takes():
+    """Host mirrors of csrc/gae.hip's gae_halo_publish / unpack kernels (pufferlib_amd.dist): a SUM of the ranks' zero-padded buffers
+    returns every published float bit for bit (-0.0, denormals, inf), and a halo longer than a shard is filled from several."""
     from pufferlib_amd import dist as pdist
-    maps = [torch.tensor([0.5, 1.0], dtype=torch.float64), torch.tensor([2.0, -1.0], dtype=torch.float64),
-            torch.tensor([0.25, 4.0], dtype=torch.float64)]
-    # rank 0: M1(M2(0)) = 2*4 - 1 = 7;  rank 1: M2(0) = 4;  rank 2: nothing follows
-    assert float(pdist.gae_fold_later(maps, 0)[0]) == 7.0
-    assert float(pdist.gae_fold_later(maps, 1)[0]) == 4.0
-    assert float(pdist.gae_fold_later(maps, 2)[0]) == 0.0
+    assert pdist.gae_halo_rows(0.99, 0.95) == 544 and pdist.gae_halo_rows(0.999, 0.99) == 0 and pdist.gae_halo_rows(0.5, 0.0) == 16
+    world, n, H = 4, 5, 12
+    rng = np.random.RandomState(0)
+    rows = [[rng.randn(n).astype(np.float32) for _ in range(3)] for _ in range(world)]
+    rows[1][1][0], rows[2][2][4], rows[3][0][1] = np.float32(-0.0), np.float32(1e-42), np.float32(np.inf)
+    total = sum(pdist.gae_halo_pack(*rows[q], q, world, H) for q in range(world))
+    for q in range(world):
+        halo = pdist.gae_halo_unpack(total, q, world, n, H)
+        for k in range(3):
+            want = np.concatenate([rows[p][k] for p in range(q + 1, world)] + [np.zeros(0, np.float32)])[:H]
+            assert np.array_equal(halo[k].view(np.uint32), want.view(np.uint32)), (q, k)
+    assert len(pdist.gae_halo_unpack(total, 0, world, n, H)[0]) == 12 and len(pdist.gae_halo_unpack(total, 3, world, n, H)[0]) == 0
 
 
 @pytest.mark.parametrize('recurrent', [False, True])
@@ -482,7 +490,8 @@ def test_early_gae_key_follows_in_place_edits_and_hyperparameters():
     from pufferlib_amd.namespace import Namespace
     B = 64
     rdv = torch.zeros(3, B + 1)
-    ex = Namespace(_rdv=rdv, rewards=rdv[0, :B], dones=rdv[1, :B], values=rdv[2, :B], batch_size=B, num_envs=4, num_minibatches=2)
+    ex = Namespace(_rdv=rdv, rewards=rdv[0, :B], dones=rdv[1, :B], values=rdv[2, :B], advantages=torch.zeros(B), returns=torch.zeros(B),
+                   batch_size=B, num_envs=4, num_minibatches=2)
     data = Namespace(config=Namespace(gamma=0.99, gae_lambda=0.95, bptt_horizon=8, norm_adv=True), experience=ex)
     k0 = cp._gae_key(data)
     assert cp._gae_key(data) == k0
@@ -497,4 +506,8 @@ def test_early_gae_key_follows_in_place_edits_and_hyperparameters():
     data.config.gamma = 0.99
     assert cp._gae_key(data) == k2
     ex.num_minibatches = 4
+    assert cp._gae_key(data) != k2
+    ex.num_minibatches = 2
+    assert cp._gae_key(data) == k2
+    ex.values = ex.values.clone()                         # re-bound to another tensor (advisor, round 5): the address is part of the key
     assert cp._gae_key(data) != k2
