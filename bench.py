@@ -555,6 +555,8 @@ def main():
                              '(PFA_DIST_BACKEND=gloo runs the ranks on shared devices for a functional check)')
         dev_index = local_rank % ndev
         torch.cuda.set_device(dev_index)
+        from pufferlib_amd import dist as pdist
+        pdist.pin_rank(local_rank, world, device_index=dev_index)      # this rank's share of the cores next to its GPU (PFA_RANK_AFFINITY=0: off)
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{dev_index}'))
         else:
@@ -628,6 +630,9 @@ def main():
         snap.update({k: tm[k].elapsed for k in ('evaluate', 'train') if k in tm})
         return snap
 
+    if world > 1 and data.native_dp:
+        from pufferlib_amd import dist as pdist
+        pdist.wait_stats(reset=True)             # peer-wait telemetry of the timed region only
     barrier()
     prof0 = profile_snapshot()
     t0 = time.perf_counter()
@@ -637,6 +642,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof1 = profile_snapshot()
+    peer_wait = pdist.wait_stats(reset=True) if (world > 1 and data.native_dp) else None
     L.pfa_timing_enable(0)
     # clean_pufferl.Profile's breakdown over the timed region, ms per step.  The section timers bracket kernel ENQUEUES (the device
     # runs asynchronously); eval_time / train_time are the wall timers of evaluate() / train(), each ending in one stream sync.
@@ -650,6 +656,17 @@ def main():
         dist.all_reduce(t)                       # every rank's own wall time of the timed region
         rank_ms = [float(x) / K * 1e3 for x in t.cpu()]
         dt = max(float(x) for x in t.cpu())      # the contract's MAX over ranks
+        # per rank: where it is pinned, and how long its launches stood waiting for the slowest peer (in-kernel wall-clock ticks,
+        # csrc/p2p_ll.hpp ll_wait_report) — the rank that arrives last waits for the transport only, the others for the skew on top
+        from pufferlib_amd import dist as pdist
+        aff = pdist._native.get('affinity') or {}
+        pr = torch.zeros(world, 8, dtype=torch.float64, device='cuda')
+        pr[rank, :4] = torch.tensor([aff.get('numa_node', -1), aff.get('cpus', 0), aff.get('first', -1), aff.get('last', -1)], dtype=torch.float64)
+        if peer_wait is not None:
+            pr[rank, 4:] = torch.tensor([peer_wait['grad_exchange_wait_us'], peer_wait['grad_exchange_workgroups'],
+                                         peer_wait['small_exchange_wait_us'], peer_wait['small_exchange_chunks']], dtype=torch.float64)
+        dist.all_reduce(pr)
+        per_rank = pr.cpu().tolist()
 
     # sustained leg (untimed by the contract, reported next to it): the same loop for >= --sustained-seconds, so that a
     # sampler with a seconds-scale period (the driver's rocm-smi poll) sees the device busy; iteration count agreed on rank 0
@@ -912,6 +929,17 @@ def main():
                            'transport': {'grad_bucket': ('p2p' if on_p2p else 'rccl' if (data.native_dp and info['rccl']) else 'torch'),
                                          'grad_bucket_bytes': bucket_bytes,
                                          'small_reductions': ('p2p' if info['p2p'] else 'rccl' if (data.native_dp and info['rccl']) else 'torch')},
+                           # rank r: its CPU share (cores of its GPU's NUMA node, split among the ranks on that node) and the mean time its
+                           # launches stood waiting for the slowest peer; per step = per exchange x exchanges.  min over ranks ~ transport
+                           # latency, the spread above it = rank skew (what pinning and the skew budget below are about)
+                           'affinity': [{'numa_node': int(x[0]), 'cpus': int(x[1]), 'first': int(x[2]), 'last': int(x[3])} for x in per_rank],
+                           'rank_ms_per_step': [round(x, 4) for x in rank_ms],
+                           'peer_wait': None if peer_wait is None else {
+                               'grad_exchange_wait_us': [round(x[4], 2) for x in per_rank],
+                               'small_exchange_wait_us': [round(x[6], 2) for x in per_rank],
+                               'wait_us_per_step': [round(x[4] * EPOCHS * NMB + x[6] * 2, 1) for x in per_rank],
+                               'what': 'in-kernel 100 MHz wall-clock ticks a workgroup spent spinning for peer data, longest lane, mean '
+                                       'over the workgroups of the timed region'},
                            'rccl_nranks': info['rccl_nranks'], 'p2p_selftest_passed': info['p2p_selftest'], 'p2p_status': info['p2p_status'],
                            'allreduce_calls': {'p2p': info['p2p_calls'], 'p2p_flag_in_data': info['p2p_ll_calls'], 'rccl_native': info['rccl_calls']},
                            # what one step (evaluate + train) exchanges, and the budget >= 6x weak scaling at 8 ranks leaves for it:
@@ -919,8 +947,9 @@ def main():
                            'collectives_per_step': {'gradient_exchanges': EPOCHS * NMB, 'small_all_reduces': 2,
                                                     'what': f'{EPOCHS * NMB} optimizer-step exchanges of the {bucket_bytes}-byte bucket (inside the reduce + '
                                                             'Adam launch on the fused peer path: 2 launches per optimizer step, else an all-reduce of its '
-                                                            'own: 4); 1 all-reduce of [episode-statistic sums | 6 GAE numbers per rank] at the end of '
-                                                            'evaluate(), 1 of [advantage sums | explained-variance sums] after GAE'},
+                                                            'own: 4); at the end of evaluate(): 1 all-reduce of [episode-statistic sums | the GAE halo rows of every '
+                                                            'rank], then GAE, then 1 of [advantage sums | explained-variance sums]; train() holds none but the '
+                                                            'optimizer steps\''},
                            'transports': transports}
         if world == 1 and args.no_cpu_baseline and args.self_check and args.policy == 'mlp':
             out['self_check'] = self_check(data, pol)

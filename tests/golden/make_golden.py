@@ -26,6 +26,9 @@ Fixtures written (all small, committed):
                      frames are re-derivable from recorded frame numbers, big tensors recorded as digests (sum, |sum|, 64 samples)
   ppo_cnn_lstm.npz   same as ppo_cnn with pufferlib.models.LSTMWrapper(input_size=512, hidden_size=512) on top and frameworks.cleanrl.RecurrentPolicy —
                      the `Recurrent` policy of environments/atari/torch.py:4-6 (`make_golden.py cnn_lstm`)
+  ppo_c1_mlp / ppo_c1_lstm / ppo_demo_lstm / ppo_c2_mlp.npz   the same call sequence at BASELINE's own sizes, digest form (`make_golden.py big`,
+                     gen_big): configs[0] (64 x 128), the shape `demo.py --env squared` trains (config.yaml:498-509), one iteration of
+                     configs[1] (4096 x 128)
   ppo_spaces.npz     same as ppo_mlp on ocean make_spaces: Dict observation emulated to 108-byte rows, Dict action emulated to
                      MultiDiscrete([2, 2]) -> models.Default's per-head decoders and sample_logits' list branch (cleanrl.py:25-47)
 """
@@ -719,6 +722,140 @@ def gen_ppo_cnn(num_envs=4, horizon=16, iters=1, use_rnn=False):
     print(fname, len(out), 'arrays; losses it0', out['it0.losses'])
 
 
+def sha(a):
+    """sha256 of the array's bytes (C order) as a numpy string: the fingerprint of a tensor that must match bit for bit."""
+    import hashlib
+    return np.array(hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest())
+
+
+def gen_ppo_big(tag, use_rnn, num_envs, horizon, minibatch, bptt, epochs, lr, iters, total_timesteps=None, store_noise=True):
+    """clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) by the UNMODIFIED reference at BASELINE's own sizes, recorded in
+    digest form: what must match bit for bit as sha256 (observations, rewards, dones in storage order) or in
+    full where the replay needs it (actions, initial weights, the multinomial noise unless `store_noise` is off), what must match
+    within 1e-5 as digest(): sum, |sum|, 64 evenly spaced elements (values, log-probabilities, advantages, returns, LSTM state, updated
+    weights and Adam moments), and the scalars (losses, learning rates, statistics, step counts).  store_noise=False (C2: 16.8 MB per
+    rollout): only digest() of the noise and the recipe — the noise IS torch.manual_seed(seed) followed by one
+    torch.empty(N, A).exponential_(1) per step (torch.multinomial's own draw, asserted below), which the test box regenerates; the
+    replay falls back to the recorded actions where the box's torch draws other numbers."""
+    import pufferlib
+    import pufferlib.vector
+    import pufferlib.models
+    import pufferlib.frameworks.cleanrl
+    import pufferlib.environments.ocean as ocean
+    import clean_pufferl
+
+    class _NoUtil:
+        def __init__(self, *a, **k):
+            self.cpu_util = self.cpu_mem = self.gpu_util = self.gpu_mem = [0]
+
+        def stop(self):
+            pass
+
+    clean_pufferl.Utilization = _NoUtil
+    clean_pufferl.print_dashboard = lambda *a, **k: None
+    clean_pufferl.save_checkpoint = lambda data: None
+
+    batch = num_envs * horizon
+    config = pufferlib.namespace(
+        env='squared', seed=1, torch_deterministic=True, cpu_offload=False, device='cpu',
+        total_timesteps=total_timesteps or batch * 8, learning_rate=lr, anneal_lr=True, gamma=0.99, gae_lambda=0.95,
+        update_epochs=epochs, norm_adv=True, clip_coef=0.1, clip_vloss=True, vf_coef=0.5, vf_clip_coef=0.1,
+        max_grad_norm=0.5, ent_coef=0.01, target_kl=None, batch_size=batch, minibatch_size=minibatch,
+        bptt_horizon=bptt, compile=False, compile_mode='reduce-overhead', checkpoint_interval=10 ** 9,
+        data_dir='/tmp/golden_experiments', exp_id='golden')
+    vec = pufferlib.vector.make(ocean.env_creator('squared'), num_envs=num_envs, backend=pufferlib.vector.Serial)
+    torch.manual_seed(1)
+    policy = pufferlib.models.Default(vec.driver_env, hidden_size=128)
+    if use_rnn:
+        policy = pufferlib.models.LSTMWrapper(vec.driver_env, policy, input_size=128, hidden_size=128)
+        policy = pufferlib.frameworks.cleanrl.RecurrentPolicy(policy)
+    else:
+        policy = pufferlib.frameworks.cleanrl.Policy(policy)
+    out = {}
+    for k, v in policy.state_dict().items():
+        out['w0.' + k] = v.detach().numpy().copy()
+    noise = []
+    orig_multinomial = torch.multinomial
+
+    def recording_multinomial(p, n, *a, **kw):
+        st = torch.get_rng_state()
+        res = orig_multinomial(p, n, *a, **kw)
+        st2 = torch.get_rng_state()
+        torch.set_rng_state(st)
+        q = torch.empty_like(p).exponential_(1)
+        assert torch.equal((p / q).argmax(-1, keepdim=True), res), 'multinomial != argmax(p/q)'
+        torch.set_rng_state(st2)
+        noise.append(q.numpy().copy())
+        return res
+
+    torch.multinomial = recording_multinomial
+    import time
+    t_start = time.time()
+    try:
+        data = clean_pufferl.create(config, vec, policy)
+        exp = data.experience
+        for it in range(iters):
+            noise.clear()
+            clean_pufferl.evaluate(data)
+            nz = np.stack(noise)                                               # (T, N, A)
+            assert nz.shape == (horizon, num_envs, 8) and nz.dtype == np.float32
+            if store_noise:
+                out[f'it{it}.noise'] = nz
+            out[f'it{it}.noise_digest'] = digest(nz)
+            out[f'it{it}.obs_sha'] = sha(exp.obs.numpy().reshape(batch, -1).astype(np.int8))        # storage (step-major) order
+            out[f'it{it}.rewards_sha'] = sha(exp.rewards_np.astype(np.float32))
+            out[f'it{it}.dones_sha'] = sha(exp.dones_np.astype(np.float32))
+            out[f'it{it}.rewards_sum'] = np.array(float(exp.rewards_np.astype(np.float64).sum()))
+            out[f'it{it}.dones_sum'] = np.array(float(exp.dones_np.astype(np.float64).sum()))
+            out[f'it{it}.actions'] = exp.actions_np.copy().astype(np.int8)
+            out[f'it{it}.logprobs'] = digest(exp.logprobs_np)
+            out[f'it{it}.values'] = digest(exp.values_np)
+            out[f'it{it}.global_step'] = np.array(data.global_step, np.int64)
+            out[f'it{it}.stats'] = np.array([data.stats.get('episode_return', np.nan), data.stats.get('episode_length', np.nan),
+                                             data.stats.get('score', np.nan)], np.float64)
+            if use_rnn:
+                out[f'it{it}.lstm_h'] = digest(exp.lstm_h.numpy())
+                out[f'it{it}.lstm_c'] = digest(exp.lstm_c.numpy())
+            lr_used = data.optimizer.param_groups[0]['lr']
+            clean_pufferl.train(data)
+            out[f'it{it}.lr_used'] = np.array(lr_used, np.float64)
+            out[f'it{it}.lr_next'] = np.array(data.optimizer.param_groups[0]['lr'], np.float64)
+            out[f'it{it}.advantages'] = digest(exp.b_advantages.numpy())        # (nmb, minibatch) order
+            out[f'it{it}.returns'] = digest(exp.b_returns.numpy())
+            L = data.losses
+            out[f'it{it}.losses'] = np.array([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac,
+                                              L.explained_variance], np.float64)
+            st = data.optimizer.state_dict()['state']
+            names = [k for k, _ in policy.named_parameters()]
+            for k, v in policy.state_dict().items():
+                out[f'it{it}.w.' + k] = digest(v.detach().numpy())
+            for i, nme in enumerate(names):
+                out[f'it{it}.m.' + nme] = digest(st[i]['exp_avg'].numpy())
+                out[f'it{it}.v.' + nme] = digest(st[i]['exp_avg_sq'].numpy())
+            print(f'  ppo_{tag} it{it}: {time.time() - t_start:.1f} s, losses', out[f'it{it}.losses'][:3])
+    finally:
+        torch.multinomial = orig_multinomial
+    out['config'] = np.array([num_envs, horizon, config.minibatch_size, config.bptt_horizon, config.update_epochs,
+                              config.total_timesteps, iters], np.int64)
+    out['hparams'] = np.array([config.learning_rate, config.gamma, config.gae_lambda, config.clip_coef, config.vf_coef,
+                               config.vf_clip_coef, config.max_grad_norm, config.ent_coef], np.float64)
+    out['torch_version'] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(HERE, f'ppo_{tag}.npz'), **out)
+    print(f'ppo_{tag}.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, f'ppo_{tag}.npz')) // 1024, 'KiB')
+
+
+def gen_big():
+    """The reference at BASELINE's own sizes (`make_golden.py big`; ~1 minute of reference CPU time):
+      ppo_c1_mlp / ppo_c1_lstm  configs[0]: 64 envs x 128 steps, minibatch 2048, bptt 16, 4 epochs (config.yaml:12-41 defaults)
+      ppo_demo_lstm             what `demo.py --env squared` really trains (config.yaml:498-509): 8 envs, batch 1024, minibatch 128,
+                                bptt 4, lr 0.017, LSTM — a partition the one-pass GAE sums refuse (bptt < 8): the un-fused path
+      ppo_c2_mlp                ONE iteration of configs[1]: 4096 envs x 128 steps, 4 minibatches x 4 epochs"""
+    gen_ppo_big('c1_mlp', False, 64, 128, 2048, 16, 4, 2.5e-4, iters=2)
+    gen_ppo_big('c1_lstm', True, 64, 128, 2048, 16, 4, 2.5e-4, iters=2)
+    gen_ppo_big('demo_lstm', True, 8, 128, 128, 4, 4, 0.017, iters=3, total_timesteps=30_000)
+    gen_ppo_big('c2_mlp', False, 4096, 128, 131072, 16, 4, 2.5e-4, iters=1, store_noise=False)
+
+
 if __name__ == '__main__':
     if len(sys.argv) > 1 and sys.argv[1] == 'cnn':
         gen_ppo_cnn()
@@ -728,6 +865,9 @@ if __name__ == '__main__':
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'mp':
         gen_ppo_mp()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'big':      # the reference at BASELINE's own sizes, digest form
+        gen_big()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == 'wide':     # pufferlib.models.Default(hidden_size=256): outside the fused kernels' width
         gen_ppo('mlp_h256', use_rnn=False, hidden=256)
@@ -752,3 +892,4 @@ if __name__ == '__main__':
     gen_ppo_mp()
     gen_ppo_cnn()
     gen_ppo_cnn(use_rnn=True)
+    gen_big()

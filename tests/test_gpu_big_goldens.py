@@ -1,0 +1,108 @@
+"""The HIP path against the UNMODIFIED reference at BASELINE's own sizes: fixtures tests/golden/ppo_c1_mlp,
+ppo_c1_lstm, ppo_demo_lstm, ppo_c2_mlp.npz were produced by `tests/golden/make_golden.py big` (gen_ppo_big) running
+/root/reference's clean_pufferl.create / evaluate / train (clean_pufferl.py:30-292) over pufferlib.vector.Serial on ocean squared:
+
+  c1_mlp, c1_lstm   configs[0]: 64 envs x 128 steps, minibatch 2048, bptt 16, 4 epochs, 2 iterations
+  demo_lstm         what `demo.py --env squared` trains (config.yaml:498-509): 8 envs x 128, minibatch 128, bptt 4, lr 0.017, LSTM,
+                    3 iterations — 8 minibatches of 4-row segments: the partition the one-pass GAE sums refuse (the un-fused path)
+  c2_mlp            ONE iteration of configs[1]: 4096 envs x 128 steps, 4 minibatches x 4 epochs (the bench workload itself)
+
+Bit for bit: actions, observations / rewards / dones (sha256 of the storage-order bytes), step counts, episode statistics.
+Within 1e-5 (north_star): log-probabilities, values, advantages, returns, LSTM state, losses, updated weights; Adam moments at their own
+scale.  Big tensors are compared through make_golden.digest (sum, |sum|, 64 evenly spaced elements)."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(__file__))
+from cnn_golden import digest  # noqa: E402
+from test_gpu_ppo import _config, _step_major  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _close(got, want, what, atol=1e-5, rtol=1e-5):
+    """digest(got) vs the recorded digest: the 64 samples element-wise, the sums with the same tolerance per element on average."""
+    got = np.asarray(got)
+    d = digest(got)
+    np.testing.assert_allclose(d[2:], want[2:], rtol=rtol, atol=atol, err_msg=what)
+    tol = 0.1 * atol * got.size + rtol * abs(want[1])
+    assert abs(d[0] - want[0]) <= tol and abs(d[1] - want[1]) <= tol, (what, d[:2], want[:2], tol)
+
+
+def _noise(g, it, T, N, A, actions):
+    """The multinomial noise of iteration `it`: recorded (c1 / demo); else regenerated the way the reference drew it —
+    torch.manual_seed(seed), one torch.empty(N, A).exponential_(1) per step (torch.multinomial's own draw; make_golden asserts it) —
+    and checked against the recorded digest.  A test box whose torch draws other numbers (another MKL code path) replays the RECORDED
+    ACTIONS instead: noise that makes argmax(p / q) the recorded action whatever p is.  Returns (noise, how)."""
+    if f'it{it}.noise' in g.files:
+        return g[f'it{it}.noise'], 'recorded'
+    torch.manual_seed(1)
+    nz = None
+    for _ in range(it + 1):
+        nz = np.stack([torch.empty(N, A).exponential_(1).numpy() for _ in range(T)])
+    if np.array_equal(digest(nz), g[f'it{it}.noise_digest']):
+        return nz, 'regenerated'
+    q = np.ones((T, N, A), np.float32)
+    np.put_along_axis(q, actions.reshape(T, N, 1).astype(np.int64), np.float32(1e-30), axis=2)
+    return q, 'recorded actions'
+
+
+@pytest.mark.parametrize('tag,recurrent', [('c1_mlp', False), ('c1_lstm', True), ('demo_lstm', True), ('c2_mlp', False)])
+def test_replay_of_the_reference_at_baseline_sizes(golden_dir, tag, recurrent):
+    from pufferlib_amd import clean_pufferl, cleanrl, models, vector
+    g = np.load(os.path.join(golden_dir, f'ppo_{tag}.npz'))
+    n, horizon, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    B = n * horizon
+    vec = vector.make(vector.make_squared, num_envs=n, backend=vector.Squared)
+    base = models.Default(vec.driver_env)
+    pol = cleanrl.RecurrentPolicy(models.LSTMWrapper(vec.driver_env, base)) if recurrent else cleanrl.Policy(base)
+    pol.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith('w0.')})
+    data = clean_pufferl.create(_config(n, horizon, mbs, bptt, epochs, total, [float(x) for x in g['hparams']]), vec, pol)
+    exp = data.experience
+    how = None
+    for it in range(iters):
+        assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_used'])) < 1e-12
+        want_actions = g[f'it{it}.actions']
+        nz, how = _noise(g, it, horizon, n, 8, want_actions)
+        data.noise = torch.as_tensor(nz)
+        stats, _ = clean_pufferl.evaluate(data)
+        # the integer side: bit for bit
+        assert np.array_equal(_step_major(exp.actions, n, horizon), want_actions.astype(np.int32)), (tag, it, how)
+        assert _sha(_step_major(exp.obs, n, horizon)[:, :49].astype(np.int8)) == str(g[f'it{it}.obs_sha']), (tag, it)
+        rew, don = _step_major(exp.rewards, n, horizon), _step_major(exp.dones, n, horizon)
+        assert _sha(rew.astype(np.float32)) == str(g[f'it{it}.rewards_sha']) and _sha(don.astype(np.float32)) == str(g[f'it{it}.dones_sha'])
+        assert float(rew.astype(np.float64).sum()) == float(g[f'it{it}.rewards_sum']) and float(don.sum()) == float(g[f'it{it}.dones_sum'])
+        assert data.global_step == int(g[f'it{it}.global_step'])
+        np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']], g[f'it{it}.stats'], rtol=1e-9)
+        # the policy side: 1e-5
+        _close(_step_major(exp.logprobs, n, horizon), g[f'it{it}.logprobs'], 'logprobs')
+        _close(_step_major(exp.values, n, horizon), g[f'it{it}.values'], 'values')
+        if recurrent:
+            _close(exp.lstm_h.cpu().numpy(), g[f'it{it}.lstm_h'], 'lstm_h')
+            _close(exp.lstm_c.cpu().numpy(), g[f'it{it}.lstm_c'], 'lstm_c')
+        clean_pufferl.train(data)
+        idx = torch.stack([exp.minibatch_rows_index(m) for m in range(exp.num_minibatches)])     # the reference's (nmb, minibatch) order
+        _close(exp.advantages[idx].cpu().numpy(), g[f'it{it}.advantages'], 'advantages')
+        _close(exp.returns[idx].cpu().numpy(), g[f'it{it}.returns'], 'returns')
+        L = data.losses
+        got = [L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=1e-5, atol=1e-5, err_msg=f'{tag} it{it} ({how})')
+        assert abs(data.optimizer.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-12
+        sd = pol.state_dict()
+        for k in sd:
+            _close(sd[k].cpu().numpy(), g[f'it{it}.w.{k}'], f'{tag} it{it} weight {k}')
+        m_, v_ = data.flat_params.split(data.optimizer.exp_avg), data.flat_params.split(data.optimizer.exp_avg_sq)
+        for k in m_:
+            key = ('policy.' + k) if (not recurrent or k.startswith('recurrent.')) else ('policy.policy.' + k)
+            _close(m_[k].cpu().numpy(), g[f'it{it}.m.{key}'], f'{tag} it{it} exp_avg {k}', atol=1e-6, rtol=2e-4)
+            _close(v_[k].cpu().numpy(), g[f'it{it}.v.{key}'], f'{tag} it{it} exp_avg_sq {k}', atol=1e-8, rtol=2e-4)
+    print(f'[big golden] {tag}: {iters} iteration(s) replayed, action noise {how}')

@@ -395,3 +395,21 @@ def test_a_timeout_on_one_rank_is_an_error_on_every_rank_in_the_same_update(tmp_
     got = [np.load(tmp_path / f'st{q}.npz') for q in range(world)]
     assert [int(g['status'][0]) for g in got] == [2, 1, 2]
     assert all(int(g['raised'][0]) == 1 and int(g['recovered'][0]) == 1 and int(g['status_after'][0]) == 0 for g in got)
+
+
+def test_injected_rank_skew_shows_up_as_peer_wait_on_the_ranks_that_were_on_time(tmp_path):
+    """one rank's host thread is held back in front of every evaluate() (tools/dp_jitter.py); the in-kernel
+    peer-wait telemetry (csrc/p2p_ll.hpp ll_wait_report, csrc/p2p.hip; pufferlib_amd.dist.wait_stats) must say so — the rank that was on
+    time waits about the injected time per step (in the first exchange after the rollout: the small all-reduce at the end of evaluate()),
+    the late rank does not — the iteration takes about that much longer, and the replicas stay bit-identical."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), 'tools'))
+    import dp_jitter
+    res = dp_jitter.run(world=2, envs=256, horizon=32, iters=12, warmup=2, skews=(0, 2000), late_rank=1, out=str(tmp_path / 'jitter.json'),
+                        timeout_s=400)
+    assert res['replicas_identical'] and res['p2p_status'] == 0
+    quiet, skewed = res['legs']
+    assert skewed['injected_skew_us'] == 2000
+    on_time, late = skewed['wait_us_per_step']
+    assert on_time > quiet['wait_us_per_step'][0] + 1000, (quiet, skewed)         # rank 0 stands waiting for rank 1 ...
+    assert on_time > late + 1000, (quiet, skewed)                                  # ... which itself finds its peer's data there
+    assert skewed['ms_per_step'] > quiet['ms_per_step'] + 1.0, (quiet, skewed)     # nothing hides a late rank: the step grows by about the skew

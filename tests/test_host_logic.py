@@ -511,3 +511,28 @@ def test_early_gae_key_follows_in_place_edits_and_hyperparameters():
     assert cp._gae_key(data) == k2
     ex.values = ex.values.clone()                         # re-bound to another tensor (advisor, round 5): the address is part of the key
     assert cp._gae_key(data) != k2
+
+
+def test_rank_affinity_plan_keeps_every_rank_next_to_its_gpu_and_off_its_neighbours_cores():
+    """pufferlib_amd.dist.plan_affinity (the planning half of pin_rank): 8 ranks on a 2-socket host whose GPUs 0-3 / 4-7 hang off
+    NUMA node 0 / 1 — every rank gets a quarter of ITS node's allowed CPUs, disjoint from its neighbours'; without NUMA information
+    (VM, container) the allowed CPUs are split evenly; a mask too small to split is shared; cpulist parsing."""
+    from pufferlib_amd import dist as pdist
+    assert pdist._parse_cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    node_cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    allowed = set(range(256))
+    shares = [pdist.plan_affinity(r, 8, nodes, node_cpus, allowed) for r in range(8)]
+    for r, (node, share) in enumerate(shares):
+        assert node == nodes[r] and len(share) == 32 and set(share) <= set(node_cpus[node])
+    assert len(set().union(*[set(s) for _, s in shares])) == 256               # disjoint and complete
+    # a restricted mask (cgroup / taskset): only what is allowed, still on the right node
+    node, share = pdist.plan_affinity(5, 8, nodes, node_cpus, set(range(60, 80)))
+    assert node == 1 and set(share) <= set(range(64, 80)) and len(share) == 4
+    # no NUMA information: an even split of the mask
+    got = [pdist.plan_affinity(r, 2, [-1, -1], {}, set(range(8))) for r in range(2)]
+    assert got == [(-1, [0, 1, 2, 3]), (-1, [4, 5, 6, 7])]
+    # fewer allowed CPUs than ranks: everybody shares them (never an empty mask)
+    assert pdist.plan_affinity(2, 4, [-1] * 4, {}, {3, 7}) == (-1, [3, 7])
+    # the GPU's node has no allowed CPU at all: fall back to the mask
+    assert pdist.plan_affinity(0, 2, [1, 1], node_cpus, {0, 1, 2, 3}) == (-1, [0, 1])
