@@ -728,7 +728,7 @@ def sha(a):
     return np.array(hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest())
 
 
-def gen_ppo_big(tag, use_rnn, num_envs, horizon, minibatch, bptt, epochs, lr, iters, total_timesteps=None, store_noise=True):
+def gen_ppo_big(tag, use_rnn, num_envs, horizon, minibatch, bptt, epochs, lr, iters, total_timesteps=None, store_noise=True, full_state=False):
     """clean_pufferl.create/evaluate/train (clean_pufferl.py:30-292) by the UNMODIFIED reference at BASELINE's own sizes, recorded in
     digest form: what must match bit for bit as sha256 (observations, rewards, dones in storage order) or in
     full where the replay needs it (actions, initial weights, the multinomial noise unless `store_noise` is off), what must match
@@ -736,7 +736,10 @@ def gen_ppo_big(tag, use_rnn, num_envs, horizon, minibatch, bptt, epochs, lr, it
     weights and Adam moments), and the scalars (losses, learning rates, statistics, step counts).  store_noise=False (C2: 16.8 MB per
     rollout): only digest() of the noise and the recipe — the noise IS torch.manual_seed(seed) followed by one
     torch.empty(N, A).exponential_(1) per step (torch.multinomial's own draw, asserted below), which the test box regenerates; the
-    replay falls back to the recorded actions where the box's torch draws other numbers."""
+    replay falls back to the recorded actions where the box's torch draws other numbers.
+    full_state: weights and Adam moments after every iteration but the last also in full (`it{k}.full.w.* / m.* / v.*`), so that a
+    replay can continue from the reference's exact state (the demo shape's 32 Adam steps at lr 0.017 sit on a knife edge: see
+    tests/test_oracle_golden.py::test_demo_shape_update_sits_on_a_knife_edge)."""
     import pufferlib
     import pufferlib.vector
     import pufferlib.models
@@ -832,6 +835,13 @@ def gen_ppo_big(tag, use_rnn, num_envs, horizon, minibatch, bptt, epochs, lr, it
             for i, nme in enumerate(names):
                 out[f'it{it}.m.' + nme] = digest(st[i]['exp_avg'].numpy())
                 out[f'it{it}.v.' + nme] = digest(st[i]['exp_avg_sq'].numpy())
+            if full_state and it < iters - 1:
+                for k, v in policy.state_dict().items():
+                    out[f'it{it}.full.w.' + k] = v.detach().numpy().copy()
+                for i, nme in enumerate(names):
+                    out[f'it{it}.full.m.' + nme] = st[i]['exp_avg'].numpy().copy()
+                    out[f'it{it}.full.v.' + nme] = st[i]['exp_avg_sq'].numpy().copy()
+                out[f'it{it}.full.step'] = np.array(int(st[0]['step']), np.int64)
             print(f'  ppo_{tag} it{it}: {time.time() - t_start:.1f} s, losses', out[f'it{it}.losses'][:3])
     finally:
         torch.multinomial = orig_multinomial
@@ -852,7 +862,7 @@ def gen_big():
       ppo_c2_mlp                ONE iteration of configs[1]: 4096 envs x 128 steps, 4 minibatches x 4 epochs"""
     gen_ppo_big('c1_mlp', False, 64, 128, 2048, 16, 4, 2.5e-4, iters=2)
     gen_ppo_big('c1_lstm', True, 64, 128, 2048, 16, 4, 2.5e-4, iters=2)
-    gen_ppo_big('demo_lstm', True, 8, 128, 128, 4, 4, 0.017, iters=3, total_timesteps=30_000)
+    gen_ppo_big('demo_lstm', True, 8, 128, 128, 4, 4, 0.017, iters=2, total_timesteps=30_000, full_state=True)
     gen_ppo_big('c2_mlp', False, 4096, 128, 131072, 16, 4, 2.5e-4, iters=1, store_noise=False)
 
 

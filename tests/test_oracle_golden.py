@@ -1,6 +1,7 @@
 """Pin the CPU oracle (oracle/) against outputs of the unmodified reference (tests/golden/*.npz,
 produced by tests/golden/make_golden.py) and the known answers in SURVEY.md Appendix B."""
 import os
+import sys
 import random
 
 import numpy as np
@@ -8,6 +9,9 @@ import pytest
 import torch
 
 from oracle import c_oracle, ppo_torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import cnn_golden  # noqa: E402
 
 
 def _load(golden_dir, name):
@@ -150,6 +154,99 @@ def test_ppo_replay_matches_reference(golden_dir, tag):
             np.testing.assert_allclose(m[name], g[f'it{it}.m.' + key], rtol=1e-4, atol=1e-7, err_msg=name)
             np.testing.assert_allclose(v[name], g[f'it{it}.v.' + key], rtol=1e-4, atol=1e-9, err_msg=name)
         assert abs(tr.opt.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-15
+
+
+def _close_digest(got, want, what, atol=1e-6, rtol=1e-5):
+    got = np.asarray(got)
+    d = cnn_golden.digest(got)
+    np.testing.assert_allclose(d[2:], want[2:], rtol=rtol, atol=atol, err_msg=what)
+    tol = 0.1 * atol * got.size + rtol * abs(want[1])
+    assert abs(d[0] - want[0]) <= tol and abs(d[1] - want[1]) <= tol, (what, d[:2], want[:2], tol)
+
+
+@pytest.mark.parametrize('tag', ['c1_mlp', 'c1_lstm', 'demo_lstm', 'c2_mlp'])
+def test_ppo_replay_matches_reference_at_baseline_sizes(golden_dir, tag):
+    """The oracle against the reference at BASELINE's own sizes (digest-form fixtures of `make_golden.py big`): configs[0] with both
+    policies, the shape demo.py --env squared trains (bptt 4, 8 minibatches, lr 0.017), one iteration of configs[1] (4096 x 128).
+    c2's multinomial noise is not stored (16.8 MB): regenerated as the reference drew it when this box's torch draws the same
+    numbers (digest check), else noise that forces the recorded actions."""
+    import hashlib
+    torch.set_num_threads(8 if tag == 'c2_mlp' else 1)
+    g, pol, tr, iters = _replay(golden_dir, f'{tag}')
+    n, horizon = int(g['config'][0]), int(g['config'][1])
+    recurrent = tag.endswith('lstm')
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    for it in range(iters):
+        assert abs(tr.opt.param_groups[0]['lr'] - float(g[f'it{it}.lr_used'])) < 1e-15
+        if f'it{it}.noise' in g.files:
+            noise = g[f'it{it}.noise']
+        else:
+            torch.manual_seed(1)
+            for _ in range(it + 1):
+                noise = np.stack([torch.empty(n, 8).exponential_(1).numpy() for _ in range(horizon)])
+            if not np.array_equal(cnn_golden.digest(noise), g[f'it{it}.noise_digest']):
+                noise = np.ones((horizon, n, 8), np.float32)
+                np.put_along_axis(noise, g[f'it{it}.actions'].reshape(horizon, n, 1).astype(np.int64), np.float32(1e-30), axis=2)
+        stats = tr.evaluate(noise)
+        assert np.array_equal(tr.actions, g[f'it{it}.actions'].astype(np.int64)), 'actions differ'
+        assert sha(tr.obs.numpy().astype(np.int8)) == str(g[f'it{it}.obs_sha'])
+        assert sha(tr.rewards.astype(np.float32)) == str(g[f'it{it}.rewards_sha']) and sha(tr.dones.astype(np.float32)) == str(g[f'it{it}.dones_sha'])
+        _close_digest(tr.logprobs, g[f'it{it}.logprobs'], 'logprobs')
+        _close_digest(tr.values, g[f'it{it}.values'], 'values')
+        assert tr.global_step == int(g[f'it{it}.global_step'])
+        np.testing.assert_allclose([stats['episode_return'], stats['episode_length'], stats['score']], g[f'it{it}.stats'], rtol=1e-12)
+        L = tr.train()
+        _close_digest(tr.b_advantages.numpy(), g[f'it{it}.advantages'], 'advantages')
+        _close_digest(tr.b_returns.numpy(), g[f'it{it}.returns'], 'returns')
+        got = [L['policy_loss'], L['value_loss'], L['entropy'], L['old_approx_kl'], L['approx_kl'], L['clipfrac'], L['explained_variance']]
+        np.testing.assert_allclose(got, g[f'it{it}.losses'], rtol=2e-5, atol=1e-6)
+        prefix = 'policy.policy.' if recurrent else 'policy.'
+        m, v = tr.adam_moments()
+        for name, arr in pol.state_arrays().items():
+            key = ('policy.recurrent.' + name) if name.endswith('_l0') else (prefix + name)
+            _close_digest(arr, g[f'it{it}.w.' + key], name, atol=2e-6)
+            _close_digest(m[name], g[f'it{it}.m.' + key], name, atol=1e-7, rtol=2e-4)
+            _close_digest(v[name], g[f'it{it}.v.' + key], name, atol=1e-9, rtol=2e-4)
+        assert abs(tr.opt.param_groups[0]['lr'] - float(g[f'it{it}.lr_next'])) < 1e-15
+
+
+def test_demo_shape_update_sits_on_a_knife_edge(golden_dir):
+    """Why tests/test_gpu_big_goldens.py tolerates a few isolated weight entries on the demo shape (config.yaml:498-509: lr 0.017,
+    4 epochs x 8 minibatches of 128 rows): the reference's OWN update is not reproducible to 1e-5 in every entry there.  The oracle
+    (bit-compatible with the reference on this fixture: test above) re-run with every gradient entry multiplied by 1 + 1e-6 N(0, 1) —
+    the size of any re-ordered fp32 summation — lands either on the recorded weights (all entries within 2e-6) or on ANOTHER set:
+    a few dozen entries of the encoder (one hidden unit, the few observation cells occupied in one row) off by up to ~7e-3, the rest
+    unchanged.  One row sits within rounding distance of a branch point (a ReLU kink / a clipping branch), and Adam's 32 steps at
+    lr 0.017 turn the flipped branch into a visible offset of exactly those entries."""
+    torch.set_num_threads(1)
+    g = _load(golden_dir, 'ppo_demo_lstm.npz')
+
+    def run(eps, seed):
+        _, pol, tr, _ = _replay(golden_dir, 'demo_lstm')
+        gen = torch.Generator().manual_seed(seed)
+        plain = tr.opt.step
+
+        def step(*a, **k):
+            if eps:
+                with torch.no_grad():
+                    for p in pol.params:
+                        if p.grad is not None:
+                            p.grad.mul_(1 + eps * torch.randn(p.grad.shape, generator=gen))
+            return plain(*a, **k)
+        tr.opt.step = step
+        tr.evaluate(g['it0.noise'])
+        tr.train()
+        return pol.state_arrays()
+    base = run(0.0, 0)
+    outcomes = []
+    for seed in range(4):
+        w = run(1e-6, seed)
+        worst = max(float(np.abs(w[k] - base[k]).max()) for k in base)
+        n_off = sum(int((np.abs(w[k] - base[k]) > 1e-5).sum()) for k in base)
+        total = sum(base[k].size for k in base)
+        outcomes.append((worst, n_off))
+        assert worst < 2e-6 or (1e-4 < worst < 0.5 * 0.017 and n_off < 0.01 * total), (seed, worst, n_off)
+    assert any(w < 2e-6 for w, _ in outcomes) and any(w > 1e-4 for w, _ in outcomes), outcomes      # both branches are reachable
 
 
 def test_conv_ppo_replay_matches_reference(golden_dir):
