@@ -14,7 +14,7 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                duration measured with HIP events on the launch stream over the timed region (every 17th launch
                bracketed: the event packets serialise the queue)
   cpu_baseline kind "reference": the UNMODIFIED reference's Serial CPU path timed on this box model by tools/gpu_jobs/
-               with_reference.sh (profiles/r05_reference_cpu_on_gpu_box.json; used when the box fingerprint matches), with the
+               with_reference.sh (profiles/r06_reference_cpu_on_gpu_box.json; used when the box fingerprint matches), with the
                live timing of the CPU oracle port (C env + torch-fp32 policy/update, oracle/) on a bounded sample of the same
                workload on this box's host cores riding along (`port_live`; it IS the baseline when no record matches)
 """
@@ -89,25 +89,27 @@ def _oracle_trainer(n, seed=1):
 
 def reference_cpu_baseline(config_key, port):
     """cpu_baseline with kind = "reference": the UNMODIFIED reference's own CPU path (clean_pufferl + pufferlib.vector.Serial + c_gae.pyx),
-    timed on a box of THIS model by tools/gpu_jobs/with_reference.sh and recorded in profiles/r05_reference_cpu_on_gpu_box.json
+    timed on a box of THIS model by tools/gpu_jobs/with_reference.sh and recorded in profiles/r06_reference_cpu_on_gpu_box.json
     (the reference cannot be read at bench time: /root/reference does not exist on the GPU box; the job ships it once in a git-ignored
     staging directory).  Used only when the record's box fingerprint (CPU model + logical core count) is this box's; otherwise, and
     when the file is absent, the live port timing `port` is returned unchanged.  The live port timing of this run rides along."""
-    path = os.path.join(REPO, 'profiles', 'r05_reference_cpu_on_gpu_box.json')
+    path = os.path.join(REPO, 'profiles', 'r06_reference_cpu_on_gpu_box.json')
     try:
         doc = json.load(open(path))
         box, s = doc['box'], doc['summary'][config_key]
     except Exception:
         return port
-    if box.get('cpu_model') != _cpu_model() or box.get('cores_logical') != (os.cpu_count() or 1):
-        return dict(port, reference_record_refused=f"{os.path.relpath(path, REPO)} was taken on {box.get('cpu_model')} x{box.get('cores_logical')}, "
-                                                   f"this box is {_cpu_model()} x{os.cpu_count()}")
+    import torch
+    if box.get('cpu_model') != _cpu_model() or box.get('cores_logical') != (os.cpu_count() or 1) or box.get('torch') != torch.__version__:
+        return dict(port, reference_record_refused=f"{os.path.relpath(path, REPO)} was taken on {box.get('cpu_model')} x{box.get('cores_logical')} "
+                                                   f"with torch {box.get('torch')}, this box is {_cpu_model()} x{os.cpu_count()} with torch {torch.__version__}")
     ser, best = s['serial'], s['best']
     return dict(value=ser['value'], unit='env_steps/s', cores=max(int(ser['torch_threads']), int(ser['cores_used'])), cores_available=box['cores_logical'],
                 cores_physical=box['cores_physical'], cpu_model=box['cpu_model'], kind='reference',
                 sample=f"{ser['iterations']} evaluate+train iteration(s) of {ser['envs']} envs x {ser['horizon']} steps after 1 warm-up: {ser['what']}; "
                        f"env stepping on 1 core (Serial), torch on {ser['torch_threads']} threads",
-                measured='recorded on a box of this model (fingerprint matched: CPU model + logical cores), not re-timed in this run',
+                measured=f"recorded {box.get('date')} on a box of this model (fingerprint matched: CPU model + logical cores + torch version), not re-timed in "
+                         'this run; the live port timing of THIS run is `port_live`',
                 source=os.path.relpath(path, REPO) + ' (tools/gpu_jobs/with_reference.sh -> tools/time_reference.py)',
                 breakdown_s_per_iter=dict(evaluate=ser['evaluate_s_per_iter'], train=ser['train_s_per_iter'], **ser['profile']),
                 best_vectoriser=dict(value=best['value'], backend=best['backend'], workers=best['workers'], torch_threads=best['torch_threads']),
@@ -619,7 +621,7 @@ def main():
     # 17th one is bracketed (17 is coprime to the 16 launches of a step: every epoch x minibatch position gets sampled, ~19 launches
     # of a 20-step region; rounds 2-5 bracketed every 5th, which tools/step_times.py shows as ~20 us of every 1.27 ms step — the
     # same loop without the brackets, from a cold start); the conv update's launches differ in shape and are all bracketed.
-    event_stride = 1 if (args.policy in ('cnn', 'wide') and not wide_fused) else int(os.environ.get('PFA_BENCH_EVENT_STRIDE', '17'))
+    event_stride = 1 if (args.policy in ('cnn', 'wide') and not wide_fused) else 17
     L.pfa_timing_stride(event_stride)
     L.pfa_timing_reset()
     L.pfa_timing_enable(1)   # dominant kernel only
@@ -871,7 +873,7 @@ def main():
                          'avg_launch_ms': avg_ms, 'launches': launches, 'bracketed': f'every {event_stride}. launch of the timed region' if event_stride > 1 else 'every launch of the timed region',
                          # ppo_mlp_grad's launch carries its own HIP events (hipExtLaunchKernelGGL start/stop: the dispatch's begin and end,
                          # what rocprofv3's kernel trace reports); the other kernels are bracketed by events recorded on their stream
-                         'timing': ('HIP events attached to the dispatch (hip_ext.h start/stop)' if args.policy == 'mlp' and os.environ.get('PFA_TIMING_EXT', '1') != '0'
+                         'timing': ('HIP events attached to the dispatch (hip_ext.h start/stop)' if args.policy == 'mlp'
                                     else 'HIP events recorded on the launch stream before / after the launch'),
                          'flop_per_launch': flop_row * rows_per_launch},
             'kernel_ms_per_step': breakdown,
@@ -964,7 +966,7 @@ def main():
                 out['self_check'] = self_check_c4()
                 data = vec = pol = None
             if args.workload == 'c4' and not cnn_lstm:
-                out['cpu_baseline'] = cpu_baseline_c4()
+                out['cpu_baseline'] = reference_cpu_baseline('c4', cpu_baseline_c4())
             elif args.workload == 'c3':
                 out['cpu_baseline'] = reference_cpu_baseline('c3', cpu_baseline_c3())
             elif args.policy == 'mlp':          # the headline configuration

@@ -39,9 +39,12 @@ int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms
 /* ------------------------------------------------------------------------------------------
  * GAE — replaces c_gae.compute_gae (c_gae.pyx:11-32), called from clean_pufferl.py:168-169.
  * One reverse affine scan over the whole flat (env-major) batch, crossing env boundaries exactly
- * like the reference; advantages[n-1] = 0.  The result is the BIT PATTERN of the reference's sequential fp32 loop (every thread
- * warms up on the elements behind its own until it sits on the reference's rounded sequence: csrc/gae.hip gae_exact_kernel) for
- * gamma * gae_lambda up to ~0.985, within a few ulps above.  `returns` (nullable) = advantages + values
+ * like the reference; advantages[n-1] = 0.  Contract: within 1e-5 of the reference's sequential fp32 loop, always.  In practice much
+ * closer: every thread warms up on the elements behind its own (csrc/gae.hip gae_exact_kernel) so that it sits ON the reference's
+ * rounded sequence, and for gamma * gae_lambda up to ~0.985 the result is the reference's bit pattern on typical data (every case the
+ * tests hold, 524 288 rows, done rates 0 - 25 %); the argument is a contraction in real arithmetic, so isolated entries may sit
+ * 1 ulp off on data with an extreme dynamic range inside one 1024-element window, and a few ulps off above ~0.985.
+ * `returns` (nullable) = advantages + values
  * (clean_pufferl.py:482).  workspace >= pfa_gae_workspace_bytes(n).
  * ------------------------------------------------------------------------------------------ */
 size_t pfa_gae_workspace_bytes(int64_t n);
@@ -446,10 +449,13 @@ int pfa_ppo_mlp_grad_mfma_per_tile(int32_t obs_dim, int32_t obs_stride, int32_t 
 /* Which kernel pfa_ppo_mlp_grad / pfa_ppo_mlp_train launch for these dimensions and local minibatch rows under the current product
  * form (pfa_igemm_set_products): 0 = ppo_mlp_grad_kernel (exact fp32 MFMA chains), 1 = ppo_mlp_grad_bf16_kernel (csrc/ppo_bf16.hpp:
  * the opt-in form, the 7x7 grid on 64-float rows with minibatches of whole 32-row tiles; everything else stays on 0). */
-/* pfa_ppo_mlp_train's reduce + Adam launch hands the clip norm's pieces over grid-wide; the wait is bounded (PFA_GRID_TIMEOUT_MS,
+/* pfa_ppo_mlp_train's reduce + Adam launch hands the clip norm's pieces over grid-wide; the wait is bounded (PFA_WAIT_TIMEOUT_MS,
  * default 10 000) and the one-launch form is only used when the runtime's occupancy says all its workgroups are resident at once.
  * 0 = ok, 1 = a wait ran out (the parameters hold NaN since).  A plain host read, no synchronisation. */
 int pfa_ppo_grid_status(void);
+/* Clears the word once it has been reported (returns the value it held), so that the recovery the error message names — PFA_FUSED_ADAM=0
+ * and restored parameters — can happen inside the same process. */
+int pfa_ppo_grid_reset(void);
 int pfa_ppo_mlp_grad_path(const pfa_mlp_dims *dims, int64_t mb_rows);
 /* clip_grad_norm_(max_grad_norm) + Adam(eps) step (:240-244; torch.optim.Adam single-tensor semantics, bias
  * correction with `step` = 1-based optimizer step count).  grad_scale multiplies grads first.
@@ -473,8 +479,8 @@ int pfa_adam_clip_step(float *params, const float *grads, float *exp_avg, float 
  * pfa_dist_all_reduce_f32 (peer path as a launch of its own, else the RCCL communicator of pfa_dist_init) on `stream`.
  * Single rank: sum of the partials, clip norm and Adam are one launch as well (PFA_FUSED_ADAM=0: the two-kernel form of
  * pfa_ppo_mlp_grad + pfa_adam_clip_step, bit-identical results).  The one-launch form hands the pieces of the clip norm from
- * workgroup to workgroup through the norm-piece area of the workspace ({value, launch generation} words); this call zeroes
- * that area before its first launch. */
+ * workgroup to workgroup through {value, launch generation} words in a small LIBRARY-OWNED device buffer (one per workspace pointer,
+ * allocated and cleared on first use): the workspace itself needs no initialisation and may be recycled freely. */
 int pfa_ppo_mlp_train(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,
                       const pfa_ppo_hparams *hp, const double *adv_stats, float *grads, float *exp_avg,
                       float *exp_avg_sq, int64_t opt_step, float lr, float beta1, float beta2, float eps,
@@ -726,7 +732,7 @@ int pfa_rows_perm(const float *src, int32_t lds_, float *dst, int32_t ldd, const
  * sums the slots in rank order (one hop instead of a ring's 2 (R-1); identical bits on every rank).  pfa_p2p_alloc creates
  * this rank's fine-grained buffer (slots of cap_bytes) and returns its 64-byte IPC handle; the caller gathers all handles
  * (any transport) and passes them, rank order, to pfa_p2p_open.  Once open, pfa_dist_all_reduce_* and the native train loop
- * use it for every bucket that fits.  World size <= 8 (one node).  The flag waits are bounded (PFA_P2P_TIMEOUT_MS, default
+ * use it for every bucket that fits.  World size <= 8 (one node).  The flag waits are bounded (PFA_WAIT_TIMEOUT_MS, default
  * 30 000): a wait that runs out fills its part of the bucket with NaN and raises the status word.  pfa_p2p_status (a plain
  * host read, no synchronisation): 0 ok, 1 a wait of this rank ran out (a peer never arrived), 2 a peer reported one (the ranks' status
  * words ride every flag-in-data exchange: csrc/p2p_ll.hpp), -1 not open.

@@ -282,6 +282,7 @@ _SIGNATURES = {
     'pfa_p2p_close': (C.c_int, []),
     'pfa_p2p_status': (C.c_int, []),
     'pfa_ppo_grid_status': (C.c_int, []),
+    'pfa_ppo_grid_reset': (C.c_int, []),
     'pfa_p2p_seq': (C.c_int64, []),
     'pfa_p2p_reset': (C.c_int, [C.c_int64]),
     'pfa_p2p_debug_set_status': (C.c_int, [C.c_int]),

@@ -477,12 +477,11 @@ def evaluate(data):
         # The tape does not depend on actions: draw the NEXT rollout's reset rounds on the side stream while THIS
         # rollout runs (its small workgroup co-resides with the rollout's).  The ring slots it writes belong to the
         # rollout before this one, which `start_point` guarantees has finished.
-        if 3 * (vecenv._rounds_needed(T) + 1) <= vecenv.tape_rounds and os.environ.get('PFA_TAPE_PREFETCH', '1') != '0':
+        if 3 * (vecenv._rounds_needed(T) + 1) <= vecenv.tape_rounds:
             with torch.cuda.stream(data.tape_stream):
                 data.tape_stream.wait_event(start_point)
                 vecenv.ensure_tape(T)
-                if (data.noise is None and data.lstm_engine is None and os.environ.get('PFA_NOISE_PREFETCH', '1') != '0'
-                        and getattr(data, '_noise_cur', None) is not None):
+                if data.noise is None and data.lstm_engine is None and getattr(data, '_noise_cur', None) is not None:
                     # ... and the NEXT rollout's action noise (16.8 MB of writes that depend on nothing but the stream position),
                     # into the buffer the running rollout is not reading
                     nxt = _noise_buffer(data, T, N, fp.num_actions, vecenv.device, other_than=data._noise_cur)
@@ -882,7 +881,8 @@ def train(data):
             if check_peers:
                 pdist.raise_if_peer_lost()           # the peer all-reduce's bounded waits: a lost rank is an error here, never a stale sum
             if _lib.lib().pfa_ppo_grid_status() != 0:
-                raise RuntimeError('the grid-wide hand-off of the fused reduce + Adam launch timed out (PFA_GRID_TIMEOUT_MS): the '
+                _lib.lib().pfa_ppo_grid_reset()      # reported once: the recovery named below can then proceed in this process
+                raise RuntimeError('the grid-wide hand-off of the fused reduce + Adam launch timed out (PFA_WAIT_TIMEOUT_MS): the '
                                    'device is shared or CU-masked so that its workgroups were not resident together; the parameters '
                                    'hold NaN.  Set PFA_FUSED_ADAM=0 (two-kernel form) and restore a checkpoint')
             s_y, s_yy, s_a, s_aa = acc[6:10]

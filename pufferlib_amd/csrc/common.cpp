@@ -52,14 +52,8 @@ void timing_end(void *stop, hipStream_t stream) {
 }
 // An event pair for a launch that carries its own events (hipExtLaunchKernelGGL: the runtime stamps them with the dispatch's begin
 // and end, the same two timestamps rocprofv3's kernel trace reports) — nothing is recorded here.  false: timing is off for this
-// launch (or PFA_TIMING_EXT=0 asks for the stream-position bracket instead).
-bool timing_ext_mode() {
-    static const bool ext = [] {
-        const char *e = getenv("PFA_TIMING_EXT");
-        return !(e && e[0] == '0');
-    }();
-    return ext;
-}
+// launch.
+bool timing_ext_mode() { return true; }
 bool timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop) {
     const bool ext = timing_ext_mode();
     if (!ext || g_timing == 0 || (g_timing == 1 && g_selected != name)) return false;

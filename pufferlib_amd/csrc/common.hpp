@@ -13,7 +13,7 @@ void set_error(const char *fmt, ...);
 bool timing_enabled();
 void *timing_begin(const char *name, hipStream_t stream);  // records the start event when timing is on
 void timing_end(void *stop, hipStream_t stream);
-bool timing_ext_mode();                                                  // PFA_TIMING_EXT != 0 (default)
+bool timing_ext_mode();                                                  // launches that carry their own events (hipExtLaunchKernelGGL)
 bool timing_pair(const char *name, hipEvent_t *start, hipEvent_t *stop);  // for launches that carry their own events (hip_ext.h)
 
 struct ScopedKernelTimer {  // brackets ONE kernel launch with HIP events on its own stream (bench.py roofline)

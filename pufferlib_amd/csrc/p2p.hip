@@ -15,7 +15,7 @@
 // has pushed call s+1, i.e. finished reading call s.
 //
 // A lost peer ends in an error, not a hung GPU and not a silently wrong sum: the flag wait is bounded in wall-clock time
-// (100 MHz counter; default 30 s, PFA_P2P_TIMEOUT_MS), and a wait that runs out (a) raises the status word — host-pinned
+// (100 MHz counter; default 30 s, PFA_WAIT_TIMEOUT_MS), and a wait that runs out (a) raises the status word — host-pinned
 // memory, so the host reads it without a copy or a synchronisation (pfa_p2p_status; clean_pufferl.train() checks it after
 // every update and raises) — and (b) POISONS the chunk it could not complete with NaN, so that losses, weights and every
 // isfinite check downstream fail even where nobody looks at the status.
@@ -169,13 +169,9 @@ int p2p_all_reduce(void *buf, size_t count, bool f64, hipStream_t stream) {
     ++g_p2p.calls;
     const int phase = (int)(seq & 1);
     // Workgroups per call: a chunk is pushed to every peer by ONE workgroup, so the chunk size sets how many store streams run
-    // next to each other on the links.  4 KB (10 workgroups for the MLP policy's 38 KB bucket) unless PFA_P2P_CHUNK_BYTES says otherwise;
+    // next to each other on the links.  4 KB (10 workgroups for the MLP policy's 38 KB bucket);
     // at most kP2pChunks workgroups (a flag per source and chunk).
-    static const long long chunk_bytes = [] {
-        const char *e = std::getenv("PFA_P2P_CHUNK_BYTES");
-        const long long v = e ? std::atoll(e) : 0;
-        return v >= 256 ? v : 4096ll;
-    }();
+    constexpr long long chunk_bytes = 4096;
     long long chunks = (long long)((bytes + chunk_bytes - 1) / chunk_bytes);
     chunks = chunks < 1 ? 1 : (chunks > kP2pChunks ? kP2pChunks : chunks);
     ScopedKernelTimer timer("p2p_all_reduce", stream);
@@ -217,7 +213,7 @@ extern "C" int pfa_p2p_alloc(int64_t cap_bytes, int32_t world, uint8_t *handle64
     *(volatile int *)st = 0;
     g_p2p.status = (int *)st;
     long long ms = 30000;
-    if (const char *e = std::getenv("PFA_P2P_TIMEOUT_MS")) {
+    if (const char *e = std::getenv("PFA_WAIT_TIMEOUT_MS")) {
         const long long v = std::atoll(e);
         if (v > 0) ms = v;
     }

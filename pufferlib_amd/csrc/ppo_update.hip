@@ -23,6 +23,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <unordered_map>
+
 #include "common.hpp"
 #include "mlp_tile.hpp"
 #include "sampler.hpp"
@@ -836,10 +838,10 @@ constexpr int kAdamThreads = 256;   // adam_clip_kernel's workgroup: its norm su
 // generation — no counter, no fence (a release fence here writes back the whole L2, megabytes of the gradient kernel's partials
 // still dirty in it: measured, it made the one-launch form slower than the two kernels it replaces).
 struct GridWords {
-    unsigned long long *words;   // [workgroups][2], zeroed once per pfa_ppo_mlp_train call
+    unsigned long long *words;   // [workgroups][2], library-owned, zeroed once when allocated (grid_words_of)
     unsigned gen;                // never 0, different for every launch of the process
     int *status;                 // host-pinned word: raised when the hand-off's bounded wait ran out (pfa_ppo_grid_status)
-    long long timeout_ticks;     // of the 100 MHz wall clock (PFA_GRID_TIMEOUT_MS, default 10 s)
+    long long timeout_ticks;     // of the 100 MHz wall clock (PFA_WAIT_TIMEOUT_MS, default 10 s)
 };
 struct AdamArgs {
     float *params, *exp_avg, *exp_avg_sq;
@@ -1202,14 +1204,12 @@ static size_t partials_bytes(const pfa_mlp_dims *dims) {   // (the opt-in bf16 f
 static double *norm_partials_of(void *workspace, const pfa_mlp_dims *dims) {  // after the gradient partials
     return (double *)((char *)workspace + partials_bytes(dims));
 }
-// The grid hand-off words live behind everything else in the workspace, in a region nothing but ppo_reduce_adam_kernel writes: a word
-// only ever holds {value bits, generation of the launch that wrote it}, generations never repeat within a process, and the buffer
-// starts zeroed (generation 0 is never used) — so the region needs no clearing between calls (rounds 4: one hipMemsetAsync per
-// pfa_ppo_mlp_train call, 4.4 us + a dispatch gap per update, because the words shared their place with f64 norm pieces of the
-// two-kernel form whose bit patterns could pass for a generation).  The caller allocates the workspace zero-initialised ONCE.
-static size_t grid_words_bytes_max(const pfa_mlp_dims *dims) {
-    return align_up(((native_count(dims->obs_stride) + 63) / 64) * 2 * sizeof(unsigned long long), 256) + 256;
-}
+// The grid hand-off words are LIBRARY-OWNED (advisor, round 5: they used to live at the end of the caller's workspace, whose contract then
+// silently was "zeroed once and never written by anybody else"): one small device buffer per workspace pointer, allocated and cleared
+// on first use (grid_words_of below).  A word only ever holds {value bits, generation of the launch that wrote it}, generations never
+// repeat within a process and generation 0 is never used — so the buffer needs no clearing between launches, and a recycled or
+// uninitialised caller workspace cannot pass for a hand-off.
+constexpr size_t kGridWordsBytes = 16384;   // 2 words per workgroup of the reduce + Adam launch (<= 600 workgroups)
 static size_t tail_bytes(const pfa_mlp_dims *dims, int nmb) {   // what follows the partials: adv-stat partials / norm pieces (shared)
     const size_t native = native_count(dims->obs_stride);
     const size_t advp = align_up((size_t)nmb * 64 * 2 * sizeof(double), 256);
@@ -1232,8 +1232,8 @@ extern "C" size_t pfa_ppo_workspace_bytes(const pfa_mlp_dims *dims, int64_t batc
     if (!dims || !hp || hp->num_minibatches < 1) return 0;
     (void)batch_rows;
     static_assert(kAdvChunks == 64, "tail_bytes assumes 64 chunks");
-    // [gradient partials | adv-stat partials / norm pieces (shared) | grid hand-off words of the one-launch reduce + Adam]
-    return partials_bytes(dims) + tail_bytes(dims, hp->num_minibatches) + 256 + grid_words_bytes_max(dims);
+    // [gradient partials | adv-stat partials / norm pieces (shared)]
+    return partials_bytes(dims) + tail_bytes(dims, hp->num_minibatches) + 256;
 }
 
 extern "C" int pfa_ppo_adv_stats(const pfa_experience *exp, int64_t batch_rows, const pfa_ppo_hparams *hp, double *stats,
@@ -1334,7 +1334,6 @@ static int launch_grad(const pfa_experience *exp, int64_t batch_rows, int32_t mb
     else PFA_LAUNCH_GRAD_KM(DPV, DPV / 4, false)
     {
         // bench.py's roofline leg: the launch carries its own events (stamped with the dispatch's begin and end); with
-        // PFA_TIMING_EXT=0 the stream-position bracket of the other kernels is used instead (it adds the dispatch gap, ~2.4 us)
         hipEvent_t grad_ev0 = nullptr, grad_ev1 = nullptr;
         const bool grad_timed = timing_pair("ppo_mlp_grad", &grad_ev0, &grad_ev1);
         ScopedKernelTimer timer(timing_ext_mode() ? nullptr : "ppo_mlp_grad", (hipStream_t)stream);
@@ -1425,8 +1424,23 @@ extern "C" int pfa_adam_clip_step(float *params, const float *grads, float *exp_
 }
 
 // Kernels B + C in one launch (ppo_reduce_adam_kernel); `ll` non-null: with the data-parallel exchange inside.
-static unsigned long long *grid_words_of(void *workspace, const pfa_mlp_dims *dims, int nmb) {   // their own region at the end of the workspace
-    return (unsigned long long *)((char *)workspace + partials_bytes(dims) + tail_bytes(dims, nmb) + 256);
+static unsigned long long *grid_words_of(void *workspace) {   // one library-owned, zero-initialised buffer per trainer (keyed on its workspace)
+    static std::unordered_map<void *, unsigned long long *> words;
+    auto it = words.find(workspace);
+    if (it != words.end()) return it->second;
+    if (words.size() >= 64) {   // trainers come and go: start over (nothing of a finished launch lives in the words)
+        (void)hipDeviceSynchronize();
+        for (auto &kv : words) (void)hipFree(kv.second);
+        words.clear();
+    }
+    void *p = nullptr;
+    if (hipMalloc(&p, kGridWordsBytes) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, kGridWordsBytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(p);
+        return nullptr;
+    }
+    words[workspace] = (unsigned long long *)p;
+    return (unsigned long long *)p;
 }
 static int *grid_status_word() {   // host-pinned, device-visible, one per process
     static int *word = nullptr;
@@ -1441,7 +1455,7 @@ static int *grid_status_word() {   // host-pinned, device-visible, one per proce
 static long long grid_timeout_ticks() {
     static const long long ticks = [] {
         long long ms = 10000;
-        if (const char *e = std::getenv("PFA_GRID_TIMEOUT_MS")) {
+        if (const char *e = std::getenv("PFA_WAIT_TIMEOUT_MS")) {
             const long long v = std::atoll(e);
             if (v > 0) ms = v;
         }
@@ -1497,7 +1511,11 @@ static int launch_reduce_adam(const pfa_mlp_dims *dims, int nmb, int grid, float
     if (gen == 0) gen = (unsigned)(++launches);
     int *gstatus = grid_status_word();
     PFA_REQUIRE(gstatus, "ppo.train: cannot allocate the grid hand-off's status word");
-    const GridWords gw{grid_words_of(workspace, dims, nmb), gen, gstatus, grid_timeout_ticks()};
+    unsigned long long *gwords = grid_words_of(workspace);
+    PFA_REQUIRE(gwords, "ppo.train: cannot allocate the grid hand-off words");
+    PFA_REQUIRE((size_t)((native_count(dims->obs_stride) + 63) / 64) * 2 * sizeof(unsigned long long) <= kGridWordsBytes, "ppo.train: hand-off words too small");
+    (void)nmb;
+    const GridWords gw{gwords, gen, gstatus, grid_timeout_ticks()};
     const LlArgs none{};
     ScopedKernelTimer timer("ppo_reduce_adam", stream);
 #define PFA_LAUNCH_RA(DPV, KTMV, COLV, PERMV)                                                                                        \
@@ -1533,6 +1551,15 @@ static bool env_on(const char *name, bool dflt) {
 extern "C" int pfa_ppo_grid_status(void) {
     int *w = grid_status_word();
     return w ? *(volatile int *)w : 0;
+}
+// Clears the word once it has been reported (the parameters still hold NaN: restore them), so that the recovery the error names —
+// PFA_FUSED_ADAM=0 + a checkpoint — can happen inside the same process.  Returns the value it cleared.
+extern "C" int pfa_ppo_grid_reset(void) {
+    int *w = grid_status_word();
+    if (!w) return 0;
+    const int was = *(volatile int *)w;
+    *(volatile int *)w = 0;
+    return was;
 }
 
 extern "C" int pfa_ppo_mlp_train_logged(const pfa_experience *exp, int64_t batch_rows, float *params, const pfa_mlp_dims *dims,

@@ -238,8 +238,9 @@ __global__ void __launch_bounds__(kTapeThreads) squared_tape_kernel(SquaredView 
 // Tape fill, single-target form (num_targets == 1: random.sample(pop, 1) is ONE _randbelow, so word w yields a draw iff
 // (w >> (32 - bits)) < n_pop, independently of every other word).  The work then splits into
 //   (1) the only sequential part: the raw MT19937 words.  x[k+624] = twist(x[k], x[k+1], x[k+397]) lets 227 consecutive
-//       words be computed at once; ONE wavefront slides that 227-word window over an LDS ring (no workgroup barriers, one
-//       SIMD slot: it runs under the rollout without slowing it) and streams the raw words to scratch — `squared_tape_words`;
+//       words be computed at once; ONE small workgroup slides that 227-word window through LDS, two steps per barrier (one extra
+//       wavefront on the SIMDs of a single CU: it runs under the rollout without slowing it) and streams the raw words to scratch —
+//       `squared_tape_words`;
 //   (2) everything else in parallel over all words: temper, test, count (`squared_tape_count`), then exclusive offsets,
 //       compaction into (round, env) tape slots, and the stream state after the last word consumed (`squared_tape_select`).
 // The number of words the draws will need is only known statistically (acceptance n_pop / 2^bits), so (1) produces the
@@ -260,17 +261,28 @@ struct TapeJob {          // written by the words kernel, read by the parallel p
     int blocks;           // regenerated blocks after block 0
 };
 
-__global__ void __launch_bounds__(64) squared_tape_words_kernel(SquaredView v, uint32_t *raw, TapeJob *job, int rounds, int blocks) {
-    // The stream is laid out LINEARLY in LDS (x[base + i] at lin[w + i]) so that every operand of a step sits at a constant
-    // offset from one moving pointer; when the window reaches the end, its last 624 words move back to the front.
+// x[n] = x[n - 227] ^ g(x[n - 624], x[n - 623]): the word 227 back enters with a plain XOR, everything else depends on words at
+// least 397 back.  One SLOT per thread (227 slots = the words of one step; four wavefronts, the last with 35 lanes) and TWO steps
+// per barrier: both steps' g operands lie in the 624 words in front of the super-step (454 + 1 of them), the second step's
+// XOR operand is the first step's word of the same slot (a register), and so is the next super-step's.  The chain per 454 words
+// is then one LDS round trip (store -> barrier -> load), g, two XORs — instead of a single wavefront issuing every load and store
+// of two 227-word steps itself (round 5: 209 us for a 128-step rollout's words, hidden only while a train() follows every
+// evaluate()).  The stream still slides LINEARLY through LDS (x[base + i] at lin[w + i]); when the
+// window reaches the end its last 624 words move back to the front.
+constexpr int kTapeWordThreads = 256;
+__device__ __forceinline__ uint32_t mt_g(uint32_t cur, uint32_t nxt) {   // mt_twist(cur, nxt, far) == far ^ mt_g(cur, nxt)
+    const uint32_t y = (cur & 0x80000000u) | (nxt & 0x7fffffffu);
+    return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+__global__ void __launch_bounds__(kTapeWordThreads) squared_tape_words_kernel(SquaredView v, uint32_t *raw, TapeJob *job, int rounds, int blocks) {
     __shared__ uint32_t lin[kTapeLin];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < kMtN; i += 64) {
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kMtN; i += kTapeWordThreads) {
         const uint32_t w = v.hdr->mt[i];
         lin[i] = w;
         raw[i] = w;
     }
-    if (lane == 0) {
+    if (tid == 0) {
         const int idx0 = v.hdr->mt_idx;
         job->first_round = v.hdr->rounds_filled;
         job->need = (long long)rounds * v.n;
@@ -279,48 +291,33 @@ __global__ void __launch_bounds__(64) squared_tape_words_kernel(SquaredView v, u
         job->avail = (long long)(blocks + 1) * kMtN - idx0;
     }
     lds_barrier();
-    // new words x[624 + k], k in [0, blocks*624), in whole 227-word steps (the last step may run past the end: the scratch has
-    // the slack, the extra words are simply more of the same stream).  Lane l owns words j = 64 r + l (r < 4; r = 3: l < 35) of
-    // every step.  The `far` operand x[k + 397] of a step is the word the SAME (r, lane) slot produced one step earlier
-    // (k + 397 - 624 = k - 227), so the step-to-step dependency stays in registers; `cur` / `nxt` were written at least two
-    // steps back and are fetched one step ahead.  One wavefront, LDS operations complete in issue order: no barrier in the loop.
-    const int steps = (blocks * kMtN + kMtStep - 1) / kMtStep;
-    uint32_t far[4], cur[4], nxt[4];
-    const uint32_t *src = lin + lane;      // &x[base + lane]
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {          // (r = 3, lanes >= 35: slots this lane does not own — read, never stored)
-        far[r] = src[r * 64 + kMtM];
-        cur[r] = src[r * 64];
-        nxt[r] = src[r * 64 + 1];
-    }
-    uint32_t *out = raw + kMtN + lane;     // &raw[624 + base + lane]
-    int w = 0;                             // window start inside lin (uniform)
-    for (int st = 0; st < steps; ++st) {
-        uint32_t cur1[4], nxt1[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {      // operands of step st + 1: written in step st - 1 or earlier
-            cur1[r] = src[kMtStep + r * 64];
-            nxt1[r] = src[kMtStep + r * 64 + 1];
+    // new words x[624 + k], k in [0, blocks * 624), in whole super-steps of 2 x 227 (the last one may run past the end: the scratch
+    // has the slack, the extra words are simply more of the same stream)
+    const int supers = (blocks * kMtN + 2 * kMtStep - 1) / (2 * kMtStep);
+    const bool own = tid < kMtStep;
+    uint32_t far = own ? lin[tid + kMtM] : 0u;     // x[base + tid + 397]: from here on the word this slot produced one step earlier
+    uint32_t *out = raw + kMtN + tid;
+    int w = 0;                                     // window start inside lin (uniform)
+    for (int ss = 0; ss < supers; ++ss) {
+        if (own) {
+            const uint32_t *src = lin + w + tid;
+            const uint32_t c0 = src[0], n0 = src[1], c1 = src[kMtStep], n1 = src[kMtStep + 1];
+            const uint32_t a = far ^ mt_g(c0, n0);
+            const uint32_t b = a ^ mt_g(c1, n1);
+            lin[w + kMtN + tid] = a;
+            lin[w + kMtN + kMtStep + tid] = b;
+            out[0] = a;
+            out[kMtStep] = b;
+            far = b;
         }
-        uint32_t *dst = lin + w + kMtN + lane;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint32_t x = mt_twist(cur[r], nxt[r], far[r]);
-            if (r < 3 || lane < kMtStep - 192) {
-                dst[r * 64] = x;
-                out[r * 64] = x;
-            }
-            far[r] = x;
-            cur[r] = cur1[r];
-            nxt[r] = nxt1[r];
-        }
-        w += kMtStep;
-        out += kMtStep;
-        if (w + kMtN + 2 * kMtStep + 64 > kTapeLin) {     // (uniform) move the window back to the front
-            for (int i = lane; i < kMtN; i += 64) lin[i] = lin[w + i];
+        w += 2 * kMtStep;
+        out += 2 * kMtStep;
+        lds_barrier();
+        if (w + kMtN + 2 * kMtStep + 8 > kTapeLin) {       // (uniform) move the window back to the front: [w, w + 624) and [0, 624) are disjoint
+            for (int i = tid; i < kMtN; i += kTapeWordThreads) lin[i] = lin[w + i];
             w = 0;
+            lds_barrier();
         }
-        src = lin + w + lane;
     }
 }
 
@@ -581,7 +578,7 @@ extern "C" int pfa_squared_fill_tape(void *state, const pfa_squared_config *cfg,
     SquaredView v = squared_view(state, *cfg);
     ScopedKernelTimer timer("squared_tape", (hipStream_t)stream);
     if (cfg->num_targets == 1) {
-        // single-target form: one wavefront of raw words + two parallel passes (see above); needs room in the seeding scratch
+        // single-target form: one small workgroup of raw words + two parallel passes (see above); needs room in the seeding scratch
         const int n_pop = 8 * cfg->distance_to_target;
         int bits = 0;
         while ((1 << bits) <= n_pop) ++bits;                       // n_pop.bit_length()
@@ -590,12 +587,12 @@ extern "C" int pfa_squared_fill_tape(void *state, const pfa_squared_config *cfg,
         const long long blocks = (long long)(words / kMtN) + 1;
         const long long chunks = ((blocks + 1) * kMtN + kSelChunk - 1) / kSelChunk;
         const long long scratch_words = (long long)kMtN * cfg->num_envs;
-        const long long used = (blocks + 1) * kMtN + kMtStep + chunks + 64;    // raw words (+ one step of slack), counts, job
+        const long long used = (blocks + 1) * kMtN + 2 * kMtStep + chunks + 64;    // raw words (+ one super-step of slack), counts, job
         if (used <= scratch_words && blocks < (1 << 21)) {
             uint32_t *raw = v.seed_mt;
-            int *counts = (int *)(raw + (blocks + 1) * kMtN + kMtStep);
+            int *counts = (int *)(raw + (blocks + 1) * kMtN + 2 * kMtStep);
             TapeJob *job = (TapeJob *)(((uintptr_t)(counts + chunks) + 15) & ~(uintptr_t)15);
-            hipLaunchKernelGGL(squared_tape_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, v, raw, job, (int)rounds, (int)blocks);
+            hipLaunchKernelGGL(squared_tape_words_kernel, dim3(1), dim3(kTapeWordThreads), 0, (hipStream_t)stream, v, raw, job, (int)rounds, (int)blocks);
             hipLaunchKernelGGL(squared_tape_count_kernel, dim3((unsigned)chunks), dim3(kSelThreads), 0, (hipStream_t)stream, v,
                                (const uint32_t *)raw, (const TapeJob *)job, counts);
             hipLaunchKernelGGL(squared_tape_select_kernel, dim3((unsigned)chunks), dim3(kSelThreads), 0, (hipStream_t)stream, v,

@@ -334,13 +334,13 @@ def init_p2p(bucket_bytes):
 
 def init_native(force_single=False, bucket_bytes=0, small_bytes=0):
     """Native collectives for the update: the optimizer-step all-reduce (and the few small reductions around it) are enqueued
-    from native code on the compute stream, with no stream hand-off.  Two transports, picked by ``PFA_ALLREDUCE``:
-      ``rccl``            this process's own RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp); the 128-byte id
-                          travels from rank 0 through the already-initialised torch.distributed group; ``PFA_NATIVE_RCCL=0``
-                          disables it;
-      ``p2p`` (default)   additionally the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every bucket of up to
-                          ``bucket_bytes`` (<= 1 MiB) — one hop over the xGMI mesh instead of a ring; it is opened only if its
-                          self-test against torch.distributed passes on every rank; larger buckets stay on RCCL.
+    from native code on the compute stream, with no stream hand-off.  Two transports; ``PFA_ALLREDUCE`` names the ones allowed
+    (comma list; default ``p2p,rccl``; ``torch`` = neither: every collective goes through torch.distributed):
+      ``rccl``   this process's own RCCL communicator inside libpufferlib_amd.so (csrc/dist.cpp); the 128-byte id travels from
+                 rank 0 through the already-initialised torch.distributed group;
+      ``p2p``    the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every bucket of up to ``bucket_bytes`` (<= 1 MiB) — one hop
+                 over the xGMI mesh instead of a ring; it is opened only if its self-test against torch.distributed passes on every
+                 rank; larger buckets go to RCCL (when allowed), else torch.distributed.
     ``small_bytes``: the largest of the update's other (f64) exchanges — the GAE halo rows next to the episode statistics — so that the
     peer path's slots hold it too and no exchange of an iteration needs a second transport.
     Returns True when a native transport is up on EVERY rank (agreement by MIN all-reduce); otherwise all ranks use
@@ -350,13 +350,13 @@ def init_native(force_single=False, bucket_bytes=0, small_bytes=0):
     import torch
     from . import _lib
     d, rank, w = world()
-    mode = os.environ.get('PFA_ALLREDUCE', 'p2p').lower()          # 'p2p' = peer path for small buckets + RCCL; 'rccl' = RCCL only
+    mode = [m.strip() for m in os.environ.get('PFA_ALLREDUCE', 'p2p,rccl').lower().split(',')]
     p2p_ok = False
     # one hop pays for latency-bound buckets; a multi-MB bucket (the conv policy's 6.7 MB) is bandwidth-bound and stays on RCCL
     if 'p2p' in mode and w > 1 and 0 < bucket_bytes <= P2P_MAX_BUCKET:
         p2p_ok = init_p2p(max(int(bucket_bytes), int(small_bytes), 65536))
         _native.update(p2p=p2p_ok)
-    if os.environ.get('PFA_NATIVE_RCCL', '1') == '0':
+    if 'rccl' not in mode:
         _native.update(ready=p2p_ok, world=w if p2p_ok else 1)
         return p2p_ok
     if w == 1 and not force_single:
@@ -432,7 +432,7 @@ def raise_if_peer_lost():
     from . import _lib
     st = _lib.lib().pfa_p2p_status() if _native.get('p2p') else 0
     if st > 0:
-        raise RuntimeError(('data-parallel all-reduce over the peer path timed out waiting for a rank (PFA_P2P_TIMEOUT_MS)' if st == 1 else
+        raise RuntimeError(('data-parallel all-reduce over the peer path timed out waiting for a rank (PFA_WAIT_TIMEOUT_MS)' if st == 1 else
                             'a peer rank reported a timed-out exchange over the peer path (its replica holds NaN)')
                            + '; the gradients of this update are invalid on every rank.  Recovery: restore the parameters '
                              '(try_load_checkpoint / broadcast) and call pufferlib_amd.dist.reset_p2p() on every rank')

@@ -393,18 +393,20 @@ class Evaluator:
             net.encode(src[lo:lo + m], m, out[lo:lo + m], ldo)
 
 
+USE_TILE_VIEW = True
+
+
 def tile_view(gp):
     """pfa_mlp_view of a plain Default(hidden 64 / 128 / 256 / 512, one Discrete head of <= 15 actions, rows of <= 64 floats): the
     rollout-mode forward of such a policy runs the register-resident tile kernels of csrc/rollout.hip — the standalone forward for
     the protocol path (policy(obs), Engine.policy_step) and the persistent fused rollout on vector.Squared — straight from the
     module's tensors (their addresses never change: every parameter is a view of the flat buffer).  None for any other shape: the
-    GEMM path.  PFA_WIDE_TILE=0 turns it off (A/B timing)."""
-    import os
+    GEMM path.  (`USE_TILE_VIEW = False` on this module sends every shape down the GEMM path: the tests compare the two.)"""
     if getattr(gp, '_tile_view', False) is not False:
         return gp._tile_view
     view = None
     if (isinstance(gp, GeneralParams) and gp.kind == 'mlp' and gp.lstm is None and not gp.multidiscrete and gp.obs_stride in (16, 32, 64)
-            and gp.num_actions <= 15 and os.environ.get('PFA_WIDE_TILE', '1') != '0'):
+            and gp.num_actions <= 15 and USE_TILE_VIEW):
         m, v = gp.mlp, gp.views
         t = {k: v[gp.name_of(p)] for k, p in (('w1', m.encoder.weight), ('b1', m.encoder.bias), ('w2', m.decoder.weight), ('b2', m.decoder.bias),
                                               ('wv', m.value_head.weight), ('bv', m.value_head.bias))}
@@ -433,10 +435,9 @@ class Engine:
         self._upd = None
         self.mlp_view = tile_view(gp)
         # ... and the fused forward + loss + backward kernel of csrc/ppo_wide.hip for the widths it is built for (64 / 256 / 512)
-        import os
         self.wide_ws = self._wide_gview = None
         # (pfa_ppo_wide_grad tiles minibatches in 16-row blocks: any other minibatch size trains through the GEMM path of update())
-        if (self.mlp_view is not None and os.environ.get('PFA_WIDE_FUSED', '1') != '0'
+        if (self.mlp_view is not None
                 and (experience is None or experience.minibatch_size % 16 == 0)
                 and _lib.lib().pfa_ppo_wide_supported(C.byref(self.mlp_view))):
             self.wide_ws = torch.empty(int(_lib.lib().pfa_ppo_wide_workspace_bytes(C.byref(self.mlp_view))), dtype=torch.uint8, device=self.dev)

@@ -27,21 +27,17 @@ def eager():
     return os.environ.get('PFA_LAZY_READBACK', '0') in ('', '0')
 
 
-def _spin_us():
-    try:
-        return max(0.0, float(os.environ.get('PFA_SPIN_WAIT_US', '2000')))
-    except ValueError:
-        return 2000.0
+SPIN_WAIT_US = 2000.0      # wait_event's poll window (0 = block at once)
 
 
 def wait_event(event):
-    """Wait for a recorded event the way a latency-bound caller wants it: poll ``event.query()`` for up to PFA_SPIN_WAIT_US
-    microseconds (default 2000; 0 = block at once), then fall back to the runtime's blocking wait.  The two readbacks of an
+    """Wait for a recorded event the way a latency-bound caller wants it: poll ``event.query()`` for up to SPIN_WAIT_US
+    microseconds (2000; 0 = block at once), then fall back to the runtime's blocking wait.  The two readbacks of an
     iteration are waited for while the device still has ~0.2-1 ms of queued work, so the runtime's own wait has long left its
     short active phase and parked the thread by the time the event fires — the wake-up then costs tens of microseconds of idle
     device, twice per iteration.  A polling host thread sees the event within a query's latency.  Long waits (a 0.7 s conv
     update) burn the poll window once and then block as before."""
-    spin = _spin_us()
+    spin = SPIN_WAIT_US
     if spin > 0:
         query = event.query
         deadline = time.perf_counter() + spin * 1e-6
@@ -57,11 +53,11 @@ _direct = {'ok': None}
 
 
 def direct_ok(device):
-    """True when a kernel can write the trainer's report numbers straight into pinned host memory (PFA_DIRECT_READBACK=0 turns it
-    off): checked ONCE with a real launch — pfa_train_log_pack into a pinned buffer, known numbers back after an event wait — so a
+    """True when a kernel can write the trainer's report numbers straight into pinned host memory: checked ONCE with a real
+    launch — pfa_train_log_pack into a pinned buffer, known numbers back after an event wait — so a
     runtime where pinned host memory is not device-writable falls back to the copy instead of reporting garbage."""
     if _direct['ok'] is None:
-        ok = os.environ.get('PFA_DIRECT_READBACK', '1') not in ('', '0')
+        ok = True
         if ok:
             try:
                 import torch

@@ -1,5 +1,5 @@
 """Data parallel on real kernels: two ranks share the one GPU of the test box and talk through gloo
-(device tensors, torch.distributed fallback path: PFA_NATIVE_RCCL=0), each owning a shard of the envs.  The contract:
+(device tensors; PFA_ALLREDUCE=torch: the torch.distributed fallback path), each owning a shard of the envs.  The contract:
 the update of R ranks on their shards == the update of ONE process on the rank-major concatenation of those shards
 (GAE as a single flat scan across the shard boundary, global-minibatch advantage normalisation, summed gradients, one clip
 norm), both ranks hold bit-identical parameters after every step, and episode statistics / step counts are global.
@@ -72,18 +72,18 @@ def _loop(n_local, world, recurrent, inject=None):
 
 TRANSPORTS = {
     # torch.distributed (gloo on device tensors) for every collective: the fallback path
-    'torch': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='rccl'),
+    'torch': dict(PFA_ALLREDUCE='torch'),
     # the one-shot peer-mapped all-reduce (csrc/p2p.hip) for every collective of the update: IPC-mapped slots work between two
     # processes on one device exactly as between two devices
-    'p2p': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p'),
+    'p2p': dict(PFA_ALLREDUCE='p2p'),
     # ... with the MLP policy's optimizer-step exchange as an all-reduce launch of its own instead of inside the reduce + Adam launch
-    'p2p-unfused': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p', PFA_FUSED_DP='0'),
+    'p2p-unfused': dict(PFA_ALLREDUCE='p2p', PFA_FUSED_DP='0'),
     # ... with the sharded GAE and its two exchanges in train() instead of at the end of evaluate() (what a host vecenv's evaluate,
     # which does not publish, and callers that rewrite the experience between the two calls get)
-    'p2p-late-gae': dict(PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p', PFA_EARLY_GAE='0'),
+    'p2p-late-gae': dict(PFA_ALLREDUCE='p2p', PFA_EARLY_GAE='0'),
     # the native RCCL communicator: two ranks on ONE device are refused by RCCL ("duplicate GPU"); the refusal must be clean
     # on both ranks (no hang, torch's own RCCL instance unharmed) and the run must continue on the fallback path
-    'rccl-refused': dict(PFA_NATIVE_RCCL='1', PFA_ALLREDUCE='rccl'),
+    'rccl-refused': dict(PFA_ALLREDUCE='rccl'),
 }
 
 
@@ -211,7 +211,7 @@ def test_two_ranks_on_one_gpu_equal_single_process_run(tmp_path, recurrent, tran
 
 def _p2p_worker(rank, world, port, out_dir, sizes=(1, 7, 9497, 9497, 153752, 262144, 3, 9497), reps=4):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='20000')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_WAIT_TIMEOUT_MS='20000')
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -268,7 +268,7 @@ def test_eight_ranks_on_one_gpu_run_the_full_slot_and_flag_logic(tmp_path):
 
 def _p2p_skew_worker(rank, world, port, out_dir, calls=300):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='20000')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_WAIT_TIMEOUT_MS='20000')
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -310,7 +310,7 @@ def test_back_to_back_peer_all_reduces_under_rank_skew(tmp_path):
 
 def _p2p_lost_peer_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='700')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_WAIT_TIMEOUT_MS='700')
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import torch.distributed as dist
     torch.cuda.set_device(0)
@@ -358,7 +358,7 @@ def test_lost_peer_is_an_error_not_a_stale_sum(tmp_path):
 
 def _p2p_status_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_P2P_TIMEOUT_MS='2000')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_WAIT_TIMEOUT_MS='2000')
     sys.path.insert(0, os.path.dirname(os.path.dirname(__file__)))
     import torch.distributed as dist
     torch.cuda.set_device(0)

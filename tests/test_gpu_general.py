@@ -630,7 +630,7 @@ def test_wide_fused_rollout_equals_stepwise_protocol_bit_for_bit(hidden, nt, mon
     """Default(hidden 64 / 256 / 512) on vector.Squared: evaluate()'s ONE persistent kernel (csrc/rollout.hip templated on the hidden
     tiles per wave, W1 fragments of that width in registers) == T x {recv, policy(obs), store, send} through the public protocol,
     bit for bit — policy(obs) runs the same tile code as a launch of its own (pfa_mlp_view_forward_sample).  And the GEMM path the
-    same policy took before (PFA_WIDE_TILE=0: igemm rows + head kernels per step) agrees within the fp32 tolerance."""
+    same policy took before (general.USE_TILE_VIEW = False: igemm rows + head kernels per step) agrees within the fp32 tolerance."""
     from pufferlib_amd import clean_pufferl, cleanrl, general, models, vector
     from test_gpu_ppo import _config, _t
     n, horizon = 48, 20          # not a multiple of 16 envs: the masked tail tile
@@ -667,7 +667,7 @@ def test_wide_fused_rollout_equals_stepwise_protocol_bit_for_bit(hidden, nt, mon
     assert torch.equal(vec.rewards, vec2.rewards) and torch.equal(vec.terminals, vec2.terminals)
 
     # the GEMM path on the recorded observations, under the noise the fused rollout drew
-    monkeypatch.setenv('PFA_WIDE_TILE', '0')
+    monkeypatch.setattr(general, 'USE_TILE_VIEW', False)
     vec3, pol3 = make()
     pol3.load_state_dict(pol.state_dict())
     obs_all = torch.cat(obs_l).cuda()

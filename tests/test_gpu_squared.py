@@ -95,3 +95,42 @@ def test_reset_step_helpers_and_lazy_infos():
         assert infos == []
     st = v.episode_stats().cpu().numpy()
     assert st[0] == 16 and st[2] == 16 * 3   # two finished 3-step episodes per env
+
+
+def test_reset_target_tape_keeps_ahead_of_back_to_back_rollouts():
+    """with update_epochs = num_minibatches = 1 (the only setting in which north_star's "single
+    all-reduce per update" is literal) train() shrinks to one optimizer step, rollouts run nearly back to back, and the side-stream
+    draw of the NEXT rollout's reset targets (the sequential MT19937 recurrence: csrc/squared.hip squared_tape_words_kernel) has one
+    rollout's time to finish.  20 iterations at the BASELINE shape: never a tape underrun (evaluate() raises on one), and the whole
+    tape draw (words + the two parallel passes) takes at most 0.6 of the rollout it hides under."""
+    import ctypes as C
+    import torch
+    from pufferlib_amd import _lib, clean_pufferl, cleanrl, models, vector
+    from test_gpu_ppo import _config
+    n, horizon = 4096, 128
+    B = n * horizon
+    vec = vector.make(vector.make_squared, num_envs=n, backend=vector.Squared, obs_stride=64)
+    torch.manual_seed(3)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    data = clean_pufferl.create(_config(n, horizon, B, 16, 1, B * 64, [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01], seed=2), vec, pol)
+    L = _lib.lib()
+    for _ in range(4):
+        clean_pufferl.evaluate(data)
+        clean_pufferl.train(data)
+    L.pfa_timing_reset()
+    L.pfa_timing_enable(2)
+    for _ in range(20):
+        stats, _ = clean_pufferl.evaluate(data)      # (a tape underrun raises here, from the readback's flag)
+        clean_pufferl.train(data)
+    torch.cuda.synchronize()
+    L.pfa_timing_enable(0)
+
+    def ms(name):
+        k, t = C.c_int64(0), C.c_double(0.0)
+        _lib.check(L.pfa_timing_read(name.encode(), C.byref(k), C.byref(t)), 'timing_read')
+        return k.value, t.value
+    (n_tape, t_tape), (n_roll, t_roll) = ms('squared_tape'), ms('rollout_mlp_squared')
+    assert n_tape == 20 and n_roll == 20, (n_tape, n_roll)
+    print(f'[tape] {t_tape / n_tape * 1e3:.1f} us per draw vs {t_roll / n_roll * 1e3:.1f} us per rollout')
+    assert t_tape / n_tape <= 0.6 * t_roll / n_roll, (t_tape / n_tape, t_roll / n_roll)
+    assert np.isfinite(stats['episode_return']) and torch.isfinite(data.flat_params.flat).all()

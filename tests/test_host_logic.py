@@ -463,22 +463,20 @@ class _FakeEvent:
 
 def test_readback_wait_polls_first_and_blocks_after_the_window(monkeypatch):
     """readback.wait_event: the two per-iteration readbacks are polled (no parked thread to wake while the device idles); a wait
-    that outlasts PFA_SPIN_WAIT_US falls back to the runtime's blocking wait, and PFA_SPIN_WAIT_US=0 blocks at once."""
+    that outlasts readback.SPIN_WAIT_US falls back to the runtime's blocking wait, and a window of 0 blocks at once."""
     from pufferlib_amd import readback as rb
-    monkeypatch.setenv('PFA_SPIN_WAIT_US', '100000')
+    monkeypatch.setattr(rb, 'SPIN_WAIT_US', 100000.0)
     ev = _FakeEvent(ready_after=5)
     rb.wait_event(ev)
     assert ev.queries == 6 and ev.syncs == 0
-    monkeypatch.setenv('PFA_SPIN_WAIT_US', '200')
+    monkeypatch.setattr(rb, 'SPIN_WAIT_US', 200.0)
     ev = _FakeEvent(ready_after=None)
     rb.wait_event(ev)
     assert ev.queries >= 1 and ev.syncs == 1
-    monkeypatch.setenv('PFA_SPIN_WAIT_US', '0')
+    monkeypatch.setattr(rb, 'SPIN_WAIT_US', 0.0)
     ev = _FakeEvent(ready_after=0)
     rb.wait_event(ev)
     assert ev.queries == 0 and ev.syncs == 1
-    monkeypatch.setenv('PFA_SPIN_WAIT_US', 'not a number')
-    assert rb._spin_us() == 2000.0
 
 
 def test_early_gae_key_follows_in_place_edits_and_hyperparameters():

@@ -1,16 +1,17 @@
-"""gpurun_out/r05_reference_cpu_on_gpu_box.jsonl (one line per tools/time_reference.py run of tools/gpu_jobs/with_reference_job.sh)
--> profiles/r05_reference_cpu_on_gpu_box.json: the box fingerprint, every run, and per configuration the Serial figure (north_star's
+"""gpurun_out/r06_reference_cpu_on_gpu_box.jsonl (one line per tools/time_reference.py run of tools/gpu_jobs/with_reference_job.sh)
+-> profiles/r06_reference_cpu_on_gpu_box.json: the box fingerprint, every run, and per configuration the Serial figure (north_star's
 "serial-vec CPU path") and the best figure over all backends / thread counts tried.  bench.py reads this file."""
 import json
 import os
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, 'gpurun_out', 'r05_reference_cpu_on_gpu_box.jsonl')
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, 'gpurun_out', 'r06_reference_cpu_on_gpu_box.jsonl')
 runs = [json.loads(l) for l in open(src) if l.strip().startswith('{')]
 assert runs, 'no runs'
 box = {k: runs[0][k] for k in ('cpu_model', 'cores_physical', 'cores_logical', 'torch')}
-assert all(all(r[k] == box[k] for k in box) for r in runs), 'runs from different boxes'
+box['date'] = runs[0].get('date')
+assert all(all(r[k] == box[k] for k in box if k != 'date') for r in runs), 'runs from different boxes'
 summary = {}
 for cfg in sorted({r['config'] for r in runs}):
     rs = [r for r in runs if r['config'] == cfg]
@@ -23,7 +24,7 @@ doc = dict(what='the UNMODIFIED reference (PufferLib 1.0.1: clean_pufferl.create
                 'c_gae.pyx via pyximport) timed on the GPU box\'s own host cores by tools/gpu_jobs/with_reference.sh (the reference files '
                 'travel in a git-ignored staging directory that is removed after the job); BASELINE.md section 3 configurations',
            box=box, summary=summary, runs=runs)
-out = os.path.join(REPO, 'profiles', 'r05_reference_cpu_on_gpu_box.json')
+out = os.path.join(REPO, 'profiles', 'r06_reference_cpu_on_gpu_box.json')
 json.dump(doc, open(out, 'w'), indent=1)
 print(out)
 for cfg, s in summary.items():

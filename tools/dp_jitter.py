@@ -42,7 +42,7 @@ def _hold(us):
 
 def worker(rank, world, port, envs, horizon, iters, warmup, skews, late_rank, out_path):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
-                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_NATIVE_RCCL='0', PFA_ALLREDUCE='p2p')
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', PFA_ALLREDUCE='p2p')
     import torch
     import torch.distributed as dist
     torch.cuda.set_device(rank % torch.cuda.device_count())
