@@ -53,6 +53,16 @@ __host__ __device__ constexpr int wide_waves(int hidden, int kku) { return PFA_W
 __host__ __device__ constexpr int wide_waves_per_simd(int ms, int kku, int nw) { return nw == 8 ? 2 : wide_wgs_per_cu(ms, kku); }
 __host__ __device__ constexpr bool wide_heads_in_lds(int ms, int kku, int nw) { return ms == 4 && wide_waves_per_simd(ms, kku, nw) > 1; }
 __host__ __device__ constexpr bool wide_small_pass(int ms, int kku, int nw) { return wide_waves_per_simd(ms, kku, nw) > 1; }
+#ifndef PFA_WIDE_STREAMS
+#define PFA_WIDE_STREAMS 1   // 0 = the co-resident tile streams of a CU as separate workgroups, each with its own gradient partial (round 5)
+#endif
+// Tile STREAMS per workgroup.  Where a CU holds two (four) four-wave groups, they used to be two (four) workgroups — and every
+// workgroup leaves its own gradient partial: 512 x 67.6 KB at hidden 256 = 34.6 MB written per launch and read again by the reduce
+// launch, as much as the minibatch's rows themselves (2.07x the algorithmic traffic by the counters, VERDICT rounds 4 and 5).  As ONE
+// workgroup of ST four-wave streams — each stream its own tiles, X / hidden / dout patches and partial out^T, all streams behind
+// the same two barriers per tile — the streams add their accumulators up through LDS at the end (fixed order) and the workgroup
+// writes ONE partial: half (a quarter) of the partial traffic in both launches.
+__host__ __device__ constexpr int wide_streams(int ms, int kku, int nw) { return PFA_WIDE_STREAMS && nw == 4 ? wide_wgs_per_cu(ms, kku) : 1; }
 
 // One workgroup partial (floats), fragment order.  MT = H / 16 hidden tiles, KTM 16-column tiles of dW1 on MFMA (+ COL: the
 // one trailing column 16 KTM, for rows of 16 KTM + 1 real columns like the 7x7 grid's 49).
@@ -76,36 +86,48 @@ __host__ __device__ inline WideLayout wide_layout(int hidden, int ktm, bool col)
 
 // LDS map (floats): two X tiles, the four partial out^T tiles, one hidden-slice patch and one dout patch per wave, the W2v
 // B-fragment table and the encoder bias.
-template <int DP, int MS, int KKU, int NW = 4>
+template <int DP, int MS, int KKU, int NW = 4, int KTM = 4>
 struct WideLds {
+    static constexpr int ST = wide_streams(MS, KKU, NW);
     static constexpr int XS = XTile<DP>::XS, HSW = 16 * MS + 4, DSW = 20;
+    // per stream: [ST][kStream]
     static constexpr int kXs = 0;                          // [2][16 * XS]
     static constexpr int kPart = kXs + 2 * 16 * XS;        // [NW][16 * 16]
     static constexpr int kHs = kPart + NW * kOut * 16;     // [NW][16 * HSW]
     static constexpr int kDs = kHs + NW * 16 * HSW;        // [NW][16 * DSW]
-    static constexpr int kWb = kDs + NW * 16 * DSW;        // [NW MS][64][4]
+    static constexpr int kStream = kDs + NW * 16 * DSW;
+    // shared by the streams (stream 0 writes them before the first barrier)
+    static constexpr int kWb = ST * kStream;               // [NW MS][64][4]
     static constexpr int kB1 = kWb + NW * MS * 256;        // [16 NW MS]
     static constexpr int kWa = kB1 + 16 * NW * MS;         // [NW MS][64][4]: the heads' A fragments (wide_heads_in_lds)
-    static constexpr int kFloats = kWa + (wide_heads_in_lds(MS, KKU, NW) ? NW * MS * 256 : 0);
+    static constexpr int kTiles = kWa + (wide_heads_in_lds(MS, KKU, NW) ? NW * MS * 256 : 0);
+    // after the tile loop the same memory carries the accumulators of streams 1 .. ST-1 to stream 0: [ST - 1][NW][kAcc][64]
+    static constexpr int kAcc = 4 * KTM * MS + 4 * MS + 2 * MS + 4 + 6;
+    static constexpr int kHand = (ST - 1) * NW * kAcc * 64;
+    static constexpr int kFloats = kTiles > kHand ? kTiles : kHand;
 };
 
 template <int DP, int KKU, int KTM, bool COL, int MS, int NW = 4>
-__global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo_wide_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, MlpView pv, pfa_ppo_hparams hp,
+__global__ void __launch_bounds__(64 * NW * wide_streams(MS, KKU, NW), wide_waves_per_simd(MS, KKU, NW)) ppo_wide_grad_kernel(pfa_experience ex, RowMap map, long long mb_rows, MlpView pv, pfa_ppo_hparams hp,
                                                                     const double *adv_stats /* [nmb][2] */, double global_rows, float *partials) {
-    using LD = WideLds<DP, MS, KKU, NW>;
-    constexpr int XS = LD::XS, V = DP / 4, HSW = LD::HSW, DSW = LD::DSW, MT = NW * MS;
+    using LD = WideLds<DP, MS, KKU, NW, KTM>;
+    constexpr int XS = LD::XS, V = DP / 4, HSW = LD::HSW, DSW = LD::DSW, MT = NW * MS, ST = LD::ST;
     constexpr bool DEDUP = PFA_WIDE_DEDUP && NW == 8;
     constexpr bool LATE_PREFETCH = NW == 8;
     static_assert(NW == 4 || NW == 8, "waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds_all[];
+    // stream st = four-wave group of this workgroup (uniform per wave); wv = the wave's hidden slice within its stream
+    const int st = ST > 1 ? wave_id() / NW : 0, wv = ST > 1 ? wave_id() % NW : wave_id();
+    const int tl = (int)threadIdx.x - st * 64 * NW;     // thread index within the stream
+    float *lds = lds_all + st * LD::kStream;            // this stream's tiles; the fragment tables below are shared
     float *part = lds + LD::kPart;             // [NW][16 * 16] partial out^T per wave
-    const int lane = lane_id(), wv = wave_id(), c = lane & 15, g = lane >> 4;
+    const int lane = lane_id(), c = lane & 15, g = lane >> 4;
     const int a = pv.a;
     // (eight-wave form with DEDUP: wave w + 4 reads the dout patch its SIMD partner w wrote)
     float *hs = lds + LD::kHs + wv * 16 * HSW, *ds = lds + LD::kDs + ((PFA_WIDE_DEDUP && NW == 8) ? (wv & 3) : wv) * 16 * DSW;
-    float *wbt = lds + LD::kWb, *b1s = lds + LD::kB1;
+    float *wbt = lds_all + LD::kWb, *b1s = lds_all + LD::kB1;
     constexpr bool W2L = wide_heads_in_lds(MS, KKU, NW);
-    float *wat = lds + LD::kWa;
+    float *wat = lds_all + LD::kWa;
 
     // ---- this wave's slice of the policy, as MFMA fragments, for the whole launch: W1 and the heads' A fragments in registers, the
     // B fragments of dh = dout . W2v and the encoder bias in LDS (written and read by this wave only) ------------------------------
@@ -123,10 +145,15 @@ __global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo
             wa[r] = pv.w2v(c, 16 * m + 4 * g + r);            // A[i = o = c][k-slot g] of the heads, u = 16m + 4g + r
             wb[r] = pv.w2v(4 * g + r, 16 * m + c);            // B[k-slot g][j = u = 16m + c] of dh = dout . W2v, o = 4g + r
         }
-        if constexpr (W2L) *reinterpret_cast<f32x4 *>(wat + (m * 64 + lane) * 4) = wa;
-        else w2f[i] = wa;
-        *reinterpret_cast<f32x4 *>(wbt + (m * 64 + lane) * 4) = wb;
-        if (lane < 16) b1s[16 * m + lane] = pv.b1[16 * m + lane];
+        if constexpr (W2L) {
+            if (st == 0) *reinterpret_cast<f32x4 *>(wat + (m * 64 + lane) * 4) = wa;
+        } else {
+            w2f[i] = wa;
+        }
+        if (st == 0) {   // (the other streams read the tables behind the loop's first barrier)
+            *reinterpret_cast<f32x4 *>(wbt + (m * 64 + lane) * 4) = wb;
+            if (lane < 16) b1s[16 * m + lane] = pv.b1[16 * m + lane];
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) bo[r] = pv.b2v(4 * g + r);
@@ -159,7 +186,8 @@ __global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo
     for (int i = 0; i < 6; ++i) stats[i] = 0.0f;
 
     const long long tiles = mb_rows / 16;
-    const int J = (int)((tiles + gridDim.x - 1) / gridDim.x);   // the same for every workgroup: everybody runs the same barriers
+    const long long GS = (long long)gridDim.x * ST, gs = (long long)blockIdx.x * ST + st;   // tile streams of the launch, this one
+    const int J = (int)((tiles + GS - 1) / GS);   // the same for every stream: everybody runs the same barriers
     const bool aligned = (map.horizon & 15) == 0;
 
     // register prefetch of the next tile: one float4 of X per thread (threads < 16 V) + the per-row scalars (every wave its own copy)
@@ -173,7 +201,7 @@ __global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo
         if (ok) {
             const unsigned fr = map.tile_row((unsigned)tile, first, c, aligned);
             rspre = RowScalars{ex.actions[fr], ex.logprobs[fr], ex.values[fr], ex.advantages[fr], ex.returns[fr], 1.0f};
-            const int idx = threadIdx.x;
+            const int idx = tl;
             if (idx < 16 * V) {
                 const int r = idx / V, c4 = idx - r * V;
                 const unsigned row = map.tile_row((unsigned)tile, first, r, aligned);
@@ -181,18 +209,18 @@ __global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo
             }
         }
     };
-    prefetch(blockIdx.x);
+    prefetch(gs);
 
     for (int j = 0; j < J; ++j) {
         float *xs = lds + LD::kXs + (j & 1) * 16 * XS;
-        if ((int)threadIdx.x < 16 * V) {
-            const int r = threadIdx.x / V, c4 = threadIdx.x - r * V;
+        if (tl < 16 * V) {
+            const int r = tl / V, c4 = tl - r * V;
             float2 *d = reinterpret_cast<float2 *>(xs + r * XS + 4 * c4);
             d[0] = make_float2(xpre.x, xpre.y);
             d[1] = make_float2(xpre.z, xpre.w);
         }
         const RowScalars rs = rspre;
-        if constexpr (!LATE_PREFETCH) prefetch((long long)blockIdx.x + (long long)(j + 1) * gridDim.x);
+        if constexpr (!LATE_PREFETCH) prefetch(gs + (long long)(j + 1) * GS);
         __syncthreads();   // X(j) visible; every wave is done with tile j-1 (its partials and the other X slot)
 
         // ---- forward slice ---------------------------------------------------------------------------------------------------
@@ -270,7 +298,7 @@ __global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo
         }
         // (two waves per SIMD: the next tile's rows and scalars are fetched from here, behind the loss, so that they and this tile's
         // scalars are never live together — the ~2500 cycles of the backward's MFMAs cover the fetch)
-        if constexpr (LATE_PREFETCH) prefetch((long long)blockIdx.x + (long long)(j + 1) * gridDim.x);
+        if constexpr (LATE_PREFETCH) prefetch(gs + (long long)(j + 1) * GS);
         if constexpr (DEDUP) {
             __syncthreads();   // d loss / d out of waves 0-3 -> their SIMD partners
             if (wv >= 4) dout = *reinterpret_cast<const f32x4 *>(ds + c * DSW + 4 * g);
@@ -324,6 +352,35 @@ __global__ void __launch_bounds__(64 * NW, wide_waves_per_simd(MS, KKU, NW)) ppo
         }
     }
 
+    // ---- streams 1 .. ST-1 hand their accumulators to stream 0 through LDS (the tile buffers are dead), added in stream order ----------
+    if constexpr (ST > 1) {
+        constexpr int kAcc = LD::kAcc;
+        __syncthreads();   // every stream is done with its last tile
+        auto slot = [&](int s, int k) -> float & { return lds_all[(((s - 1) * NW + wv) * kAcc + k) * 64 + lane]; };
+        auto each = [&](auto &&f) {   // the same walk over the accumulators for the writer and the reader: v <- f(v, k)
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < MS; ++i) {
+#pragma unroll
+                for (int kt = 0; kt < KTM; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc_dw1[kt][i][r] = f(acc_dw1[kt][i][r], k++);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc_dw2[i][r] = f(acc_dw2[i][r], k++);
+                db1[i] = f(db1[i], k++);
+                acc_col[i] = f(acc_col[i], k++);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) db2[r] = f(db2[r], k++);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) stats[i] = f(stats[i], k++);
+        };
+        if (st > 0) each([&](float v, int k) { slot(st, k) = v; return v; });
+        __syncthreads();
+        if (st > 0) return;
+#pragma unroll
+        for (int s = 1; s < ST; ++s) each([&](float v, int k) { return v + slot(s, k); });
+    }
     // ---- this workgroup's partial: every wave its own slices, fragment order ------------------------------------------------------
     const WideLayout L = wide_layout(16 * MT, KTM, COL);
     float *dst = partials + (size_t)blockIdx.x * L.kCount;
@@ -443,13 +500,17 @@ static int wide_shape(const pfa_mlp_view *p, int *ktm, bool *col, int *kku) {
     *kku = grid49 ? 13 : p->obs_stride / 4;
     return 0;
 }
+static int wide_streams_of(int hidden, int kku) {
+    const int nw = wide_waves(hidden, kku);
+    return wide_streams(hidden / (16 * nw), kku, nw);
+}
 static int wide_slots(int hidden, int kku) {   // workgroups the chip holds at once
     const int nw = wide_waves(hidden, kku);
-    return 256 * (nw == 8 ? 1 : wide_wgs_per_cu(hidden / 64, kku));
+    return 256 * (nw == 8 ? 1 : wide_wgs_per_cu(hidden / 64, kku)) / wide_streams_of(hidden, kku);
 }
 static int wide_grid(int64_t mb_rows, int hidden, int kku) {   // one workgroup per resident slot, fewer when the minibatch is small
-    const int64_t tiles = mb_rows / 16, slots = wide_slots(hidden, kku);
-    return (int)(tiles < slots ? (tiles < 1 ? 1 : tiles) : slots);
+    const int64_t st = wide_streams_of(hidden, kku), wgs = (mb_rows / 16 + st - 1) / st, slots = wide_slots(hidden, kku);
+    return (int)(wgs < slots ? (wgs < 1 ? 1 : wgs) : slots);
 }
 
 }  // namespace pfa
@@ -493,14 +554,15 @@ extern "C" int pfa_ppo_wide_grad(const pfa_experience *exp, int64_t batch_rows, 
 #define PFA_WIDE_LAUNCH(DPV, KKUV, KTMV, COLV, HV)                                                                                        \
     {                                                                                                                                    \
         constexpr int NWV = wide_waves(HV, KKUV), MSV = HV / (16 * NWV);                                                                 \
-        constexpr size_t lds_bytes = (size_t)WideLds<DPV, MSV, KKUV, NWV>::kFloats * sizeof(float);                                      \
+        constexpr size_t lds_bytes = (size_t)WideLds<DPV, MSV, KKUV, NWV, KTMV>::kFloats * sizeof(float);                                \
+        constexpr int STV = wide_streams(MSV, KKUV, NWV);                                      \
         static bool attr_set = false;                                                                                                    \
         if (!attr_set) {                                                                                                                 \
             PFA_CHECK_HIP(hipFuncSetAttribute((const void *)ppo_wide_grad_kernel<DPV, KKUV, KTMV, COLV, MSV, NWV>,                        \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                              \
             attr_set = true;                                                                                                             \
         }                                                                                                                                \
-        hipLaunchKernelGGL((ppo_wide_grad_kernel<DPV, KKUV, KTMV, COLV, MSV, NWV>), dim3(grid), dim3(64 * NWV), lds_bytes,                \
+        hipLaunchKernelGGL((ppo_wide_grad_kernel<DPV, KKUV, KTMV, COLV, MSV, NWV>), dim3(grid), dim3(64 * NWV * STV), lds_bytes,                \
                            (hipStream_t)stream, *exp, map, (long long)mbs, pv, *hp, adv_stats, (double)global_mb_rows, partials);        \
     }
 #define PFA_WIDE_DP(HV)                                                                \
