@@ -602,6 +602,12 @@ int pfa_lstm_heads_loss(const float *h, const pfa_experience *exp, int64_t batch
 size_t pfa_gemm_tn_workspace_bytes(int32_t mo, int32_t no, int64_t k);
 int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t mo,
                     int32_t no, int64_t k, void *workspace, pfa_stream_t stream);
+/* Two products that share their first operand in ONE pass over it: c0[mo][128] = a^T b0, c1[mo][128] = a^T b1 (mo a multiple of
+ * 128) — the recurrent layer's dW_ih = dG^T xe and dW_hh = dG^T h_prev (autograd's two matmuls in nn.LSTM's backward,
+ * clean_pufferl.py:244): dG is fetched and staged once instead of twice.  workspace >= pfa_gemm_tn2_workspace_bytes. */
+size_t pfa_gemm_tn2_workspace_bytes(int32_t mo, int64_t k);
+int pfa_gemm_tn2_f32(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, float *c0, int64_t ldc0,
+                     float *c1, int64_t ldc1, int32_t mo, int64_t k, void *workspace, pfa_stream_t stream);
 /* Scatter into the flat gradient vector (MLP block + LSTM block layout): g16 [16][128] = dout^T h (rows < A ->
  * decoder.weight, row A -> value_head.weight), bsum16 = column sums of dout (-> decoder.bias, value_head.bias), and
  * d bias_hh_l0 = d bias_ih_l0 (already in place). */

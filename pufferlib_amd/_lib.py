@@ -244,6 +244,8 @@ _SIGNATURES = {
     'pfa_lstm_seq_backward': (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, P, P, P, P, P, P, P]),
     'pfa_gemm_tn_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     'pfa_gemm_tn_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, P, P]),
+    'pfa_gemm_tn2_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int64]),
+    'pfa_gemm_tn2_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, P, C.c_int64, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int64, P, P]),
     'pfa_lstm_finish_grads': (C.c_int, [P, C.POINTER(MlpDims), P, P, P]),
     'pfa_sumsq_partials': (C.c_int, [P, C.c_int64, P, C.c_int32, P]),
     'pfa_dist_unique_id': (C.c_int, [P]),

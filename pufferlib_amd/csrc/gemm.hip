@@ -32,7 +32,8 @@ struct GemmTnCfg {
 template <int WR, int WC, int MI, int NI>
 __global__ void __launch_bounds__(kGemmThreads, 2)
     gemm_tn_partial_kernel(const float *__restrict__ A, long long lda, const float *__restrict__ B, long long ldb, int mo, int no,
-                           long long K, long long k_per_split, float *__restrict__ partial) {
+                           long long K, long long k_per_split, float *__restrict__ partial, const float *__restrict__ B2 = nullptr,
+                           long long ldb2 = 0, int nb = 0) {   // B2 != null: output columns >= nb come from B2[k][col - nb] (two-operand form)
     using Cfg = GemmTnCfg<WR, WC, MI, NI>;
     __shared__ float lds[2 * Cfg::kStageFloats];
     const int tid = threadIdx.x, lane = tid & 63, wv = wave_id();
@@ -66,7 +67,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2)
             const int idx = tid + q * kGemmThreads;
             const int row = idx / (Cfg::TN / 4), col = (idx % (Cfg::TN / 4)) * 4;
             const bool ok = idx < Cfg::kB4 && kb + row < k_hi;
-            rb[q] = ok ? *(const float4 *)(B + (kb + row) * ldb + j0 + col) : float4{0.f, 0.f, 0.f, 0.f};
+            const float *src = (B2 && j0 + col >= nb) ? B2 + (kb + row) * ldb2 + (j0 + col - nb) : B + (kb + row) * ldb + j0 + col;
+            rb[q] = ok ? *(const float4 *)src : float4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stash = [&](int buf) {
@@ -122,7 +124,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2)
 // pass 2: 64 float4 column groups x 4 split quarters per workgroup; each thread sums its quarter of the splits (4 loads in
 // flight), the quarters are combined through LDS in a fixed order -> deterministic, and latency- rather than issue-bound.
 __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ partial, int splits, int mo, int no,
-                                                            float *__restrict__ C, long long ldc) {
+                                                            float *__restrict__ C, long long ldc, float *__restrict__ C2 = nullptr,
+                                                            long long ldc2 = 0, int nb = 0) {   // C2 != null: columns >= nb go to C2[i][col - nb]
     __shared__ double sh[3][64][4];
     const int col4 = threadIdx.x & 63, quarter = threadIdx.x >> 6;
     const int idx4 = blockIdx.x * 64 + col4;  // float4 index into the mo x no output
@@ -155,13 +158,13 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__rest
 #pragma unroll
         for (int k = 0; k < 3; ++k) s0 += sh[k][col4][0], s1 += sh[k][col4][1], s2 += sh[k][col4][2], s3 += sh[k][col4][3];
         const int e = idx4 * 4, i = e / no, j = e % no;  // no % 4 == 0: the four values stay in one row
-        float *out = C + (long long)i * ldc + j;
+        float *out = (C2 && j >= nb) ? C2 + (long long)i * ldc2 + (j - nb) : C + (long long)i * ldc + j;
         out[0] = (float)s0, out[1] = (float)s1, out[2] = (float)s2, out[3] = (float)s3;
     }
 }
 
 struct GemmTnPlan {
-    int cfg;  // 0: 128x128, 1: 128x64, 2: 16x128, 3: 128x32, 4: 128x16, 5: 128x160
+    int cfg;  // 0: 128x128, 1: 128x64, 2: 16x128, 3: 128x32, 4: 128x16, 5: 128x160, 6: 128x256 (the two-operand form)
     int tm, tn, tiles, splits;
     long long k_per_split;
 };
@@ -237,6 +240,45 @@ extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int6
     PFA_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no / 4 + 63) / 64)), dim3(256), 0, st, partial, p.splits, mo, no, c,
                        (long long)ldc);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// C0 = A^T B0 and C1 = A^T B1 in ONE pass over A (n0 = n1 = 128 columns each, mo a multiple of 128): the recurrent layer's two
+// weight gradients dW_ih = dG^T xe and dW_hh = dG^T h_prev share their 512-column operand dG, which as two products was staged
+// through LDS twice per k slab and fetched from HBM twice (268 MB per minibatch each time at BASELINE configs[2]).  One 128 x 256
+// output tile per workgroup: 12 fragment reads per 32 MFMAs instead of 8 per 16.  Same split / fixed-order f64 reduction as above.
+extern "C" size_t pfa_gemm_tn2_workspace_bytes(int32_t mo, int64_t k) {
+    if (mo <= 0 || mo % 128 || k <= 0) return 0;
+    GemmTnPlan p;
+    if (!gemm_tn_plan(mo, 128, k, p)) return 0;     // (the same split count as the 128 x 128 tiling: tiles = mo / 128)
+    return (size_t)p.splits * mo * 256 * sizeof(float);
+}
+extern "C" int pfa_gemm_tn2_f32(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, float *c0, int64_t ldc0,
+                                float *c1, int64_t ldc1, int32_t mo, int64_t k, void *workspace, pfa_stream_t stream) {
+    PFA_REQUIRE(a && b0 && b1 && c0 && c1 && workspace && mo > 0 && mo % 128 == 0 && k > 0, "gemm_tn2: bad arguments (mo must be a multiple of 128)");
+    PFA_REQUIRE(lda >= mo && ldb0 >= 128 && ldb1 >= 128 && ldc0 >= 128 && ldc1 >= 128 && lda % 4 == 0 && ldb0 % 4 == 0 && ldb1 % 4 == 0,
+                "gemm_tn2: row strides must cover the tile and be 16-byte multiples");
+    PFA_REQUIRE(((uintptr_t)a | (uintptr_t)b0 | (uintptr_t)b1) % 16 == 0, "gemm_tn2: operands must be 16-byte aligned");
+    GemmTnPlan p;
+    PFA_REQUIRE(gemm_tn_plan(mo, 128, k, p), "gemm_tn2: no plan");
+    const int tiles = mo / 128, no = 256;
+    long long want = (512 + tiles - 1) / tiles;
+    const long long max_splits = (k + 8 * kGemmBK - 1) / (8 * kGemmBK);
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    long long per = (k + want - 1) / want;
+    per = (per + kGemmBK - 1) / kGemmBK * kGemmBK;
+    const int splits = (int)((k + per - 1) / per);
+    PFA_REQUIRE((size_t)splits * mo * no * sizeof(float) <= pfa_gemm_tn2_workspace_bytes(mo, k), "gemm_tn2: split plan exceeds the workspace");
+    float *partial = (float *)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    ScopedKernelTimer timer("gemm_tn", st);
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 8>), dim3((unsigned)tiles, (unsigned)splits), dim3(kGemmThreads), 0, st, a, (long long)lda, b0,
+                       (long long)ldb0, mo, no, (long long)k, per, partial, b1, (long long)ldb1, 128);
+    PFA_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no / 4 + 63) / 64)), dim3(256), 0, st, partial, splits, mo, no, c0, (long long)ldc0,
+                       c1, (long long)ldc1, 128);
     PFA_LAUNCH_CHECK();
     return 0;
 }

@@ -28,6 +28,10 @@
 #include "common.hpp"
 #include "mlp_tile.hpp"
 
+#ifndef PFA_IG_TILE64
+#define PFA_IG_TILE64 0
+#endif
+
 namespace pfa {
 
 constexpr int kIgThreads = 256;
@@ -869,7 +873,13 @@ extern "C" int pfa_igemm_rows(const pfa_igemm_operand *a, int64_t M, int32_t K, 
             PFA_IG_ROWS(kADense, 1, 1);
         }
     } else if (N % 64 == 0) {
+#if PFA_IG_TILE64 == 1     // experiment (tools/igemm_bench.py): 64 x 64 tiles, 20 KB of LDS per workgroup -> 8 instead of 5 waves per SIMD
+        PFA_IG_ROWS_MODE(1, 4)
+#elif PFA_IG_TILE64 == 2   // ... or 128 x 32: 25.6 KB, 6 waves per SIMD
+        PFA_IG_ROWS_MODE(2, 2)
+#else
         PFA_IG_ROWS_MODE(2, 4)
+#endif
     } else if (N % 32 == 0) {
         PFA_IG_ROWS_MODE(2, 2)   // (128 x 32 beats 256 x 32: the smaller stage keeps more workgroups per CU)
     } else {

@@ -87,8 +87,8 @@ class Engine:
         self.ws = torch.empty(L.pfa_lstm_heads_loss_workspace_bytes(),
                               dtype=torch.uint8, device=dev)
         shapes = [(4 * H, H), (H, DP), (16, H)]
-        self.gemm_ws = torch.empty(max(L.pfa_gemm_tn_workspace_bytes(mo, no, M) for mo, no in shapes), dtype=torch.uint8,
-                                   device=dev)
+        self.gemm_ws = torch.empty(max([L.pfa_gemm_tn_workspace_bytes(mo, no, M) for mo, no in shapes] + [L.pfa_gemm_tn2_workspace_bytes(4 * H, M)]),
+                                   dtype=torch.uint8, device=dev)
         self.g16 = torch.empty(16, H, device=dev)
         self.bwd_ws = torch.empty(L.pfa_lstm_seq_backward_workspace_bytes(R), dtype=torch.uint8, device=dev)
         self.norm_partials = torch.empty(256, dtype=torch.float64, device=dev)
@@ -179,8 +179,10 @@ class Engine:
         dG = self.dG.view(M, 4 * H)
         gW1p = fp.encoder_weight_padded(grads[:fp.count])
         self._gemm_tn(self.dxe, self.obs_tm, gW1p)
-        self._gemm_tn(dG, self.xe, gv['recurrent.weight_ih_l0'])
-        self._gemm_tn(dG, self.Hs[:Th].view(M, H), gv['recurrent.weight_hh_l0'])
+        # dW_ih = dG^T xe and dW_hh = dG^T h_prev in one pass over dG (pfa_gemm_tn2_f32)
+        hp_, gih, ghh = self.Hs[:Th].view(M, H), gv['recurrent.weight_ih_l0'], gv['recurrent.weight_hh_l0']
+        _lib.check(L.pfa_gemm_tn2_f32(_lib.ptr(dG), dG.stride(0), _lib.ptr(self.xe), self.xe.stride(0), _lib.ptr(hp_), hp_.stride(0), _lib.ptr(gih),
+                                      gih.stride(0), _lib.ptr(ghh), ghh.stride(0), 4 * H, M, _lib.ptr(self.gemm_ws), stream), 'gemm_tn2')
         self._gemm_tn(self.dout, h_all, self.g16)                   # [16][128]: rows < A decoder, row A value head
         _lib.check(L.pfa_lstm_finish_grads(_lib.ptr(grads), C.byref(fp.dims), _lib.ptr(self.g16), _lib.ptr(self.bsum16), stream),
                    'lstm_finish_grads')

@@ -127,6 +127,36 @@ def test_gemm_tn_matches_f64_contraction(mo, no, k, pad):
     assert torch.equal(out2, out.contiguous())
 
 
+@pytest.mark.parametrize('mo,k,pad', [(512, 131072, 0), (512, 4099, 0), (128, 37, 16), (256, 10000, 0)])
+def test_gemm_tn2_is_the_two_products_in_one_pass_over_the_shared_operand(mo, k, pad):
+    """pfa_gemm_tn2_f32: c0 = a^T b0 and c1 = a^T b1 (the recurrent layer's dW_ih = dG^T xe and dW_hh = dG^T h_prev) from one pass
+    over a — vs the f64 contractions; operands in separate buffers with their own strides, outputs into separate (strided) tensors,
+    ragged k; deterministic."""
+    from pufferlib_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator(device='cuda').manual_seed(mo + k)
+    a = torch.randn(k, mo + pad, device='cuda', generator=g)[:, :mo]
+    b0 = torch.randn(k, 128, device='cuda', generator=g)
+    b1 = torch.randn(k, 128 + 2 * pad, device='cuda', generator=g)[:, :128]
+    o0_full, o1 = torch.full((mo, 136), float('nan'), device='cuda'), torch.full((mo, 128), float('nan'), device='cuda')
+    o0 = o0_full[:, :128]
+    nbytes = L.pfa_gemm_tn2_workspace_bytes(mo, k)
+    assert nbytes > 0 and L.pfa_gemm_tn2_workspace_bytes(96, k) == 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+
+    def run(c0, c1):
+        _lib.check(L.pfa_gemm_tn2_f32(_lib.ptr(a), a.stride(0), _lib.ptr(b0), b0.stride(0), _lib.ptr(b1), b1.stride(0), _lib.ptr(c0), c0.stride(0),
+                                      _lib.ptr(c1), c1.stride(0), mo, k, _lib.ptr(ws), _lib.stream_handle()), 'gemm_tn2')
+    run(o0, o1)
+    tol = 2e-6 * (k ** 0.5) * 4 + 1e-5
+    assert (o0.double() - a.double().t() @ b0.double()).abs().max().item() <= tol
+    assert (o1.double() - a.double().t() @ b1.double()).abs().max().item() <= tol
+    assert torch.isnan(o0_full[:, 128:]).all()
+    p0, p1 = torch.empty(mo, 128, device='cuda'), torch.empty(mo, 128, device='cuda')
+    run(p0, p1)
+    assert torch.equal(p0, o0.contiguous()) and torch.equal(p1, o1)
+
+
 def test_gemm_tn_rejects_unsupported_shapes():
     from pufferlib_amd import _lib
     from pufferlib_amd.exceptions import ExtensionError
