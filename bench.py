@@ -303,6 +303,77 @@ def self_check(data, pol):
                 tolerance=1e-5, checker='oracle/ppo_torch.py + oracle/puffer_oracle.c')
 
 
+def reference_replay_check():
+    """The headline configuration against the UNMODIFIED REFERENCE itself: one whole iteration of BASELINE
+    configs[1] — 4096 envs x 128 steps, 4 minibatches x 4 epochs = 16 optimizer steps — recorded from /root/reference's
+    clean_pufferl.create / evaluate / train by tests/golden/make_golden.py (`big`: tests/golden/ppo_c2_mlp.npz, digest form) and
+    replayed HERE on the HIP path from the same initial weights: actions / observations / rewards / dones bit for bit, losses,
+    advantages, values and the updated weights within north_star's 1e-5.  The multinomial noise is regenerated as the reference drew
+    it (torch.manual_seed(1), one exponential_ per step; checked against the recorded digest) — a box whose torch draws other
+    numbers replays the recorded actions instead.  Untimed; the fixture is data (it travels with the repository)."""
+    import hashlib
+    import numpy as np
+    import torch
+    from pufferlib_amd import clean_pufferl, cleanrl, models, namespace, vector
+    path = os.path.join(REPO, 'tests', 'golden', 'ppo_c2_mlp.npz')
+    if not os.path.exists(path):
+        return dict(skipped='tests/golden/ppo_c2_mlp.npz not found')
+    g = np.load(path)
+    n, T, mbs, bptt, epochs, total, iters = (int(x) for x in g['config'])
+    lr, gamma, lam, clip, vf_coef, vf_clip, mgn, ent = (float(x) for x in g['hparams'])
+    B = n * T
+
+    def digest(a, samples=64):
+        f = np.asarray(a, np.float64).reshape(-1)
+        idx = np.linspace(0, f.size - 1, min(samples, f.size)).astype(np.int64)
+        return np.concatenate([[f.sum(), np.abs(f).sum()], f[idx]])
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()   # noqa: E731
+    sm = lambda x: x.view(n, T, *x.shape[1:]).transpose(0, 1).reshape(B, *x.shape[1:]).cpu().numpy()   # noqa: E731
+    vec = vector.make(vector.make_squared, num_envs=n, backend=vector.Squared)
+    pol = cleanrl.Policy(models.Default(vec.driver_env))
+    pol.load_state_dict({k[3:]: torch.as_tensor(g[k]) for k in g.files if k.startswith('w0.')})
+    cfg = namespace(env='squared', seed=1, torch_deterministic=True, device='cuda', total_timesteps=total, learning_rate=lr, anneal_lr=True,
+                    gamma=gamma, gae_lambda=lam, update_epochs=epochs, norm_adv=True, clip_coef=clip, clip_vloss=True, vf_coef=vf_coef,
+                    vf_clip_coef=vf_clip, max_grad_norm=mgn, ent_coef=ent, target_kl=None, batch_size=B, minibatch_size=mbs, bptt_horizon=bptt,
+                    checkpoint_interval=0, data_dir='/tmp/pfa_bench', exp_id='replay')
+    data = clean_pufferl.create(cfg, vec, pol)
+    state = torch.get_rng_state()
+    torch.manual_seed(1)
+    nz = np.stack([torch.empty(n, 8).exponential_(1).numpy() for _ in range(T)])
+    torch.set_rng_state(state)
+    how = 'regenerated from torch.manual_seed(1)'
+    if not np.array_equal(digest(nz), g['it0.noise_digest']):
+        nz = np.ones((T, n, 8), np.float32)
+        np.put_along_axis(nz, g['it0.actions'].reshape(T, n, 1).astype(np.int64), np.float32(1e-30), axis=2)
+        how = 'recorded actions (this torch draws other exponentials than the recording box)'
+    data.noise = torch.as_tensor(nz)
+    stats, _ = clean_pufferl.evaluate(data)
+    exp = data.experience
+    exact = (np.array_equal(sm(exp.actions), g['it0.actions'].astype(np.int32))
+             and sha(sm(exp.obs)[:, :49].astype(np.int8)) == str(g['it0.obs_sha'])
+             and sha(sm(exp.rewards).astype(np.float32)) == str(g['it0.rewards_sha'])
+             and sha(sm(exp.dones).astype(np.float32)) == str(g['it0.dones_sha'])
+             and data.global_step == int(g['it0.global_step']))
+    stats_err = float(np.max(np.abs(np.array([stats['episode_return'], stats['episode_length'], stats['score']]) - g['it0.stats'])))
+
+    def derr(got, key):      # largest error over the digest's 64 samples, and of the mean
+        d, want = digest(got), g[key]
+        return max(float(np.abs(d[2:] - want[2:]).max()), abs(float(d[0] - want[0])) / np.asarray(got).size)
+    val_err = max(derr(sm(exp.values), 'it0.values'), derr(sm(exp.logprobs), 'it0.logprobs'))
+    clean_pufferl.train(data)
+    idx = torch.stack([exp.minibatch_rows_index(m) for m in range(exp.num_minibatches)])
+    adv_err = max(derr(exp.advantages[idx].cpu().numpy(), 'it0.advantages'), derr(exp.returns[idx].cpu().numpy(), 'it0.returns'))
+    L = data.losses
+    got = np.array([L.policy_loss, L.value_loss, L.entropy, L.old_approx_kl, L.approx_kl, L.clipfrac, L.explained_variance])
+    loss_err = float(np.max(np.abs(got - g['it0.losses'])))
+    w_err = max(derr(v.cpu().numpy(), f'it0.w.{k}') for k, v in pol.state_dict().items())
+    assert exact, 'integer side differs from the reference recording'
+    assert max(val_err, adv_err, loss_err, w_err) <= 1e-5 and stats_err <= 1e-9, (val_err, adv_err, loss_err, w_err, stats_err)
+    return dict(fixture='tests/golden/ppo_c2_mlp.npz (the unmodified reference, tests/golden/make_golden.py big)', rows=B, optimizer_steps=epochs * (B // mbs),
+                actions_obs_rewards_dones_bit_exact=bool(exact), action_noise=how, max_abs_logprob_value_err=val_err,
+                max_abs_advantage_return_err=adv_err, max_abs_loss_err=loss_err, max_abs_weight_err=w_err, tolerance=1e-5)
+
+
 class _StubVec:
     """What oracle.ppo_torch.Trainer asks of a vecenv when its experience is injected (never stepped)."""
 
@@ -955,9 +1026,13 @@ def main():
                            'transports': transports}
         if world == 1 and args.no_cpu_baseline and args.self_check and args.policy == 'mlp':
             out['self_check'] = self_check(data, pol)
+            if args.products == 'fp32':
+                out['self_check']['reference_replay'] = reference_replay_check()
         if world == 1 and not args.no_cpu_baseline:
             if args.policy == 'mlp':
                 out['self_check'] = self_check(data, pol)
+                if args.products == 'fp32':
+                    out['self_check']['reference_replay'] = reference_replay_check()
             elif args.workload == 'c3':
                 out['self_check'] = self_check_c3(data, pol)
             elif args.workload == 'c4' and not cnn_lstm and args.products == 'fp32':
