@@ -4,7 +4,7 @@ END TO END on the device engine: `python -m pufferlib_amd.demo --reference <stag
 Needs a GPU *and* the reference's files.  The GPU box has no /root/reference, so the files arrive as the git-ignored staging
 directory `_refstage/` that tools/gpu_jobs/with_reference.sh ships with one gpurun job (tools/stage_reference.py) and removes
 afterwards; without it (the driver's round-end run) the tests skip.  The recorded outcome of the staged run is
-profiles/r05_demo_end_to_end.json.
+profiles/r06_demo_end_to_end.json.
 
 demo.py swallows exceptions (`except Exception: print; os._exit(0)`, demo.py:196-198), so the exit code proves nothing: the
 driver below records what the loop did and the test asserts on the record.
@@ -89,7 +89,7 @@ def run_demo(tmp_path, extra, timeout=900):
     r = subprocess.run([sys.executable, '-X', 'faulthandler', '-c', DRIVER, STAGE, str(out)] + extra, cwd=tmp_path, env=env, capture_output=True, text=True,
                        timeout=timeout)
     os.makedirs(os.path.join(REPO, 'gpurun_out'), exist_ok=True)
-    with open(os.path.join(REPO, 'gpurun_out', 'r05_demo_process_output.txt'), 'a') as f:   # (pytest elides long assertion messages)
+    with open(os.path.join(REPO, 'gpurun_out', 'r06_demo_process_output.txt'), 'a') as f:   # (pytest elides long assertion messages)
         f.write(f'==== {extra}\n---- returncode {r.returncode}\n---- stdout\n{r.stdout[-20000:]}\n---- stderr\n{r.stderr[-20000:]}\n')
     assert out.exists(), ('demo.py did not reach clean_pufferl.close()', r.stdout[-1500:], r.stderr[-1500:])
     return json.load(open(out)), r
@@ -128,7 +128,7 @@ def test_unmodified_demo_py_trains_squared_end_to_end_on_the_device_engine(tmp_p
                    final_global_step=rec['final_global_step'], score_first10=first, score_last10=last,
                    episode_return_first10=rets[:10], episode_return_last10=rets[-10:], checkpoints=sorted(ckpts),
                    stdout_tail=r.stdout[-600:]),
-              open(os.path.join(REPO, 'gpurun_out', 'r05_demo_end_to_end.json'), 'w'), indent=1)
+              open(os.path.join(REPO, 'gpurun_out', 'r06_demo_end_to_end.json'), 'w'), indent=1)
 
 
 @needs_stage

@@ -13,7 +13,7 @@ Multiprocessing, c_gae.pyx through pyximport) on this machine's CPU cores, on th
 The reference is imported read-only from --reference (default: the staged copy `_refstage/` that tools/gpu_jobs/with_reference.sh
 ships to the GPU box, else /root/reference); gymnasium / gym / pettingzoo come from tests/shims.  One JSON line per run; with
 --out the line is also appended to that file (tools/gpu_jobs/with_reference.sh collects them into
-profiles/r05_reference_cpu_on_gpu_box.json).
+profiles/r06_reference_cpu_on_gpu_box.json).
 
     PYTHONDONTWRITEBYTECODE=1 python tools/time_reference.py --config c2 [--backend serial|multiprocessing] [--workers W]
                                                              [--threads T] [--iters K] [--reference DIR] [--out FILE]
