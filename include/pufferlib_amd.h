@@ -562,10 +562,15 @@ int pfa_rollout_lstm_synth(void *state, const pfa_synth_config *cfg, const float
  * forward keeps what autograd would keep (xe, gate activations i,f,g,o, c_t, h_t).  backward takes d loss / d h_t through
  * the heads (dh_heads, from pfa_lstm_heads_loss) and produces dgates (d loss / d gate pre-activations), dxe (d loss / d the
  * encoder pre-activations, relu' applied) and the bias gradients gate_bias_grad [512] (= d b_ih = d b_hh) and
- * enc_bias_grad [128]; wpack_bwd from pfa_lstm_pack_bwd (same size as wpack). */
+ * enc_bias_grad [128]; wpack_bwd from pfa_lstm_pack_bwd (same size as wpack; pfa_lstm_pack_both: both re-tilings in one launch).
+ * init_slot: where the carried-in state is read — 0: slot 0 of hs / cs as it is; k in 1..steps: slot k (the previous minibatch's final
+ * state, clean_pufferl.py:188-191), copied into slot 0 by the kernel; < 0: zero state (lstm_state = None, :176), slot 0 zeroed.
+ * backward with gate_bias_grad = enc_bias_grad = NULL leaves the per-workgroup column sums in `workspace` ([ceil(rows / 32)][640])
+ * for the caller's own reduction (pfa_reduce_multi, kind 1). */
 int pfa_lstm_pack_bwd(const float *params, const pfa_mlp_dims *dims, void *wpack_bwd, pfa_stream_t stream);
+int pfa_lstm_pack_both(const float *params, const pfa_mlp_dims *dims, void *wpack, void *wpack_bwd, pfa_stream_t stream);
 int pfa_lstm_seq_forward(const float *obs_tm, int64_t rows, int32_t steps, const float *params, const pfa_mlp_dims *dims,
-                         const void *wpack, float *xe, float *gates_act, float *hs, float *cs, pfa_stream_t stream);
+                         const void *wpack, float *xe, float *gates_act, float *hs, float *cs, int32_t init_slot, pfa_stream_t stream);
 size_t pfa_lstm_seq_backward_workspace_bytes(int64_t rows);
 int pfa_lstm_seq_backward(const float *gates_act, const float *cs, const float *xe, const float *dh_heads, int64_t rows,
                           int32_t steps, const void *wpack_bwd, float *dgates, float *dxe, float *gate_bias_grad,
@@ -606,6 +611,25 @@ int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int64_t ldb, fl
  * 128) — the recurrent layer's dW_ih = dG^T xe and dW_hh = dG^T h_prev (autograd's two matmuls in nn.LSTM's backward,
  * clean_pufferl.py:244): dG is fetched and staged once instead of twice.  workspace >= pfa_gemm_tn2_workspace_bytes. */
 size_t pfa_gemm_tn2_workspace_bytes(int32_t mo, int64_t k);
+/* The same products as their split partials only, each handing back the reduction that finishes it, and up to six such reductions in
+ * ONE launch (the recurrent update's three weight-gradient products + its bias column sums were four latency-bound launches in a row).
+ *   kind 0  c[i][j] (j < nb or c2 == NULL) / c2[i][j - nb] <- f64 fixed-order sum over `splits` partials [mo][no]
+ *   kind 1  c[col] (col < nb) / c2[col - nb] <- column sums of `splits` rows of `no` floats (per-workgroup partial sums)
+ * pfa_gemm_tn*_partial_f32 fill in everything of `job` but c / ldc / c2 / ldc2 (tn2 sets nb = 128). */
+typedef struct pfa_reduce_job {
+    int32_t kind, splits, mo, no;
+    const float *partial;
+    float *c;
+    int64_t ldc;
+    float *c2;
+    int64_t ldc2;
+    int32_t nb, reserved;
+} pfa_reduce_job;
+int pfa_gemm_tn_partial_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int32_t mo, int32_t no, int64_t k, void *workspace,
+                            pfa_reduce_job *job, pfa_stream_t stream);
+int pfa_gemm_tn2_partial_f32(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, int32_t mo, int64_t k,
+                             void *workspace, pfa_reduce_job *job, pfa_stream_t stream);
+int pfa_reduce_multi(const pfa_reduce_job *jobs, int32_t njobs, pfa_stream_t stream);
 int pfa_gemm_tn2_f32(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, float *c0, int64_t ldc0,
                      float *c1, int64_t ldc1, int32_t mo, int64_t k, void *workspace, pfa_stream_t stream);
 /* Scatter into the flat gradient vector (MLP block + LSTM block layout): g16 [16][128] = dout^T h (rows < A ->

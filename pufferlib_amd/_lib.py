@@ -122,6 +122,11 @@ class Experience(C.Structure):
                 ('horizon_T', C.c_int32)]
 
 
+class ReduceJob(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('splits', C.c_int32), ('mo', C.c_int32), ('no', C.c_int32), ('partial', C.c_void_p), ('c', C.c_void_p),
+                ('ldc', C.c_int64), ('c2', C.c_void_p), ('ldc2', C.c_int64), ('nb', C.c_int32), ('reserved', C.c_int32)]
+
+
 class PpoHparams(C.Structure):
     _fields_ = [('clip_coef', C.c_float), ('vf_clip_coef', C.c_float), ('vf_coef', C.c_float), ('ent_coef', C.c_float),
                 ('norm_adv', C.c_int32), ('clip_vloss', C.c_int32), ('num_minibatches', C.c_int32),
@@ -239,12 +244,16 @@ _SIGNATURES = {
     'pfa_rollout_lstm_synth': (C.c_int, [P, C.POINTER(SynthConfig), P, C.POINTER(MlpDims), P, P, P, C.POINTER(Experience),
                                            P, C.POINTER(NoiseKey), C.c_int64, P, P, P, P, P, P]),
     'pfa_lstm_pack_bwd': (C.c_int, [P, C.POINTER(MlpDims), P, P]),
-    'pfa_lstm_seq_forward': (C.c_int, [P, C.c_int64, C.c_int32, P, C.POINTER(MlpDims), P, P, P, P, P, P]),
+    'pfa_lstm_seq_forward': (C.c_int, [P, C.c_int64, C.c_int32, P, C.POINTER(MlpDims), P, P, P, P, P, C.c_int32, P]),
+    'pfa_lstm_pack_both': (C.c_int, [P, C.POINTER(MlpDims), P, P, P]),
     'pfa_lstm_seq_backward_workspace_bytes': (C.c_size_t, [C.c_int64]),
     'pfa_lstm_seq_backward': (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, P, P, P, P, P, P, P]),
     'pfa_gemm_tn_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int64]),
     'pfa_gemm_tn_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, P, P]),
     'pfa_gemm_tn2_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int64]),
+    'pfa_gemm_tn_partial_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int32, C.c_int64, P, C.POINTER(ReduceJob), P]),
+    'pfa_gemm_tn2_partial_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int64, P, C.POINTER(ReduceJob), P]),
+    'pfa_reduce_multi': (C.c_int, [C.POINTER(ReduceJob), C.c_int32, P]),
     'pfa_gemm_tn2_f32': (C.c_int, [P, C.c_int64, P, C.c_int64, P, C.c_int64, P, C.c_int64, P, C.c_int64, C.c_int32, C.c_int64, P, P]),
     'pfa_lstm_finish_grads': (C.c_int, [P, C.POINTER(MlpDims), P, P, P]),
     'pfa_sumsq_partials': (C.c_int, [P, C.c_int64, P, C.c_int32, P]),

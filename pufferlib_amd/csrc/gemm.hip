@@ -123,12 +123,11 @@ __global__ void __launch_bounds__(kGemmThreads, 2)
 
 // pass 2: 64 float4 column groups x 4 split quarters per workgroup; each thread sums its quarter of the splits (4 loads in
 // flight), the quarters are combined through LDS in a fixed order -> deterministic, and latency- rather than issue-bound.
-__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ partial, int splits, int mo, int no,
-                                                            float *__restrict__ C, long long ldc, float *__restrict__ C2 = nullptr,
-                                                            long long ldc2 = 0, int nb = 0) {   // C2 != null: columns >= nb go to C2[i][col - nb]
-    __shared__ double sh[3][64][4];
+__device__ __forceinline__ void gemm_tn_reduce_block(const float *__restrict__ partial, int splits, int mo, int no, float *__restrict__ C,
+                                                     long long ldc, float *__restrict__ C2, long long ldc2, int nb, int block,
+                                                     double (*sh)[64][4]) {   // C2 != null: columns >= nb go to C2[i][col - nb]
     const int col4 = threadIdx.x & 63, quarter = threadIdx.x >> 6;
-    const int idx4 = blockIdx.x * 64 + col4;  // float4 index into the mo x no output
+    const int idx4 = block * 64 + col4;  // float4 index into the mo x no output
     const int total4 = mo * no / 4;
     const size_t stride4 = (size_t)mo * no / 4;
     const float4 *p4 = reinterpret_cast<const float4 *>(partial);
@@ -161,6 +160,63 @@ __global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__rest
         float *out = (C2 && j >= nb) ? C2 + (long long)i * ldc2 + (j - nb) : C + (long long)i * ldc + j;
         out[0] = (float)s0, out[1] = (float)s1, out[2] = (float)s2, out[3] = (float)s3;
     }
+}
+// pass 2: 64 float4 column groups x 4 split quarters per workgroup; each thread sums its quarter of the splits (4 loads in
+// flight), the quarters are combined through LDS in a fixed order -> deterministic, and latency- rather than issue-bound.
+__global__ void __launch_bounds__(256) gemm_tn_reduce_kernel(const float *__restrict__ partial, int splits, int mo, int no,
+                                                            float *__restrict__ C, long long ldc, float *__restrict__ C2 = nullptr,
+                                                            long long ldc2 = 0, int nb = 0) {
+    __shared__ double sh[3][64][4];
+    gemm_tn_reduce_block(partial, splits, mo, no, C, ldc, C2, ldc2, nb, (int)blockIdx.x, sh);
+}
+
+// Column sums of per-workgroup partials [groups][cols] -> out0[col] (col < nb) / out1[col - nb]: one block per 64 columns, 4 group
+// quarters combined through LDS in a fixed order (the recurrent update's bias gradients, csrc/lstm_seq.hip lstm_bias_final_kernel's sum).
+__device__ __forceinline__ void colsum_reduce_block(const float *__restrict__ partial, int groups, int cols, int nb, float *__restrict__ out0,
+                                                    float *__restrict__ out1, int block, float (*shf)[64]) {
+    const int cl = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+    const int col = block * 64 + cl;
+    const int per = (groups + 3) / 4;
+    const int lo = quarter * per, hi = lo + per < groups ? lo + per : groups;
+    float s0 = 0.0f, s1 = 0.0f;
+    if (col < cols) {
+        int i = lo;
+        for (; i + 2 <= hi; i += 2) {
+            s0 += partial[(size_t)i * cols + col];
+            s1 += partial[(size_t)(i + 1) * cols + col];
+        }
+        if (i < hi) s0 += partial[(size_t)i * cols + col];
+    }
+    shf[quarter][cl] = s0 + s1;
+    __syncthreads();
+    if (quarter == 0 && col < cols) {
+        const float s = (shf[0][cl] + shf[1][cl]) + (shf[2][cl] + shf[3][cl]);
+        if (col < nb) out0[col] = s;
+        else out1[col - nb] = s;
+    }
+}
+
+// Several of these reductions in ONE launch (the recurrent update: three weight-gradient products + the bias column sums used to be
+// four latency-bound launches of 10-14 us each in a row): block b belongs to the job whose block range holds it.
+constexpr int kReduceJobsMax = 6;
+struct ReduceJobs {
+    pfa_reduce_job job[kReduceJobsMax];
+    int first_block[kReduceJobsMax + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256) reduce_multi_kernel(ReduceJobs J) {
+    __shared__ double sh[3][64][4];
+    __shared__ float shf[4][64];
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < kReduceJobsMax; ++q)
+        if (q < J.n && (int)blockIdx.x >= J.first_block[q]) j = q;
+    const pfa_reduce_job &jb = J.job[j];
+    const int block = (int)blockIdx.x - J.first_block[j];
+    if (jb.kind == 0)
+        gemm_tn_reduce_block(jb.partial, jb.splits, jb.mo, jb.no, jb.c, jb.ldc, jb.c2, jb.ldc2, jb.nb, block, sh);
+    else
+        colsum_reduce_block(jb.partial, jb.splits, jb.no, jb.nb, jb.c, jb.c2, block, shf);
 }
 
 struct GemmTnPlan {
@@ -208,17 +264,14 @@ extern "C" size_t pfa_gemm_tn_workspace_bytes(int32_t mo, int32_t no, int64_t k)
     return (size_t)p.splits * mo * no * sizeof(float);
 }
 
-extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t mo,
-                               int32_t no, int64_t k, void *workspace, pfa_stream_t stream) {
-    PFA_REQUIRE(a && b && c && workspace && mo > 0 && no > 0 && k > 0, "gemm_tn: bad arguments");
-    PFA_REQUIRE(lda >= mo && ldb >= no && ldc >= no && lda % 4 == 0 && ldb % 4 == 0, "gemm_tn: row strides must cover the tile and be 16-byte multiples");
+static int gemm_tn_launch_partial(const float *a, int64_t lda, const float *b, int64_t ldb, int32_t mo, int32_t no, int64_t k, void *workspace,
+                                  GemmTnPlan &p, hipStream_t st) {
+    PFA_REQUIRE(a && b && workspace && mo > 0 && no > 0 && k > 0, "gemm_tn: bad arguments");
+    PFA_REQUIRE(lda >= mo && ldb >= no && lda % 4 == 0 && ldb % 4 == 0, "gemm_tn: row strides must cover the tile and be 16-byte multiples");
     PFA_REQUIRE(((uintptr_t)a | (uintptr_t)b) % 16 == 0, "gemm_tn: operands must be 16-byte aligned");
-    GemmTnPlan p;
     PFA_REQUIRE(gemm_tn_plan(mo, no, k, p), "gemm_tn: supported shapes are (128a x 16b) and (16a x 128b)");
     const dim3 grid((unsigned)p.tiles, (unsigned)p.splits);
     float *partial = (float *)workspace;
-    hipStream_t st = (hipStream_t)stream;
-    ScopedKernelTimer timer("gemm_tn", st);
     if (p.cfg == 0)
         hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 4>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
                            mo, no, (long long)k, p.k_per_split, partial);
@@ -238,9 +291,31 @@ extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int6
         hipLaunchKernelGGL((gemm_tn_partial_kernel<1, 4, 1, 2>), grid, dim3(kGemmThreads), 0, st, a, (long long)lda, b, (long long)ldb,
                            mo, no, (long long)k, p.k_per_split, partial);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no / 4 + 63) / 64)), dim3(256), 0, st, partial, p.splits, mo, no, c,
+    return 0;
+}
+
+extern "C" int pfa_gemm_tn_f32(const float *a, int64_t lda, const float *b, int64_t ldb, float *c, int64_t ldc, int32_t mo,
+                               int32_t no, int64_t k, void *workspace, pfa_stream_t stream) {
+    PFA_REQUIRE(c && ldc >= no, "gemm_tn: bad output");
+    GemmTnPlan p;
+    hipStream_t st = (hipStream_t)stream;
+    ScopedKernelTimer timer("gemm_tn", st);
+    if (int rc = gemm_tn_launch_partial(a, lda, b, ldb, mo, no, k, workspace, p, st)) return rc;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no / 4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, p.splits, mo, no, c,
                        (long long)ldc);
     PFA_LAUNCH_CHECK();
+    return 0;
+}
+
+// The split partials only: `job` receives the reduction that finishes the product (kind 0; fill in c / ldc), for pfa_reduce_multi.
+extern "C" int pfa_gemm_tn_partial_f32(const float *a, int64_t lda, const float *b, int64_t ldb, int32_t mo, int32_t no, int64_t k, void *workspace,
+                                       pfa_reduce_job *job, pfa_stream_t stream) {
+    PFA_REQUIRE(job != nullptr, "gemm_tn_partial: null job");
+    GemmTnPlan p;
+    hipStream_t st = (hipStream_t)stream;
+    ScopedKernelTimer timer("gemm_tn", st);
+    if (int rc = gemm_tn_launch_partial(a, lda, b, ldb, mo, no, k, workspace, p, st)) return rc;
+    *job = pfa_reduce_job{0, p.splits, mo, no, (const float *)workspace, nullptr, 0, nullptr, 0, 0, 0};
     return 0;
 }
 
@@ -254,14 +329,12 @@ extern "C" size_t pfa_gemm_tn2_workspace_bytes(int32_t mo, int64_t k) {
     if (!gemm_tn_plan(mo, 128, k, p)) return 0;     // (the same split count as the 128 x 128 tiling: tiles = mo / 128)
     return (size_t)p.splits * mo * 256 * sizeof(float);
 }
-extern "C" int pfa_gemm_tn2_f32(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, float *c0, int64_t ldc0,
-                                float *c1, int64_t ldc1, int32_t mo, int64_t k, void *workspace, pfa_stream_t stream) {
-    PFA_REQUIRE(a && b0 && b1 && c0 && c1 && workspace && mo > 0 && mo % 128 == 0 && k > 0, "gemm_tn2: bad arguments (mo must be a multiple of 128)");
-    PFA_REQUIRE(lda >= mo && ldb0 >= 128 && ldb1 >= 128 && ldc0 >= 128 && ldc1 >= 128 && lda % 4 == 0 && ldb0 % 4 == 0 && ldb1 % 4 == 0,
+static int gemm_tn2_launch_partial(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, int32_t mo, int64_t k,
+                                   void *workspace, int *splits_out, hipStream_t st) {
+    PFA_REQUIRE(a && b0 && b1 && workspace && mo > 0 && mo % 128 == 0 && k > 0, "gemm_tn2: bad arguments (mo must be a multiple of 128)");
+    PFA_REQUIRE(lda >= mo && ldb0 >= 128 && ldb1 >= 128 && lda % 4 == 0 && ldb0 % 4 == 0 && ldb1 % 4 == 0,
                 "gemm_tn2: row strides must cover the tile and be 16-byte multiples");
     PFA_REQUIRE(((uintptr_t)a | (uintptr_t)b0 | (uintptr_t)b1) % 16 == 0, "gemm_tn2: operands must be 16-byte aligned");
-    GemmTnPlan p;
-    PFA_REQUIRE(gemm_tn_plan(mo, 128, k, p), "gemm_tn2: no plan");
     const int tiles = mo / 128, no = 256;
     long long want = (512 + tiles - 1) / tiles;
     const long long max_splits = (k + 8 * kGemmBK - 1) / (8 * kGemmBK);
@@ -271,14 +344,54 @@ extern "C" int pfa_gemm_tn2_f32(const float *a, int64_t lda, const float *b0, in
     per = (per + kGemmBK - 1) / kGemmBK * kGemmBK;
     const int splits = (int)((k + per - 1) / per);
     PFA_REQUIRE((size_t)splits * mo * no * sizeof(float) <= pfa_gemm_tn2_workspace_bytes(mo, k), "gemm_tn2: split plan exceeds the workspace");
-    float *partial = (float *)workspace;
+    hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 8>), dim3((unsigned)tiles, (unsigned)splits), dim3(kGemmThreads), 0, st, a, (long long)lda, b0,
+                       (long long)ldb0, mo, no, (long long)k, per, (float *)workspace, b1, (long long)ldb1, 128);
+    PFA_LAUNCH_CHECK();
+    *splits_out = splits;
+    return 0;
+}
+extern "C" int pfa_gemm_tn2_f32(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, float *c0, int64_t ldc0,
+                                float *c1, int64_t ldc1, int32_t mo, int64_t k, void *workspace, pfa_stream_t stream) {
+    PFA_REQUIRE(c0 && c1 && ldc0 >= 128 && ldc1 >= 128, "gemm_tn2: bad outputs");
     hipStream_t st = (hipStream_t)stream;
     ScopedKernelTimer timer("gemm_tn", st);
-    hipLaunchKernelGGL((gemm_tn_partial_kernel<2, 2, 4, 8>), dim3((unsigned)tiles, (unsigned)splits), dim3(kGemmThreads), 0, st, a, (long long)lda, b0,
-                       (long long)ldb0, mo, no, (long long)k, per, partial, b1, (long long)ldb1, 128);
+    int splits = 0;
+    if (int rc = gemm_tn2_launch_partial(a, lda, b0, ldb0, b1, ldb1, mo, k, workspace, &splits, st)) return rc;
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * 256 / 4 + 63) / 64)), dim3(256), 0, st, (const float *)workspace, splits, mo, 256, c0,
+                       (long long)ldc0, c1, (long long)ldc1, 128);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((unsigned)((mo * no / 4 + 63) / 64)), dim3(256), 0, st, partial, splits, mo, no, c0, (long long)ldc0,
-                       c1, (long long)ldc1, 128);
+    return 0;
+}
+extern "C" int pfa_gemm_tn2_partial_f32(const float *a, int64_t lda, const float *b0, int64_t ldb0, const float *b1, int64_t ldb1, int32_t mo, int64_t k,
+                                        void *workspace, pfa_reduce_job *job, pfa_stream_t stream) {
+    PFA_REQUIRE(job != nullptr, "gemm_tn2_partial: null job");
+    hipStream_t st = (hipStream_t)stream;
+    ScopedKernelTimer timer("gemm_tn", st);
+    int splits = 0;
+    if (int rc = gemm_tn2_launch_partial(a, lda, b0, ldb0, b1, ldb1, mo, k, workspace, &splits, st)) return rc;
+    *job = pfa_reduce_job{0, splits, mo, 256, (const float *)workspace, nullptr, 0, nullptr, 0, 128, 0};
+    return 0;
+}
+
+// Up to six reductions in ONE launch.  kind 0: the f64 fixed-order sum of `splits` partial products [mo][no] -> c[i][j] (c2 != NULL:
+// columns j >= nb -> c2[i][j - nb]); kind 1: column sums of [splits][no] per-workgroup partials -> c[col] for col < nb, c2[col - nb] else.
+extern "C" int pfa_reduce_multi(const pfa_reduce_job *jobs, int32_t njobs, pfa_stream_t stream) {
+    PFA_REQUIRE(jobs && njobs >= 1 && njobs <= kReduceJobsMax, "reduce_multi: 1..%d jobs", kReduceJobsMax);
+    ReduceJobs J{};
+    J.n = njobs;
+    int blocks = 0;
+    for (int q = 0; q < njobs; ++q) {
+        const pfa_reduce_job &jb = jobs[q];
+        PFA_REQUIRE(jb.partial && jb.c && jb.splits >= 1 && jb.no >= 1 && (jb.kind == 1 || (jb.kind == 0 && jb.mo >= 1 && jb.no % 4 == 0 && jb.ldc >= (jb.c2 ? jb.nb : jb.no))),
+                    "reduce_multi: bad job %d", q);
+        PFA_REQUIRE(jb.kind == 0 || jb.nb >= jb.no || jb.c2, "reduce_multi: job %d needs c2 for columns >= nb", q);
+        J.job[q] = jb;
+        J.first_block[q] = blocks;
+        blocks += jb.kind == 0 ? (jb.mo * jb.no / 4 + 63) / 64 : (jb.no + 63) / 64;
+    }
+    J.first_block[njobs] = blocks;
+    ScopedKernelTimer timer("reduce_multi", (hipStream_t)stream);
+    hipLaunchKernelGGL(reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, J);
     PFA_LAUNCH_CHECK();
     return 0;
 }

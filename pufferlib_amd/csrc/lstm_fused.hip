@@ -25,12 +25,7 @@ namespace pfa {
 __global__ void __launch_bounds__(256) lstm_pack_kernel(const float *__restrict__ params, int dp, int a, float4 *__restrict__ dst) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= kGatePackFloats / 4) return;
-    const LstmOffsets lo = lstm_offsets(dp, a);
-    const int lane = idx & 63, ct = (idx >> 6) & 7, kq = (idx >> 9) & 15, w = idx >> 13;
-    const int c = lane & 15, g = lane >> 4;
-    const int col = gate_col(w, ct, c), k0 = 16 * kq + 4 * g;
-    const float *src = k0 < kLH ? params + lo.w_ih + col * kLH + k0 : params + lo.w_hh + col * kLH + (k0 - kLH);
-    dst[idx] = make_float4(src[0], src[1], src[2], src[3]);  // the flat parameter vector is only 4-byte aligned here
+    dst[idx] = lstm_pack_fwd_elem(params, dp, a, idx);
 }
 
 // Shared LDS block of the two kernels.

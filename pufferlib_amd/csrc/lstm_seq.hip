@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
                                                                    const float *__restrict__ params, int a,
                                                                    const float4 *__restrict__ wpack, float *__restrict__ xe,
                                                                    float *__restrict__ gates_act, float *__restrict__ Hs,
-                                                                   float *__restrict__ Cs) {
+                                                                   float *__restrict__ Cs, int init_slot) {
     constexpr int V = DP / 4;
     __shared__ SeqFwdLds<DP> L;
     LstmFrags<DP> w;
@@ -47,10 +47,19 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
     const long long first = (long long)blockIdx.x * kSeqRows;
     const int uoff = 32 * wv + 4 * g;
     f32x4 cst[kSeqRT][2];
+    // initial state: slot `init_slot` of Hs / Cs (0: it is already where the backward pass and dW_hh read it; k > 0: the previous
+    // minibatch's final state, clean_pufferl.py:188-191; < 0: lstm_state = None, :176), copied into slot 0 by the workgroup that owns
+    // the rows — no copy / fill launch in front of this one
+    const float *h0 = init_slot < 0 ? nullptr : Hs + (size_t)init_slot * R * kLH;
+    const float *c0 = init_slot < 0 ? nullptr : Cs + (size_t)init_slot * R * kLH;
 #pragma unroll
     for (int rt = 0; rt < kSeqRT; ++rt) {
-        load_hstate(Hs, first + 16 * rt, R, L.xh[0][rt]);
-        load_cstate(Cs, first + 16 * rt + c, first + 16 * rt + c < R, cst[rt]);
+        load_hstate(h0, first + 16 * rt, R, L.xh[0][rt]);
+        load_cstate(c0, first + 16 * rt + c, c0 && first + 16 * rt + c < R, cst[rt]);
+        if (init_slot != 0) {
+            store_hstate(Hs, first + 16 * rt, R, L.xh[0][rt]);    // (the same thread wrote these LDS elements)
+            store_cstate(Cs, first + 16 * rt + c, first + 16 * rt + c < R, cst[rt]);
+        }
         lstm_stage_obs<DP>(obs_tm, first + 16 * rt, R, L.xs[rt]);
     }
     __syncthreads();
@@ -142,9 +151,14 @@ __global__ void __launch_bounds__(kLstmThreads) lstm_seq_fwd_kernel(const float 
 
 // dst float4 index ((w*32 + cq)*4 + kt)*64 + lane  <-  { Wcat[16cq + 4g + s][k(w, kt, c)] : s = 0..3 },
 // k(w, kt, i) = 128*(kt >> 1) + 32w + 16*(kt & 1) + i   (kt 0,1: the xe half -> dxe;  kt 2,3: the h half -> dh_{t-1})
-__global__ void __launch_bounds__(256) lstm_pack_bwd_kernel(const float *__restrict__ params, int dp, int a, float4 *__restrict__ dst) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= kGatePackFloats / 4) return;
+__global__ void __launch_bounds__(256) lstm_pack_bwd_kernel(const float *__restrict__ params, int dp, int a, float4 *__restrict__ dst,
+                                                            float4 *__restrict__ fwd_dst = nullptr) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= kGatePackFloats / 4) {   // second half of the grid (pfa_lstm_pack_both): the forward pack of csrc/lstm_fused.hip
+        idx -= kGatePackFloats / 4;
+        if (fwd_dst && idx < kGatePackFloats / 4) fwd_dst[idx] = lstm_pack_fwd_elem(params, dp, a, idx);
+        return;
+    }
     const LstmOffsets lo = lstm_offsets(dp, a);
     const int lane = idx & 63, kt = (idx >> 6) & 3, cq = (idx >> 8) & 31, w = idx >> 13;
     const int c = lane & 15, g = lane >> 4;
@@ -363,6 +377,16 @@ static int check_seq_dims(const pfa_mlp_dims *d) {
 
 using namespace pfa;
 
+// Both re-tilings of [W_ih | W_hh] an optimizer step needs (forward A fragments, csrc/lstm_fused.hip; backward A fragments) in ONE launch.
+extern "C" int pfa_lstm_pack_both(const float *params, const pfa_mlp_dims *dims, void *wpack, void *wpack_bwd, pfa_stream_t stream) {
+    if (int rc = check_seq_dims(dims)) return rc;
+    PFA_REQUIRE(params && wpack && wpack_bwd && (uintptr_t)wpack % 16 == 0 && (uintptr_t)wpack_bwd % 16 == 0, "lstm_pack_both: bad buffer");
+    hipLaunchKernelGGL(lstm_pack_bwd_kernel, dim3(2 * (kGatePackFloats / 4 / 256)), dim3(256), 0, (hipStream_t)stream, params, dims->obs_stride,
+                       dims->num_actions, (float4 *)wpack_bwd, (float4 *)wpack);
+    PFA_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int pfa_lstm_pack_bwd(const float *params, const pfa_mlp_dims *dims, void *wpack_bwd, pfa_stream_t stream) {
     if (int rc = check_seq_dims(dims)) return rc;
     PFA_REQUIRE(params && wpack_bwd && (uintptr_t)wpack_bwd % 16 == 0, "lstm_pack_bwd: bad buffer");
@@ -373,16 +397,17 @@ extern "C" int pfa_lstm_pack_bwd(const float *params, const pfa_mlp_dims *dims, 
 }
 
 extern "C" int pfa_lstm_seq_forward(const float *obs_tm, int64_t rows, int32_t steps, const float *params, const pfa_mlp_dims *dims,
-                                    const void *wpack, float *xe, float *gates_act, float *hs, float *cs, pfa_stream_t stream) {
+                                    const void *wpack, float *xe, float *gates_act, float *hs, float *cs, int32_t init_slot, pfa_stream_t stream) {
     if (int rc = check_seq_dims(dims)) return rc;
     PFA_REQUIRE(rows >= 1 && steps >= 1, "lstm_seq_forward: empty minibatch");
     PFA_REQUIRE(obs_tm && params && wpack && xe && gates_act && hs && cs, "lstm_seq_forward: null buffer");
+    PFA_REQUIRE(init_slot <= steps, "lstm_seq_forward: init_slot %d out of range (-1 = zero state, 0 .. steps)", init_slot);
     const unsigned grid = (unsigned)((rows + kSeqRows - 1) / kSeqRows);
     ScopedKernelTimer timer("lstm_seq_fwd", (hipStream_t)stream);
     PFA_SEQ_DISPATCH_DP(dims->obs_stride,
                         hipLaunchKernelGGL(lstm_seq_fwd_kernel<DP>, dim3(grid), dim3(kLstmThreads), 0, (hipStream_t)stream, obs_tm,
                                            (long long)rows, (int)steps, params, dims->num_actions, (const float4 *)wpack, xe,
-                                           gates_act, hs, cs));
+                                           gates_act, hs, cs, (int)(init_slot < 0 ? -1 : init_slot)));
     PFA_LAUNCH_CHECK();
     return 0;
 }
@@ -396,7 +421,7 @@ extern "C" int pfa_lstm_seq_backward(const float *gates_act, const float *cs, co
                                      int32_t steps, const void *wpack_bwd, float *dgates, float *dxe, float *gate_bias_grad,
                                      float *enc_bias_grad, void *workspace, pfa_stream_t stream) {
     PFA_REQUIRE(rows >= 1 && steps >= 1, "lstm_seq_backward: empty minibatch");
-    PFA_REQUIRE(gates_act && cs && xe && dh_heads && wpack_bwd && dgates && dxe && gate_bias_grad && enc_bias_grad && workspace,
+    PFA_REQUIRE(gates_act && cs && xe && dh_heads && wpack_bwd && dgates && dxe && workspace && (!gate_bias_grad == !enc_bias_grad),
                 "lstm_seq_backward: null buffer");
     const unsigned grid = (unsigned)((rows + kSeqRows - 1) / kSeqRows);
     hipStream_t st = (hipStream_t)stream;
@@ -408,6 +433,7 @@ extern "C" int pfa_lstm_seq_backward(const float *gates_act, const float *cs, co
         hipLaunchKernelGGL(lstm_seq_bwd_kernel<false>, dim3(grid), dim3(kLstmThreads), 0, st, gates_act, cs, xe, dh_heads, (long long)rows,
                            (int)steps, (const float4 *)wpack_bwd, dgates, dxe, (float *)workspace);
     PFA_LAUNCH_CHECK();
+    if (!gate_bias_grad) return 0;   // the caller sums the per-workgroup column sums itself (pfa_reduce_multi, kind 1: [groups][640])
     hipLaunchKernelGGL(lstm_bias_final_kernel, dim3(kBiasCols / 64), dim3(256), 0, st, (const float *)workspace, (int)grid,
                        gate_bias_grad, enc_bias_grad);
     PFA_LAUNCH_CHECK();

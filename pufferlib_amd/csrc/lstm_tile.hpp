@@ -78,6 +78,16 @@ struct LstmFrags {
     }
 };
 
+// One float4 of the forward gate pack: dst index ((w*16 + kq)*8 + ct)*64 + lane  <-  Wcat[col(w, ct, c)][16kq + 4g .. +3]
+__device__ __forceinline__ float4 lstm_pack_fwd_elem(const float *__restrict__ params, int dp, int a, int idx) {
+    const LstmOffsets lo = lstm_offsets(dp, a);
+    const int lane = idx & 63, ct = (idx >> 6) & 7, kq = (idx >> 9) & 15, w = idx >> 13;
+    const int c = lane & 15, g = lane >> 4;
+    const int col = gate_col(w, ct, c), k0 = 16 * kq + 4 * g;
+    const float *src = k0 < kLH ? params + lo.w_ih + col * kLH + k0 : params + lo.w_hh + col * kLH + (k0 - kLH);
+    return make_float4(src[0], src[1], src[2], src[3]);  // the flat parameter vector is only 4-byte aligned here
+}
+
 // b_ih + b_hh -> LDS [512], all threads of the workgroup (the cell update reads it as float4 per column tile).
 __device__ __forceinline__ void stage_gate_bias(const float *params, int dp, int a, float *gbias) {
     const LstmOffsets lo = lstm_offsets(dp, a);
@@ -267,7 +277,7 @@ __device__ __forceinline__ void load_hstate(const float *hglob, long long first_
     for (int idx = threadIdx.x; idx < 16 * (kLH / 4); idx += kLstmThreads) {
         const int r = idx / (kLH / 4), c4 = idx % (kLH / 4);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (first_row + r < rows) v = *reinterpret_cast<const float4 *>(hglob + (first_row + r) * kLH + 4 * c4);
+        if (hglob && first_row + r < rows) v = *reinterpret_cast<const float4 *>(hglob + (first_row + r) * kLH + 4 * c4);   // (null: zero state)
         *reinterpret_cast<float4 *>(xh + r * kXHS + kLH + 4 * c4) = v;
     }
 }

@@ -87,8 +87,9 @@ class Engine:
         self.ws = torch.empty(L.pfa_lstm_heads_loss_workspace_bytes(),
                               dtype=torch.uint8, device=dev)
         shapes = [(4 * H, H), (H, DP), (16, H)]
-        self.gemm_ws = torch.empty(max([L.pfa_gemm_tn_workspace_bytes(mo, no, M) for mo, no in shapes] + [L.pfa_gemm_tn2_workspace_bytes(4 * H, M)]),
-                                   dtype=torch.uint8, device=dev)
+        # one split-partial workspace per weight-gradient product: the three products' partials are summed by ONE launch (pfa_reduce_multi)
+        self.gemm_ws = [torch.empty(nb, dtype=torch.uint8, device=dev) for nb in
+                        (L.pfa_gemm_tn_workspace_bytes(H, DP, M), L.pfa_gemm_tn2_workspace_bytes(4 * H, M), L.pfa_gemm_tn_workspace_bytes(16, H, M))]
         self.g16 = torch.empty(16, H, device=dev)
         self.bwd_ws = torch.empty(L.pfa_lstm_seq_backward_workspace_bytes(R), dtype=torch.uint8, device=dev)
         self.norm_partials = torch.empty(256, dtype=torch.float64, device=dev)
@@ -152,15 +153,13 @@ class Engine:
                        'gather_obs')
             if keep:
                 self._gathered = {k for k in self._gathered if k[0] == self.update_id} | {(self.update_id, mb)}
-        if mb == 0 or self.state is None:      # lstm_state = None at the start of every epoch (clean_pufferl.py:176)
-            self.Hs[0].zero_()
-            self.Cs[0].zero_()
-        else:                                   # carried across minibatches, detached (clean_pufferl.py:188-191):
-            self.Hs[0].copy_(self.Hs[Th])       # the previous minibatch's final state is still in slot Th
-            self.Cs[0].copy_(self.Cs[Th])
-        pack_gates(fp, self.wpack)              # the weights changed in the previous optimizer step
+        # lstm_state = None at the start of every epoch (clean_pufferl.py:176), else carried across minibatches, detached (:188-191):
+        # the previous minibatch's final state is still in slot Th, and the forward kernel itself moves it (or zeros) into slot 0
+        init_slot = -1 if (mb == 0 or self.state is None) else Th
+        # both re-tilings of the gate matrix in one launch (the weights changed in the previous optimizer step)
+        _lib.check(L.pfa_lstm_pack_both(_lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(self.wpack), _lib.ptr(self.wpack_bwd), stream), 'lstm_pack_both')
         _lib.check(L.pfa_lstm_seq_forward(_lib.ptr(self.obs_tm), R, Th, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(self.wpack),
-                                          _lib.ptr(self.xe), _lib.ptr(self.gates), _lib.ptr(self.Hs), _lib.ptr(self.Cs), stream),
+                                          _lib.ptr(self.xe), _lib.ptr(self.gates), _lib.ptr(self.Hs), _lib.ptr(self.Cs), init_slot, stream),
                    'lstm_seq_forward')
         self.state = True
         h_all = self.Hs[1:].view(M, H)
@@ -171,19 +170,27 @@ class Engine:
                                          _lib.ptr(loss_sums), _lib.ptr(self.bsum16), _lib.ptr(self.ws), stream), 'lstm_heads_loss')
         # ---- back-propagation through time (csrc/lstm_seq.hip) + weight gradients (csrc/gemm.hip) ----------------------
         gv = fp.split(grads[:fp.count])
-        _lib.check(L.pfa_lstm_pack_bwd(_lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(self.wpack_bwd), stream), 'lstm_pack_bwd')
+        # (bias gradients: the kernel leaves its per-workgroup column sums in bwd_ws; they are summed with the products' partials below)
         _lib.check(L.pfa_lstm_seq_backward(_lib.ptr(self.gates), _lib.ptr(self.Cs), _lib.ptr(self.xe), _lib.ptr(self.dh_heads), R, Th,
-                                           _lib.ptr(self.wpack_bwd), _lib.ptr(self.dG), _lib.ptr(self.dxe),
-                                           _lib.ptr(gv['recurrent.bias_ih_l0']), _lib.ptr(gv['encoder.bias']), _lib.ptr(self.bwd_ws),
+                                           _lib.ptr(self.wpack_bwd), _lib.ptr(self.dG), _lib.ptr(self.dxe), None, None, _lib.ptr(self.bwd_ws),
                                            stream), 'lstm_seq_backward')
         dG = self.dG.view(M, 4 * H)
         gW1p = fp.encoder_weight_padded(grads[:fp.count])
-        self._gemm_tn(self.dxe, self.obs_tm, gW1p)
-        # dW_ih = dG^T xe and dW_hh = dG^T h_prev in one pass over dG (pfa_gemm_tn2_f32)
         hp_, gih, ghh = self.Hs[:Th].view(M, H), gv['recurrent.weight_ih_l0'], gv['recurrent.weight_hh_l0']
-        _lib.check(L.pfa_gemm_tn2_f32(_lib.ptr(dG), dG.stride(0), _lib.ptr(self.xe), self.xe.stride(0), _lib.ptr(hp_), hp_.stride(0), _lib.ptr(gih),
-                                      gih.stride(0), _lib.ptr(ghh), ghh.stride(0), 4 * H, M, _lib.ptr(self.gemm_ws), stream), 'gemm_tn2')
-        self._gemm_tn(self.dout, h_all, self.g16)                   # [16][128]: rows < A decoder, row A value head
+        jobs = (_lib.ReduceJob * 4)()
+        # dW1 = dxe^T obs;  dW_ih = dG^T xe and dW_hh = dG^T h_prev in one pass over dG;  [16][128] heads: rows < A decoder, row A value head
+        _lib.check(L.pfa_gemm_tn_partial_f32(_lib.ptr(self.dxe), self.dxe.stride(0), _lib.ptr(self.obs_tm), self.obs_tm.stride(0), H, self.obs_tm.shape[1], M,
+                                             _lib.ptr(self.gemm_ws[0]), C.byref(jobs[0]), stream), 'gemm_tn dW1')
+        _lib.check(L.pfa_gemm_tn2_partial_f32(_lib.ptr(dG), dG.stride(0), _lib.ptr(self.xe), self.xe.stride(0), _lib.ptr(hp_), hp_.stride(0), 4 * H, M,
+                                              _lib.ptr(self.gemm_ws[1]), C.byref(jobs[1]), stream), 'gemm_tn2 dW_ih dW_hh')
+        _lib.check(L.pfa_gemm_tn_partial_f32(_lib.ptr(self.dout), self.dout.stride(0), _lib.ptr(h_all), h_all.stride(0), 16, H, M,
+                                             _lib.ptr(self.gemm_ws[2]), C.byref(jobs[2]), stream), 'gemm_tn heads')
+        jobs[0].c, jobs[0].ldc = gW1p.data_ptr(), gW1p.stride(0)
+        jobs[1].c, jobs[1].ldc, jobs[1].c2, jobs[1].ldc2 = gih.data_ptr(), gih.stride(0), ghh.data_ptr(), ghh.stride(0)
+        jobs[2].c, jobs[2].ldc = self.g16.data_ptr(), self.g16.stride(0)
+        gb, eb = gv['recurrent.bias_ih_l0'], gv['encoder.bias']
+        jobs[3] = _lib.ReduceJob(1, (R + 31) // 32, 1, 4 * H + H, self.bwd_ws.data_ptr(), gb.data_ptr(), 0, eb.data_ptr(), 0, 4 * H, 0)
+        _lib.check(L.pfa_reduce_multi(jobs, 4, stream), 'reduce_multi')
         _lib.check(L.pfa_lstm_finish_grads(_lib.ptr(grads), C.byref(fp.dims), _lib.ptr(self.g16), _lib.ptr(self.bsum16), stream),
                    'lstm_finish_grads')
 
@@ -191,7 +198,7 @@ class Engine:
         """out[mo][no] = a[k][mo]^T b[k][no] — the weight-gradient contraction over the minibatch rows (csrc/gemm.hip)."""
         L = _lib.lib()
         _lib.check(L.pfa_gemm_tn_f32(_lib.ptr(a), a.stride(0), _lib.ptr(b), b.stride(0), _lib.ptr(out), out.stride(0),
-                                     a.shape[1], b.shape[1], a.shape[0], _lib.ptr(self.gemm_ws), _lib.stream_handle()), 'gemm_tn')
+                                     a.shape[1], b.shape[1], a.shape[0], _lib.ptr(self.gemm_ws[1]), _lib.stream_handle()), 'gemm_tn')
         return out
 
     def clip_adam(self, grads, opt, max_grad_norm, loss_acc, loss_scale):

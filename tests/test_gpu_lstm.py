@@ -259,7 +259,7 @@ def test_lstm_seq_forward_backward_match_torch_autograd(R, Th):
     wpack = plstm.pack_gates(fp)
     st = _lib.stream_handle()
     _lib.check(L.pfa_lstm_seq_forward(_lib.ptr(obs), R, Th, _lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(wpack), _lib.ptr(xe),
-                                      _lib.ptr(gates), _lib.ptr(Hs), _lib.ptr(Cs), st), 'fwd')
+                                      _lib.ptr(gates), _lib.ptr(Hs), _lib.ptr(Cs), 0, st), 'fwd')
     wb = torch.empty_like(wpack)
     _lib.check(L.pfa_lstm_pack_bwd(_lib.ptr(fp.flat), C.byref(fp.dims), _lib.ptr(wb), st), 'pack_bwd')
     dG = torch.full((Th, R, 512), float('nan'), device=dev)
