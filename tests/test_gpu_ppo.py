@@ -576,3 +576,35 @@ def test_report_rides_the_updates_last_launch(n, horizon, epochs):
     torch.cuda.synchronize()
     assert packed.value == 1
     assert torch.equal(out10[:6], acc[:6]) and torch.equal(out10[6:], ev4) and float(acc[:3].abs().sum()) > 0
+
+
+def test_update_does_not_depend_on_what_the_caller_left_in_the_workspace():
+    """Advisor (round 5): the grid-wide hand-off words of the one-launch reduce + Adam used to live at the end of the caller's workspace,
+    whose contract silently was "zeroed once, written by nobody else" — a recycled buffer whose bits happened to look like the
+    launch generation would have been read as a norm piece.  They are library-owned now (csrc/ppo_update.hip grid_words_of): an update
+    over a workspace full of 0xFF bytes, and one over a workspace that held another trainer's data, give the bits of the clean run."""
+    from pufferlib_amd import _lib, clean_pufferl
+    hp = [2.5e-4, 0.99, 0.95, 0.1, 0.5, 0.1, 0.5, 0.01]
+    n, horizon = 256, 32
+    outs = []
+    for fill in (None, 0xFF, 'recycled'):
+        torch.manual_seed(3)
+        vec, pol = _make(n)
+        data = clean_pufferl.create(_config(n, horizon, n * horizon // 4, 16, 2, n * horizon * 8, hp, seed=5), vec, pol)
+        for it in range(2):
+            clean_pufferl.evaluate(data)
+            if fill == 0xFF:
+                torch.cuda.synchronize()
+                data._gae_done = None                     # (the early GAE pass keeps its sums in the workspace: let train() redo it)
+                data.workspace.fill_(0xFF)
+            elif fill == 'recycled':
+                torch.cuda.synchronize()
+                data._gae_done = None
+                data.workspace.copy_(torch.randint(0, 256, data.workspace.shape, dtype=torch.uint8, device='cuda',
+                                                   generator=torch.Generator(device='cuda').manual_seed(it)))
+            clean_pufferl.train(data)
+        assert _lib.lib().pfa_ppo_grid_status() == 0
+        outs.append((data.flat_params.flat.clone(), dict(data.losses)))
+    for flat, losses in outs[1:]:
+        assert torch.equal(flat, outs[0][0]) and repr(losses) == repr(outs[0][1])
+    assert _lib.lib().pfa_ppo_grid_reset() == 0           # nothing was raised; the reset entry point reports the value it cleared
