@@ -491,12 +491,19 @@ def self_check_c4():
 
 
 def _free_port():
+    """A free listening port BELOW the kernel's ephemeral range (32768-60999): an ephemeral one can be taken as the source port of a peer's
+    connection attempt between this probe and rank 0's bind (seen once as EADDRINUSE in a full-suite run)."""
+    import random
     import socket
-    so = socket.socket()
-    so.bind(('127.0.0.1', 0))
-    port = so.getsockname()[1]
-    so.close()
-    return port
+    for _ in range(128):
+        p = random.randint(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(('127.0.0.1', p))
+                return p
+            except OSError:
+                continue
+    raise RuntimeError('no free port in 20000-32000')
 
 
 def self_spawn(args):

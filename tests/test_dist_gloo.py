@@ -22,9 +22,19 @@ HP = dict(lr=2.5e-4, clip=0.1, vf_coef=0.5, vf_clip=0.1, max_grad_norm=0.5, ent_
 
 
 def _free_port():
-    with socket.socket() as s:
-        s.bind(('127.0.0.1', 0))
-        return s.getsockname()[1]
+    """A free listening port BELOW the kernel's ephemeral range (32768-60999): an ephemeral one can be taken as the source port of a peer's
+    connection attempt between this probe and rank 0's bind (seen once as EADDRINUSE in a full-suite run)."""
+    import random
+    import socket
+    for _ in range(128):
+        p = random.randint(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(('127.0.0.1', p))
+                return p
+            except OSError:
+                continue
+    raise RuntimeError('no free port in 20000-32000')
 
 
 def _make_batch(world):

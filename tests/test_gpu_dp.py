@@ -22,11 +22,19 @@ N_PER_RANK, HORIZON, ITERS = 32, 16, 2
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A free listening port BELOW the kernel's ephemeral range (32768-60999): an ephemeral one can be taken as the source port of a peer's
+    connection attempt between this probe and rank 0's bind (seen once as EADDRINUSE in a full-suite run)."""
+    import random
+    import socket
+    for _ in range(128):
+        p = random.randint(20000, 32000)
+        with socket.socket() as s:
+            try:
+                s.bind(('127.0.0.1', p))
+                return p
+            except OSError:
+                continue
+    raise RuntimeError('no free port in 20000-32000')
 
 
 CONV = 'conv'      # third policy kind next to recurrent = False / True: models.Convolutional on vector.Frames (4 envs x 8 steps per rank)
