@@ -41,7 +41,8 @@ int pfa_timing_read(const char *kernel, int64_t *launches_host, double *total_ms
  * One reverse affine scan over the whole flat (env-major) batch, crossing env boundaries exactly
  * like the reference; advantages[n-1] = 0.  Contract: within 1e-5 of the reference's sequential fp32 loop, always.  In practice much
  * closer: every thread warms up on the elements behind its own (csrc/gae.hip gae_exact_kernel) so that it sits ON the reference's
- * rounded sequence, and for gamma * gae_lambda up to ~0.985 the result is the reference's bit pattern on typical data (every case the
+ * rounded sequence, and for gamma * gae_lambda up to ~0.985 the result is the reference's bit pattern on typical data (one launch up to
+ * 0.984: the walkers start from zero inside a 1024- or 2048-element window; two launches with f64 chunk maps above) (every case the
  * tests hold, 524 288 rows, done rates 0 - 25 %); the argument is a contraction in real arithmetic, so isolated entries may sit
  * 1 ulp off on data with an extreme dynamic range inside one 1024-element window, and a few ulps off above ~0.985.
  * `returns` (nullable) = advantages + values
@@ -73,7 +74,7 @@ int pfa_gae_sums_f32(const float *dones, const float *values, const float *rewar
  * min(n, H) rows, H = pfa_gae_halo_rows(gamma, gae_lambda), next to `n_extra` other f64 sums of the caller (episode statistics);
  * ONE all-reduce(SUM) of out[n_extra + 3 world min(n, H)]; every rank drops the rows that follow its shard behind its arrays
  * (which hold n + H elements) and runs the single-rank kernel over them: advantages are the BITS of the single flat scan.
- *   pfa_gae_halo_rows      H (a multiple of 8, <= 1032); 0 = gamma * gae_lambda > 0.968: use the f64-carry form below
+ *   pfa_gae_halo_rows      H (a multiple of 8, <= 2056); 0 = gamma * gae_lambda > 0.984: use the f64-carry form below
  *   pfa_gae_halo_publish   out[0 .. n_extra) = extra, then [world][3][min(n, H)] bit patterns as f64 (zeros in the peers' places)
  *   pfa_gae_halo_unpack    gathered = out + n_extra; returns halo_len = min(H, rows that follow this shard) (>= 0), < 0 on error
  *   pfa_gae_halo_f32       the scan; adv_stats != NULL: + this rank's share of pfa_gae_sums_f32's sums (same shape rules) */

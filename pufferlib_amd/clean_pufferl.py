@@ -99,7 +99,7 @@ class HipAdam:
         self.param_groups[0]['lr'] = sd['param_groups'][0]['lr']
 
 
-GAE_HALO_MAX = 1032
+GAE_HALO_MAX = 2056
 
 
 class Experience:
@@ -131,7 +131,7 @@ class Experience:
         self.actions = torch.zeros(B, dtype=torch.int32, device=device)
         self.logprobs = torch.zeros(B, dtype=torch.float32, device=device)
         # room behind rewards / dones / values for the halo of the data-parallel GAE: the rows that follow this rank's shard in the
-        # rank-major flat batch (csrc/gae.hip gae_halo_*: at most the self-starting window's 1024 + 8)
+        # rank-major flat batch (csrc/gae.hip gae_halo_*: at most the self-starting window's 2048 + 8)
         self._rdv = torch.zeros(3, B + GAE_HALO_MAX, dtype=torch.float32, device=device)
         self.rewards, self.dones, self.values = self._rdv[0, :B], self._rdv[1, :B], self._rdv[2, :B]
         self.advantages = torch.zeros(B, dtype=torch.float32, device=device)
@@ -669,7 +669,7 @@ def _all_reduce_f64(data, buf, what):
 def _publish_gae(data, extra=None):
     """First half of the data-parallel GAE: what the other ranks need from this rank's rows + `extra` (f64 sums that ride along: the
     episode statistics) -> ONE all-reduce(SUM).  Returns the all-reduced `extra` (a view of the exchange buffer).
-    Halo form (csrc/gae.hip gae_halo_*, gamma lambda <= 0.968): the bit patterns of the shard's first rows, so that every rank runs
+    Halo form (csrc/gae.hip gae_halo_*, gamma lambda <= 0.984): the bit patterns of the shard's first rows, so that every rank runs
     the single-rank kernel over its rows + the rows that follow them — the flat scan's own bits.  Otherwise the f64-carry form: six
     numbers per rank (interior map, last value, first row), a few ulps from the flat scan at the shard ends."""
     config, ex = data.config, data.experience

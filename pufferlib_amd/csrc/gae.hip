@@ -211,17 +211,20 @@ struct GaeSums {
 // of pass 1 (no gae_aggregate launch) nor the block scan.  Every walker starts from x = 0 at `warm` elements behind its items: the
 // start error is then the advantage itself instead of a few of its ulps, and 24 more binary orders of contraction
 // ((gamma lambda)^warm <= 1e-7 * 2^-24) bring it as far below one ulp as the f64-seeded form is after its shorter warm-up — 536
-// elements instead of 264 at the defaults, inside the 1024-element window for gamma lambda <= 0.968.  Beyond the end of the array
+// elements instead of 264 at the defaults, inside the 1024-element window for gamma lambda <= 0.968 (CT = 128), inside the 2048-element one up to 0.984 (CT = 256).  Beyond the end of the array
 // the window holds (0, 0) pairs, where x = 0 IS the reference's value (adv[n-1] = 0, c_gae.pyx:24).
-template <bool SUMS, bool SELF>
-__global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *dones, const float *values, const float *rewards, float *adv,
+// CT = walker threads = chunk / 8: 128 (chunks and windows of 1024 elements: every form) or, self-starting form only, 256 (2048: the
+// warm-up of gamma lambda up to 0.984 fits the window, so those discounts also run as ONE launch, and sharded over ranks as the halo form)
+template <bool SUMS, bool SELF, int CT = kGaeChunkThreads>
+__global__ void __launch_bounds__(2 * CT) gae_exact_kernel(const float *dones, const float *values, const float *rewards, float *adv,
                                                                float *ret, long long n, long long n_read, float gamma, float lam,
                                                                const Affine *agg, int nchunks, int warm, GaeSums sums) {
-    __shared__ Affine sh[SELF ? 1 : kGaeThreads / 64];
+    constexpr int kChunk = CT * kGaeItems, kWin = 2 * kChunk, kNT = 2 * CT;
+    __shared__ Affine sh[SELF ? 1 : kNT / 64];
     __shared__ double s_carry;
-    __shared__ float2 cd[kGaeBlock + kGaeBlock / 8];      // (coef, delta) of the window's elements, index i + i / 8
-    __shared__ float start[SELF ? 1 : kGaeThreads];       // f64-accurate advantage at element 8 (t + 1) of the window
-    __shared__ double sh_s[SUMS ? 4 : 1][SUMS ? kGaeChunkThreads : 1];
+    __shared__ float2 cd[kWin + kWin / 8];      // (coef, delta) of the window's elements, index i + i / 8
+    __shared__ float start[SELF ? 1 : kNT];       // f64-accurate advantage at element 8 (t + 1) of the window
+    __shared__ double sh_s[SUMS ? 4 : 1][SUMS ? CT : 1];
     const int tid = threadIdx.x;
     // carry-in of the WINDOW (chunks b, b + 1) = (agg[b+2] o ... o agg[nchunks-1])(0), composed in order by wave 0
     if (!SELF && wave_id() == 0) {
@@ -240,14 +243,14 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
         }
         if (lane == 0) s_carry = f.d;   // applied to 0: nothing follows the array
     }
-    const long long s = (long long)blockIdx.x * kGaeChunk + (long long)tid * kGaeItems;
+    const long long s = (long long)blockIdx.x * kChunk + (long long)tid * kGaeItems;
     GaeItems it;
     // SELF: only the window elements a walker can reach are fetched (the last walker starts at element 1024 + 8 + warm)
-    const bool feeds = !SELF || tid * kGaeItems < kGaeChunk + kGaeItems + warm;
+    const bool feeds = !SELF || tid * kGaeItems < kChunk + kGaeItems + warm;
     if (feeds) gae_load(dones, values, rewards, s, n_read, it);
     if constexpr (!SELF) {
         Affine mine = gae_thread_map(it, s, n, gamma, lam, true), after;
-        block_suffix_scan(mine, after, sh);  // contains the __syncthreads that publishes s_carry
+        block_suffix_scan<kNT>(mine, after, sh);  // contains the __syncthreads that publishes s_carry
         start[tid] = (float)(after.c * s_carry + after.d);
     }
     if (feeds) {
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
     float advv[kGaeItems];
 #pragma unroll
     for (int i = 0; i < kGaeItems; ++i) advv[i] = 0.0f;
-    if (tid < kGaeChunkThreads) {
+    if (tid < CT) {
         PFA_GAE_FP
         const int first = tid * kGaeItems + kGaeItems;          // window element behind this thread's items
         float x = SELF ? 0.0f : start[tid + (warm >> 3)];       // advantage at window element first + warm (8-aligned); SELF: see above
@@ -299,7 +302,7 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
     }
     if constexpr (SUMS) {
         double a1 = 0.0, a2 = 0.0, y1 = 0.0, y2 = 0.0;
-        if (tid < kGaeChunkThreads) {
+        if (tid < CT) {
             // y_pred of flat index j is values[(j % N) * T + j / N]: issue the thread's eight gathers together
             float yp[kGaeItems];
             const long long e0 = s % sums.num_envs, t0 = s / sums.num_envs;
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(kGaeThreads) gae_exact_kernel(const float *don
         __syncthreads();
         const int G = sums.bptt / kGaeItems, P = G * sums.nmb;   // threads per segment, per cycle of minibatches
         // fixed tree down to one entry per (minibatch, position in the segment): t and t + stride share both while stride >= P
-        for (int stride = kGaeChunkThreads / 2; stride >= P; stride >>= 1) {
+        for (int stride = CT / 2; stride >= P; stride >>= 1) {
             if (tid < stride) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sh_s[q][tid] += sh_s[q][tid + stride];
@@ -487,8 +490,8 @@ static int gae_warm(float gamma, float lam) {
 }
 
 // Warm-up elements of the self-starting form (gae_exact_kernel<.., SELF>): the start error is the advantage itself, so the
-// contraction has to cover the 24 bits of an fp32 mantissa on top of gae_warm's margin.  0 = the window (1024 elements) is too
-// short for this gamma lambda (> 0.968): the f64-seeded two-launch form runs.  PFA_GAE_SELF=0 forces the latter (A/B, fallback).
+// contraction has to cover the 24 bits of an fp32 mantissa on top of gae_warm's margin.  0 = even the 2048-element window is too
+// short for this gamma lambda (> 0.984): the f64-seeded two-launch form runs.  PFA_GAE_SELF=0 forces the latter (A/B, fallback).
 static int gae_warm_self(float gamma, float lam) {
     const char *e = std::getenv("PFA_GAE_SELF");   // (read per call: the tests flip it inside one process)
     if (e && e[0] == '0') return 0;
@@ -496,7 +499,23 @@ static int gae_warm_self(float gamma, float lam) {
     if (!(gl > 0.0)) return 8;
     if (gl >= 0.999) return 0;
     const double w = std::ceil(std::log(1e-7 * 5.9604644775390625e-08) / std::log(gl) / 8.0) * 8.0;
-    return w <= (double)kGaeChunk ? (int)(w < 8.0 ? 8.0 : w) : 0;
+    return w <= 2.0 * kGaeChunk ? (int)(w < 8.0 ? 8.0 : w) : 0;   // (<= 1024: chunks of 1024; <= 2048, gamma lambda <= 0.984: chunks of 2048)
+}
+
+// The self-starting form for `ws` warm-up elements over n rows reading n_read (>= n: the data-parallel halo); returns its chunk count.
+template <bool SUMS>
+static int64_t launch_gae_self(const float *dones, const float *values, const float *rewards, float *advantages, float *returns, int64_t n,
+                               int64_t n_read, float gamma, float gae_lambda, int ws, GaeSums sums, hipStream_t st) {
+    if (ws <= kGaeChunk) {
+        const int64_t nc = (n + kGaeChunk - 1) / kGaeChunk;
+        hipLaunchKernelGGL((gae_exact_kernel<SUMS, true, kGaeChunkThreads>), dim3((unsigned)nc), dim3(2 * kGaeChunkThreads), 0, st, dones, values, rewards,
+                           advantages, returns, (long long)n, (long long)n_read, gamma, gae_lambda, (const Affine *)nullptr, (int)nc, ws, sums);
+        return nc;
+    }
+    const int64_t nc = (n + 2 * kGaeChunk - 1) / (2 * kGaeChunk);
+    hipLaunchKernelGGL((gae_exact_kernel<SUMS, true, 2 * kGaeChunkThreads>), dim3((unsigned)nc), dim3(4 * kGaeChunkThreads), 0, st, dones, values, rewards,
+                       advantages, returns, (long long)n, (long long)n_read, gamma, gae_lambda, (const Affine *)nullptr, (int)nc, ws, sums);
+    return nc;
 }
 
 extern "C" int pfa_gae_f32(const float *dones, const float *values, const float *rewards, float *advantages, float *returns,
@@ -509,8 +528,7 @@ extern "C" int pfa_gae_f32(const float *dones, const float *values, const float 
     Affine *agg = (Affine *)workspace;
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // both passes
     if (const int ws = gae_warm_self(gamma, gae_lambda)) {   // one launch: the window warms itself up (no chunk maps)
-        hipLaunchKernelGGL((gae_exact_kernel<false, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                           advantages, returns, (long long)n, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, GaeSums{});
+        launch_gae_self<false>(dones, values, rewards, advantages, returns, n, n, gamma, gae_lambda, ws, GaeSums{}, (hipStream_t)stream);
         PFA_LAUNCH_CHECK();
         return 0;
     }
@@ -550,9 +568,9 @@ extern "C" int pfa_gae_sums_f32(const float *dones, const float *values, const f
     GaeSums sums{(double *)((char *)workspace + align_up((size_t)nc * sizeof(Affine), 256)), num_minibatches, bptt_horizon, num_envs,
                  (int)(n / num_envs)};
     ScopedKernelTimer timer("gae", (hipStream_t)stream);  // all launches (three; two in the self-starting form)
+    int64_t nparts = nc;
     if (const int ws = gae_warm_self(gamma, gae_lambda)) {
-        hipLaunchKernelGGL((gae_exact_kernel<true, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                           advantages, returns, (long long)n, (long long)n, gamma, gae_lambda, agg, (int)nc, ws, sums);
+        nparts = launch_gae_self<true>(dones, values, rewards, advantages, returns, n, n, gamma, gae_lambda, ws, sums, (hipStream_t)stream);
     } else {
         hipLaunchKernelGGL(gae_aggregate_kernel<kGaeChunkThreads>, dim3((unsigned)nc), dim3(kGaeChunkThreads), 0, (hipStream_t)stream, dones, values,
                            rewards, (long long)n, gamma, gae_lambda, agg, 0);
@@ -561,7 +579,7 @@ extern "C" int pfa_gae_sums_f32(const float *dones, const float *values, const f
                            advantages, returns, (long long)n, (long long)n, gamma, gae_lambda, agg, (int)nc, gae_warm(gamma, gae_lambda), sums);
     }
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nc,
+    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nparts,
                        (int)num_minibatches, adv_stats, ev4, zero8);
     PFA_LAUNCH_CHECK();
     return 0;
@@ -617,7 +635,7 @@ extern "C" int pfa_gae_shard_fold(const double *gathered, int32_t rank, int32_t 
 }
 
 // Halo form of the data-parallel scan (see gae_halo_publish_kernel).  pfa_gae_halo_rows: H for this gamma lambda, 0 when the
-// self-starting window cannot serve it (gamma lambda > 0.968, or PFA_GAE_SELF=0): the f64-carry form above runs then.
+// self-starting window cannot serve it (gamma lambda > 0.984, or PFA_GAE_SELF=0): the f64-carry form above runs then.
 //   publish  out[n_extra + 3 world min(n, H)] <- extra | this rank's first rows as bit patterns (zeros in the other ranks' places)
 //   (the caller all-reduces `out`, SUM)
 //   unpack   gathered = out + n_extra: rows n .. n + halo_len of the three arrays <- the rows that follow this shard in the
@@ -668,9 +686,7 @@ extern "C" int pfa_gae_halo_f32(const float *dones, const float *values, const f
     PFA_REQUIRE(nc <= 0x7fffffff, "gae: batch too large");
     ScopedKernelTimer timer("gae", (hipStream_t)stream);
     if (!adv_stats) {
-        hipLaunchKernelGGL((gae_exact_kernel<false, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                           advantages, returns, (long long)n, (long long)(n + halo_len), gamma, gae_lambda, (const Affine *)nullptr, (int)nc, ws,
-                           GaeSums{});
+        launch_gae_self<false>(dones, values, rewards, advantages, returns, n, n + halo_len, gamma, gae_lambda, ws, GaeSums{}, (hipStream_t)stream);
         PFA_LAUNCH_CHECK();
         return 0;
     }
@@ -678,10 +694,9 @@ extern "C" int pfa_gae_halo_f32(const float *dones, const float *values, const f
     PFA_REQUIRE(ev4 && workspace, "gae_halo: null buffer");
     GaeSums sums{(double *)((char *)workspace + align_up((size_t)nc * sizeof(Affine), 256)), num_minibatches, bptt_horizon, num_envs,
                  (int)(n / num_envs)};
-    hipLaunchKernelGGL((gae_exact_kernel<true, true>), dim3((unsigned)nc), dim3(kGaeThreads), 0, (hipStream_t)stream, dones, values, rewards,
-                       advantages, returns, (long long)n, (long long)(n + halo_len), gamma, gae_lambda, (const Affine *)nullptr, (int)nc, ws, sums);
+    const int64_t nparts = launch_gae_self<true>(dones, values, rewards, advantages, returns, n, n + halo_len, gamma, gae_lambda, ws, sums, (hipStream_t)stream);
     PFA_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nc,
+    hipLaunchKernelGGL(gae_sums_final_kernel, dim3((unsigned)(2 * num_minibatches + 4)), dim3(64), 0, (hipStream_t)stream, sums.part, (int)nparts,
                        (int)num_minibatches, adv_stats, ev4, zero8);
     PFA_LAUNCH_CHECK();
     return 0;

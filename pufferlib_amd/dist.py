@@ -12,7 +12,7 @@ Sharding contract
     global minibatch m;
   * GAE is the reference's single scan over the rank-major flat batch, bit for bit: every rank's first rows travel (as bit
     patterns, next to the episode statistics) in ONE all-reduce at the end of evaluate(), every rank runs the single-rank kernel
-    over its shard + the rows that follow it (csrc/gae.hip gae_halo_*; gamma lambda > 0.968: six numbers per rank and an f64 carry,
+    over its shard + the rows that follow it (csrc/gae.hip gae_halo_*; gamma lambda > 0.984: six numbers per rank and an f64 carry,
     a few ulps at the shard ends);
   * then ONE all-reduce(SUM) of the per-minibatch advantage sums [nmb][2] and the explained-variance sums (f64) so every rank
     normalises with the global-minibatch mean / unbiased std — also at the end of evaluate(); per optimizer step ONE all-reduce(SUM) of the flat bucket
@@ -179,7 +179,7 @@ def normalisation_from_sums(s1, s2, count):
 def gae_halo_rows(gamma, lam):
     """Host mirror of pfa_gae_halo_rows (csrc/gae.hip): rows a shard needs from behind its end so that every walker of the
     self-starting window sits on the flat scan's rounded sequence — warm-up ((gamma lambda)^warm <= 1e-7 * 2^-24, a multiple of 8)
-    + 8; 0 when that exceeds the kernel's 1024-element window (gamma lambda > 0.968)."""
+    + 8; 0 when that exceeds the kernel's largest (2048-element) window (gamma lambda > 0.984)."""
     import numpy as np
     gl = float(np.float32(gamma) * np.float32(lam))
     if not gl > 0.0:
@@ -187,7 +187,7 @@ def gae_halo_rows(gamma, lam):
     if gl >= 0.999:
         return 0
     w = math.ceil(math.log(1e-7 * 2.0 ** -24) / math.log(gl) / 8.0) * 8
-    return int(max(w, 8)) + 8 if w <= 1024 else 0
+    return int(max(w, 8)) + 8 if w <= 2048 else 0
 
 
 def gae_halo_pack(dones, values, rewards, rank, world, H):

@@ -193,10 +193,10 @@ def _gae_inputs(n):
     return dn, v, r
 
 
-@pytest.mark.parametrize('n,world,gl', [(3000, 3, (0.99, 0.95)), (600, 3, (0.99, 0.95)), (1200, 2, (0.995, 0.97))])
+@pytest.mark.parametrize('n,world,gl', [(3000, 3, (0.99, 0.95)), (600, 3, (0.99, 0.95)), (1200, 2, (0.995, 0.97)), (4000, 2, (0.995, 0.985))])
 def test_halo_sharded_gae_is_the_flat_scan_bit_for_bit(tmp_path, n, world, gl):
     """3000 / 3: the halo (544 rows) comes from the next shard alone; 600 / 3: shards of 200 rows — rank 0's halo is all of rank 1
-    and rank 2, and the pinned last element of the batch sits inside it; 0.995 x 0.97: a 936-row halo."""
+    and rank 2, and the pinned last element of the batch sits inside it; 0.995 x 0.97: a 936-row halo; 0.995 x 0.985: 1640 rows (the 2048-element window)."""
     mp.spawn(_gae_halo_worker, args=(world, _free_port(), str(tmp_path), n, *gl), nprocs=world, join=True)
     got = np.concatenate([np.load(tmp_path / f'adv{q}.npy') for q in range(world)]).astype(np.float32)
     sys.path.insert(0, REPO)

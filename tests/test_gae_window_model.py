@@ -37,7 +37,7 @@ def window_gae(r, v, d, gamma, lam, warm):
     return adv[:n]
 
 
-@pytest.mark.parametrize('gamma,lam', [(0.99, 0.95), (0.995, 0.97), (0.9, 0.8)])
+@pytest.mark.parametrize('gamma,lam', [(0.99, 0.95), (0.995, 0.97), (0.9, 0.8), (0.995, 0.985)])
 @pytest.mark.parametrize('p_done,scale', [(0.0, 1.0), (0.001, 1.0), (0.15, 1.0), (0.0005, 1e4)])
 def test_window_started_from_zero_lands_on_the_reference_sequence(gamma, lam, p_done, scale):
     rng = np.random.default_rng(int(gamma * 1000) + int(p_done * 10000))
@@ -46,7 +46,7 @@ def test_window_started_from_zero_lands_on_the_reference_sequence(gamma, lam, p_
     v = (rng.standard_normal(n) * scale).astype(f32)
     d = (rng.random(n) < p_done).astype(f32)
     warm = warm_self(gamma, lam)
-    assert warm % 8 == 0 and warm <= 1024                 # fits the kernel's 1024-element window for these products
+    assert warm % 8 == 0 and warm <= 2048                 # fits the kernel's 1024- (gamma lambda <= 0.968) or 2048-element window
     want = c_oracle.compute_gae(d, v, r, gamma, lam)
     got = window_gae(r, v, d, gamma, lam, warm)
     assert np.array_equal(got.view(np.uint32), np.asarray(want, f32).view(np.uint32))

@@ -89,7 +89,7 @@ TRANSPORTS = {
     # ... with the sharded GAE and its two exchanges in train() instead of at the end of evaluate() (what a host vecenv's evaluate,
     # which does not publish, and callers that rewrite the experience between the two calls get)
     'p2p-late-gae': dict(PFA_ALLREDUCE='p2p', PFA_EARLY_GAE='0'),
-    # ... with the f64-carry shard form of the GAE (what gamma * lambda > 0.968 selects: six numbers per rank instead of the halo rows; a few
+    # ... with the f64-carry shard form of the GAE (what gamma * lambda > 0.984 selects: six numbers per rank instead of the halo rows; a few
     # ulps from the flat scan at the shard ends instead of its bits)
     'p2p-f64-gae': dict(PFA_ALLREDUCE='p2p', PFA_GAE_SELF='0'),
     # the native RCCL communicator: two ranks on ONE device are refused by RCCL ("duplicate GPU"); the refusal must be clean

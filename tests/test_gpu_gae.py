@@ -41,7 +41,7 @@ def test_golden_cases(golden_dir):
 def gae_form(request, monkeypatch):
     """Both single-array forms of csrc/gae.hip: one launch whose walkers start from 0 far enough behind their items (the default
     where gamma lambda lets the 1024-element window do it), and pass 1's f64 chunk maps seeding a shorter warm-up (PFA_GAE_SELF=0;
-    what runs for gamma lambda > 0.968)."""
+    what runs for gamma lambda > 0.984)."""
     monkeypatch.setenv('PFA_GAE_SELF', '1' if request.param.startswith('self') else '0')
     return request.param
 
@@ -63,7 +63,7 @@ def test_vs_oracle_full_size(n, p_done, gae_form):
     assert np.array_equal(got, want), (int((got != want).sum()), float(np.abs(got - want).max()))
 
 
-@pytest.mark.parametrize('gamma,lam', [(0.99, 0.95), (0.9, 0.8), (0.997, 0.97), (1.0, 1.0), (0.5, 0.0)])
+@pytest.mark.parametrize('gamma,lam', [(0.99, 0.95), (0.9, 0.8), (0.997, 0.97), (0.995, 0.985), (1.0, 1.0), (0.5, 0.0)])
 def test_bit_identical_to_the_sequential_loop_for_other_discounts(gamma, lam, gae_form):
     """gamma lambda up to ~0.985 (here 0.967): the warm-up (ln 1e-7 / ln(gamma lambda) elements, at most 1024) has contracted the
     start error away and the result is c_gae's bit pattern; at gamma = lambda = 1 nothing contracts and the kernel is what every scan
@@ -75,7 +75,7 @@ def test_bit_identical_to_the_sequential_loop_for_other_discounts(gamma, lam, ga
     v, r = rng.randn(n).astype(np.float32), rng.randn(n).astype(np.float32)
     want = c_oracle.compute_gae(d, v, r, gamma, lam)
     got = hip_gae(d, v, r, gamma, lam)
-    if gamma * lam < 0.98:
+    if gamma * lam < 0.981:
         assert np.array_equal(got, want), (int((got != want).sum()), float(np.abs(got - want).max()))
     else:
         np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-4 * max(1.0, float(np.abs(want).max())))
@@ -101,7 +101,8 @@ def test_empty_is_noop():
 
 @pytest.mark.parametrize('n,shards,p_done,gl', [(524288, 8, 0.01, (0.99, 0.95)), (524288, 8, 0.0, (0.99, 0.95)), (12288, 3, 0.2, (0.99, 0.95)),
                                                   (4096, 8, 0.0, (0.99, 0.95)), (4100, 2, 0.0, (0.99, 0.95)), (1600, 8, 0.02, (0.995, 0.97)),
-                                                  (7, 7, 0.3, (0.99, 0.95)), (16, 8, 0.5, (0.9, 0.8)), (64 * 48, 4, 0.05, (0.99, 0.95))])
+                                                  (7, 7, 0.3, (0.99, 0.95)), (16, 8, 0.5, (0.9, 0.8)), (64 * 48, 4, 0.05, (0.99, 0.95)),
+                                                  (262144, 8, 0.003, (0.995, 0.985)), (6000, 3, 0.0, (0.995, 0.985))])
 def test_sharded_halo_form_is_the_flat_scan_bit_for_bit(n, shards, p_done, gl):
     """The form clean_pufferl runs data parallel (round 6): every shard publishes the bit patterns of its first min(m, H) rows
     (pfa_gae_halo_publish, next to extra sums that ride along), the host sums the zero-padded buffers (the all-reduce), every shard
@@ -123,7 +124,7 @@ def test_sharded_halo_form_is_the_flat_scan_bit_for_bit(n, shards, p_done, gl):
     flat = hip_gae(d, v, r, gamma, lam)
     m = n // shards
     H = int(L.pfa_gae_halo_rows(gamma, lam))
-    assert H > 0 and H % 8 == 0 and H <= 1032
+    assert H > 0 and H % 8 == 0 and H <= 2056
     hp = min(m, H)
     st = _lib.stream_handle()
     size = 3 + 3 * shards * hp
@@ -179,6 +180,7 @@ def test_halo_form_is_refused_outside_the_self_starting_window():
     from pufferlib_amd import _lib
     L = _lib.lib()
     assert L.pfa_gae_halo_rows(0.99, 0.95) == 544 and L.pfa_gae_halo_rows(0.9, 0.8) % 8 == 0
+    assert L.pfa_gae_halo_rows(0.995, 0.985) == 1640               # gamma lambda 0.98: the 2048-element window (1632 warm-up elements + 8)
     assert L.pfa_gae_halo_rows(0.999, 0.99) == 0                   # the f64-carry form (pfa_gae_shard_publish / fold / pass2) serves these
     assert L.pfa_gae_halo_publish(None, None, None, 16, 0.999, 0.99, None, 0, None, 0, 2, None) != 0
     assert b'self-starting' in L.pfa_last_error()

@@ -88,6 +88,7 @@ def test_gae_halo_rows_travel_as_bit_patterns_and_come_from_as_many_later_shards
     returns every published float bit for bit (-0.0, denormals, inf), and a halo longer than a shard is filled from several."""
     from pufferlib_amd import dist as pdist
     assert pdist.gae_halo_rows(0.99, 0.95) == 544 and pdist.gae_halo_rows(0.999, 0.99) == 0 and pdist.gae_halo_rows(0.5, 0.0) == 16
+    assert pdist.gae_halo_rows(0.995, 0.985) == 1640
     world, n, H = 4, 5, 12
     rng = np.random.RandomState(0)
     rows = [[rng.randn(n).astype(np.float32) for _ in range(3)] for _ in range(world)]
